@@ -1,0 +1,65 @@
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name):
+    return torch.load(os.path.join(GOLDEN, name), map_location="cpu", weights_only=False)
+
+
+WEIGHT_SEED = 7
+
+
+@pytest.fixture(scope="session")
+def oracle_agent():
+    """AgentSD (oracle state dicts) with the same name-keyed weights the fixtures were made with."""
+    return make_oracle_agent()
+
+
+def make_oracle_agent(dtype=torch.float32, attn_depths=(0, 0, 0, 0)):
+    from diamond_amd.testing import fill_state_dict_
+    from oracle import diamond_oracle as O
+
+    shapes = load_golden("state_dict_keys.pt")
+    sd = {k: torch.empty(s) for k, s in shapes.items()}
+    if any(attn_depths):
+        # attention parameters of the extra attention blocks (not in the default tree)
+        lvls = [i for i, a in enumerate(attn_depths) if a]
+        L = len(attn_depths)
+        for lvl in lvls:
+            for grp, n in ((f"d_blocks.{lvl}", 2), (f"u_blocks.{L - 1 - lvl}", 3)):
+                for i in range(n):
+                    p = f"denoiser.inner_model.unet.{grp}.resblocks.{i}.attn"
+                    sd[p + ".norm.norm.weight"] = torch.empty(64)
+                    sd[p + ".norm.norm.bias"] = torch.empty(64)
+                    sd[p + ".qkv_proj.weight"] = torch.empty(192, 64, 1, 1)
+                    sd[p + ".qkv_proj.bias"] = torch.empty(192)
+                    sd[p + ".out_proj.weight"] = torch.empty(64, 64, 1, 1)
+                    sd[p + ".out_proj.bias"] = torch.empty(64)
+    fill_state_dict_(sd, WEIGHT_SEED)
+
+    def sub(prefix):
+        return {k[len(prefix) + 1:]: v.to(dtype) for k, v in sd.items() if k.startswith(prefix + ".")}
+
+    return O.AgentSD(denoiser=sub("denoiser"), rew_end_model=sub("rew_end_model"), actor_critic=sub("actor_critic"),
+                     dspec=O.DenoiserSpec(attn_depths=tuple(attn_depths)))
