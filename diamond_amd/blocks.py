@@ -1,0 +1,248 @@
+"""Parameter containers + native execution of the DIAMOND building blocks.
+
+Each class keeps the reference's attribute names and parameter shapes (models/blocks.py)
+so that `state_dict()` keys, `Agent.load` (agent.py:48-62) and `configure_opt`
+(utils.py:129-166) keep working, but none of them computes anything in PyTorch: `run()`
+issues hand-written HIP kernels through `diamond_amd.engine` on NHWC activations.  Calling
+`forward()` (the reference's eager NCHW entry point) converts layouts at the boundary and
+calls `run()`; on a CPU tensor it raises -- there is no fallback path.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import engine as E
+from . import native as nv
+from .engine import Act, NormSpec
+
+GN_GROUP_SIZE = 32
+GN_EPS = 1e-5
+ATTN_HEAD_DIM = 8
+
+
+def conv3x3(cin: int, cout: int, stride: int = 1) -> nn.Conv2d:
+    return nn.Conv2d(cin, cout, kernel_size=3, stride=stride, padding=1)
+
+
+def conv1x1(cin: int, cout: int) -> nn.Conv2d:
+    return nn.Conv2d(cin, cout, kernel_size=1, stride=1, padding=0)
+
+
+def _groups(c: int) -> int:
+    return max(1, c // GN_GROUP_SIZE)
+
+
+class RunCtx:
+    """Per-forward state shared by the blocks: packed-weight cache and the batched FiLM
+    table ((B, sum 2C) = every AdaGroupNorm.linear of the network applied to `cond` in ONE
+    GEMM -- they all consume the same cond vector, blocks.py:171-177)."""
+
+    def __init__(self, cache: E.PackCache, film: Optional["FilmTable"] = None, table: Optional[Tensor] = None,
+                 naive: Optional[bool] = None):
+        self.cache = cache
+        self.film = film
+        self.table = table
+        self.naive = naive
+
+    def film_spec(self, norm: "AdaGroupNorm", c_start: int = 0) -> NormSpec:
+        off = self.film.offset[id(norm)]
+        c = norm.in_channels
+        stride = self.table.stride(0)
+        return NormSpec(mul=self.table[:, off + c_start:], add=self.table[:, off + c + c_start:], mul_stride=stride,
+                        add_stride=stride, plus_one=True)
+
+
+class FilmTable:
+    """Concatenation of all AdaGroupNorm linears of a network, in module order."""
+
+    def __init__(self, root: nn.Module):
+        self.norms: List[AdaGroupNorm] = [m for m in root.modules() if isinstance(m, AdaGroupNorm)]
+        self.offset: Dict[int, int] = {}
+        off = 0
+        for m in self.norms:
+            self.offset[id(m)] = off
+            off += 2 * m.in_channels
+        self.total = off
+        self._packed: Optional[Tuple[Tuple[int, ...], Tensor, Tensor]] = None
+
+    def weights(self) -> Tuple[Tensor, Tensor]:
+        ver = tuple(m.linear.weight._version + m.linear.bias._version for m in self.norms)
+        dev = self.norms[0].linear.weight.device
+        if self._packed is None or self._packed[0] != ver or self._packed[1].device != dev:
+            w = torch.cat([m.linear.weight.detach().float() for m in self.norms], dim=0).contiguous()
+            b = torch.cat([m.linear.bias.detach().float() for m in self.norms], dim=0).contiguous()
+            self._packed = (ver, w, b)
+        return self._packed[1], self._packed[2]
+
+    def compute(self, cond: Tensor) -> Tensor:
+        w, b = self.weights()
+        return E.linear(cond, w, b)
+
+
+class GroupNorm(nn.Module):
+    def __init__(self, in_channels: int) -> None:
+        super().__init__()
+        self.norm = nn.GroupNorm(_groups(in_channels), in_channels, eps=GN_EPS)
+
+    def spec(self, ctx: RunCtx) -> NormSpec:
+        return NormSpec(mul=ctx.cache.f32(self.norm.weight), add=ctx.cache.f32(self.norm.bias))
+
+
+class AdaGroupNorm(nn.Module):
+    """GroupNorm without affine followed by FiLM from `cond` (reference blocks.py:34-45).
+    Never runs on its own: its statistics come from the producer's epilogue and its affine
+    is applied inside the consumer convolution's load path."""
+
+    def __init__(self, in_channels: int, cond_channels: int) -> None:
+        super().__init__()
+        self.in_channels = in_channels
+        self.num_groups = _groups(in_channels)
+        self.linear = nn.Linear(cond_channels, in_channels * 2)
+
+
+class SelfAttention2d(nn.Module):
+    def __init__(self, in_channels: int, head_dim: int = ATTN_HEAD_DIM) -> None:
+        super().__init__()
+        self.n_head = max(1, in_channels // head_dim)
+        assert in_channels % self.n_head == 0
+        self.norm = GroupNorm(in_channels)
+        self.qkv_proj = conv1x1(in_channels, in_channels * 3)
+        self.out_proj = conv1x1(in_channels, in_channels)
+        nn.init.zeros_(self.out_proj.weight)
+        nn.init.zeros_(self.out_proj.bias)
+
+    def run(self, ctx: RunCtx, x: Act) -> Act:
+        c = x.C
+        spec = self.norm.spec(ctx)
+        # GN affine fused into the qkv 1x1 conv's load; out_proj adds the NORMALISED input
+        # back (reference blocks.py:64,72), recomputed from x + its statistics in the epilogue.
+        qkv = E.conv2d([(x, nv.PROLOGUE_NORM, spec)], ctx.cache.conv_weight(self.qkv_proj), ctx.cache.conv_bias(self.qkv_proj),
+                       3 * c, taps=1, want_stats=False, naive=ctx.naive)
+        y = E.attention(qkv, c, c // self.n_head)
+        return E.conv2d([(Act(y), nv.PROLOGUE_NONE, None)], ctx.cache.conv_weight(self.out_proj),
+                        ctx.cache.conv_bias(self.out_proj), c, taps=1, residual=x, residual_norm=spec, naive=ctx.naive)
+
+
+class FourierFeatures(nn.Module):
+    def __init__(self, cond_channels: int) -> None:
+        super().__init__()
+        assert cond_channels % 2 == 0
+        self.register_buffer("weight", torch.randn(1, cond_channels // 2))
+
+
+class Downsample(nn.Module):
+    def __init__(self, in_channels: int) -> None:
+        super().__init__()
+        self.conv = conv3x3(in_channels, in_channels, stride=2)
+        nn.init.orthogonal_(self.conv.weight)
+
+    def run(self, ctx: RunCtx, x: Act) -> Act:
+        return E.conv2d([(x, nv.PROLOGUE_NONE, None)], ctx.cache.conv_weight(self.conv), ctx.cache.conv_bias(self.conv),
+                        self.conv.out_channels, stride=2, naive=ctx.naive)
+
+
+class Upsample(nn.Module):
+    def __init__(self, in_channels: int) -> None:
+        super().__init__()
+        self.conv = conv3x3(in_channels, in_channels)
+
+    def run(self, ctx: RunCtx, x: Act) -> Act:
+        # nearest x2 is folded into the conv's gather: in[y >> 1][x >> 1]
+        return E.conv2d([(x, nv.PROLOGUE_NONE, None)], ctx.cache.conv_weight(self.conv), ctx.cache.conv_bias(self.conv),
+                        self.conv.out_channels, upsample=True, naive=ctx.naive)
+
+
+class SmallResBlock(nn.Module):
+    """skip(x) + Conv3x3(SiLU(GroupNorm(x)))  (reference blocks.py:116-123)."""
+
+    def __init__(self, in_channels: int, out_channels: int) -> None:
+        super().__init__()
+        self.f = nn.Sequential(GroupNorm(in_channels), nn.SiLU(inplace=True), conv3x3(in_channels, out_channels))
+        self.skip_projection = nn.Identity() if in_channels == out_channels else conv1x1(in_channels, out_channels)
+
+
+class ResBlock(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, cond_channels: int, attn: bool) -> None:
+        super().__init__()
+        self.proj = conv1x1(in_channels, out_channels) if in_channels != out_channels else nn.Identity()
+        self.norm1 = AdaGroupNorm(in_channels, cond_channels)
+        self.conv1 = conv3x3(in_channels, out_channels)
+        self.norm2 = AdaGroupNorm(out_channels, cond_channels)
+        self.conv2 = conv3x3(out_channels, out_channels)
+        self.attn = SelfAttention2d(out_channels) if attn else nn.Identity()
+        nn.init.zeros_(self.conv2.weight)
+
+    def run(self, ctx: RunCtx, xs: Sequence[Act]) -> Act:
+        """xs: the channel-concatenated inputs (never materialised: the conv reads both)."""
+        cout = self.conv1.out_channels
+        if isinstance(self.proj, nn.Identity):
+            assert len(xs) == 1
+            r = xs[0]
+        else:
+            r = E.conv2d([(a, nv.PROLOGUE_NONE, None) for a in xs], ctx.cache.conv_weight(self.proj),
+                         ctx.cache.conv_bias(self.proj), cout, taps=1, want_stats=False, naive=ctx.naive)
+        srcs, c0 = [], 0
+        for a in xs:
+            srcs.append((a, nv.PROLOGUE_NORM_SILU, ctx.film_spec(self.norm1, c0)))
+            c0 += a.C
+        h = E.conv2d(srcs, ctx.cache.conv_weight(self.conv1), ctx.cache.conv_bias(self.conv1), cout, naive=ctx.naive)
+        h = E.conv2d([(h, nv.PROLOGUE_NORM_SILU, ctx.film_spec(self.norm2))], ctx.cache.conv_weight(self.conv2),
+                     ctx.cache.conv_bias(self.conv2), cout, residual=r, naive=ctx.naive)
+        if not isinstance(self.attn, nn.Identity):
+            h = self.attn.run(ctx, h)
+        return h
+
+
+class ResBlocks(nn.Module):
+    def __init__(self, list_in_channels: List[int], list_out_channels: List[int], cond_channels: int, attn: bool) -> None:
+        super().__init__()
+        assert len(list_in_channels) == len(list_out_channels)
+        self.in_channels = list_in_channels[0]
+        self.resblocks = nn.ModuleList(
+            [ResBlock(i, o, cond_channels, attn) for i, o in zip(list_in_channels, list_out_channels)])
+
+    def run(self, ctx: RunCtx, x: Act, to_cat: Optional[List[Act]] = None) -> Tuple[Act, List[Act]]:
+        outs = []
+        for i, blk in enumerate(self.resblocks):
+            x = blk.run(ctx, [x] if to_cat is None else [x, to_cat[i]])
+            outs.append(x)
+        return x, outs
+
+
+class UNet(nn.Module):
+    def __init__(self, cond_channels: int, depths: List[int], channels: List[int], attn_depths: List[int]) -> None:
+        super().__init__()
+        assert len(depths) == len(channels) == len(attn_depths)
+        self._num_down = len(channels) - 1
+        d_blocks, u_blocks = [], []
+        for i, n in enumerate(depths):
+            c1, c2 = channels[max(0, i - 1)], channels[i]
+            d_blocks.append(ResBlocks([c1] + [c2] * (n - 1), [c2] * n, cond_channels, bool(attn_depths[i])))
+            u_blocks.append(ResBlocks([2 * c2] * n + [c1 + c2], [c2] * n + [c1], cond_channels, bool(attn_depths[i])))
+        self.d_blocks = nn.ModuleList(d_blocks)
+        self.u_blocks = nn.ModuleList(reversed(u_blocks))  # deepest level first, like the reference
+        self.mid_blocks = ResBlocks([channels[-1]] * 2, [channels[-1]] * 2, cond_channels, True)
+        self.downsamples = nn.ModuleList([nn.Identity()] + [Downsample(c) for c in channels[:-1]])
+        self.upsamples = nn.ModuleList([nn.Identity()] + [Upsample(c) for c in reversed(channels[:-1])])
+
+    def run(self, ctx: RunCtx, x: Act) -> Act:
+        m = 2 ** self._num_down
+        assert x.shape[1] % max(8, m) == 0 and x.shape[2] % max(8, m) == 0, \
+            "the native U-Net needs H, W multiples of 8 (the reference pads to 2**num_down, blocks.py:227-229)"
+        skips: List[List[Act]] = []
+        for blocks, down in zip(self.d_blocks, self.downsamples):
+            if not isinstance(down, nn.Identity):
+                x = down.run(ctx, x)
+            x_down = x
+            x, outs = blocks.run(ctx, x)
+            skips.append([x_down] + outs)
+        x, _ = self.mid_blocks.run(ctx, x)
+        for blocks, up, skip in zip(self.u_blocks, self.upsamples, reversed(skips)):
+            if not isinstance(up, nn.Identity):
+                x = up.run(ctx, x)
+            x, _ = blocks.run(ctx, x, skip[::-1])
+        return x

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Build libdiamond_hip.so for gfx950 (cross-compiles without a GPU).  In-tree output:
+# diamond_amd/libdiamond_hip.so (git-ignored, travels to the GPU box with the snapshot).
+set -euo pipefail
+cd "$(dirname "$0")"
+OUT=../libdiamond_hip.so
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result"
+mkdir -p build
+pids=()
+for f in dmd_conv.hip dmd_linear.hip dmd_attention.hip dmd_pointwise.hip dmd_capi.cpp; do
+  o=build/${f%.*}.o
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ dmd_common.h -nt "$o" ] || [ ../../include/diamond_hip.h -nt "$o" ]; then
+    ( hipcc $FLAGS -x hip -c "$f" -o "$o" ${EXTRA_HIPCC_FLAGS:-} ) &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o "$OUT"
+echo "built $(realpath $OUT)"

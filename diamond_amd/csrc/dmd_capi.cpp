@@ -1,0 +1,17 @@
+// Error reporting and ABI version of libdiamond_hip.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/diamond_hip.h"
+
+static thread_local char g_err[512] = "";
+
+void dmd_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* dmd_last_error(void) { return g_err; }
+extern "C" int dmd_abi_version(void) { return 1; }

@@ -1,0 +1,72 @@
+// Shared helpers for libdiamond_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/diamond_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define DMD_GN_EPS 1e-5  // models/blocks.py:13
+
+void dmd_set_error(const char* fmt, ...);
+
+#define DMD_CHECK_ARG(cond, ...)  \
+  do {                            \
+    if (!(cond)) {                \
+      dmd_set_error(__VA_ARGS__); \
+      return 1;                   \
+    }                             \
+  } while (0)
+
+#define DMD_LAUNCH_CHECK()                                            \
+  do {                                                                \
+    hipError_t e_ = hipGetLastError();                                \
+    if (e_ != hipSuccess) {                                           \
+      dmd_set_error("launch failed: %s", hipGetErrorString(e_));      \
+      return 2;                                                       \
+    }                                                                 \
+  } while (0)
+
+// F.silu = x * sigmoid(x).  Accurate expf and IEEE division on purpose (no fast-math): the
+// conv kernels are MFMA-bound, the prologue VALU work is hidden.
+__device__ __forceinline__ float dmd_silu(float v) { return v / (1.0f + expf(-v)); }
+__device__ __forceinline__ float dmd_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// mean / rstd of a GroupNorm group from T per-tile fp64 partial sums (fixed order).
+__device__ __forceinline__ void dmd_finalize_stats(const double* st, int T, double count, float* mean, float* rstd) {
+  double s = 0.0, ss = 0.0;
+  for (int t = 0; t < T; ++t) {
+    s += st[2 * t];
+    ss += st[2 * t + 1];
+  }
+  const double m = s / count;
+  double var = ss / count - m * m;
+  var = var < 0.0 ? 0.0 : var;
+  *mean = (float)m;
+  *rstd = (float)(1.0 / sqrt(var + (double)DMD_GN_EPS));
+}
+
+__device__ __forceinline__ double dmd_wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// EDM preconditioning scalars, op-for-op in fp32 like compute_conditioners (denoiser.py:66-72).
+struct DmdCond {
+  float c_in, c_out, c_skip, c_noise;
+};
+__device__ __forceinline__ DmdCond dmd_conditioners(float sigma, dmd_edm_cfg cfg) {
+  const float off2 = (float)(cfg.sigma_offset_noise * cfg.sigma_offset_noise);
+  const float sd2 = (float)(cfg.sigma_data * cfg.sigma_data);
+  const float s = sqrtf(sigma * sigma + off2);
+  const float den = s * s + sd2;
+  DmdCond c;
+  c.c_in = 1.0f / sqrtf(den);
+  c.c_skip = sd2 / den;
+  c.c_out = s * sqrtf(c.c_skip);
+  c.c_noise = logf(s) / 4.0f;
+  return c;
+}

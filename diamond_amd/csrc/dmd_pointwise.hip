@@ -1,0 +1,320 @@
+// Pointwise / small kernels of the imagined-rollout path: EDM preconditioning and sampler
+// updates (denoiser.py:66-84, diffusion_sampler.py:45-56), the cond embedding
+// (blocks.py:84-87, inner_model.py:27-30), layout shuffles at the NCHW API boundary,
+// GroupNorm partial statistics, 2x2 max-pool (actor_critic.py:108-109), the LSTM cell
+// nonlinearity and Categorical sampling with injected exponential draws.
+// All HBM-bound: coalesced, 16-byte accesses where the layout allows, one pass.
+#include "dmd_common.h"
+
+// ---- cat(obs / sigma_data, x * c_in) : NCHW -> NHWC(CPad) ------------------------------------
+// One thread per pixel; NCHW reads are coalesced across threads (consecutive pixels), the
+// NHWC writes are CPad*4 = 64 contiguous bytes per thread.
+__global__ void edm_pack_input_kernel(const float* __restrict__ x, const float* __restrict__ obs,
+                                      const float* __restrict__ sigma, int sigma_stride, dmd_edm_cfg cfg,
+                                      float* __restrict__ out, int N, int Cx, int Cobs, int HW, int CPad) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)N * HW) return;
+  const int n = idx / HW;
+  const int pix = idx - (size_t)n * HW;
+  const DmdCond c = dmd_conditioners(sigma[(size_t)n * sigma_stride], cfg);
+  const float sd = (float)cfg.sigma_data;
+  float* o = out + idx * CPad;
+  for (int ch = 0; ch < CPad; ch += 4) {
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int cc = ch + e;
+      float t = 0.f;
+      if (cc < Cobs)
+        t = obs[((size_t)n * Cobs + cc) * HW + pix] / sd;  // rescaled_obs = obs / sigma_data, denoiser.py:75
+      else if (cc < Cobs + Cx)
+        t = x[((size_t)n * Cx + (cc - Cobs)) * HW + pix] * c.c_in;  // denoiser.py:76
+      v[e] = t;
+    }
+    *(f32x4*)(o + ch) = v;
+  }
+}
+
+// ---- cond input: [cos(f) | sin(f)] + flatten(Embedding(act)),  f = 2 pi c_noise w -----------
+__global__ void cond_embed_kernel(const float* __restrict__ sigma, int sigma_stride, dmd_edm_cfg cfg,
+                                  const float* __restrict__ fw, const int64_t* __restrict__ act,
+                                  const float* __restrict__ emb, float* __restrict__ out, int N, int half, int T, int E) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int D = 2 * half;
+  if (idx >= N * D) return;
+  const int n = idx / D, jj = idx - n * D;
+  const DmdCond c = dmd_conditioners(sigma[(size_t)n * sigma_stride], cfg);
+  // blocks.py:86: f = 2 * math.pi * input.unsqueeze(1) @ weight   (left to right: (2 pi c) * w)
+  const float two_pi_c = (float)(2.0 * 3.141592653589793) * c.c_noise;
+  const int k = jj < half ? jj : jj - half;
+  const float f = two_pi_c * fw[k];
+  float v = jj < half ? cosf(f) : sinf(f);
+  const int t = jj / E, e = jj - t * E;  // flatten (T, E) -> T*E == D
+  v += emb[(size_t)act[(size_t)n * T + t] * E + e];
+  out[idx] = v;
+}
+
+// ---- denoised = quantise(c_skip * x + c_out * F) (denoiser.py:81-83) -------------------------
+__device__ __forceinline__ float dmd_quantise(float d) {
+  d = fminf(fmaxf(d, -1.0f), 1.0f);       // clamp(-1, 1)
+  d = d + 1.0f;                           // add(1)
+  d = d / 2.0f;                           // div(2)
+  d = d * 255.0f;                         // mul(255)
+  const float q = (float)(uint8_t)d;      // byte(): truncation toward zero, value in [0, 255]
+  return (q / 255.0f) * 2.0f - 1.0f;      // div(255).mul(2).sub(1)
+}
+
+__global__ void edm_denoised_kernel(const float* __restrict__ x, const float* __restrict__ f,
+                                    const float* __restrict__ sigma, int sigma_stride, dmd_edm_cfg cfg,
+                                    float* __restrict__ den, int N, int64_t per_sample) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * per_sample) return;
+  const int n = idx / per_sample;
+  const DmdCond c = dmd_conditioners(sigma[(size_t)n * sigma_stride], cfg);
+  const float a = c.c_skip * x[idx];
+  const float b = c.c_out * f[idx];
+  den[idx] = dmd_quantise(a + b);
+}
+
+__global__ void euler_step_kernel(const float* __restrict__ x, const float* __restrict__ den, float sigma_hat, float dt,
+                                  float* __restrict__ xo, int64_t n) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const float xv = x[idx];
+  const float d = (xv - den[idx]) / sigma_hat;  // diffusion_sampler.py:45
+  xo[idx] = xv + d * dt;                        // :49
+}
+
+// ---- NCHW <-> NHWC(CPad) ---------------------------------------------------------------------
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int C, int HW, int CPad) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)N * HW) return;
+  const int n = idx / HW;
+  const int pix = idx - (size_t)n * HW;
+  float* o = out + idx * CPad;
+  for (int ch = 0; ch < CPad; ch += 4) {
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (ch + e) < C ? in[((size_t)n * C + ch + e) * HW + pix] : 0.f;
+    *(f32x4*)(o + ch) = v;
+  }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int C, int HW, int CPad) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)N * HW) return;
+  const int n = idx / HW;
+  const int pix = idx - (size_t)n * HW;
+  const float* i = in + idx * CPad;
+  for (int ch = 0; ch < C; ++ch) out[((size_t)n * C + ch) * HW + pix] = i[ch];
+}
+
+// ---- GroupNorm partial statistics of an NHWC tensor: one tile per image ----------------------
+// grid (G, N), 256 threads: thread -> (pixel stripe, channel quad of the group)
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int HW, int C) {
+  __shared__ double red[4][2];
+  const int g = blockIdx.x, n = blockIdx.y, G = gridDim.x;
+  const int tid = threadIdx.x;
+  const int quad = tid & 7;  // 8 quads = 32 channels
+  double s = 0.0, ss = 0.0;
+  for (int pix = tid >> 3; pix < HW; pix += 32) {
+    const f32x4 v = *(const f32x4*)(x + ((size_t)n * HW + pix) * C + g * DMD_GN_GROUP + quad * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const double d = (double)v[e];
+      s += d;
+      ss += d * d;
+    }
+  }
+  s = dmd_wave_sum(s);
+  ss = dmd_wave_sum(ss);
+  if ((tid & 63) == 0) {
+    red[tid >> 6][0] = s;
+    red[tid >> 6][1] = ss;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < 4; ++w) {
+      a += red[w][0];
+      b += red[w][1];
+    }
+    stats[((size_t)n * G + g) * 2] = a;
+    stats[((size_t)n * G + g) * 2 + 1] = b;
+  }
+}
+
+// ---- 2x2 max pool, NHWC; one thread per (output pixel, channel quad) ---------------------------
+// argmax: index 0..3 (dy*2+dx) of the FIRST maximum in scan order (ATen max_pool2d picks the
+// first max it meets scanning h then w; ties only matter for the backward routing).
+__global__ void maxpool2_kernel(const float* __restrict__ x, float* __restrict__ out, uint8_t* __restrict__ argmax, int N,
+                                int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2, Cq = C / 4;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)N * Ho * Wo * Cq) return;
+  const int cq = idx % Cq;
+  const size_t op = idx / Cq;
+  const int ox = op % Wo;
+  const int oy = (op / Wo) % Ho;
+  const int n = op / ((size_t)Wo * Ho);
+  f32x4 best;
+  int bi[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int iy = oy * 2 + (k >> 1), ix = ox * 2 + (k & 1);
+    const f32x4 v = *(const f32x4*)(x + (((size_t)n * H + iy) * W + ix) * C + cq * 4);
+    if (k == 0)
+      best = v;
+    else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (v[e] > best[e] || v[e] != v[e]) {  // NaN propagates like ATen
+          best[e] = v[e];
+          bi[e] = k;
+        }
+    }
+  }
+  *(f32x4*)(out + op * C + cq * 4) = best;
+  if (argmax) {
+    uint32_t packed = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+    *(uint32_t*)(argmax + op * C + cq * 4) = packed;
+  }
+}
+
+// ---- LSTM cell nonlinearity (gate order i, f, g, o) --------------------------------------------
+__global__ void lstm_pointwise_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev,
+                                      float* __restrict__ h, float* __restrict__ c, int N, int Hd) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * Hd) return;
+  const int n = idx / Hd, k = idx - n * Hd;
+  const float* gr = gates + (size_t)n * 4 * Hd;
+  const float ig = dmd_sigmoid(gr[k]);
+  const float fg = dmd_sigmoid(gr[Hd + k]);
+  const float gg = tanhf(gr[2 * Hd + k]);
+  const float og = dmd_sigmoid(gr[3 * Hd + k]);
+  const float cn = fg * c_prev[idx] + ig * gg;
+  c[idx] = cn;
+  h[idx] = og * tanhf(cn);
+}
+
+// ---- Categorical(logits).sample() with injected E ~ Exp(1): argmax(softmax(logits) / E) -------
+__global__ void categorical_sample_kernel(const float* __restrict__ logits, const float* __restrict__ expo,
+                                          int64_t* __restrict__ out, int N, int A) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float* l = logits + (size_t)n * A;
+  const float* e = expo + (size_t)n * A;
+  // torch: Categorical(logits=l) keeps ln = l - logsumexp(l); probs = softmax(ln)
+  float m = -INFINITY;
+  for (int a = 0; a < A; ++a) m = fmaxf(m, l[a]);
+  float sum = 0.f;
+  for (int a = 0; a < A; ++a) sum += expf(l[a] - m);
+  const float lse = m + logf(sum);
+  float m2 = -INFINITY;
+  for (int a = 0; a < A; ++a) m2 = fmaxf(m2, l[a] - lse);
+  float sum2 = 0.f;
+  for (int a = 0; a < A; ++a) sum2 += expf((l[a] - lse) - m2);
+  float best = -INFINITY;
+  int bi = 0;
+  for (int a = 0; a < A; ++a) {
+    const float p = expf((l[a] - lse) - m2) / sum2;
+    const float v = p / e[a];
+    if (v > best) {
+      best = v;
+      bi = a;
+    }
+  }
+  out[n] = bi;
+}
+
+// ------------------------------------------------------------------------------------------------
+static inline unsigned nblk(size_t n, int b) { return (unsigned)((n + b - 1) / b); }
+
+extern "C" int dmd_edm_pack_input(const float* x, const float* obs, const float* sigma, int sigma_stride, dmd_edm_cfg cfg,
+                                  float* out, int N, int Cx, int Cobs, int H, int W, int CPad, dmd_stream_t stream) {
+  DMD_CHECK_ARG(x && obs && sigma && out, "edm_pack_input: null");
+  DMD_CHECK_ARG(CPad % 4 == 0 && CPad >= Cx + Cobs, "edm_pack_input: CPad");
+  hipLaunchKernelGGL(edm_pack_input_kernel, dim3(nblk((size_t)N * H * W, 256)), dim3(256), 0, (hipStream_t)stream, x, obs,
+                     sigma, sigma_stride, cfg, out, N, Cx, Cobs, H * W, CPad);
+  DMD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dmd_cond_embed(const float* sigma, int sigma_stride, dmd_edm_cfg cfg, const float* fw, const int64_t* act,
+                              const float* emb, float* out, int N, int half, int T, int E, dmd_stream_t stream) {
+  DMD_CHECK_ARG(sigma && fw && act && emb && out, "cond_embed: null");
+  DMD_CHECK_ARG(T * E == 2 * half, "cond_embed: T*E (%d) != cond channels (%d)", T * E, 2 * half);
+  hipLaunchKernelGGL(cond_embed_kernel, dim3(nblk((size_t)N * 2 * half, 256)), dim3(256), 0, (hipStream_t)stream, sigma,
+                     sigma_stride, cfg, fw, act, emb, out, N, half, T, E);
+  DMD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dmd_edm_denoised(const float* x, const float* f, const float* sigma, int sigma_stride, dmd_edm_cfg cfg,
+                                float* den, int N, int64_t per_sample, dmd_stream_t stream) {
+  DMD_CHECK_ARG(x && f && sigma && den, "edm_denoised: null");
+  hipLaunchKernelGGL(edm_denoised_kernel, dim3(nblk((size_t)N * per_sample, 256)), dim3(256), 0, (hipStream_t)stream, x, f,
+                     sigma, sigma_stride, cfg, den, N, per_sample);
+  DMD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dmd_euler_step(const float* x, const float* den, float sigma_hat, float dt, float* xo, int64_t n,
+                              dmd_stream_t stream) {
+  DMD_CHECK_ARG(x && den && xo, "euler_step: null");
+  hipLaunchKernelGGL(euler_step_kernel, dim3(nblk((size_t)n, 256)), dim3(256), 0, (hipStream_t)stream, x, den, sigma_hat, dt,
+                     xo, n);
+  DMD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dmd_nchw_to_nhwc(const float* in, float* out, int N, int C, int H, int W, int CPad, dmd_stream_t stream) {
+  DMD_CHECK_ARG(in && out && CPad % 4 == 0 && CPad >= C, "nchw_to_nhwc: args");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(nblk((size_t)N * H * W, 256)), dim3(256), 0, (hipStream_t)stream, in, out, N, C,
+                     H * W, CPad);
+  DMD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dmd_nhwc_to_nchw(const float* in, float* out, int N, int C, int H, int W, int CPad, dmd_stream_t stream) {
+  DMD_CHECK_ARG(in && out && CPad >= C, "nhwc_to_nchw: args");
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(nblk((size_t)N * H * W, 256)), dim3(256), 0, (hipStream_t)stream, in, out, N, C,
+                     H * W, CPad);
+  DMD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dmd_gn_stats(const float* x, double* stats, int N, int HW, int C, dmd_stream_t stream) {
+  DMD_CHECK_ARG(x && stats && C % DMD_GN_GROUP == 0, "gn_stats: C %% 32");
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(C / DMD_GN_GROUP, N), dim3(256), 0, (hipStream_t)stream, x, stats, HW, C);
+  DMD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dmd_maxpool2(const float* x, float* out, uint8_t* argmax, double* out_stats, int N, int H, int W, int C,
+                            dmd_stream_t stream) {
+  DMD_CHECK_ARG(x && out && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "maxpool2: args");
+  hipLaunchKernelGGL(maxpool2_kernel, dim3(nblk((size_t)N * (H / 2) * (W / 2) * (C / 4), 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, out, argmax, N, H, W, C);
+  DMD_LAUNCH_CHECK();
+  if (out_stats) return dmd_gn_stats(out, out_stats, N, (H / 2) * (W / 2), C, stream);
+  return 0;
+}
+
+extern "C" int dmd_lstm_pointwise(const float* gates, const float* c_prev, float* h, float* c, int N, int Hd,
+                                  dmd_stream_t stream) {
+  DMD_CHECK_ARG(gates && c_prev && h && c, "lstm_pointwise: null");
+  hipLaunchKernelGGL(lstm_pointwise_kernel, dim3(nblk((size_t)N * Hd, 256)), dim3(256), 0, (hipStream_t)stream, gates, c_prev,
+                     h, c, N, Hd);
+  DMD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dmd_categorical_sample(const float* logits, const float* expo, int64_t* out, int N, int A,
+                                      dmd_stream_t stream) {
+  DMD_CHECK_ARG(logits && expo && out && A > 0, "categorical_sample: args");
+  hipLaunchKernelGGL(categorical_sample_kernel, dim3(nblk((size_t)N, 64)), dim3(64), 0, (hipStream_t)stream, logits, expo, out,
+                     N, A);
+  DMD_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,91 @@
+"""Karras-schedule Euler / Heun sampler (reference models/diffusion/diffusion_sampler.py).
+
+The sigma schedule is evaluated once on the host (the reference compares 0-dim DEVICE
+tensors inside the loop, forcing a sync per step, diffusion_sampler.py:39,47); the update
+`x + (x - D)/sigma_hat * dt` is one fused HIP kernel per step.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import native as nv
+from .denoiser import Denoiser
+
+
+@dataclass
+class DiffusionSamplerConfig:
+    num_steps_denoising: int
+    sigma_min: float = 2e-3
+    sigma_max: float = 5
+    rho: int = 7
+    order: int = 1
+    s_churn: float = 0
+    s_tmin: float = 0
+    s_tmax: float = float("inf")
+    s_noise: float = 1
+
+
+def build_sigmas(num_steps: int, sigma_min: float, sigma_max: float, rho: int, device: torch.device) -> Tensor:
+    """Karras et al. schedule + trailing 0, evaluated in fp32 exactly like the reference
+    (linspace then ** rho, diffusion_sampler.py:61-66) -- on the CPU so the values are the
+    CPU reference's bit for bit, then moved."""
+    lo = sigma_min ** (1 / rho)
+    hi = sigma_max ** (1 / rho)
+    ramp = torch.linspace(0, 1, num_steps)
+    s = (hi + ramp * (lo - hi)) ** rho
+    return torch.cat((s, s.new_zeros(1))).to(device)
+
+
+class DiffusionSampler:
+    def __init__(self, denoiser: Denoiser, cfg: DiffusionSamplerConfig) -> None:
+        self.denoiser = denoiser
+        self.cfg = cfg
+        self.sigmas = build_sigmas(cfg.num_steps_denoising, cfg.sigma_min, cfg.sigma_max, cfg.rho, denoiser.device)
+        self._host_sigmas = self.sigmas.detach().cpu()  # fp32 values, compared on the host
+        # test hook: replaces torch.randn for the initial noise / churn draws (host-injected RNG)
+        self.noise_fn: Optional[Callable[[Tuple[int, ...], torch.device], Tensor]] = None
+
+    def _randn(self, shape, device) -> Tensor:
+        if self.noise_fn is not None:
+            return self.noise_fn(tuple(shape), device)
+        return torch.randn(*shape, device=device)
+
+    @torch.no_grad()
+    def sample(self, prev_obs: Tensor, prev_act: Tensor) -> Tuple[Tensor, List[Tensor]]:
+        device = prev_obs.device
+        b, t, c, h, w = prev_obs.size()
+        obs = prev_obs.reshape(b, t * c, h, w)
+        sig = self._host_sigmas
+        gamma_ = min(self.cfg.s_churn / (len(sig) - 1), 2 ** 0.5 - 1)
+        x = self._randn((b, c, h, w), device)
+        trajectory = [x]
+        for sigma, next_sigma in zip(sig[:-1], sig[1:]):  # 0-dim fp32 CPU tensors
+            gamma = gamma_ if self.cfg.s_tmin <= sigma <= self.cfg.s_tmax else 0
+            sigma_hat = sigma * (gamma + 1)
+            if gamma > 0:
+                eps = self._randn(x.shape, device) * self.cfg.s_noise
+                x = x + eps * float((sigma_hat ** 2 - sigma ** 2) ** 0.5)
+            denoised = self.denoiser.denoise(x, sigma, obs, prev_act)  # sigma, not sigma_hat: reference :44
+            dt = next_sigma - sigma_hat  # fp32 subtraction like the reference
+            if self.cfg.order == 1 or next_sigma == 0:
+                x = self._euler(x, denoised, float(sigma_hat), float(dt))
+            else:
+                x_2 = self._euler(x, denoised, float(sigma_hat), float(dt))
+                s_in = torch.ones(b, device=device) * float(next_sigma)
+                denoised_2 = self.denoiser.denoise(x_2, s_in, obs, prev_act)
+                d = (x - denoised) / float(sigma_hat)
+                d_2 = (x_2 - denoised_2) / float(next_sigma)
+                x = x + (d + d_2) / 2 * float(dt)
+            trajectory.append(x)
+        return x, trajectory
+
+    @staticmethod
+    def _euler(x: Tensor, denoised: Tensor, sigma_hat: float, dt: float) -> Tensor:
+        out = torch.empty_like(x)
+        nv.check(nv.lib().dmd_euler_step(nv.fptr(x.contiguous()), nv.fptr(denoised), sigma_hat, dt, nv.fptr(out), x.numel(),
+                                         nv.stream()), "dmd_euler_step")
+        return out

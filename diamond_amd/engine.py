@@ -1,0 +1,219 @@
+"""Host-side op layer over the C ABI: NHWC activations that carry their GroupNorm partial
+statistics, packed-weight cache, and one Python call per kernel launch.
+
+This is plumbing only -- every FLOP of the U-Net / encoders happens in libdiamond_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import native as nv
+
+_USE_NAIVE = os.environ.get("DIAMOND_CONV_IMPL", "mfma") == "naive"  # debugging aid only (still HIP)
+
+
+class LaunchProfiler:
+    """Optional per-launch HIP-event timing of dmd_conv2d (bench.py's roofline pass).  Events
+    are recorded on torch's current stream == the stream the kernels are launched on."""
+
+    def __init__(self) -> None:
+        self.records: List[Tuple[str, float, float, torch.cuda.Event, torch.cuda.Event]] = []
+
+    def summary(self) -> Dict[str, Dict[str, float]]:
+        torch.cuda.synchronize()
+        out: Dict[str, Dict[str, float]] = {}
+        for key, flops, nbytes, e0, e1 in self.records:
+            d = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        return out
+
+
+PROFILER: Optional[LaunchProfiler] = None
+
+
+def kernel_key(p) -> str:
+    """Name of the conv_mfma_kernel<ConvGeom<WN, CFGB, TAPS, STRIDE>> instantiation dmd_conv2d picks."""
+    wn = 4 if p.CoutPad % 64 == 0 else (2 if p.CoutPad % 32 == 0 else 1)
+    return f"conv_mfma<WN{wn},{'B' if p.W % 16 else 'A'},taps{p.taps},s{p.stride}>"
+
+
+@dataclass
+class Act:
+    """NHWC fp32 activation (N, H, W, C) + fp64 partial GroupNorm sums (N, C/32, T, 2)."""
+    t: Tensor
+    stats: Optional[Tensor] = None
+    tiles: int = 0
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+    @property
+    def C(self) -> int:
+        return self.t.shape[3]
+
+
+@dataclass
+class NormSpec:
+    """How a consumer normalises an Act: FiLM (mul/add rows of the batched AdaGN table) or
+    GroupNorm affine parameters."""
+    mul: Optional[Tensor]
+    add: Optional[Tensor]
+    mul_stride: int = 0
+    add_stride: int = 0
+    plus_one: bool = False
+
+    def to_native(self, a: Act) -> nv.Norm:
+        assert a.stats is not None, "normalising an activation that has no statistics"
+        return nv.make_norm(a.stats, a.tiles, self.mul, self.add, self.mul_stride, self.add_stride, self.plus_one)
+
+
+class PackCache:
+    """Kernel-layout copies of nn.Module parameters, refreshed when a parameter changes
+    (optimizer steps bump `Tensor._version`).  Parameters keep the reference's OIHW / (out,in)
+    layouts so checkpoints stay interchangeable (agent.py:48-62)."""
+
+    def __init__(self) -> None:
+        self._store: Dict[Tuple[int, str], Tuple[int, Tensor]] = {}
+
+    def get(self, p: Tensor, kind: str, fn):
+        key = (id(p), kind)
+        hit = self._store.get(key)
+        ver = p._version
+        if hit is None or hit[0] != ver or hit[1].device != p.device:
+            hit = (ver, fn(p))
+            self._store[key] = hit
+        return hit[1]
+
+    def conv_weight(self, conv: nn.Conv2d, cout_padded: Optional[int] = None) -> Tensor:
+        return self.get(conv.weight, f"convw{cout_padded}", lambda w: nv.pack_conv_weight(w, cout_padded))
+
+    def conv_bias(self, conv: nn.Conv2d, cout_padded: Optional[int] = None) -> Optional[Tensor]:
+        if conv.bias is None:
+            return None
+        n = cout_padded or nv.cout_pad(conv.out_channels)
+        return self.get(conv.bias, f"convb{n}", lambda b: nv.pad_vector(b, n))
+
+    def f32(self, p: Tensor) -> Tensor:
+        return self.get(p, "f32", lambda t: t.detach().float().contiguous())
+
+
+def new_stats(n: int, c: int, tiles: int, device) -> Tensor:
+    return torch.empty(n, max(1, c // nv.GN_GROUP), tiles, 2, device=device, dtype=torch.float64)
+
+
+def conv2d(
+    srcs: Sequence[Tuple[Act, int, Optional[NormSpec]]],  # (activation, prologue, norm)
+    w_packed: Tensor,
+    bias: Optional[Tensor],
+    cout: int,
+    *,
+    taps: int = 9,
+    stride: int = 1,
+    upsample: bool = False,
+    residual: Optional[Act] = None,
+    residual_norm: Optional[NormSpec] = None,
+    want_stats: bool = True,
+    out_nchw: bool = False,
+    cout_padded: Optional[int] = None,
+    naive: Optional[bool] = None,
+) -> Act:
+    a0 = srcs[0][0]
+    n, hs, ws, _ = a0.shape
+    if upsample:
+        h, w = hs * 2, ws * 2
+    else:
+        h, w = hs // stride, ws // stride
+    dev = a0.t.device
+    p = nv.ConvParams()
+    p.N, p.H, p.W = n, h, w
+    p.Cout = cout
+    p.CoutPad = cout_padded or nv.cout_pad(cout)
+    p.taps, p.stride, p.upsample, p.nsrc = taps, stride, int(upsample), len(srcs)
+    for i, (a, prologue, norm) in enumerate(srcs):
+        assert a.t.is_contiguous() and a.t.dtype == torch.float32 and tuple(a.shape[:3]) == (n, hs, ws)
+        p.src[i].x = nv.ptr(a.t)
+        p.src[i].C = a.C
+        p.src[i].prologue = prologue
+        if prologue != nv.PROLOGUE_NONE:
+            p.src[i].norm = norm.to_native(a)
+    p.w = nv.ptr(w_packed)
+    p.bias = nv.ptr(bias)
+    if residual is not None:
+        assert tuple(residual.shape) == (n, h, w, cout) and residual.t.is_contiguous()
+        p.residual = nv.ptr(residual.t)
+        if residual_norm is not None:
+            p.residual_norm = residual_norm.to_native(residual)
+    if out_nchw:
+        out = torch.empty(n, cout, h, w, device=dev, dtype=torch.float32)
+    else:
+        out = torch.empty(n, h, w, cout, device=dev, dtype=torch.float32)
+    p.out = nv.ptr(out)
+    p.out_nchw = int(out_nchw)
+    stats, tiles = None, 0
+    if want_stats:
+        tiles = nv.conv_stat_tiles(h, w)
+        stats = new_stats(n, cout, tiles, dev)
+        p.out_stats = nv.ptr(stats)
+    use_naive = _USE_NAIVE if naive is None else naive
+    fn = nv.lib().dmd_conv2d_naive if use_naive else nv.lib().dmd_conv2d
+    if PROFILER is not None:
+        cin = sum(a.C for a, _, _ in srcs)
+        flops = 2.0 * n * h * w * cout * cin * taps  # algorithmic: MAC = 2, real channels
+        nbytes = 4.0 * (sum(a.t.numel() for a, _, _ in srcs) + out.numel() + (residual.t.numel() if residual is not None else 0))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        nv.check(fn(C.byref(p), nv.stream()), "dmd_conv2d")
+        e1.record()
+        PROFILER.records.append((kernel_key(p), flops, nbytes, e0, e1))
+    else:
+        nv.check(fn(C.byref(p), nv.stream()), "dmd_conv2d")
+    return Act(out, stats, tiles)
+
+
+def gn_stats(t: Tensor) -> Act:
+    """Attach (single-tile) GroupNorm statistics to an NHWC tensor no dmd kernel produced."""
+    n, h, w, c = t.shape
+    stats = new_stats(n, c, 1, t.device)
+    nv.check(nv.lib().dmd_gn_stats(nv.fptr(t), nv.ptr(stats), n, h * w, c, nv.stream()), "dmd_gn_stats")
+    return Act(t, stats, 1)
+
+
+def nchw_to_nhwc(x: Tensor, cpad: Optional[int] = None) -> Tensor:
+    n, c, h, w = x.shape
+    cp = cpad or c
+    out = torch.empty(n, h, w, cp, device=x.device, dtype=torch.float32)
+    nv.check(nv.lib().dmd_nchw_to_nhwc(nv.fptr(x.contiguous()), nv.fptr(out), n, c, h, w, cp, nv.stream()), "dmd_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x: Tensor, c: Optional[int] = None) -> Tensor:
+    n, h, w, cp = x.shape
+    c = c or cp
+    out = torch.empty(n, c, h, w, device=x.device, dtype=torch.float32)
+    nv.check(nv.lib().dmd_nhwc_to_nchw(nv.fptr(x), nv.fptr(out), n, c, h, w, cp, nv.stream()), "dmd_nhwc_to_nchw")
+    return out
+
+
+def attention(qkv: Act, c: int, head_dim: int = 8) -> Tensor:
+    n, h, w, c3 = qkv.shape
+    assert c3 == 3 * c
+    out = torch.empty(n, h, w, c, device=qkv.t.device, dtype=torch.float32)
+    nv.check(nv.lib().dmd_attention(nv.fptr(qkv.t), nv.fptr(out), n, h * w, c, head_dim, nv.stream()), "dmd_attention")
+    return out
+
+
+def linear(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, silu: bool = False, out: Optional[Tensor] = None,
+           accumulate: bool = False) -> Tensor:
+    if out is None:
+        out = torch.empty(a.shape[0], w.shape[0], device=a.device, dtype=torch.float32)
+    return nv.linear(a, w, bias, out, accumulate=accumulate, silu=silu)

@@ -1,0 +1,70 @@
+"""U-Net wrapper of the EDM denoiser (reference models/diffusion/inner_model.py:23-49), native."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+from torch import Tensor, nn
+
+from . import engine as E
+from . import native as nv
+from .blocks import FilmTable, FourierFeatures, GroupNorm, RunCtx, UNet, conv3x3
+
+
+@dataclass
+class InnerModelConfig:
+    img_channels: int
+    num_steps_conditioning: int
+    cond_channels: int
+    depths: List[int]
+    channels: List[int]
+    attn_depths: List[bool]
+    num_actions: Optional[int] = None
+
+
+class InnerModel(nn.Module):
+    def __init__(self, cfg: InnerModelConfig) -> None:
+        super().__init__()
+        self.cfg = cfg
+        self.noise_emb = FourierFeatures(cfg.cond_channels)
+        self.act_emb = nn.Sequential(
+            nn.Embedding(cfg.num_actions, cfg.cond_channels // cfg.num_steps_conditioning), nn.Flatten())
+        self.cond_proj = nn.Sequential(
+            nn.Linear(cfg.cond_channels, cfg.cond_channels), nn.SiLU(), nn.Linear(cfg.cond_channels, cfg.cond_channels))
+        self.conv_in = conv3x3((cfg.num_steps_conditioning + 1) * cfg.img_channels, cfg.channels[0])
+        self.unet = UNet(cfg.cond_channels, cfg.depths, cfg.channels, cfg.attn_depths)
+        self.norm_out = GroupNorm(cfg.channels[0])
+        self.conv_out = conv3x3(cfg.channels[0], cfg.img_channels)
+        nn.init.zeros_(self.conv_out.weight)
+        # host-side launch state (not parameters)
+        self._cache = E.PackCache()
+        self._film: Optional[FilmTable] = None
+
+    # -- native pieces -------------------------------------------------------------------
+    def cond_vector(self, sigma: Tensor, sigma_stride: int, act: Tensor, edm: nv.EdmCfg) -> Tensor:
+        """cond_proj(noise_emb(c_noise(sigma)) + act_emb(act))  (reference :45); c_noise is
+        derived from sigma on the device (denoiser.py:66-72)."""
+        n, t = act.shape
+        emb = self.act_emb[0].weight
+        half = self.noise_emb.weight.shape[1]
+        x = torch.empty(n, 2 * half, device=act.device, dtype=torch.float32)
+        nv.check(nv.lib().dmd_cond_embed(nv.fptr(sigma), sigma_stride, edm, nv.fptr(self._cache.f32(self.noise_emb.weight)),
+                                         nv.ptr(act.contiguous()), nv.fptr(self._cache.f32(emb)), nv.fptr(x), n, half, t,
+                                         emb.shape[1], nv.stream()), "dmd_cond_embed")
+        l0, l2 = self.cond_proj[0], self.cond_proj[2]
+        y = E.linear(x, self._cache.f32(l0.weight), self._cache.f32(l0.bias), silu=True)
+        return E.linear(y, self._cache.f32(l2.weight), self._cache.f32(l2.bias))
+
+    def run(self, packed_in: Tensor, cond: Tensor, naive: Optional[bool] = None) -> Tensor:
+        """packed_in: NHWC16 [obs/sigma_data | noisy*c_in | 0]; returns F as NCHW (N,3,H,W)."""
+        if self._film is None:
+            self._film = FilmTable(self.unet)
+        table = self._film.compute(cond)
+        ctx = RunCtx(self._cache, self._film, table, naive)
+        x = E.conv2d([(E.Act(packed_in), nv.PROLOGUE_NONE, None)], self._cache.conv_weight(self.conv_in),
+                     self._cache.conv_bias(self.conv_in), self.conv_in.out_channels, naive=naive)
+        x = self.unet.run(ctx, x)
+        return E.conv2d([(x, nv.PROLOGUE_NORM_SILU, self.norm_out.spec(ctx))], self._cache.conv_weight(self.conv_out),
+                        self._cache.conv_bias(self.conv_out), self.conv_out.out_channels, want_stats=False, out_nchw=True,
+                        naive=naive).t

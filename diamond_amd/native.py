@@ -1,0 +1,176 @@
+"""ctypes binding of libdiamond_hip.so (the C ABI declared in include/diamond_hip.h).
+
+Only raw device pointers, sizes and a hipStream_t cross the boundary.  There is NO CPU or
+PyTorch fallback: if the library is missing, or an op is given a non-GPU tensor, the call
+raises.  The stream is always torch's current stream so that torch ops (allocation, RNG,
+optimizer, RCCL) and the hand-written kernels are ordered and graph-capturable together.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdiamond_hip.so")
+
+PROLOGUE_NONE, PROLOGUE_NORM_SILU, PROLOGUE_NORM = 0, 1, 2
+GN_GROUP = 32
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+class Norm(C.Structure):
+    _fields_ = [("stats", C.c_void_p), ("stat_tiles", C.c_int32), ("mul_plus_one", C.c_int32), ("mul", C.c_void_p),
+                ("add", C.c_void_p), ("mul_stride", C.c_int64), ("add_stride", C.c_int64)]
+
+
+class ConvSrc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("C", C.c_int32), ("prologue", C.c_int32), ("norm", Norm)]
+
+
+class ConvParams(C.Structure):
+    _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cout", C.c_int32), ("CoutPad", C.c_int32),
+                ("taps", C.c_int32), ("stride", C.c_int32), ("upsample", C.c_int32), ("nsrc", C.c_int32),
+                ("src", ConvSrc * 2), ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p),
+                ("residual_norm", Norm), ("out", C.c_void_p), ("out_nchw", C.c_int32), ("reserved", C.c_int32),
+                ("out_stats", C.c_void_p)]
+
+
+class LinearParams(C.Structure):
+    _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("A", C.c_void_p), ("lda", C.c_int64),
+                ("W", C.c_void_p), ("ldw", C.c_int64), ("bias", C.c_void_p), ("C", C.c_void_p), ("ldc", C.c_int64),
+                ("accumulate", C.c_int32), ("silu", C.c_int32)]
+
+
+class EdmCfg(C.Structure):
+    _fields_ = [("sigma_data", C.c_double), ("sigma_offset_noise", C.c_double)]
+
+
+EXPORTS = (
+    "dmd_conv2d", "dmd_conv2d_naive", "dmd_conv_stat_tiles", "dmd_pack_conv_weight", "dmd_linear", "dmd_attention",
+    "dmd_edm_pack_input", "dmd_cond_embed", "dmd_edm_denoised", "dmd_euler_step", "dmd_nchw_to_nhwc",
+    "dmd_nhwc_to_nchw", "dmd_gn_stats", "dmd_maxpool2", "dmd_lstm_pointwise", "dmd_categorical_sample",
+    "dmd_last_error", "dmd_abi_version",
+)
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(diamond_amd has no CPU/PyTorch fallback for its kernels)")
+        L = C.CDLL(LIB_PATH)
+        L.dmd_last_error.restype = C.c_char_p
+        for name in EXPORTS:
+            getattr(L, name)  # AttributeError if the ABI is incomplete
+        L.dmd_conv2d.argtypes = [C.POINTER(ConvParams), C.c_void_p]
+        L.dmd_conv2d_naive.argtypes = [C.POINTER(ConvParams), C.c_void_p]
+        L.dmd_linear.argtypes = [C.POINTER(LinearParams), C.c_void_p]
+        L.dmd_pack_conv_weight.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.dmd_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.dmd_edm_pack_input.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, EdmCfg, C.c_void_p, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.dmd_cond_embed.argtypes = [C.c_void_p, C.c_int, EdmCfg, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.dmd_edm_denoised.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, EdmCfg, C.c_void_p, C.c_int, C.c_int64,
+                                       C.c_void_p]
+        L.dmd_euler_step.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]
+        L.dmd_nchw_to_nhwc.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.dmd_nhwc_to_nchw.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.dmd_gn_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.dmd_maxpool2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p]
+        L.dmd_lstm_pointwise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.dmd_categorical_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.dmd_conv_stat_tiles.argtypes = [C.c_int, C.c_int]
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (rc={rc}): {lib().dmd_last_error().decode()}")
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("diamond_amd kernels need GPU tensors (there is no CPU path)")
+    return t.data_ptr()
+
+
+def fptr(t: Optional[Tensor]) -> Optional[int]:
+    if t is not None:
+        assert t.dtype == torch.float32 and t.is_contiguous(), (t.dtype, t.shape, t.stride())
+    return ptr(t)
+
+
+def conv_stat_tiles(h: int, w: int) -> int:
+    return (h // 8) * (w // (8 if w % 16 else 16))
+
+
+def cout_pad(cout: int) -> int:
+    return (cout + 15) // 16 * 16
+
+
+def make_norm(stats: Optional[Tensor] = None, stat_tiles: int = 0, mul: Optional[Tensor] = None,
+              add: Optional[Tensor] = None, mul_stride: int = 0, add_stride: int = 0, plus_one: bool = False) -> Norm:
+    n = Norm()
+    n.stats = ptr(stats)
+    n.stat_tiles = stat_tiles
+    n.mul_plus_one = int(plus_one)
+    n.mul = ptr(mul)
+    n.add = ptr(add)
+    n.mul_stride = mul_stride
+    n.add_stride = add_stride
+    return n
+
+
+def pack_conv_weight(w_oihw: Tensor, cout_padded: Optional[int] = None) -> Tensor:
+    """OIHW (nn.Conv2d.weight) -> packed [CinPad/16][taps][CoutPad][16] on the same device."""
+    cout, cin, k, _ = w_oihw.shape
+    cp = cout_padded or cout_pad(cout)
+    cinp = (cin + 15) // 16 * 16
+    w = w_oihw.detach().contiguous().float()
+    out = torch.empty(cinp // 16 * k * k * cp * 16, device=w.device, dtype=torch.float32)
+    check(lib().dmd_pack_conv_weight(fptr(w), fptr(out), cout, cin, k, cp, cinp, stream()), "dmd_pack_conv_weight")
+    return out
+
+
+def pad_vector(v: Optional[Tensor], n: int) -> Optional[Tensor]:
+    if v is None:
+        return None
+    out = torch.zeros(n, device=v.device, dtype=torch.float32)
+    out[: v.numel()] = v.detach().float()
+    return out
+
+
+def linear(a: Tensor, w: Tensor, bias: Optional[Tensor], out: Tensor, accumulate: bool = False, silu: bool = False) -> Tensor:
+    """out[M,N] (+)= a[M,K] @ w[N,K]^T + bias; row strides taken from the tensors."""
+    p = LinearParams()
+    p.M, p.K = a.shape
+    p.N = w.shape[0]
+    assert w.shape[1] == p.K and out.shape == (p.M, p.N), (a.shape, w.shape, out.shape)
+    assert a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1
+    p.A, p.lda = ptr(a), a.stride(0)
+    p.W, p.ldw = ptr(w), w.stride(0)
+    p.bias = ptr(bias)
+    p.C, p.ldc = ptr(out), out.stride(0)
+    p.accumulate, p.silu = int(accumulate), int(silu)
+    check(lib().dmd_linear(C.byref(p), stream()), "dmd_linear")
+    return out

@@ -1,0 +1,155 @@
+/* diamond_hip.h -- C ABI of libdiamond_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for DIAMOND's imagined-rollout hot path.  The reference
+ * (eloialonso/diamond) has no FFI: every op below replaces a chain of ATen calls issued by
+ * the cited reference Python lines.  All pointers are DEVICE pointers (HBM) unless noted,
+ * all floating-point tensors are fp32, activations are NHWC, every entry point is
+ * asynchronous on the given hipStream_t, allocates nothing, synchronises nothing and is
+ * graph-capturable.  Return value: 0 = launched, non-zero = invalid arguments (message via
+ * dmd_last_error()).  No exceptions cross this boundary.
+ */
+#ifndef DIAMOND_HIP_H
+#define DIAMOND_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dmd_stream_t; /* hipStream_t */
+
+#define DMD_PROLOGUE_NONE 0      /* conv consumes the source as stored                       */
+#define DMD_PROLOGUE_NORM_SILU 1 /* GroupNorm(+FiLM|affine) then SiLU fused into the load    */
+#define DMD_PROLOGUE_NORM 2      /* GroupNorm(+affine) only (attention pre-norm)             */
+
+#define DMD_GN_GROUP 32 /* models/blocks.py:12 GN_GROUP_SIZE */
+
+/* GroupNorm statistics travel between kernels as per-tile partial sums in fp64:
+ * stats[((n * G + g) * T + t) * 2 + {0: sum x, 1: sum x^2}], G = C / 32, T = producer tiles
+ * per image.  The consumer reduces the T partials in a fixed order (deterministic). */
+typedef struct dmd_norm {
+  const double* stats;   /* NULL <=> no normalisation                                  */
+  int32_t stat_tiles;    /* T                                                          */
+  int32_t mul_plus_one;  /* 1: y = xn * (1 + mul) + add  (AdaGroupNorm, blocks.py:41-45) */
+                         /* 0: y = xn * mul + add        (nn.GroupNorm affine, :28-31)  */
+  const float* mul;      /* [n * mul_stride + c]                                       */
+  const float* add;      /* [n * add_stride + c]                                       */
+  int64_t mul_stride;    /* 0 for per-channel parameters shared by the batch           */
+  int64_t add_stride;
+} dmd_norm;
+
+typedef struct dmd_conv_src {
+  const float* x;   /* NHWC (N, Hs, Ws, C) */
+  int32_t C;        /* channels, multiple of 16 */
+  int32_t prologue; /* DMD_PROLOGUE_* */
+  dmd_norm norm;
+} dmd_conv_src;
+
+/* dmd_conv2d: 3x3 (pad 1, stride 1|2) or 1x1 convolution as an implicit GEMM on
+ * v_mfma_f32_16x16x4_f32 (exact fp32 fma chain), with
+ *   - channel concatenation of up to two sources       (torch.cat, blocks.py:174; inner_model.py:46)
+ *   - nearest x2 upsampling folded into the gather      (Upsample.forward blocks.py:108-110)
+ *   - GroupNorm/AdaGroupNorm + SiLU fused into the load (blocks.py:143-144; inner_model.py:48)
+ *   - bias, residual add (optionally of the normalised residual, blocks.py:72) in the epilogue
+ *   - GroupNorm partial statistics of the OUTPUT emitted by the epilogue.
+ * Replaces F.conv2d call sites blocks.py:18-19,96,109,119,133-138 / inner_model.py:36,41. */
+typedef struct dmd_conv_params {
+  int32_t N, H, W;   /* batch and OUTPUT spatial size (H, W multiples of 8)            */
+  int32_t Cout;      /* real output channels                                           */
+  int32_t CoutPad;   /* Cout rounded up to 16/32/64-channel groups (weights are padded) */
+  int32_t taps;      /* 9: 3x3 pad 1;  1: 1x1 pad 0                                    */
+  int32_t stride;    /* 1 or 2 (taps == 9 only)                                        */
+  int32_t upsample;  /* 1: sources stored at (H/2, W/2), nearest x2 before the conv    */
+  int32_t nsrc;      /* 1 or 2                                                         */
+  dmd_conv_src src[2];
+  const float* w;    /* packed [Cin_total/16][taps][CoutPad][16]  (see dmd_pack_conv_weight) */
+  const float* bias; /* [CoutPad] or NULL                                               */
+  const float* residual; /* NHWC (N, H, W, Cout) or NULL                                */
+  dmd_norm residual_norm; /* optional GroupNorm(+affine) applied to the residual        */
+  float* out;        /* NHWC (N, H, W, Cout), or NCHW (N, Cout, H, W) if out_nchw       */
+  int32_t out_nchw;
+  int32_t reserved;
+  double* out_stats; /* (N, Cout/32, T, 2) partial sums of the output, or NULL          */
+} dmd_conv_params;
+
+int dmd_conv2d(const dmd_conv_params* p, dmd_stream_t stream);
+/* number of GroupNorm stat tiles per image a dmd_conv2d with output (H, W) emits */
+int dmd_conv_stat_tiles(int H, int W);
+/* OIHW (Cout, Cin, k, k) fp32 -> packed layout; Cin padded to 16, Cout padded to CoutPad. */
+int dmd_pack_conv_weight(const float* oihw, float* packed, int Cout, int Cin, int k, int CoutPad, int CinPad,
+                         dmd_stream_t stream);
+
+/* Debug/verification twin of dmd_conv2d: one thread per output element, plain fp32 fma
+ * loops, identical parameters and semantics (used by tests to localise MFMA-path bugs). */
+int dmd_conv2d_naive(const dmd_conv_params* p, dmd_stream_t stream);
+
+/* dmd_linear: C[M,N] (+)= A[M,K] . W[N,K]^T + bias[N], optional SiLU.  nn.Linear call sites:
+ * AdaGroupNorm.linear blocks.py:39,44 (all of a forward batched into one call), cond_proj
+ * inner_model.py:31-35, LSTM gates, actor/critic heads actor_critic.py:47-48,73. */
+typedef struct dmd_linear_params {
+  int32_t M, N, K;   /* K multiple of 16 */
+  const float* A; int64_t lda;
+  const float* W; int64_t ldw;
+  const float* bias; /* [N] or NULL */
+  float* C; int64_t ldc;
+  int32_t accumulate; /* 1: C += ... */
+  int32_t silu;       /* 1: C = silu(...) */
+} dmd_linear_params;
+int dmd_linear(const dmd_linear_params* p, dmd_stream_t stream);
+
+/* dmd_attention: softmax(q k^T / sqrt(d)) v per (image, head) over T tokens, streaming
+ * K/V tiles through LDS with an online softmax.  qkv is NHWC (N, T, 3C): q | k | v channel
+ * thirds, head h = channels [h*d, (h+1)*d) of each third (blocks.py:66-71).  d == 8. */
+int dmd_attention(const float* qkv, float* out, int N, int T, int C, int head_dim, dmd_stream_t stream);
+
+/* ---- EDM preconditioning / sampler pointwise (denoiser.py:66-84, diffusion_sampler.py:45-56) ---- */
+typedef struct dmd_edm_cfg {
+  double sigma_data;         /* 0.5  (python floats in the reference: squared in double, */
+  double sigma_offset_noise; /* 0.3   then cast to fp32 when they meet a tensor)         */
+} dmd_edm_cfg;
+
+/* cat(obs / sigma_data, x * c_in(sigma)) -> NHWC with CPad channels (zero padded).
+ * x (N, Cx, H, W), obs (N, Cobs, H, W) NCHW.  sigma: device pointer (per-sample, stride
+ * sigma_stride in {0,1}). */
+int dmd_edm_pack_input(const float* x, const float* obs, const float* sigma, int sigma_stride, dmd_edm_cfg cfg,
+                       float* out_nhwc, int N, int Cx, int Cobs, int H, int W, int CPad, dmd_stream_t stream);
+/* cond input: fourier(c_noise(sigma)) + flatten(embedding(act))  (blocks.py:84-87, inner_model.py:27-30,45) */
+int dmd_cond_embed(const float* sigma, int sigma_stride, dmd_edm_cfg cfg, const float* fourier_w /*[half]*/,
+                   const int64_t* act /*(N, T)*/, const float* act_emb /*(A, E)*/, float* out /*(N, 2*half)*/, int N,
+                   int half, int T, int E, dmd_stream_t stream);
+/* denoised = quantise(c_skip * x + c_out * F)  (denoiser.py:81-83); all NCHW, elementwise */
+int dmd_edm_denoised(const float* x, const float* model_out, const float* sigma, int sigma_stride, dmd_edm_cfg cfg,
+                     float* denoised, int N, int64_t per_sample, dmd_stream_t stream);
+/* x_out = x + ((x - denoised) / sigma_hat) * dt   (diffusion_sampler.py:45-49) */
+int dmd_euler_step(const float* x, const float* denoised, float sigma_hat, float dt, float* x_out, int64_t n,
+                   dmd_stream_t stream);
+
+/* NCHW (N, C, H, W) -> NHWC (N, H, W, CPad), zero padded channels */
+int dmd_nchw_to_nhwc(const float* in, float* out, int N, int C, int H, int W, int CPad, dmd_stream_t stream);
+int dmd_nhwc_to_nchw(const float* in, float* out, int N, int C, int H, int W, int CPad, dmd_stream_t stream);
+
+/* GroupNorm partial statistics of an NHWC tensor (one tile per image): for tensors that
+ * no dmd_* kernel produced. */
+int dmd_gn_stats(const float* x, double* stats, int N, int HW, int C, dmd_stream_t stream);
+
+/* 2x2 max pooling, NHWC, also emits GroupNorm stats of the pooled output and the argmax
+ * (0..3) for the backward pass (actor_critic.py:108-109). */
+int dmd_maxpool2(const float* x, float* out, uint8_t* argmax, double* out_stats, int N, int H, int W, int C,
+                 dmd_stream_t stream);
+
+/* LSTM cell pointwise: gates (N, 4*Hd) in i,f,g,o order -> h, c (nn.LSTMCell, actor_critic.py:46,72) */
+int dmd_lstm_pointwise(const float* gates, const float* c_prev, float* h, float* c, int N, int Hd,
+                       dmd_stream_t stream);
+
+/* argmax(softmax(logits) / E) with injected exponential draws E == Categorical(logits).sample()
+ * (env_loop.py:32, world_model_env.py:103-104). */
+int dmd_categorical_sample(const float* logits, const float* expo, int64_t* out, int N, int A, dmd_stream_t stream);
+
+const char* dmd_last_error(void);
+int dmd_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIAMOND_HIP_H */

@@ -1,0 +1,130 @@
+"""Drop-in boundary conformance (CPU): state-dict layout, optimizer grouping, Agent.load,
+sampler schedule, lambda-returns, and that the C-ABI library loads and exports every symbol
+declared in include/diamond_hip.h.  No kernel is launched here."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+from torch import nn
+
+import diamond_amd as D
+from tests.conftest import ROOT, load_golden
+
+
+@pytest.fixture(scope="module")
+def agent():
+    return D.Agent(D.default_agent_config())
+
+
+def test_state_dict_matches_reference_tree(agent):
+    ref = load_golden("state_dict_keys.pt")  # dumped from the instantiated reference Agent
+    mine = {k: tuple(v.shape) for k, v in agent.state_dict().items()}
+    assert list(mine.keys()) == list(ref.keys())
+    assert mine == ref
+    assert sum(p.numel() for p in agent.denoiser.parameters()) == 4405955
+    assert sum(p.numel() for p in agent.rew_end_model.parameters()) == 5900864
+    assert sum(p.numel() for p in agent.actor_critic.parameters()) == 3229637
+
+
+def test_every_parameter_is_optimizer_groupable(agent):
+    """configure_opt (reference utils.py:129-166) asserts each parameter belongs to a
+    whitelisted / blacklisted module type or is a bias."""
+    white = (nn.Linear, nn.Conv1d, nn.Conv2d, nn.LSTMCell, nn.LSTM)
+    black = (nn.LayerNorm, nn.Embedding, nn.GroupNorm)
+    for model in (agent.denoiser, agent.rew_end_model, agent.actor_critic):
+        decay, no_decay = set(), set()
+        for mn, m in model.named_modules():
+            for pn, _ in m.named_parameters():
+                fpn = f"{mn}.{pn}" if mn else pn
+                if "bias" in pn:
+                    no_decay.add(fpn)
+                elif (pn.endswith("weight") or pn.startswith("weight_")) and isinstance(m, white):
+                    decay.add(fpn)
+                elif (pn.endswith("weight") or pn.startswith("weight_")) and isinstance(m, black):
+                    no_decay.add(fpn)
+        names = {n for n, _ in model.named_parameters()}
+        assert not (decay & no_decay)
+        assert names == (decay | no_decay), names - (decay | no_decay)
+
+
+def test_agent_load_roundtrip(tmp_path, agent):
+    from diamond_amd.testing import fill_module_
+
+    other = D.Agent(D.default_agent_config())
+    fill_module_(other, 3)
+    path = tmp_path / "agent.pt"
+    torch.save(other.state_dict(), path)
+    agent.load(path, load_rew_end_model=False)
+    assert torch.equal(agent.denoiser.inner_model.conv_in.weight, other.denoiser.inner_model.conv_in.weight)
+    assert torch.equal(agent.actor_critic.lstm.weight_hh, other.actor_critic.lstm.weight_hh)
+    assert not torch.equal(agent.rew_end_model.head[0].weight, other.rew_end_model.head[0].weight)
+
+
+def test_default_init_zeroes_like_the_reference():
+    agent = D.Agent(D.default_agent_config())
+    im = agent.denoiser.inner_model
+    assert float(im.conv_out.weight.abs().max()) == 0
+    assert float(im.unet.d_blocks[0].resblocks[0].conv2.weight.abs().max()) == 0
+    assert float(im.unet.mid_blocks.resblocks[0].attn.out_proj.weight.abs().max()) == 0
+    assert float(agent.actor_critic.actor_linear.weight.abs().max()) == 0
+    b = agent.actor_critic.lstm.bias_ih
+    assert float(b[512:1024].min()) == 1 and float(b[:512].abs().max()) == 0
+
+
+def test_sigma_schedule_bit_exact_with_reference_values():
+    s = D.build_sigmas(3, 2e-3, 5.0, 7, torch.device("cpu"))
+    assert torch.equal(s, load_golden("denoiser_default.pt")["sigmas"])
+    assert s.shape == (4,) and float(s[-1]) == 0.0
+
+
+def test_lambda_returns_matches_oracle():
+    from oracle import diamond_oracle as O
+
+    g = torch.Generator().manual_seed(0)
+    rew = torch.randint(-1, 2, (5, 7), generator=g).float() * 2.5
+    end = (torch.rand(5, 7, generator=g) < 0.15).long()
+    trunc = (torch.rand(5, 7, generator=g) < 0.1).long()
+    vb = torch.randn(5, 7, generator=g)
+    for lam in (0.0, 0.95):
+        assert torch.equal(D.compute_lambda_returns(rew, end, trunc, vb, 0.985, lam),
+                           O.lambda_returns(rew, end, trunc, vb, 0.985, lam))
+
+
+def test_product_path_has_no_cpu_fallback(agent):
+    x = torch.zeros(1, 3, 64, 64)
+    with pytest.raises(Exception):
+        agent.denoiser.denoise(x, 1.0, torch.zeros(1, 12, 64, 64), torch.zeros(1, 4, dtype=torch.long))
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    from diamond_amd import native
+
+    assert os.path.exists(native.LIB_PATH), "libdiamond_hip.so missing: run __graft_entry__.build()"
+    header = open(os.path.join(ROOT, "include", "diamond_hip.h")).read()
+    declared = set(re.findall(r"\b(dmd_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 18
+    lib = ctypes.CDLL(native.LIB_PATH)
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), f"{sym} declared in include/diamond_hip.h but not exported"
+    assert set(native.EXPORTS) == declared
+    assert lib.dmd_abi_version() == 1
+    assert lib.dmd_conv_stat_tiles(64, 64) == 32 and lib.dmd_conv_stat_tiles(8, 8) == 1
+
+
+def test_struct_layouts_match_the_header():
+    """sizeof of the ctypes mirrors must equal the C structs (compiled with gcc)."""
+    import subprocess
+    import tempfile
+    from diamond_amd import native
+
+    src = '#include <stdio.h>\n#include "diamond_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu",sizeof(dmd_norm),' \
+          'sizeof(dmd_conv_src),sizeof(dmd_conv_params),sizeof(dmd_linear_params),sizeof(dmd_edm_cfg));return 0;}'
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "s.c")
+        open(c, "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", os.path.join(d, "s")])
+        sizes = [int(v) for v in subprocess.check_output([os.path.join(d, "s")]).split()]
+    mine = [ctypes.sizeof(t) for t in (native.Norm, native.ConvSrc, native.ConvParams, native.LinearParams, native.EdmCfg)]
+    assert sizes == mine

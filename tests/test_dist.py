@@ -1,0 +1,61 @@
+"""world_size-2 gloo test of the gradient all-reduce path (CPU): the mean of the two ranks'
+actor-critic gradients equals the gradient of the mean loss over the concatenated batch."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import diamond_amd as D
+    from diamond_amd.dist import GradAllReducer, broadcast_parameters
+    from diamond_amd.testing import fill_module_, synthetic_frames
+
+    torch.manual_seed(rank)  # different default init per rank: broadcast must fix it
+    ac = D.ActorCritic(D.default_agent_config().actor_critic)
+    if rank == 0:
+        fill_module_(ac, 5)
+    broadcast_parameters(ac)
+    ac.backend = "torch"  # CPU: the interim torch path only exercises the host-side collective logic
+    red = GradAllReducer(list(ac.parameters()))
+    g = torch.Generator().manual_seed(40)
+    obs_all = synthetic_frames(g, 4, 3, 64, 64)
+    obs = obs_all[rank * 2:(rank + 1) * 2]
+    out = ac.predict_act_value(obs, None)
+    (out.logits_act.square().mean() + out.val.mean()).backward()
+    flat = red.all_reduce_mean().clone()
+    if rank == 0:
+        # single-process reference over the whole batch
+        ac2 = D.ActorCritic(D.default_agent_config().actor_critic)
+        fill_module_(ac2, 5)
+        ac2.backend = "torch"
+        o = ac2.predict_act_value(obs_all, None)
+        (o.logits_act.square().mean() + o.val.mean()).backward()
+        ref = torch.cat([p.grad.reshape(-1) for p in ac2.parameters()])
+        q.put(float((flat - ref).abs().max() / ref.abs().max()))
+        q.put(all(p.grad.data_ptr() != 0 for p in ac.parameters()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_allreduce_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 1000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    err = q.get(timeout=120)
+    ok = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert err < 1e-5 and ok

@@ -1,0 +1,274 @@
+"""Per-kernel parity of libdiamond_hip (through the C ABI) on a real MI355X.
+
+Truth = float64 torch-CPU evaluation of the same op on the same seeded inputs (test
+infrastructure, not product).  Tolerances are written per test; integer / quantised results
+are compared bit-exactly.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def to_nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def gn_ref(x, groups, eps=1e-5):
+    n, c, h, w = x.shape
+    xg = x.reshape(n, groups, -1)
+    m = xg.mean(-1, keepdim=True)
+    v = (xg - m).square().mean(-1, keepdim=True)
+    return ((xg - m) / torch.sqrt(v + eps)).reshape(n, c, h, w)
+
+
+def make_act(x_nchw_cpu):
+    """NHWC device activation with single-tile GN stats."""
+    from diamond_amd import engine as E
+    t = to_nhwc(x_nchw_cpu.float()).to(DEV)
+    return E.gn_stats(t) if t.shape[3] % 32 == 0 else E.Act(t)
+
+
+CONV_CASES = [
+    # name, N, H, W (input spatial), [Cin...], Cout, taps, stride, upsample, prologue, residual, nchw
+    ("c64_16x16", 2, 16, 16, [64], 64, 9, 1, False, 1, True, False),
+    ("cat128_32x32", 2, 32, 32, [64, 64], 64, 9, 1, False, 1, True, False),
+    ("cat128_8x8_cfgB", 3, 8, 8, [64, 64], 64, 9, 1, False, 1, True, False),
+    ("down_32to16", 2, 32, 32, [64], 64, 9, 2, False, 0, False, False),
+    ("down_16to8_cfgB", 3, 16, 16, [64], 64, 9, 2, False, 0, False, False),
+    ("up_8to16", 2, 8, 8, [64], 64, 9, 1, True, 0, False, False),
+    ("up_16to32", 1, 16, 16, [64], 64, 9, 1, True, 0, False, False),
+    ("proj1x1_cat", 2, 16, 16, [64, 64], 64, 1, 1, False, 0, False, False),
+    ("proj1x1_8x8", 3, 8, 8, [64, 64], 64, 1, 1, False, 0, False, False),
+    ("qkv1x1_192", 2, 8, 8, [64], 192, 1, 1, False, 2, False, False),
+    ("conv_in16", 2, 16, 32, [16], 64, 9, 1, False, 0, False, False),
+    ("conv_out3_nchw", 2, 16, 16, [64], 3, 9, 1, False, 1, False, True),
+    ("c32_wn2", 2, 16, 16, [32], 32, 9, 1, False, 1, True, False),
+    ("c32_8x8_wn2", 3, 8, 8, [32], 32, 9, 1, False, 1, True, False),
+    ("c32to64", 2, 16, 16, [32], 64, 9, 1, False, 1, False, False),
+    ("c32_down", 2, 16, 16, [32], 32, 9, 2, False, 0, False, False),
+    ("rect_24x40", 1, 24, 40, [64], 64, 9, 1, False, 1, True, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+@pytest.mark.parametrize("impl", ["mfma", "naive"])
+def test_conv2d(case, impl):
+    from diamond_amd import engine as E, native as nv
+
+    name, n, h, w, cins, cout, taps, stride, up, prologue, use_res, nchw = case
+    g = torch.Generator().manual_seed(hash(name) % 1000)
+    k = 3 if taps == 9 else 1
+    cin = sum(cins)
+    xs = [torch.randn(n, c, h, w, generator=g, dtype=torch.float64) * 1.5 + 0.3 for c in cins]
+    wgt = torch.randn(cout, cin, k, k, generator=g, dtype=torch.float64) / math.sqrt(cin * k * k)
+    bias = torch.randn(cout, generator=g, dtype=torch.float64) * 0.1
+    scale = torch.randn(n, cin, generator=g, dtype=torch.float64) * 0.3
+    shift = torch.randn(n, cin, generator=g, dtype=torch.float64) * 0.3
+    ho, wo = (h * 2, w * 2) if up else (h // stride, w // stride)
+    res = torch.randn(n, cout, ho, wo, generator=g, dtype=torch.float64) if use_res else None
+
+    # ---- fp64 truth
+    parts, c0 = [], 0
+    for x, c in zip(xs, cins):
+        y = x
+        if prologue:
+            y = gn_ref(x, max(1, c // 32)) * (1 + scale[:, c0:c0 + c, None, None]) + shift[:, c0:c0 + c, None, None]
+            if prologue == 1:
+                y = y * torch.sigmoid(y)
+        parts.append(y)
+        c0 += c
+    xin = torch.cat(parts, 1)
+    if up:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, wgt, bias, stride=stride, padding=1 if k == 3 else 0)
+    if res is not None:
+        ref = ref + res
+
+    # ---- device
+    mul = scale.float().to(DEV).contiguous()
+    add = shift.float().to(DEV).contiguous()
+    srcs, c0 = [], 0
+    for x, c in zip(xs, cins):
+        a = make_act(x)
+        spec = None
+        if prologue:
+            spec = E.NormSpec(mul=mul[:, c0:], add=add[:, c0:], mul_stride=cin, add_stride=cin, plus_one=True)
+        srcs.append((a, prologue, spec))
+        c0 += c
+    wp = nv.pack_conv_weight(wgt.float().to(DEV))
+    bp = nv.pad_vector(bias.float().to(DEV), nv.cout_pad(cout))
+    r_act = E.Act(to_nhwc(res.float()).to(DEV)) if res is not None else None
+    want_stats = (cout % 32 == 0) and not nchw
+    out = E.conv2d(srcs, wp, bp, cout, taps=taps, stride=stride, upsample=up, residual=r_act, want_stats=want_stats,
+                   out_nchw=nchw, naive=(impl == "naive"))
+    torch.cuda.synchronize()
+    got = out.t if nchw else out.t.permute(0, 3, 1, 2)
+    err = rel_err(got, ref)
+    assert err < 2e-5, f"{name}/{impl}: rel err {err:.3e}"
+    if want_stats:
+        st = out.stats.cpu().sum(dim=2)  # (N, G, 2)
+        refg = ref.reshape(n, cout // 32, -1)
+        assert rel_err(st[..., 0], refg.sum(-1)) < 1e-4 or float((st[..., 0] - refg.sum(-1)).abs().max()) < 1e-2
+        assert rel_err(st[..., 1], refg.square().sum(-1)) < 2e-5
+
+
+def test_conv_residual_norm():
+    """out = conv1x1(y) + GN_affine(x): the attention block's `x_normed + out_proj(y)` (blocks.py:72)."""
+    from diamond_amd import engine as E, native as nv
+
+    g = torch.Generator().manual_seed(5)
+    n, c, h, w = 2, 64, 8, 8
+    x = torch.randn(n, c, h, w, generator=g, dtype=torch.float64) * 2 + 1
+    y = torch.randn(n, c, h, w, generator=g, dtype=torch.float64)
+    wgt = torch.randn(c, c, 1, 1, generator=g, dtype=torch.float64) / 8
+    bias = torch.randn(c, generator=g, dtype=torch.float64) * 0.1
+    gamma = torch.randn(c, generator=g, dtype=torch.float64) * 0.2 + 1
+    beta = torch.randn(c, generator=g, dtype=torch.float64) * 0.2
+    ref = F.conv2d(y, wgt, bias) + gn_ref(x, 2) * gamma[None, :, None, None] + beta[None, :, None, None]
+    xa = make_act(x)
+    spec = E.NormSpec(mul=gamma.float().to(DEV), add=beta.float().to(DEV))
+    out = E.conv2d([(E.Act(to_nhwc(y.float()).to(DEV)), 0, None)], nv.pack_conv_weight(wgt.float().to(DEV)),
+                   bias.float().to(DEV), c, taps=1, residual=xa, residual_norm=spec)
+    assert rel_err(out.t.permute(0, 3, 1, 2), ref) < 2e-5
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 7168, 256), (3, 4, 512), (16, 2048, 1024), (70, 5, 512), (256, 1, 512)])
+def test_linear(m, n, k):
+    from diamond_amd import engine as E
+
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g, dtype=torch.float64)
+    w = torch.randn(n, k, generator=g, dtype=torch.float64) / math.sqrt(k)
+    b = torch.randn(n, generator=g, dtype=torch.float64)
+    ref = a @ w.t() + b
+    out = E.linear(a.float().to(DEV), w.float().to(DEV), b.float().to(DEV))
+    assert rel_err(out, ref) < 1e-5
+    out2 = E.linear(a.float().to(DEV), w.float().to(DEV), None, out=out.clone(), accumulate=True)
+    assert rel_err(out2, 2 * ref - b) < 1e-5
+    out3 = E.linear(a.float().to(DEV), w.float().to(DEV), b.float().to(DEV), silu=True)
+    assert rel_err(out3, ref * torch.sigmoid(ref)) < 1e-5
+
+
+@pytest.mark.parametrize("t,c", [(64, 64), (256, 64), (1024, 64), (64, 32)])
+def test_attention(t, c):
+    from diamond_amd import engine as E
+
+    g = torch.Generator().manual_seed(t + c)
+    n, heads = 2, c // 8
+    side = int(math.sqrt(t))
+    qkv = torch.randn(n, 3 * c, side, side, generator=g, dtype=torch.float64) * 1.5
+    q, k, v = qkv.reshape(n, 3, heads, 8, t).permute(0, 1, 2, 4, 3).unbind(1)
+    att = torch.softmax(q @ k.transpose(-2, -1) / math.sqrt(8), dim=-1)
+    ref = (att @ v).transpose(2, 3).reshape(n, c, side, side)
+    out = E.attention(E.Act(to_nhwc(qkv.float()).to(DEV)), c)
+    assert rel_err(out.permute(0, 3, 1, 2), ref) < 1e-5
+
+
+def test_edm_pointwise_bit_exact():
+    """Preconditioning scalars, uint8 quantisation and the Euler update reproduce the
+    reference's fp32 op order exactly (checked against the CPU oracle's torch ops)."""
+    from diamond_amd import native as nv
+    from oracle import diamond_oracle as O
+
+    g = torch.Generator().manual_seed(3)
+    n, h, w = 3, 16, 24
+    x = torch.randn(n, 3, h, w, generator=g) * 2
+    f = torch.randn(n, 3, h, w, generator=g)
+    obs = torch.rand(n, 12, h, w, generator=g) * 2 - 1
+    spec = O.DenoiserSpec()
+    edm = nv.EdmCfg(0.5, 0.3)
+    for sigma in (torch.tensor(5.0 - 1.4e-6), torch.tensor(0.28308), torch.tensor(0.002), torch.tensor([0.7, 1.9, 0.05])):
+        c_in, c_out, c_skip, c_noise = O.conditioners(spec, sigma)
+        sig = sigma.reshape(-1).to(DEV)
+        stride = 0 if sig.numel() == 1 else 1
+        # pack
+        packed = torch.empty(n, h, w, 16, device=DEV)
+        nv.check(nv.lib().dmd_edm_pack_input(nv.fptr(x.to(DEV)), nv.fptr(obs.to(DEV)), nv.fptr(sig), stride, edm,
+                                             nv.fptr(packed), n, 3, 12, h, w, 16, nv.stream()), "pack")
+        ref = torch.cat((obs / 0.5, x * c_in, torch.zeros(n, 1, h, w)), 1).permute(0, 2, 3, 1)
+        assert torch.equal(packed.cpu(), ref), "edm_pack_input is not bit-exact"
+        # denoised
+        den = torch.empty(n, 3, h, w, device=DEV)
+        nv.check(nv.lib().dmd_edm_denoised(nv.fptr(x.to(DEV)), nv.fptr(f.to(DEV)), nv.fptr(sig), stride, edm, nv.fptr(den), n,
+                                           3 * h * w, nv.stream()), "denoised")
+        ref_d = O.quantize_frame(c_skip * x + c_out * f)
+        assert torch.equal(den.cpu(), ref_d), "edm_denoised is not bit-exact"
+    # euler
+    sigmas = O.build_sigmas(O.SamplerSpec())
+    den = O.quantize_frame(torch.randn(n, 3, h, w, generator=g))
+    out = torch.empty(n, 3, h, w, device=DEV)
+    s, nx = sigmas[0], sigmas[1]
+    nv.check(nv.lib().dmd_euler_step(nv.fptr(x.to(DEV)), nv.fptr(den.to(DEV)), float(s), float(nx - s), nv.fptr(out),
+                                     x.numel(), nv.stream()), "euler")
+    ref_x = x + (x - den) / s * (nx - s)
+    assert torch.equal(out.cpu(), ref_x), "euler_step is not bit-exact"
+
+
+def test_cond_embed():
+    from diamond_amd import native as nv
+    from oracle import diamond_oracle as O
+
+    g = torch.Generator().manual_seed(4)
+    n = 5
+    fw = torch.randn(1, 128, generator=g)
+    emb = torch.randn(4, 64, generator=g)
+    act = torch.randint(0, 4, (n, 4), generator=g)
+    sigma = torch.rand(n, generator=g) * 5 + 0.002
+    c_noise = O.conditioners(O.DenoiserSpec(), sigma)[3]
+    ref = O.fourier_features(fw, c_noise) + F.embedding(act, emb).flatten(1)
+    out = torch.empty(n, 256, device=DEV)
+    nv.check(nv.lib().dmd_cond_embed(nv.fptr(sigma.to(DEV)), 1, nv.EdmCfg(0.5, 0.3), nv.fptr(fw.to(DEV)), nv.ptr(act.to(DEV)),
+                                     nv.fptr(emb.to(DEV)), nv.fptr(out), n, 128, 4, 64, nv.stream()), "cond")
+    assert float((out.cpu() - ref).abs().max()) < 2e-6
+
+
+def test_categorical_sample_bit_exact():
+    from diamond_amd import native as nv
+    from oracle import diamond_oracle as O
+
+    g = torch.Generator().manual_seed(8)
+    for a in (4, 3, 2, 18):
+        logits = torch.randn(512, a, generator=g) * 2
+        e = torch.empty(512, a).exponential_(1, generator=g)
+        out = torch.empty(512, dtype=torch.long, device=DEV)
+        nv.check(nv.lib().dmd_categorical_sample(nv.fptr(logits.to(DEV)), nv.fptr(e.to(DEV)), nv.ptr(out), 512, a, nv.stream()),
+                 "cat")
+        assert torch.equal(out.cpu(), O.categorical_sample(logits, e))
+
+
+def test_maxpool_lstm_pointwise():
+    from diamond_amd import native as nv
+    from oracle import diamond_oracle as O
+
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 32, 16, 16, generator=g)
+    out = torch.empty(2, 8, 8, 32, device=DEV)
+    arg = torch.empty(2, 8, 8, 32, dtype=torch.uint8, device=DEV)
+    stats = torch.empty(2, 1, 1, 2, dtype=torch.float64, device=DEV)
+    nv.check(nv.lib().dmd_maxpool2(nv.fptr(to_nhwc(x).to(DEV)), nv.fptr(out), nv.ptr(arg), nv.ptr(stats), 2, 16, 16, 32,
+                                   nv.stream()), "pool")
+    ref = F.max_pool2d(x, 2)
+    assert torch.equal(out.cpu().permute(0, 3, 1, 2), ref)
+    assert rel_err(stats.cpu()[:, 0, 0, 1], ref.double().square().sum((1, 2, 3))) < 1e-6
+    # lstm cell
+    gates = torch.randn(7, 2048, generator=g) * 2
+    c0 = torch.randn(7, 512, generator=g)
+    h = torch.empty(7, 512, device=DEV)
+    c = torch.empty(7, 512, device=DEV)
+    nv.check(nv.lib().dmd_lstm_pointwise(nv.fptr(gates.to(DEV)), nv.fptr(c0.to(DEV)), nv.fptr(h), nv.fptr(c), 7, 512,
+                                         nv.stream()), "lstm")
+    i, f, gg, o = gates.double().chunk(4, 1)
+    c_ref = torch.sigmoid(f) * c0.double() + torch.sigmoid(i) * torch.tanh(gg)
+    h_ref = torch.sigmoid(o) * torch.tanh(c_ref)
+    assert rel_err(c, c_ref) < 1e-6 and rel_err(h, h_ref) < 1e-6

@@ -1,0 +1,237 @@
+"""Model-level parity on a real MI355X: Denoiser / DiffusionSampler / RewEndModel /
+WorldModelEnv+ActorCritic window vs (a) the committed golden fixtures produced by executing
+the reference and (b) the CPU oracle on the same seeded inputs.  Tolerances (north_star):
+fp32 values within 1e-4 relative (max-abs-err / max-abs-ref), integer indices bit-exact,
+quantised frames on the same uint8 level except a <=1e-4 fraction one level off."""
+import pytest
+import torch
+
+from tests.conftest import WEIGHT_SEED, load_golden, make_oracle_agent
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def u8(x):
+    return x.cpu().add(1).div(2).mul(255).round().to(torch.uint8)
+
+
+def check_quantised(mine_u8, ref_u8, max_frac):
+    diff = (mine_u8.int() - ref_u8.int()).abs()
+    assert int(diff.max()) <= 1, "a pixel differs by more than one uint8 level"
+    frac = float((diff > 0).float().mean())
+    assert frac <= max_frac, f"{frac:.2e} of pixels off by one level"
+
+
+def make_agent(attn_depths=(0, 0, 0, 0)):
+    import diamond_amd as D
+    from diamond_amd.testing import fill_module_
+
+    agent = D.Agent(D.default_agent_config(denoiser_attn_depths=attn_depths))
+    fill_module_(agent, WEIGHT_SEED)
+    return agent.to(DEV).eval()
+
+
+@pytest.fixture(scope="module")
+def agent():
+    return make_agent()
+
+
+def _denoiser_inputs(gold, b):
+    from diamond_amd.testing import synthetic_actions, synthetic_frames
+
+    g = torch.Generator().manual_seed(gold["seed"])
+    obs = synthetic_frames(g, b, 12, 64, 64)
+    act = synthetic_actions(g, 4, b, 4)
+    noise = torch.randn(b, 3, 64, 64, generator=g)
+    return obs, act, noise
+
+
+@pytest.mark.parametrize("tag,attn,b", [("default", (0, 0, 0, 0), 2), ("attn0011", (0, 0, 1, 1), 1)])
+def test_denoiser_vs_reference_golden(tag, attn, b):
+    gold = load_golden(f"denoiser_{tag}.pt")
+    ag = make_agent(attn)
+    obs, act, noise = _denoiser_inputs(gold, b)
+    sig = gold["sigmas"]
+    for i, sigma in enumerate(list(sig[:-1]) + [torch.tensor([0.7, 1.9][:b])]):
+        x = noise * sigma.reshape(-1, 1, 1, 1) + obs[:, -3:] * 0.5
+        f = ag.denoiser.compute_model_output(x.to(DEV), obs.to(DEV), act.to(DEV), sigma)
+        err = rel_err(f, gold[f"model_output_{i}"])
+        assert err < 1e-4, f"{tag} sigma#{i}: model_output rel err {err:.3e}"
+        d = ag.denoiser.denoise(x.to(DEV), sigma, obs.to(DEV), act.to(DEV))
+        check_quantised(u8(d), gold[f"denoised_u8_{i}"], max_frac=3e-4)
+
+
+def test_denoiser_not_further_from_fp64_than_cpu_fp32(agent):
+    """error of the HIP path vs an fp64 evaluation is of the same order as the
+    error of the fp32 CPU oracle vs fp64."""
+    from oracle import diamond_oracle as O
+
+    gold = load_golden("denoiser_default.pt")
+    obs, act, noise = _denoiser_inputs(gold, 2)
+    sigma = gold["sigmas"][1]
+    x = noise * sigma + obs[:, -3:] * 0.5
+    a64 = make_oracle_agent(dtype=torch.float64)
+    truth = O.model_output(a64.denoiser, a64.dspec, x.double(), sigma.double(), obs.double(), act)
+    a32 = make_oracle_agent()
+    cpu32 = O.model_output(a32.denoiser, a32.dspec, x, sigma, obs, act)
+    mine = agent.denoiser.compute_model_output(x.to(DEV), obs.to(DEV), act.to(DEV), sigma)
+    e_cpu, e_hip = rel_err(cpu32, truth), rel_err(mine, truth)
+    print(f"rel err vs fp64: cpu-fp32 {e_cpu:.3e}  hip {e_hip:.3e}")
+    assert e_hip < 1e-4 and e_hip < 10 * e_cpu + 1e-6
+
+
+def test_denoiser_mfma_equals_naive_kernels(agent):
+    gold = load_golden("denoiser_default.pt")
+    obs, act, noise = _denoiser_inputs(gold, 2)
+    sigma = gold["sigmas"][0]
+    x = (noise * sigma + obs[:, -3:] * 0.5).to(DEV)
+    a = agent.denoiser.compute_model_output(x, obs.to(DEV), act.to(DEV), sigma)
+    b = agent.denoiser.compute_model_output(x, obs.to(DEV), act.to(DEV), sigma, naive=True)
+    assert rel_err(a, b) < 2e-5
+
+
+def test_denoiser_deterministic(agent):
+    gold = load_golden("denoiser_default.pt")
+    obs, act, noise = _denoiser_inputs(gold, 2)
+    x = (noise * 5.0).to(DEV)
+    a = agent.denoiser.denoise(x, 5.0, obs.to(DEV), act.to(DEV))
+    b = agent.denoiser.denoise(x, 5.0, obs.to(DEV), act.to(DEV))
+    assert torch.equal(a, b)
+
+
+def test_sampler_teacher_forced_vs_golden(agent):
+    """Per-step parity with teacher forcing: at every step the HIP denoiser sees the
+    reference's own trajectory point, so quantisation flips cannot accumulate."""
+    import diamond_amd as D
+    from diamond_amd.testing import synthetic_actions, synthetic_frames
+
+    gold = load_golden("sampler.pt")
+    g = torch.Generator().manual_seed(gold["seed"])
+    for name, cfg, b in (("euler3", D.DiffusionSamplerConfig(num_steps_denoising=3), 2),
+                         ("heun4", D.DiffusionSamplerConfig(num_steps_denoising=4, order=2), 1)):
+        prev_obs = synthetic_frames(g, b, 4, 3, 64, 64)
+        prev_act = synthetic_actions(g, 4, b, 4)
+        sampler = D.DiffusionSampler(agent.denoiser, cfg)
+        assert torch.equal(sampler.sigmas.cpu(), gold[name]["sigmas"])
+        torch.manual_seed(gold[name]["noise_seed"])
+        noise = torch.randn(b, 3, 64, 64)
+        sampler.noise_fn = lambda shape, dev: noise.to(dev)
+        x, traj = sampler.sample(prev_obs.to(DEV), prev_act.to(DEV))
+        traj = torch.stack(traj, 1).cpu()
+        ref = gold[name]["trajectory"]
+        assert torch.equal(traj[:, 0], ref[:, 0])
+        # step 1 is a pure function of (noise, obs, act): tight.  d = (x - D)/sigma amplifies one
+        # uint8 level (2/255) by dt/sigma <= 1, so a flipped pixel moves x by at most 2/255.
+        diff = (traj[:, 1] - ref[:, 1]).abs()
+        assert float(diff.max()) <= 2 / 255 + 1e-4
+        assert float((diff > 1e-4).float().mean()) < 3e-4
+        if name == "euler3":  # free-running end frame: nearly all pixels on the reference's level
+            check_quantised(u8(x.clamp(-1, 1)), u8(gold[name]["x"].clamp(-1, 1)), max_frac=2e-3)
+
+
+def test_rew_end_model_vs_golden(agent):
+    from diamond_amd.testing import synthetic_actions, synthetic_frames
+
+    gold = load_golden("rew_end.pt")
+    g = torch.Generator().manual_seed(gold["seed"])
+    obs = synthetic_frames(g, 2, 4, 3, 64, 64).to(DEV)
+    act = synthetic_actions(g, 4, 2, 4).to(DEV)
+    m = agent.rew_end_model
+    lr, le, (hx, cx) = m.predict_rew_end(obs[:, :-1], act[:, :-1], obs[:, 1:])
+    lr2, le2, (hx2, cx2) = m.predict_rew_end(obs[:, -1:], act[:, -1:], obs[:, :1], (hx, cx))
+    for mine, key in ((lr, "logits_rew"), (le, "logits_end"), (hx, "hx"), (cx, "cx"), (lr2, "logits_rew_step"),
+                      (le2, "logits_end_step"), (hx2, "hx_step"), (cx2, "cx_step")):
+        assert tuple(mine.shape) == tuple(gold[key].shape), key
+        assert rel_err(mine, gold[key]) < 1e-4, (key, rel_err(mine, gold[key]))
+
+
+def test_actor_critic_vs_golden(agent):
+    from diamond_amd.testing import synthetic_frames
+
+    gold = load_golden("actor_critic.pt")
+    ac = agent.actor_critic
+    g = torch.Generator().manual_seed(gold["seed"])
+    b = 3
+    obs = synthetic_frames(g, b, 3, 64, 64).to(DEV)
+    obs2 = synthetic_frames(g, b, 3, 64, 64).to(DEV)
+    hx = (torch.randn(b, 512, generator=g) * 0.3).to(DEV)
+    cx = (torch.randn(b, 512, generator=g) * 0.3).to(DEV)
+    ac.zero_grad()
+    o1 = ac.predict_act_value(obs, (hx, cx))
+    o2 = ac.predict_act_value(obs2, o1.hx_cx)
+    w = torch.randn(b, 4, generator=g).to(DEV)
+    loss = (o2.logits_act * w).sum() + o2.val.square().sum() + o1.val.sum() + 0.1 * o2.hx_cx[1].sum()
+    loss.backward()
+    for mine, key in ((o1.logits_act, "logits1"), (o1.val, "val1"), (o2.logits_act, "logits2"), (o2.val, "val2"),
+                      (o2.hx_cx[0], "hx2"), (o2.hx_cx[1], "cx2")):
+        assert rel_err(mine.detach(), gold[key]) < 1e-4, key
+    assert rel_err(loss.detach(), gold["loss"]) < 1e-4
+    for k, p in ac.named_parameters():
+        n = float(gold["grad_norms"][k])
+        assert abs(float(p.grad.norm()) - n) <= 2e-4 * n + 1e-6, k
+    for k, gr in gold["grads_small"].items():
+        assert rel_err(dict(ac.named_parameters())[k].grad, gr) < 2e-4, k
+
+
+class _Loader:
+    class _BS:
+        def __init__(self, b):
+            self.batch_size = b
+
+    def __init__(self, b, seed):
+        self.batch_sampler = self._BS(b)
+        self._b, self._seed = b, seed
+
+    def __iter__(self):
+        from types import SimpleNamespace
+        from diamond_amd.testing import initial_condition_batches
+
+        for obs, act in initial_condition_batches(self._seed, self._b, 4):
+            yield SimpleNamespace(obs=obs, act=act)
+
+
+def test_full_window_vs_reference_golden():
+    """ActorCritic.forward() + backward over two BPTT windows through WorldModelEnv /
+    env_loop with host-injected draws (reference RNG order): integer
+    trajectories bit-exact as long as the frames stay on the reference's uint8 levels."""
+    import random
+    import diamond_amd as D
+
+    gold = load_golden("window.pt")
+    ag = make_agent()
+    b, t = gold["b"], gold["backup_every"]
+    env = D.WorldModelEnv(ag.denoiser, ag.rew_end_model, _Loader(b, gold["pool_seed"]),
+                          D.WorldModelEnvConfig(horizon=gold["horizon"], num_batches_to_preload=gold["preload"],
+                                                diffusion_sampler=D.DiffusionSamplerConfig(num_steps_denoising=3)))
+    ag.setup_training(D.SigmaDistributionConfig(-0.4, 1.2, 2e-3, 20),
+                      D.ActorCriticLossConfig(backup_every=t, gamma=0.985, lambda_=0.95, weight_value_loss=1.0,
+                                              weight_entropy_loss=0.001), env)
+    torch.manual_seed(gold["rng_seed"])  # CPU default generator = the stream the reference consumed
+    random.seed(0)
+    expo = lambda logits: torch.empty(logits.shape, dtype=torch.float32).exponential_(1)
+    ag.actor_critic.expo_fn = expo
+    env.expo_fn = expo
+    env.sampler.noise_fn = lambda shape, dev: torch.randn(*shape).to(dev)
+    ac = ag.actor_critic
+    for w in gold["windows"]:
+        ac.zero_grad()
+        all_obs, act, rew, end, trunc, logits_act, val, vb, _ = ac.env_loop.send(t)
+        assert torch.equal(act.cpu(), w["act"]), "sampled actions differ from the reference"
+        assert torch.equal(end.cpu(), w["end"]) and torch.equal(trunc.cpu(), w["trunc"])
+        assert torch.equal(rew.cpu(), w["rew"])
+        check_quantised(u8(all_obs), w["obs_u8"], max_frac=2e-3)
+        assert rel_err(logits_act.detach(), w["logits_act"]) < 1e-2  # quantisation-flip noise, see oracle test
+        assert rel_err(val.detach(), w["val"]) < 1e-2
+        from diamond_amd.actor_critic import actor_critic_loss
+        loss, metrics = actor_critic_loss(logits_act, val, act, rew, end, trunc, vb, ac.loss_cfg)
+        assert rel_err(loss.detach(), w["loss"]) < 1e-2
+        loss.backward()
+        for k, p in ac.named_parameters():
+            n = float(w["grad_norms"][k])
+            assert abs(float(p.grad.norm()) - n) <= 2e-2 * n + 1e-6, k
