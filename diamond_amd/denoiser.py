@@ -75,7 +75,10 @@ class Denoiser(nn.Module):
         edm = self._edm()
         cpad = (cx + cobs + 15) // 16 * 16
         packed = torch.empty(n, h, w, cpad, device=self.device, dtype=torch.float32)
-        nv.check(nv.lib().dmd_edm_pack_input(nv.fptr(noisy_next_obs.contiguous()), nv.fptr(obs.contiguous()), nv.fptr(sig),
+        # NOTE: pointers are only taken from tensors bound to a name -- a temporary made inside the
+        # argument list would be freed (and its block re-used) before the kernel is even launched.
+        xc, oc = noisy_next_obs.contiguous(), obs.contiguous()
+        nv.check(nv.lib().dmd_edm_pack_input(nv.fptr(xc), nv.fptr(oc), nv.fptr(sig),
                                              stride, edm, nv.fptr(packed), n, cx, cobs, h, w, cpad, nv.stream()),
                  "dmd_edm_pack_input")
         cond = self.inner_model.cond_vector(sig, stride, act, edm)
@@ -87,8 +90,9 @@ class Denoiser(nn.Module):
         n = noisy_next_obs.shape[0]
         sig, stride = self._sigma_arg(sigma, n)
         x = noisy_next_obs.contiguous()
+        f = model_output.contiguous()
         out = torch.empty_like(x)
-        nv.check(nv.lib().dmd_edm_denoised(nv.fptr(x), nv.fptr(model_output.contiguous()), nv.fptr(sig), stride, self._edm(),
+        nv.check(nv.lib().dmd_edm_denoised(nv.fptr(x), nv.fptr(f), nv.fptr(sig), stride, self._edm(),
                                            nv.fptr(out), n, x[0].numel(), nv.stream()), "dmd_edm_denoised")
         return out
 

@@ -85,7 +85,8 @@ class DiffusionSampler:
 
     @staticmethod
     def _euler(x: Tensor, denoised: Tensor, sigma_hat: float, dt: float) -> Tensor:
+        x = x.contiguous()
         out = torch.empty_like(x)
-        nv.check(nv.lib().dmd_euler_step(nv.fptr(x.contiguous()), nv.fptr(denoised), sigma_hat, dt, nv.fptr(out), x.numel(),
+        nv.check(nv.lib().dmd_euler_step(nv.fptr(x), nv.fptr(denoised), sigma_hat, dt, nv.fptr(out), x.numel(),
                                          nv.stream()), "dmd_euler_step")
         return out

@@ -191,8 +191,9 @@ def gn_stats(t: Tensor) -> Act:
 def nchw_to_nhwc(x: Tensor, cpad: Optional[int] = None) -> Tensor:
     n, c, h, w = x.shape
     cp = cpad or c
+    x = x.contiguous()
     out = torch.empty(n, h, w, cp, device=x.device, dtype=torch.float32)
-    nv.check(nv.lib().dmd_nchw_to_nhwc(nv.fptr(x.contiguous()), nv.fptr(out), n, c, h, w, cp, nv.stream()), "dmd_nchw_to_nhwc")
+    nv.check(nv.lib().dmd_nchw_to_nhwc(nv.fptr(x), nv.fptr(out), n, c, h, w, cp, nv.stream()), "dmd_nchw_to_nhwc")
     return out
 
 

@@ -49,8 +49,10 @@ class InnerModel(nn.Module):
         emb = self.act_emb[0].weight
         half = self.noise_emb.weight.shape[1]
         x = torch.empty(n, 2 * half, device=act.device, dtype=torch.float32)
-        nv.check(nv.lib().dmd_cond_embed(nv.fptr(sigma), sigma_stride, edm, nv.fptr(self._cache.f32(self.noise_emb.weight)),
-                                         nv.ptr(act.contiguous()), nv.fptr(self._cache.f32(emb)), nv.fptr(x), n, half, t,
+        act = act.contiguous()
+        fw, ew = self._cache.f32(self.noise_emb.weight), self._cache.f32(emb)
+        nv.check(nv.lib().dmd_cond_embed(nv.fptr(sigma), sigma_stride, edm, nv.fptr(fw),
+                                         nv.ptr(act), nv.fptr(ew), nv.fptr(x), n, half, t,
                                          emb.shape[1], nv.stream()), "dmd_cond_embed")
         l0, l2 = self.cond_proj[0], self.cond_proj[2]
         y = E.linear(x, self._cache.f32(l0.weight), self._cache.f32(l0.bias), silu=True)

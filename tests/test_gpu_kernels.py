@@ -188,19 +188,20 @@ def test_edm_pointwise_bit_exact():
     obs = torch.rand(n, 12, h, w, generator=g) * 2 - 1
     spec = O.DenoiserSpec()
     edm = nv.EdmCfg(0.5, 0.3)
+    xd, fd, obsd = x.to(DEV), f.to(DEV), obs.to(DEV)  # keep device copies alive across the launches
     for sigma in (torch.tensor(5.0 - 1.4e-6), torch.tensor(0.28308), torch.tensor(0.002), torch.tensor([0.7, 1.9, 0.05])):
         c_in, c_out, c_skip, c_noise = O.conditioners(spec, sigma)
         sig = sigma.reshape(-1).to(DEV)
         stride = 0 if sig.numel() == 1 else 1
         # pack
         packed = torch.empty(n, h, w, 16, device=DEV)
-        nv.check(nv.lib().dmd_edm_pack_input(nv.fptr(x.to(DEV)), nv.fptr(obs.to(DEV)), nv.fptr(sig), stride, edm,
+        nv.check(nv.lib().dmd_edm_pack_input(nv.fptr(xd), nv.fptr(obsd), nv.fptr(sig), stride, edm,
                                              nv.fptr(packed), n, 3, 12, h, w, 16, nv.stream()), "pack")
         ref = torch.cat((obs / 0.5, x * c_in, torch.zeros(n, 1, h, w)), 1).permute(0, 2, 3, 1)
         assert torch.equal(packed.cpu(), ref), "edm_pack_input is not bit-exact"
         # denoised
         den = torch.empty(n, 3, h, w, device=DEV)
-        nv.check(nv.lib().dmd_edm_denoised(nv.fptr(x.to(DEV)), nv.fptr(f.to(DEV)), nv.fptr(sig), stride, edm, nv.fptr(den), n,
+        nv.check(nv.lib().dmd_edm_denoised(nv.fptr(xd), nv.fptr(fd), nv.fptr(sig), stride, edm, nv.fptr(den), n,
                                            3 * h * w, nv.stream()), "denoised")
         ref_d = O.quantize_frame(c_skip * x + c_out * f)
         assert torch.equal(den.cpu(), ref_d), "edm_denoised is not bit-exact"
@@ -209,7 +210,8 @@ def test_edm_pointwise_bit_exact():
     den = O.quantize_frame(torch.randn(n, 3, h, w, generator=g))
     out = torch.empty(n, 3, h, w, device=DEV)
     s, nx = sigmas[0], sigmas[1]
-    nv.check(nv.lib().dmd_euler_step(nv.fptr(x.to(DEV)), nv.fptr(den.to(DEV)), float(s), float(nx - s), nv.fptr(out),
+    dend = den.to(DEV)
+    nv.check(nv.lib().dmd_euler_step(nv.fptr(xd), nv.fptr(dend), float(s), float(nx - s), nv.fptr(out),
                                      x.numel(), nv.stream()), "euler")
     ref_x = x + (x - den) / s * (nx - s)
     assert torch.equal(out.cpu(), ref_x), "euler_step is not bit-exact"
@@ -228,8 +230,9 @@ def test_cond_embed():
     c_noise = O.conditioners(O.DenoiserSpec(), sigma)[3]
     ref = O.fourier_features(fw, c_noise) + F.embedding(act, emb).flatten(1)
     out = torch.empty(n, 256, device=DEV)
-    nv.check(nv.lib().dmd_cond_embed(nv.fptr(sigma.to(DEV)), 1, nv.EdmCfg(0.5, 0.3), nv.fptr(fw.to(DEV)), nv.ptr(act.to(DEV)),
-                                     nv.fptr(emb.to(DEV)), nv.fptr(out), n, 128, 4, 64, nv.stream()), "cond")
+    sd, fwd, actd, embd = sigma.to(DEV), fw.to(DEV), act.to(DEV), emb.to(DEV)
+    nv.check(nv.lib().dmd_cond_embed(nv.fptr(sd), 1, nv.EdmCfg(0.5, 0.3), nv.fptr(fwd), nv.ptr(actd),
+                                     nv.fptr(embd), nv.fptr(out), n, 128, 4, 64, nv.stream()), "cond")
     assert float((out.cpu() - ref).abs().max()) < 2e-6
 
 
@@ -242,8 +245,8 @@ def test_categorical_sample_bit_exact():
         logits = torch.randn(512, a, generator=g) * 2
         e = torch.empty(512, a).exponential_(1, generator=g)
         out = torch.empty(512, dtype=torch.long, device=DEV)
-        nv.check(nv.lib().dmd_categorical_sample(nv.fptr(logits.to(DEV)), nv.fptr(e.to(DEV)), nv.ptr(out), 512, a, nv.stream()),
-                 "cat")
+        ld, ed = logits.to(DEV), e.to(DEV)
+        nv.check(nv.lib().dmd_categorical_sample(nv.fptr(ld), nv.fptr(ed), nv.ptr(out), 512, a, nv.stream()), "cat")
         assert torch.equal(out.cpu(), O.categorical_sample(logits, e))
 
 
@@ -256,8 +259,8 @@ def test_maxpool_lstm_pointwise():
     out = torch.empty(2, 8, 8, 32, device=DEV)
     arg = torch.empty(2, 8, 8, 32, dtype=torch.uint8, device=DEV)
     stats = torch.empty(2, 1, 1, 2, dtype=torch.float64, device=DEV)
-    nv.check(nv.lib().dmd_maxpool2(nv.fptr(to_nhwc(x).to(DEV)), nv.fptr(out), nv.ptr(arg), nv.ptr(stats), 2, 16, 16, 32,
-                                   nv.stream()), "pool")
+    xd = to_nhwc(x).to(DEV)
+    nv.check(nv.lib().dmd_maxpool2(nv.fptr(xd), nv.fptr(out), nv.ptr(arg), nv.ptr(stats), 2, 16, 16, 32, nv.stream()), "pool")
     ref = F.max_pool2d(x, 2)
     assert torch.equal(out.cpu().permute(0, 3, 1, 2), ref)
     assert rel_err(stats.cpu()[:, 0, 0, 1], ref.double().square().sum((1, 2, 3))) < 1e-6
@@ -266,8 +269,8 @@ def test_maxpool_lstm_pointwise():
     c0 = torch.randn(7, 512, generator=g)
     h = torch.empty(7, 512, device=DEV)
     c = torch.empty(7, 512, device=DEV)
-    nv.check(nv.lib().dmd_lstm_pointwise(nv.fptr(gates.to(DEV)), nv.fptr(c0.to(DEV)), nv.fptr(h), nv.fptr(c), 7, 512,
-                                         nv.stream()), "lstm")
+    gd, cd = gates.to(DEV), c0.to(DEV)
+    nv.check(nv.lib().dmd_lstm_pointwise(nv.fptr(gd), nv.fptr(cd), nv.fptr(h), nv.fptr(c), 7, 512, nv.stream()), "lstm")
     i, f, gg, o = gates.double().chunk(4, 1)
     c_ref = torch.sigmoid(f) * c0.double() + torch.sigmoid(i) * torch.tanh(gg)
     h_ref = torch.sigmoid(o) * torch.tanh(c_ref)
