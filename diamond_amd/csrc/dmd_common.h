@@ -54,19 +54,3 @@ __device__ __forceinline__ double dmd_wave_sum(double v) {
   return v;
 }
 
-// EDM preconditioning scalars, op-for-op in fp32 like compute_conditioners (denoiser.py:66-72).
-struct DmdCond {
-  float c_in, c_out, c_skip, c_noise;
-};
-__device__ __forceinline__ DmdCond dmd_conditioners(float sigma, dmd_edm_cfg cfg) {
-  const float off2 = (float)(cfg.sigma_offset_noise * cfg.sigma_offset_noise);
-  const float sd2 = (float)(cfg.sigma_data * cfg.sigma_data);
-  const float s = sqrtf(sigma * sigma + off2);
-  const float den = s * s + sd2;
-  DmdCond c;
-  c.c_in = 1.0f / sqrtf(den);
-  c.c_skip = sd2 / den;
-  c.c_out = s * sqrtf(c.c_skip);
-  c.c_noise = logf(s) / 4.0f;
-  return c;
-}

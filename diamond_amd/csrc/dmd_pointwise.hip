@@ -10,14 +10,13 @@
 // One thread per pixel; NCHW reads are coalesced across threads (consecutive pixels), the
 // NHWC writes are CPad*4 = 64 contiguous bytes per thread.
 __global__ void edm_pack_input_kernel(const float* __restrict__ x, const float* __restrict__ obs,
-                                      const float* __restrict__ sigma, int sigma_stride, dmd_edm_cfg cfg,
+                                      const float* __restrict__ cond, int cond_stride, float sd,
                                       float* __restrict__ out, int N, int Cx, int Cobs, int HW, int CPad) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)N * HW) return;
   const int n = idx / HW;
   const int pix = idx - (size_t)n * HW;
-  const DmdCond c = dmd_conditioners(sigma[(size_t)n * sigma_stride], cfg);
-  const float sd = (float)cfg.sigma_data;
+  const float c_in = cond[(size_t)n * cond_stride + 0];
   float* o = out + idx * CPad;
   for (int ch = 0; ch < CPad; ch += 4) {
     f32x4 v;
@@ -28,7 +27,7 @@ __global__ void edm_pack_input_kernel(const float* __restrict__ x, const float* 
       if (cc < Cobs)
         t = obs[((size_t)n * Cobs + cc) * HW + pix] / sd;  // rescaled_obs = obs / sigma_data, denoiser.py:75
       else if (cc < Cobs + Cx)
-        t = x[((size_t)n * Cx + (cc - Cobs)) * HW + pix] * c.c_in;  // denoiser.py:76
+        t = x[((size_t)n * Cx + (cc - Cobs)) * HW + pix] * c_in;  // denoiser.py:76
       v[e] = t;
     }
     *(f32x4*)(o + ch) = v;
@@ -36,16 +35,16 @@ __global__ void edm_pack_input_kernel(const float* __restrict__ x, const float* 
 }
 
 // ---- cond input: [cos(f) | sin(f)] + flatten(Embedding(act)),  f = 2 pi c_noise w -----------
-__global__ void cond_embed_kernel(const float* __restrict__ sigma, int sigma_stride, dmd_edm_cfg cfg,
+__global__ void cond_embed_kernel(const float* __restrict__ cond, int cond_stride,
                                   const float* __restrict__ fw, const int64_t* __restrict__ act,
                                   const float* __restrict__ emb, float* __restrict__ out, int N, int half, int T, int E) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int D = 2 * half;
   if (idx >= N * D) return;
   const int n = idx / D, jj = idx - n * D;
-  const DmdCond c = dmd_conditioners(sigma[(size_t)n * sigma_stride], cfg);
+  const float c_noise = cond[(size_t)n * cond_stride + 3];
   // blocks.py:86: f = 2 * math.pi * input.unsqueeze(1) @ weight   (left to right: (2 pi c) * w)
-  const float two_pi_c = (float)(2.0 * 3.141592653589793) * c.c_noise;
+  const float two_pi_c = (float)(2.0 * 3.141592653589793) * c_noise;
   const int k = jj < half ? jj : jj - half;
   const float f = two_pi_c * fw[k];
   float v = jj < half ? cosf(f) : sinf(f);
@@ -65,14 +64,14 @@ __device__ __forceinline__ float dmd_quantise(float d) {
 }
 
 __global__ void edm_denoised_kernel(const float* __restrict__ x, const float* __restrict__ f,
-                                    const float* __restrict__ sigma, int sigma_stride, dmd_edm_cfg cfg,
+                                    const float* __restrict__ cond, int cond_stride,
                                     float* __restrict__ den, int N, int64_t per_sample) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)N * per_sample) return;
   const int n = idx / per_sample;
-  const DmdCond c = dmd_conditioners(sigma[(size_t)n * sigma_stride], cfg);
-  const float a = c.c_skip * x[idx];
-  const float b = c.c_out * f[idx];
+  const float c_out = cond[(size_t)n * cond_stride + 1], c_skip = cond[(size_t)n * cond_stride + 2];
+  const float a = c_skip * x[idx];
+  const float b = c_out * f[idx];
   den[idx] = dmd_quantise(a + b);
 }
 
@@ -230,31 +229,31 @@ __global__ void categorical_sample_kernel(const float* __restrict__ logits, cons
 // ------------------------------------------------------------------------------------------------
 static inline unsigned nblk(size_t n, int b) { return (unsigned)((n + b - 1) / b); }
 
-extern "C" int dmd_edm_pack_input(const float* x, const float* obs, const float* sigma, int sigma_stride, dmd_edm_cfg cfg,
+extern "C" int dmd_edm_pack_input(const float* x, const float* obs, const float* cond, int cond_stride, float sigma_data,
                                   float* out, int N, int Cx, int Cobs, int H, int W, int CPad, dmd_stream_t stream) {
-  DMD_CHECK_ARG(x && obs && sigma && out, "edm_pack_input: null");
+  DMD_CHECK_ARG(x && obs && cond && out, "edm_pack_input: null");
   DMD_CHECK_ARG(CPad % 4 == 0 && CPad >= Cx + Cobs, "edm_pack_input: CPad");
   hipLaunchKernelGGL(edm_pack_input_kernel, dim3(nblk((size_t)N * H * W, 256)), dim3(256), 0, (hipStream_t)stream, x, obs,
-                     sigma, sigma_stride, cfg, out, N, Cx, Cobs, H * W, CPad);
+                     cond, cond_stride, sigma_data, out, N, Cx, Cobs, H * W, CPad);
   DMD_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int dmd_cond_embed(const float* sigma, int sigma_stride, dmd_edm_cfg cfg, const float* fw, const int64_t* act,
+extern "C" int dmd_cond_embed(const float* cond, int cond_stride, const float* fw, const int64_t* act,
                               const float* emb, float* out, int N, int half, int T, int E, dmd_stream_t stream) {
-  DMD_CHECK_ARG(sigma && fw && act && emb && out, "cond_embed: null");
+  DMD_CHECK_ARG(cond && fw && act && emb && out, "cond_embed: null");
   DMD_CHECK_ARG(T * E == 2 * half, "cond_embed: T*E (%d) != cond channels (%d)", T * E, 2 * half);
-  hipLaunchKernelGGL(cond_embed_kernel, dim3(nblk((size_t)N * 2 * half, 256)), dim3(256), 0, (hipStream_t)stream, sigma,
-                     sigma_stride, cfg, fw, act, emb, out, N, half, T, E);
+  hipLaunchKernelGGL(cond_embed_kernel, dim3(nblk((size_t)N * 2 * half, 256)), dim3(256), 0, (hipStream_t)stream, cond,
+                     cond_stride, fw, act, emb, out, N, half, T, E);
   DMD_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int dmd_edm_denoised(const float* x, const float* f, const float* sigma, int sigma_stride, dmd_edm_cfg cfg,
+extern "C" int dmd_edm_denoised(const float* x, const float* f, const float* cond, int cond_stride,
                                 float* den, int N, int64_t per_sample, dmd_stream_t stream) {
-  DMD_CHECK_ARG(x && f && sigma && den, "edm_denoised: null");
+  DMD_CHECK_ARG(x && f && cond && den, "edm_denoised: null");
   hipLaunchKernelGGL(edm_denoised_kernel, dim3(nblk((size_t)N * per_sample, 256)), dim3(256), 0, (hipStream_t)stream, x, f,
-                     sigma, sigma_stride, cfg, den, N, per_sample);
+                     cond, cond_stride, den, N, per_sample);
   DMD_LAUNCH_CHECK();
   return 0;
 }

@@ -37,6 +37,7 @@ class Denoiser(nn.Module):
         self.cfg = cfg
         self.inner_model = InnerModel(cfg.inner_model)
         self.sample_sigma_training = None
+        self._cond_cache = {}  # float sigma -> (1, 4) device conditioners
 
     @property
     def device(self) -> torch.device:
@@ -51,49 +52,65 @@ class Denoiser(nn.Module):
 
         self.sample_sigma_training = sample_sigma
 
-    def _edm(self) -> nv.EdmCfg:
-        return nv.EdmCfg(float(self.cfg.sigma_data), float(self.cfg.sigma_offset_noise))
+    @torch.no_grad()
+    def compute_conditioners(self, sigma: Union[Tensor, float]) -> Tuple[Tensor, int]:
+        """(c_in, c_out, c_skip, c_noise) of reference denoiser.py:66-72 as a device array
+        cond[n * stride + k], stride 0 (one sigma for the batch) or 4 (one sigma per sample).
 
-    def _sigma_arg(self, sigma: Union[Tensor, float], n: int) -> Tuple[Tensor, int]:
+        Four scalars per sample: evaluated on the HOST with the reference's own fp32 torch-CPU
+        op order, so all four are the CPU reference's values bit for bit (device sqrt/log/div are
+        not guaranteed to round like the host's); the kernels only multiply by them.  Scalar sigmas
+        (the sampler's whole schedule) are cached on the device: no host<->device traffic per
+        denoising step, and the launch sequence stays graph-capturable."""
+        key = None
         if not torch.is_tensor(sigma):
             sigma = torch.tensor(float(sigma), dtype=torch.float32)
-        sigma = sigma.to(device=self.device, dtype=torch.float32)
-        if sigma.numel() == 1:
-            return sigma.reshape(1).contiguous(), 0
-        assert sigma.numel() == n, "sigma must be a scalar or one value per sample"
-        return sigma.reshape(n).contiguous(), 1
+        if sigma.numel() == 1 and not sigma.is_cuda:
+            key = float(sigma)
+            hit = self._cond_cache.get(key)
+            if hit is not None and hit.device == self.device:
+                return hit, 0
+        s = sigma.detach().to(device="cpu", dtype=torch.float32).reshape(-1)  # sync only for device sigmas
+        s = (s ** 2 + self.cfg.sigma_offset_noise ** 2).sqrt()
+        c_in = 1 / (s ** 2 + self.cfg.sigma_data ** 2).sqrt()
+        c_skip = self.cfg.sigma_data ** 2 / (s ** 2 + self.cfg.sigma_data ** 2)
+        c_out = s * c_skip.sqrt()
+        c_noise = s.log() / 4
+        cond = torch.stack((c_in, c_out, c_skip, c_noise), dim=1).contiguous().to(self.device)
+        if key is not None:
+            if len(self._cond_cache) > 4096:
+                self._cond_cache.clear()
+            self._cond_cache[key] = cond
+        return cond, (0 if cond.shape[0] == 1 else 4)
 
     @torch.no_grad()
     def compute_model_output(self, noisy_next_obs: Tensor, obs: Tensor, act: Tensor, sigma: Union[Tensor, float],
                              naive: Optional[bool] = None) -> Tensor:
-        """F = inner_model(x * c_in, c_noise, obs / sigma_data, act)  (reference :74-77).
-        Takes sigma instead of the reference's Conditioners: the conditioners are computed
-        on the device from sigma, in fp32 with the reference's op order."""
+        """F = inner_model(x * c_in, c_noise, obs / sigma_data, act)  (reference :74-77)."""
         n, cx, h, w = noisy_next_obs.shape
         cobs = obs.shape[1]
-        sig, stride = self._sigma_arg(sigma, n)
-        edm = self._edm()
+        cond, stride = self.compute_conditioners(sigma)
+        assert stride == 0 or cond.shape[0] == n, "sigma must be a scalar or one value per sample"
         cpad = (cx + cobs + 15) // 16 * 16
         packed = torch.empty(n, h, w, cpad, device=self.device, dtype=torch.float32)
         # NOTE: pointers are only taken from tensors bound to a name -- a temporary made inside the
         # argument list would be freed (and its block re-used) before the kernel is even launched.
         xc, oc = noisy_next_obs.contiguous(), obs.contiguous()
-        nv.check(nv.lib().dmd_edm_pack_input(nv.fptr(xc), nv.fptr(oc), nv.fptr(sig),
-                                             stride, edm, nv.fptr(packed), n, cx, cobs, h, w, cpad, nv.stream()),
-                 "dmd_edm_pack_input")
-        cond = self.inner_model.cond_vector(sig, stride, act, edm)
-        return self.inner_model.run(packed, cond, naive)
+        nv.check(nv.lib().dmd_edm_pack_input(nv.fptr(xc), nv.fptr(oc), nv.fptr(cond), stride, float(self.cfg.sigma_data),
+                                             nv.fptr(packed), n, cx, cobs, h, w, cpad, nv.stream()), "dmd_edm_pack_input")
+        cvec = self.inner_model.cond_vector(cond, stride, act)
+        return self.inner_model.run(packed, cvec, naive)
 
     @torch.no_grad()
     def wrap_model_output(self, noisy_next_obs: Tensor, model_output: Tensor, sigma: Union[Tensor, float]) -> Tensor:
         """quantise(c_skip * x + c_out * F)  (reference :79-84)."""
         n = noisy_next_obs.shape[0]
-        sig, stride = self._sigma_arg(sigma, n)
+        cond, stride = self.compute_conditioners(sigma)
         x = noisy_next_obs.contiguous()
         f = model_output.contiguous()
         out = torch.empty_like(x)
-        nv.check(nv.lib().dmd_edm_denoised(nv.fptr(x), nv.fptr(f), nv.fptr(sig), stride, self._edm(),
-                                           nv.fptr(out), n, x[0].numel(), nv.stream()), "dmd_edm_denoised")
+        nv.check(nv.lib().dmd_edm_denoised(nv.fptr(x), nv.fptr(f), nv.fptr(cond), stride, nv.fptr(out), n, x[0].numel(),
+                                           nv.stream()), "dmd_edm_denoised")
         return out
 
     @torch.no_grad()

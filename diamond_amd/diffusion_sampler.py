@@ -75,8 +75,9 @@ class DiffusionSampler:
                 x = self._euler(x, denoised, float(sigma_hat), float(dt))
             else:
                 x_2 = self._euler(x, denoised, float(sigma_hat), float(dt))
-                s_in = torch.ones(b, device=device) * float(next_sigma)
-                denoised_2 = self.denoiser.denoise(x_2, s_in, obs, prev_act)
+                # the reference passes next_sigma as a (B,) tensor of equal values (:53); one scalar
+                # yields the same per-sample conditioners without a per-sample array
+                denoised_2 = self.denoiser.denoise(x_2, next_sigma, obs, prev_act)
                 d = (x - denoised) / float(sigma_hat)
                 d_2 = (x_2 - denoised_2) / float(next_sigma)
                 x = x + (d + d_2) / 2 * float(dt)

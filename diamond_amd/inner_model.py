@@ -42,18 +42,17 @@ class InnerModel(nn.Module):
         self._film: Optional[FilmTable] = None
 
     # -- native pieces -------------------------------------------------------------------
-    def cond_vector(self, sigma: Tensor, sigma_stride: int, act: Tensor, edm: nv.EdmCfg) -> Tensor:
-        """cond_proj(noise_emb(c_noise(sigma)) + act_emb(act))  (reference :45); c_noise is
-        derived from sigma on the device (denoiser.py:66-72)."""
+    def cond_vector(self, cond: Tensor, cond_stride: int, act: Tensor) -> Tensor:
+        """cond_proj(noise_emb(c_noise) + act_emb(act))  (reference :45); c_noise is entry 3 of
+        the per-sample conditioner array (Denoiser.compute_conditioners)."""
         n, t = act.shape
         emb = self.act_emb[0].weight
         half = self.noise_emb.weight.shape[1]
         x = torch.empty(n, 2 * half, device=act.device, dtype=torch.float32)
         act = act.contiguous()
         fw, ew = self._cache.f32(self.noise_emb.weight), self._cache.f32(emb)
-        nv.check(nv.lib().dmd_cond_embed(nv.fptr(sigma), sigma_stride, edm, nv.fptr(fw),
-                                         nv.ptr(act), nv.fptr(ew), nv.fptr(x), n, half, t,
-                                         emb.shape[1], nv.stream()), "dmd_cond_embed")
+        nv.check(nv.lib().dmd_cond_embed(nv.fptr(cond), cond_stride, nv.fptr(fw), nv.ptr(act), nv.fptr(ew), nv.fptr(x), n,
+                                         half, t, emb.shape[1], nv.stream()), "dmd_cond_embed")
         l0, l2 = self.cond_proj[0], self.cond_proj[2]
         y = E.linear(x, self._cache.f32(l0.weight), self._cache.f32(l0.bias), silu=True)
         return E.linear(y, self._cache.f32(l2.weight), self._cache.f32(l2.bias))

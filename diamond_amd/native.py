@@ -48,10 +48,6 @@ class LinearParams(C.Structure):
                 ("accumulate", C.c_int32), ("silu", C.c_int32)]
 
 
-class EdmCfg(C.Structure):
-    _fields_ = [("sigma_data", C.c_double), ("sigma_offset_noise", C.c_double)]
-
-
 EXPORTS = (
     "dmd_conv2d", "dmd_conv2d_naive", "dmd_conv_stat_tiles", "dmd_pack_conv_weight", "dmd_linear", "dmd_attention",
     "dmd_edm_pack_input", "dmd_cond_embed", "dmd_edm_denoised", "dmd_euler_step", "dmd_nchw_to_nhwc",
@@ -78,11 +74,11 @@ def lib() -> C.CDLL:
         L.dmd_linear.argtypes = [C.POINTER(LinearParams), C.c_void_p]
         L.dmd_pack_conv_weight.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.dmd_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-        L.dmd_edm_pack_input.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, EdmCfg, C.c_void_p, C.c_int, C.c_int,
+        L.dmd_edm_pack_input.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-        L.dmd_cond_embed.argtypes = [C.c_void_p, C.c_int, EdmCfg, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+        L.dmd_cond_embed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.c_int, C.c_int, C.c_int, C.c_void_p]
-        L.dmd_edm_denoised.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, EdmCfg, C.c_void_p, C.c_int, C.c_int64,
+        L.dmd_edm_denoised.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64,
                                        C.c_void_p]
         L.dmd_euler_step.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]
         L.dmd_nchw_to_nhwc.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]

@@ -103,23 +103,22 @@ int dmd_linear(const dmd_linear_params* p, dmd_stream_t stream);
  * thirds, head h = channels [h*d, (h+1)*d) of each third (blocks.py:66-71).  d == 8. */
 int dmd_attention(const float* qkv, float* out, int N, int T, int C, int head_dim, dmd_stream_t stream);
 
-/* ---- EDM preconditioning / sampler pointwise (denoiser.py:66-84, diffusion_sampler.py:45-56) ---- */
-typedef struct dmd_edm_cfg {
-  double sigma_data;         /* 0.5  (python floats in the reference: squared in double, */
-  double sigma_offset_noise; /* 0.3   then cast to fp32 when they meet a tensor)         */
-} dmd_edm_cfg;
+/* ---- EDM preconditioning / sampler pointwise (denoiser.py:74-84, diffusion_sampler.py:45-56) ---- */
+/* The four EDM conditioners (c_in, c_out, c_skip, c_noise; compute_conditioners denoiser.py:66-72)
+ * are four scalars per sample: the host evaluates them with the reference's own fp32 op order
+ * (bit-exact; v_sqrt_f32 is not correctly rounded) and hands them over as a device array
+ * cond[n * cond_stride + {0: c_in, 1: c_out, 2: c_skip, 3: c_noise}], cond_stride in {0, 4}. */
 
-/* cat(obs / sigma_data, x * c_in(sigma)) -> NHWC with CPad channels (zero padded).
- * x (N, Cx, H, W), obs (N, Cobs, H, W) NCHW.  sigma: device pointer (per-sample, stride
- * sigma_stride in {0,1}). */
-int dmd_edm_pack_input(const float* x, const float* obs, const float* sigma, int sigma_stride, dmd_edm_cfg cfg,
+/* cat(obs / sigma_data, x * c_in) -> NHWC with CPad channels (zero padded).
+ * x (N, Cx, H, W), obs (N, Cobs, H, W) NCHW. */
+int dmd_edm_pack_input(const float* x, const float* obs, const float* cond, int cond_stride, float sigma_data,
                        float* out_nhwc, int N, int Cx, int Cobs, int H, int W, int CPad, dmd_stream_t stream);
-/* cond input: fourier(c_noise(sigma)) + flatten(embedding(act))  (blocks.py:84-87, inner_model.py:27-30,45) */
-int dmd_cond_embed(const float* sigma, int sigma_stride, dmd_edm_cfg cfg, const float* fourier_w /*[half]*/,
+/* cond input: fourier(c_noise) + flatten(embedding(act))  (blocks.py:84-87, inner_model.py:27-30,45) */
+int dmd_cond_embed(const float* cond, int cond_stride, const float* fourier_w /*[half]*/,
                    const int64_t* act /*(N, T)*/, const float* act_emb /*(A, E)*/, float* out /*(N, 2*half)*/, int N,
                    int half, int T, int E, dmd_stream_t stream);
 /* denoised = quantise(c_skip * x + c_out * F)  (denoiser.py:81-83); all NCHW, elementwise */
-int dmd_edm_denoised(const float* x, const float* model_out, const float* sigma, int sigma_stride, dmd_edm_cfg cfg,
+int dmd_edm_denoised(const float* x, const float* model_out, const float* cond, int cond_stride,
                      float* denoised, int N, int64_t per_sample, dmd_stream_t stream);
 /* x_out = x + ((x - denoised) / sigma_hat) * dt   (diffusion_sampler.py:45-49) */
 int dmd_euler_step(const float* x, const float* denoised, float sigma_hat, float dt, float* x_out, int64_t n,

@@ -187,21 +187,21 @@ def test_edm_pointwise_bit_exact():
     f = torch.randn(n, 3, h, w, generator=g)
     obs = torch.rand(n, 12, h, w, generator=g) * 2 - 1
     spec = O.DenoiserSpec()
-    edm = nv.EdmCfg(0.5, 0.3)
     xd, fd, obsd = x.to(DEV), f.to(DEV), obs.to(DEV)  # keep device copies alive across the launches
     for sigma in (torch.tensor(5.0 - 1.4e-6), torch.tensor(0.28308), torch.tensor(0.002), torch.tensor([0.7, 1.9, 0.05])):
         c_in, c_out, c_skip, c_noise = O.conditioners(spec, sigma)
-        sig = sigma.reshape(-1).to(DEV)
-        stride = 0 if sig.numel() == 1 else 1
+        # the host evaluates the conditioners (Denoiser.compute_conditioners); the kernels only apply them
+        cond = torch.stack([c.reshape(-1) for c in (c_in, c_out, c_skip, c_noise)], dim=1).contiguous().to(DEV)
+        stride = 0 if cond.shape[0] == 1 else 4
         # pack
         packed = torch.empty(n, h, w, 16, device=DEV)
-        nv.check(nv.lib().dmd_edm_pack_input(nv.fptr(xd), nv.fptr(obsd), nv.fptr(sig), stride, edm,
+        nv.check(nv.lib().dmd_edm_pack_input(nv.fptr(xd), nv.fptr(obsd), nv.fptr(cond), stride, 0.5,
                                              nv.fptr(packed), n, 3, 12, h, w, 16, nv.stream()), "pack")
         ref = torch.cat((obs / 0.5, x * c_in, torch.zeros(n, 1, h, w)), 1).permute(0, 2, 3, 1)
         assert torch.equal(packed.cpu(), ref), "edm_pack_input is not bit-exact"
         # denoised
         den = torch.empty(n, 3, h, w, device=DEV)
-        nv.check(nv.lib().dmd_edm_denoised(nv.fptr(xd), nv.fptr(fd), nv.fptr(sig), stride, edm, nv.fptr(den), n,
+        nv.check(nv.lib().dmd_edm_denoised(nv.fptr(xd), nv.fptr(fd), nv.fptr(cond), stride, nv.fptr(den), n,
                                            3 * h * w, nv.stream()), "denoised")
         ref_d = O.quantize_frame(c_skip * x + c_out * f)
         assert torch.equal(den.cpu(), ref_d), "edm_denoised is not bit-exact"
@@ -230,8 +230,10 @@ def test_cond_embed():
     c_noise = O.conditioners(O.DenoiserSpec(), sigma)[3]
     ref = O.fourier_features(fw, c_noise) + F.embedding(act, emb).flatten(1)
     out = torch.empty(n, 256, device=DEV)
-    sd, fwd, actd, embd = sigma.to(DEV), fw.to(DEV), act.to(DEV), emb.to(DEV)
-    nv.check(nv.lib().dmd_cond_embed(nv.fptr(sd), 1, nv.EdmCfg(0.5, 0.3), nv.fptr(fwd), nv.ptr(actd),
+    cond = torch.zeros(n, 4)
+    cond[:, 3] = c_noise
+    cd, fwd, actd, embd = cond.to(DEV), fw.to(DEV), act.to(DEV), emb.to(DEV)
+    nv.check(nv.lib().dmd_cond_embed(nv.fptr(cd), 4, nv.fptr(fwd), nv.ptr(actd),
                                      nv.fptr(embd), nv.fptr(out), n, 128, 4, 64, nv.stream()), "cond")
     assert float((out.cpu() - ref).abs().max()) < 2e-6
 
