@@ -1,0 +1,191 @@
+"""Actor-critic conv encoder on hand-written HIP kernels, forward AND backward
+(reference models/actor_critic.py:101-113 `ActorCriticEncoder`, blocks.py:116-123 `SmallResBlock`).
+
+One `torch.autograd.Function` spans the whole encoder: Conv3x3 -> n x [skip(x) +
+Conv3x3(SiLU(GroupNorm(x))), MaxPool2] -> flatten.  The forward saves only the block inputs
+(with their GroupNorm statistics) and the pooling argmax; the backward recomputes the
+activations inside the wgrad kernel's staging pass.  Kernel map:
+
+  forward   dmd_conv2d (GN+SiLU prologue, bias + residual epilogue), dmd_maxpool2 (+ stats of the
+            pooled tensor for the next GroupNorm)
+  backward  dmd_maxpool2_bwd -> dmd_conv2d_wgrad (dW, db) -> dmd_conv2d on the flipped/transposed
+            weight (dgrad) -> dmd_gn_silu_bwd (dx, dgamma, dbeta; adds the skip-branch gradient)
+
+The LSTM cell and the two heads downstream are plain GEMMs + gate pointwise ops and run as
+torch ops (rocBLAS/hipBLASLt) under ordinary autograd.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import engine as E
+from . import native as nv
+from .engine import Act, NormSpec
+
+
+def _maxpool(y: Tensor) -> Tuple[Act, Tensor]:
+    n, h, w, c = y.shape
+    out = torch.empty(n, h // 2, w // 2, c, device=y.device, dtype=torch.float32)
+    arg = torch.empty(n, h // 2, w // 2, c, device=y.device, dtype=torch.uint8)
+    stats = E.new_stats(n, c, 1, y.device) if c % nv.GN_GROUP == 0 else None
+    nv.check(nv.lib().dmd_maxpool2(nv.fptr(y), nv.fptr(out), nv.ptr(arg), nv.ptr(stats), n, h, w, c, nv.stream()), "dmd_maxpool2")
+    return Act(out, stats, 1 if stats is not None else 0), arg
+
+
+def _maxpool_bwd(dp: Tensor, arg: Tensor) -> Tensor:
+    n, ho, wo, c = dp.shape
+    dx = torch.empty(n, ho * 2, wo * 2, c, device=dp.device, dtype=torch.float32)
+    nv.check(nv.lib().dmd_maxpool2_bwd(nv.fptr(dp), nv.ptr(arg), nv.fptr(dx), n, ho * 2, wo * 2, c, nv.stream()), "dmd_maxpool2_bwd")
+    return dx
+
+
+def _wgrad(x: Act, prologue: int, spec: Optional[NormSpec], dy: Tensor, taps: int, cin_real: int,
+           want_bias: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
+    n, h, w, cout = dy.shape
+    k = 3 if taps == 9 else 1
+    p = nv.WgradParams()
+    p.N, p.H, p.W, p.Cout, p.taps, p.cin_real = n, h, w, cout, taps, cin_real
+    assert x.t.is_contiguous() and dy.is_contiguous() and tuple(x.shape[:3]) == (n, h, w)
+    p.src.x = nv.ptr(x.t)
+    p.src.C = x.C
+    p.src.prologue = prologue
+    if prologue != nv.PROLOGUE_NONE:
+        p.src.norm = spec.to_native(x)
+    p.dy = nv.ptr(dy)
+    ws = torch.empty(int(nv.lib().dmd_wgrad_workspace_floats(C.byref(p))), device=dy.device, dtype=torch.float32)
+    dw = torch.empty(cout, cin_real, k, k, device=dy.device, dtype=torch.float32)
+    db = torch.empty(cout, device=dy.device, dtype=torch.float32) if want_bias else None
+    p.workspace, p.dw, p.dbias = nv.ptr(ws), nv.ptr(dw), nv.ptr(db)
+    nv.check(nv.lib().dmd_conv2d_wgrad(C.byref(p), nv.stream()), "dmd_conv2d_wgrad")
+    return dw, db
+
+
+def _gn_silu_bwd(x: Act, spec: NormSpec, da: Tensor, dskip: Optional[Tensor]) -> Tuple[Tensor, Tensor, Tensor]:
+    n, h, w, c = x.shape
+    p = nv.GnBwdParams()
+    p.N, p.HW, p.C = n, h * w, c
+    p.x = nv.ptr(x.t)
+    p.norm = spec.to_native(x)
+    p.da = nv.fptr(da)
+    p.dskip = nv.fptr(dskip)
+    dx = torch.empty_like(x.t)
+    ws = torch.empty(int(nv.lib().dmd_gn_bwd_workspace_bytes(n, h * w, c)), device=da.device, dtype=torch.uint8)
+    dmul = torch.empty(n, c, device=da.device, dtype=torch.float32)
+    dadd = torch.empty(n, c, device=da.device, dtype=torch.float32)
+    p.dx, p.workspace, p.dmul, p.dadd = nv.ptr(dx), nv.ptr(ws), nv.ptr(dmul), nv.ptr(dadd)
+    nv.check(nv.lib().dmd_gn_silu_bwd(C.byref(p), nv.stream()), "dmd_gn_silu_bwd")
+    return dx, dmul, dadd
+
+
+def _dgrad_weight(cache: E.PackCache, conv: nn.Conv2d) -> Tensor:
+    """Packed weight of the transposed convolution: w_t[ci][co][ky][kx] = w[co][ci][2-ky][2-kx]."""
+    return cache.get(conv.weight, "dgradw", lambda w: nv.pack_conv_weight(w.detach().flip(2, 3).transpose(0, 1).contiguous()))
+
+
+class _Plan:
+    """Static description of an ActorCriticEncoder: the layer list + the flat parameter order of
+    the autograd.Function."""
+
+    def __init__(self, encoder_seq: nn.Sequential) -> None:
+        from .blocks import SmallResBlock
+
+        layers = list(encoder_seq)
+        assert isinstance(layers[0], nn.Conv2d), "encoder must start with Conv3x3 (actor_critic.py:105)"
+        self.conv_in: nn.Conv2d = layers[0]
+        self.blocks: List[Tuple[SmallResBlock, bool]] = []
+        i = 1
+        while i < len(layers):
+            blk = layers[i]
+            assert isinstance(blk, SmallResBlock), type(blk)
+            pool = i + 1 < len(layers) and isinstance(layers[i + 1], nn.MaxPool2d)
+            self.blocks.append((blk, pool))
+            i += 2 if pool else 1
+        self.params: List[nn.Parameter] = [self.conv_in.weight, self.conv_in.bias]
+        for blk, _ in self.blocks:
+            gn, conv = blk.f[0].norm, blk.f[2]
+            self.params += [gn.weight, gn.bias, conv.weight, conv.bias]
+            if not isinstance(blk.skip_projection, nn.Identity):
+                self.params += [blk.skip_projection.weight, blk.skip_projection.bias]
+
+
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan: _Plan, cache: E.PackCache, obs: Tensor, *params: Tensor) -> Tensor:
+        n, cimg = obs.shape[:2]
+        x16 = E.nchw_to_nhwc(obs.detach().float(), 16)
+        ci = plan.conv_in
+        x = E.conv2d([(Act(x16), nv.PROLOGUE_NONE, None)], cache.conv_weight(ci), cache.conv_bias(ci), ci.out_channels)
+        saved = []
+        for blk, pool in plan.blocks:
+            gn, conv = blk.f[0].norm, blk.f[2]
+            spec = NormSpec(mul=cache.f32(gn.weight), add=cache.f32(gn.bias))
+            sp = blk.skip_projection
+            if isinstance(sp, nn.Identity):
+                r = x
+            else:
+                r = E.conv2d([(x, nv.PROLOGUE_NONE, None)], cache.conv_weight(sp), cache.conv_bias(sp), sp.out_channels, taps=1,
+                             want_stats=False)
+            y = E.conv2d([(x, nv.PROLOGUE_NORM_SILU, spec)], cache.conv_weight(conv), cache.conv_bias(conv), conv.out_channels,
+                         residual=r, want_stats=not pool)
+            arg = None
+            nxt = y
+            if pool:
+                nxt, arg = _maxpool(y.t)
+            saved.append((x, arg))
+            x = nxt
+        ctx.plan, ctx.cache, ctx.x16, ctx.saved = plan, cache, x16, saved
+        ctx.cimg = cimg
+        # flatten in the reference's (c, h, w) order (actor_critic.py:71)
+        return E.nhwc_to_nchw(x.t).flatten(1)
+
+    @staticmethod
+    def backward(ctx, dfeat: Tensor):
+        plan, cache = ctx.plan, ctx.cache
+        last_x, _ = ctx.saved[-1]
+        blk_last, pool_last = plan.blocks[-1]
+        cl = blk_last.f[2].out_channels
+        hl = last_x.shape[1] // (2 if pool_last else 1)
+        n = dfeat.shape[0]
+        dcur = E.nchw_to_nhwc(dfeat.detach().float().reshape(n, cl, hl, hl).contiguous())
+        grads_rev: List[Optional[Tensor]] = []
+        for (blk, pool), (x, arg) in zip(reversed(plan.blocks), reversed(ctx.saved)):
+            gn, conv = blk.f[0].norm, blk.f[2]
+            spec = NormSpec(mul=cache.f32(gn.weight), add=cache.f32(gn.bias))
+            dy = _maxpool_bwd(dcur, arg) if pool else dcur
+            dw, db = _wgrad(x, nv.PROLOGUE_NORM_SILU, spec, dy, 9, conv.in_channels)
+            da = E.conv2d([(Act(dy), nv.PROLOGUE_NONE, None)], _dgrad_weight(cache, conv), None, conv.in_channels,
+                          want_stats=False).t
+            sp = blk.skip_projection
+            g_skip: List[Optional[Tensor]] = []
+            if isinstance(sp, nn.Identity):
+                dskip = dy
+            else:
+                dws, dbs = _wgrad(x, nv.PROLOGUE_NONE, None, dy, 1, sp.in_channels)
+                dskip = E.conv2d([(Act(dy), nv.PROLOGUE_NONE, None)], _dgrad_weight(cache, sp), None, sp.in_channels, taps=1,
+                                 want_stats=False).t
+                g_skip = [dws, dbs]
+            dx, dmul, dadd = _gn_silu_bwd(x, spec, da, dskip)
+            # reversed order of [gn.weight, gn.bias, conv.weight, conv.bias, (skip.weight, skip.bias)]
+            grads_rev += list(reversed([dmul.sum(0), dadd.sum(0), dw, db] + g_skip))
+            dcur = dx
+        ci = plan.conv_in
+        dw_in, db_in = _wgrad(Act(ctx.x16), nv.PROLOGUE_NONE, None, dcur, 9, ctx.cimg)
+        grads = [dw_in, db_in] + list(reversed(grads_rev))
+        return (None, None, None, *grads)
+
+
+class NativeEncoder:
+    """Host-side launcher bound to one ActorCritic module (packed-weight cache + plan)."""
+
+    def __init__(self, encoder_seq: nn.Sequential) -> None:
+        self.plan = _Plan(encoder_seq)
+        self.cache = E.PackCache()
+
+    def __call__(self, obs: Tensor) -> Tensor:
+        if not obs.is_cuda:
+            raise RuntimeError("diamond_amd kernels need GPU tensors (there is no CPU path)")
+        return _EncoderFn.apply(self.plan, self.cache, obs.contiguous(), *self.plan.params)

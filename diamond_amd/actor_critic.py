@@ -1,10 +1,11 @@
 """Actor-critic (reference models/actor_critic.py): conv encoder + LSTMCell + heads, the
 REINFORCE-with-baseline loss over a 15-step imagined rollout, and lambda-returns.
 
-Execution: `ActorCritic.backend` selects how predict_act_value is evaluated
-  * "native": hand-written HIP forward AND backward kernels behind a torch.autograd.Function
-    (diamond_amd/ac_native.py);
-  * "torch" : PyTorch-ROCm autograd ops over the same parameters (interim / cross-check).
+Execution: the conv encoder (all of the model's convolution/GroupNorm/SiLU/pooling work)
+runs on hand-written HIP kernels, forward AND backward, behind one torch.autograd.Function
+(diamond_amd/ac_native.py).  The LSTM cell and the two linear heads are plain GEMMs + gate
+pointwise ops issued as torch ops (rocBLAS) under ordinary autograd.  There is no CPU path:
+a CPU tensor raises.
 """
 from __future__ import annotations
 
@@ -71,7 +72,8 @@ class ActorCritic(nn.Module):
         init_lstm(self.lstm)
         self.env_loop = None
         self.loss_cfg = None
-        self.backend = "torch"  # -> "native" once diamond_amd/ac_native.py lands
+        self.backend = "native"  # conv encoder fwd+bwd on libdiamond_hip (diamond_amd/ac_native.py)
+        self._native_encoder = None
         self.expo_fn = None  # test hook: injected exponential draws for action sampling
 
     @property
@@ -84,24 +86,12 @@ class ActorCritic(nn.Module):
         self.loss_cfg = loss_cfg
 
     # -- evaluation ----------------------------------------------------------------------
-    def _predict_torch(self, obs: Tensor, hx: Tensor, cx: Tensor):
-        x = obs
-        for layer in self.encoder.encoder:
-            if isinstance(layer, SmallResBlock):
-                gn, conv = layer.f[0].norm, layer.f[2]
-                y = F.conv2d(F.silu(F.group_norm(x, gn.num_groups, gn.weight, gn.bias, gn.eps)), conv.weight, conv.bias, padding=1)
-                sp = layer.skip_projection
-                x = (x if isinstance(sp, nn.Identity) else F.conv2d(x, sp.weight, sp.bias)) + y
-            elif isinstance(layer, nn.MaxPool2d):
-                x = F.max_pool2d(x, 2)
-            else:
-                x = F.conv2d(x, layer.weight, layer.bias, padding=1)
-        x = x.flatten(start_dim=1)
-        gates = F.linear(x, self.lstm.weight_ih, self.lstm.bias_ih) + F.linear(hx, self.lstm.weight_hh, self.lstm.bias_hh)
-        i, f, g, o = gates.chunk(4, dim=1)
-        cx = torch.sigmoid(f) * cx + torch.sigmoid(i) * torch.tanh(g)
-        hx = torch.sigmoid(o) * torch.tanh(cx)
-        return hx, cx
+    def encode(self, obs: Tensor) -> Tensor:
+        """Flattened (c, h, w) encoder features (reference :70-71) on the HIP kernels."""
+        if self._native_encoder is None:
+            from .ac_native import NativeEncoder
+            self._native_encoder = NativeEncoder(self.encoder.encoder)
+        return self._native_encoder(obs)
 
     def predict_act_value(self, obs: Tensor, hx_cx: Optional[Tuple[Tensor, Tensor]]) -> ActorCriticOutput:
         assert obs.ndim == 4
@@ -109,11 +99,12 @@ class ActorCritic(nn.Module):
             z = obs.new_zeros(obs.size(0), self.lstm_dim)
             hx_cx = (z, z)
         hx, cx = hx_cx
-        if self.backend == "native":
-            from .ac_native import ac_step_native
-            hx, cx = ac_step_native(self, obs, hx, cx)
-        else:
-            hx, cx = self._predict_torch(obs, hx, cx)
+        x = self.encode(obs)
+        # nn.LSTMCell (reference :72): gate order i, f, g, o
+        gates = F.linear(x, self.lstm.weight_ih, self.lstm.bias_ih) + F.linear(hx, self.lstm.weight_hh, self.lstm.bias_hh)
+        i, f, g, o = gates.chunk(4, dim=1)
+        cx = torch.sigmoid(f) * cx + torch.sigmoid(i) * torch.tanh(g)
+        hx = torch.sigmoid(o) * torch.tanh(cx)
         logits = F.linear(hx, self.actor_linear.weight, self.actor_linear.bias)
         val = F.linear(hx, self.critic_linear.weight, self.critic_linear.bias).squeeze(dim=1)
         return ActorCriticOutput(logits, val, (hx, cx))

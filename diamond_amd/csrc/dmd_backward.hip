@@ -1,0 +1,515 @@
+// Backward kernels of the actor-critic conv encoder (autograd of models/actor_critic.py:101-113,
+// models/blocks.py:116-123: Conv3x3 -> 4 x [skip(x) + Conv3x3(SiLU(GroupNorm(x))), MaxPool2]).
+//
+// The reference gets these from ATen autograd (loss.backward(), trainer.py:366).  Here:
+//   * dgrad  = dmd_conv2d on the flipped/transposed weight (host repacks it) -- no new kernel;
+//   * wgrad  = dmd_conv2d_wgrad below: dW[co][ci][tap] = sum_pixels dy[pix][co] * a[pix + tap][ci]
+//     as a GEMM whose contraction runs over PIXELS, on v_mfma_f32_16x16x4_f32 (exact fp32);
+//     the conv input a = SiLU(GroupNorm(x)) is RECOMPUTED from x + its statistics while staging
+//     (nothing but x and the pooling argmax is saved by the forward);
+//   * GroupNorm+SiLU backward = two passes (group reductions, then elementwise apply);
+//   * MaxPool backward = scatter by the saved argmax.
+#include "dmd_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// max pool 2x2 backward: dx[n, 2oy + k/2, 2ox + k%2, c] = (k == argmax) ? dpooled : 0
+// ------------------------------------------------------------------------------------------------
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ dp, const uint8_t* __restrict__ argmax, float* __restrict__ dx,
+                                    int N, int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2, Cq = C / 4;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)N * Ho * Wo * Cq) return;
+  const int cq = idx % Cq;
+  const size_t op = idx / Cq;
+  const int ox = op % Wo;
+  const int oy = (op / Wo) % Ho;
+  const int n = op / ((size_t)Wo * Ho);
+  const f32x4 g = *(const f32x4*)(dp + op * C + cq * 4);
+  const uint32_t am = *(const uint32_t*)(argmax + op * C + cq * 4);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (((am >> (8 * e)) & 0xff) == (uint32_t)k) ? g[e] : 0.f;
+    const int iy = oy * 2 + (k >> 1), ix = ox * 2 + (k & 1);
+    *(f32x4*)(dx + (((size_t)n * H + iy) * W + ix) * C + cq * 4) = v;
+  }
+}
+
+extern "C" int dmd_maxpool2_bwd(const float* dpooled, const uint8_t* argmax, float* dx, int N, int H, int W, int C,
+                                dmd_stream_t stream) {
+  DMD_CHECK_ARG(dpooled && argmax && dx, "maxpool2_bwd: null");
+  DMD_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "maxpool2_bwd: H, W even, C %% 4 == 0");
+  const size_t n = (size_t)N * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dpooled,
+                     argmax, dx, N, H, W, C);
+  DMD_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm(+affine/FiLM) + SiLU backward.
+//   forward: xh = (x - mean) * rstd ; u = xh * mul' + add ; a = silu(u)       (mul' = mul or 1 + mul)
+//   given da:  du = da * silu'(u) ; dxh = du * mul'
+//   dx = rstd * (dxh - mean_g(dxh) - xh * mean_g(dxh * xh)) [+ dskip]          (means over the group)
+//   dmul[n][c] = sum_hw du * xh ; dadd[n][c] = sum_hw du                       (host sums over n for
+//   batch-shared affine parameters)
+// Pass A: grid (T, N), T = ceil(HW / 256): partial group sums (fp64) and per-channel sums.
+// Pass B: elementwise.   Pass C: per-(n, c) reduction of the T channel partials.
+// ------------------------------------------------------------------------------------------------
+struct GnBwdElem {
+  float xh, du, dxh;
+};
+
+__device__ __forceinline__ GnBwdElem gn_bwd_elem(float x, float da, float mean, float rstd, float mul, float add) {
+  GnBwdElem r;
+  r.xh = (x - mean) * rstd;
+  const float u = r.xh * mul + add;
+  const float sg = dmd_sigmoid(u);
+  r.du = da * (sg * (1.0f + u * (1.0f - sg)));
+  r.dxh = r.du * mul;
+  return r;
+}
+
+#define GN_BWD_PIX 256  // pixels per workgroup in passes A and B
+#define GN_BWD_MAXG 8   // C <= 256
+
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const dmd_gn_bwd_params p, int T, double* __restrict__ group_partial,
+                                                            float* __restrict__ chan_partial) {
+  __shared__ float g_mean[GN_BWD_MAXG], g_rstd[GN_BWD_MAXG];
+  __shared__ double red[4][GN_BWD_MAXG][2];
+  __shared__ float cred[256][8];
+  const int t = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const int C = p.C, CQ = C / 4, G = C / DMD_GN_GROUP > 0 ? C / DMD_GN_GROUP : 1;
+  const int gsz = C / G;
+  if (tid < G) {
+    float m, r;
+    dmd_finalize_stats(p.norm.stats + ((size_t)(n * G + tid) * p.norm.stat_tiles) * 2, p.norm.stat_tiles,
+                       (double)gsz * p.HW, &m, &r);
+    g_mean[tid] = m;
+    g_rstd[tid] = r;
+  }
+  __syncthreads();
+  const int q = tid % CQ;
+  const int c0 = 4 * q;
+  const int g = c0 / gsz;
+  const float mean = g_mean[g], rstd = g_rstd[g];
+  float mul[4], add[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float m = p.norm.mul ? p.norm.mul[(size_t)n * p.norm.mul_stride + c0 + e] : 1.0f;
+    if (p.norm.mul_plus_one) m = 1.0f + m;
+    mul[e] = m;
+    add[e] = p.norm.add ? p.norm.add[(size_t)n * p.norm.add_stride + c0 + e] : 0.0f;
+  }
+  double s1 = 0.0, s2 = 0.0;
+  float dm[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
+  const int pix_end = min(p.HW, (t + 1) * GN_BWD_PIX);
+  for (int pix = t * GN_BWD_PIX + tid / CQ; pix < pix_end; pix += 256 / CQ) {
+    const size_t off = ((size_t)n * p.HW + pix) * C + c0;
+    const f32x4 xv = *(const f32x4*)(p.x + off);
+    const f32x4 dv = *(const f32x4*)(p.da + off);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const GnBwdElem r = gn_bwd_elem(xv[e], dv[e], mean, rstd, mul[e], add[e]);
+      s1 += (double)r.dxh;
+      s2 += (double)r.dxh * (double)r.xh;
+      dm[e] += r.du * r.xh;
+      db[e] += r.du;
+    }
+  }
+  // group sums: threads of a wave may belong to different groups (C = 64: quads 0-7 / 8-15)
+  for (int gg = 0; gg < G; ++gg) {
+    const double a = dmd_wave_sum(g == gg ? s1 : 0.0);
+    const double b = dmd_wave_sum(g == gg ? s2 : 0.0);
+    if ((tid & 63) == 0) {
+      red[tid >> 6][gg][0] = a;
+      red[tid >> 6][gg][1] = b;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    cred[tid][e] = dm[e];
+    cred[tid][4 + e] = db[e];
+  }
+  __syncthreads();
+  if (tid < G) {
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < 4; ++w) {
+      a += red[w][tid][0];
+      b += red[w][tid][1];
+    }
+    double* o = group_partial + ((size_t)(n * G + tid) * T + t) * 2;
+    o[0] = a;
+    o[1] = b;
+  }
+  if (tid < C) {  // channel tid: quad tid / 4, element tid % 4; fixed-order sum over the pixel lanes
+    const int qq = tid >> 2, e = tid & 3;
+    float a = 0.f, b = 0.f;
+    for (int l = 0; l < 256 / CQ; ++l) {
+      a += cred[l * CQ + qq][e];
+      b += cred[l * CQ + qq][4 + e];
+    }
+    float* o = chan_partial + (((size_t)n * T + t) * C + tid) * 2;
+    o[0] = a;
+    o[1] = b;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const dmd_gn_bwd_params p, int T, const double* __restrict__ group_partial) {
+  __shared__ float g_mean[GN_BWD_MAXG], g_rstd[GN_BWD_MAXG], g_m1[GN_BWD_MAXG], g_m2[GN_BWD_MAXG];
+  const int t = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const int C = p.C, CQ = C / 4, G = C / DMD_GN_GROUP > 0 ? C / DMD_GN_GROUP : 1;
+  const int gsz = C / G;
+  if (tid < G) {
+    float m, r;
+    const double cnt = (double)gsz * p.HW;
+    dmd_finalize_stats(p.norm.stats + ((size_t)(n * G + tid) * p.norm.stat_tiles) * 2, p.norm.stat_tiles, cnt, &m, &r);
+    g_mean[tid] = m;
+    g_rstd[tid] = r;
+    double a = 0.0, b = 0.0;
+    const double* gp = group_partial + ((size_t)(n * G + tid) * T) * 2;
+    for (int k = 0; k < T; ++k) {
+      a += gp[2 * k];
+      b += gp[2 * k + 1];
+    }
+    g_m1[tid] = (float)(a / cnt);
+    g_m2[tid] = (float)(b / cnt);
+  }
+  __syncthreads();
+  const int q = tid % CQ;
+  const int c0 = 4 * q;
+  const int g = c0 / gsz;
+  const float mean = g_mean[g], rstd = g_rstd[g], m1 = g_m1[g], m2 = g_m2[g];
+  float mul[4], add[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float m = p.norm.mul ? p.norm.mul[(size_t)n * p.norm.mul_stride + c0 + e] : 1.0f;
+    if (p.norm.mul_plus_one) m = 1.0f + m;
+    mul[e] = m;
+    add[e] = p.norm.add ? p.norm.add[(size_t)n * p.norm.add_stride + c0 + e] : 0.0f;
+  }
+  const int pix_end = min(p.HW, (t + 1) * GN_BWD_PIX);
+  for (int pix = t * GN_BWD_PIX + tid / CQ; pix < pix_end; pix += 256 / CQ) {
+    const size_t off = ((size_t)n * p.HW + pix) * C + c0;
+    const f32x4 xv = *(const f32x4*)(p.x + off);
+    const f32x4 dv = *(const f32x4*)(p.da + off);
+    f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.dskip) o = *(const f32x4*)(p.dskip + off);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const GnBwdElem r = gn_bwd_elem(xv[e], dv[e], mean, rstd, mul[e], add[e]);
+      o[e] += rstd * (r.dxh - m1 - r.xh * m2);
+    }
+    *(f32x4*)(p.dx + off) = o;
+  }
+}
+
+__global__ void gn_bwd_chan_kernel(const float* __restrict__ chan_partial, float* __restrict__ dmul, float* __restrict__ dadd,
+                                   int N, int T, int C) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * C) return;
+  const int n = idx / C, c = idx - n * C;
+  float a = 0.f, b = 0.f;
+  for (int t = 0; t < T; ++t) {
+    const float* o = chan_partial + (((size_t)n * T + t) * C + c) * 2;
+    a += o[0];
+    b += o[1];
+  }
+  dmul[idx] = a;
+  dadd[idx] = b;
+}
+
+static inline int gn_bwd_tiles(int HW) { return (HW + GN_BWD_PIX - 1) / GN_BWD_PIX; }
+
+extern "C" int64_t dmd_gn_bwd_workspace_bytes(int N, int HW, int C) {
+  const int T = gn_bwd_tiles(HW);
+  const int G = C / DMD_GN_GROUP > 0 ? C / DMD_GN_GROUP : 1;
+  return (int64_t)N * G * T * 2 * 8 + (int64_t)N * T * C * 2 * 4;
+}
+
+extern "C" int dmd_gn_silu_bwd(const dmd_gn_bwd_params* pp, dmd_stream_t stream) {
+  DMD_CHECK_ARG(pp && pp->x && pp->da && pp->dx && pp->workspace && pp->dmul && pp->dadd, "gn_silu_bwd: null");
+  DMD_CHECK_ARG(pp->norm.stats && pp->norm.stat_tiles > 0, "gn_silu_bwd: statistics missing");
+  DMD_CHECK_ARG(pp->C % 4 == 0 && pp->C <= 256 && 256 % (pp->C / 4) == 0 && (pp->C % DMD_GN_GROUP == 0 || pp->C < DMD_GN_GROUP),
+                "gn_silu_bwd: unsupported C %d", pp->C);
+  dmd_gn_bwd_params p = *pp;
+  const int T = gn_bwd_tiles(p.HW);
+  const int G = p.C / DMD_GN_GROUP > 0 ? p.C / DMD_GN_GROUP : 1;
+  double* group_partial = (double*)p.workspace;
+  float* chan_partial = (float*)((char*)p.workspace + (size_t)p.N * G * T * 2 * 8);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(T, p.N), dim3(256), 0, st, p, T, group_partial, chan_partial);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(T, p.N), dim3(256), 0, st, p, T, (const double*)group_partial);
+  hipLaunchKernelGGL(gn_bwd_chan_kernel, dim3((p.N * p.C + 255) / 256), dim3(256), 0, st, (const float*)chan_partial, p.dmul,
+                     p.dadd, p.N, T, p.C);
+  DMD_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad:  dW[co][ci][tap] = sum_{n,y,x} dy[n,y,x,co] * a[n, y + ty - 1, x + tx - 1, ci]
+//
+// GEMM view: rows = co (NCO blocks of 16), columns = (tap, ci) (NB = TAPS * NCI blocks of 16),
+// contraction = pixels, 4 per v_mfma_f32_16x16x4_f32:
+//   A operand (lane i = lane & 15, k = lane >> 4) = dy[pixel k][co i]
+//   B operand (lane j = lane & 15, k = lane >> 4) = a[pixel k shifted by the tap][ci j]
+// A workgroup (4 waves) walks a contiguous range of tiles (tile = two 8x8 pixel patches of
+// possibly different images); per tile the activated input patches (+halo, ALL input channels)
+// and the dy tile live in LDS with a row stride == 16 (mod 32) floats, which makes the
+// ds_read_b32 operand fetches (16 consecutive channels x 2 pixels per 32-lane group) conflict
+// free.  Wave w owns column blocks {w, w + 4, ...} for every row block: NCO + CB LDS reads feed
+// NCO * CB MFMAs per 4 pixels.  Accumulators stay in registers across the workgroup's tiles
+// and are written ONCE as a partial; a second kernel sums the partials in a fixed order
+// (deterministic) and scatters into the OIHW gradient.
+// ------------------------------------------------------------------------------------------------
+template <int NCO_, int NCI_, int TAPS_>
+struct WgradGeom {
+  static constexpr int NCO = NCO_, NCI = NCI_, TAPS = TAPS_;
+  static constexpr int NB = TAPS_ * NCI_;
+  static constexpr int CB = (NB + 3) / 4;
+  static constexpr int CIN = 16 * NCI_, COUT = 16 * NCO_;
+  static constexpr int PAD = TAPS_ == 9 ? 1 : 0;
+  static constexpr int PW = 8 + 2 * PAD;
+  static constexpr int PP = PW * PW;                       // patch pixels per subtile
+  static constexpr int SB = (CIN + 31) / 32 * 32 + 16;     // patch row stride (floats)
+  static constexpr int SA = (COUT + 31) / 32 * 32 + 16;    // dy row stride
+  static constexpr int PATCH_FLOATS = 2 * PP * SB;
+  static constexpr int DY_FLOATS = 128 * SA;
+  static constexpr int TAB_FLOATS = 2 * 3 * CIN;
+  static constexpr int SMEM_BYTES = (PATCH_FLOATS + DY_FLOATS + TAB_FLOATS) * 4;
+};
+
+struct SubTile {
+  int n, y0, x0;
+  bool valid;
+};
+
+__device__ __forceinline__ SubTile wgrad_subtile(int N, int H, int W, int gs) {
+  const int tx = W / 8, per_img = tx * (H / 8);
+  SubTile t;
+  t.valid = gs < N * per_img;
+  const int g2 = t.valid ? gs : 0;
+  t.n = g2 / per_img;
+  const int r = g2 - t.n * per_img;
+  t.y0 = (r / tx) * 8;
+  t.x0 = (r % tx) * 8;
+  return t;
+}
+
+template <class G>
+__global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, int tiles_total, int tiles_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* patch = smem;                        // [2][PP][SB]
+  float* dyt = smem + G::PATCH_FLOATS;        // [128][SA]
+  float* tab = dyt + G::DY_FLOATS;            // [2][3][CIN]: mean, a, add
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, kg = lane >> 4;
+
+  f32x4 acc[G::NCO][G::CB];
+#pragma unroll
+  for (int a = 0; a < G::NCO; ++a)
+#pragma unroll
+    for (int s = 0; s < G::CB; ++s) acc[a][s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // per-slot B offset: column block b = wave + 4 s -> (tap, ci block)
+  int boff[G::CB];
+#pragma unroll
+  for (int s = 0; s < G::CB; ++s) {
+    int b = wave + 4 * s;
+    b = b < G::NB ? b : 0;  // surplus slots recompute block 0 and are never stored
+    const int tap = b / G::NCI, cib = b - tap * G::NCI;
+    const int ty = G::TAPS == 9 ? tap / 3 : 0, tx = G::TAPS == 9 ? tap % 3 : 0;
+    boff[s] = (ty * G::PW + tx + kg) * G::SB + cib * 16 + i;
+  }
+  const int aoff = kg * G::SA + i;
+
+  constexpr int CQO = G::COUT / 4;  // dy channel quads
+  constexpr int CQI = G::CIN / 4;
+  f32x4 bsum = (f32x4){0.f, 0.f, 0.f, 0.f};  // bias gradient of channel quad (tid % CQO)
+  const int Cx = p.src.C;                    // == CIN (checked on the host)
+  const int tile_begin = blockIdx.x * tiles_per_wg;
+  const int tile_end = min(tiles_total, tile_begin + tiles_per_wg);
+  int tab_n0 = -1, tab_n1 = -1;
+
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    SubTile st[2];
+    st[0] = wgrad_subtile(p.N, p.H, p.W, 2 * tile);
+    st[1] = wgrad_subtile(p.N, p.H, p.W, 2 * tile + 1);
+    __syncthreads();  // previous tile's MFMA reads are done
+    if (p.src.prologue != DMD_PROLOGUE_NONE && (st[0].n != tab_n0 || st[1].n != tab_n1)) {
+      for (int c = tid; c < 2 * G::CIN; c += 256) {
+        const int s = c / G::CIN, cc = c - s * G::CIN;
+        float m, a, ad;
+        norm_entry(p.src.norm, st[s].n, cc, Cx, (double)(Cx < DMD_GN_GROUP ? Cx : DMD_GN_GROUP) * p.H * p.W, &m, &a, &ad);
+        tab[(s * 3 + 0) * G::CIN + cc] = m;
+        tab[(s * 3 + 1) * G::CIN + cc] = a;
+        tab[(s * 3 + 2) * G::CIN + cc] = ad;
+      }
+      tab_n0 = st[0].n;
+      tab_n1 = st[1].n;
+      __syncthreads();
+    }
+    // ---- stage the two activated input patches ----
+    for (int id = tid; id < 2 * G::PP * CQI; id += 256) {
+      const int q = id % CQI, pp2 = id / CQI;
+      const int s = pp2 >= G::PP ? 1 : 0;
+      const int pp = pp2 - s * G::PP;
+      const int py = pp / G::PW, px = pp - py * G::PW;
+      const SubTile t = s ? st[1] : st[0];
+      const int iy = t.y0 - G::PAD + py, ix = t.x0 - G::PAD + px;
+      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (t.valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+        v = *(const f32x4*)(p.src.x + (((size_t)t.n * p.H + iy) * p.W + ix) * Cx + 4 * q);
+        if (p.src.prologue != DMD_PROLOGUE_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int cc = 4 * q + e;
+            float u = (v[e] - tab[(s * 3 + 0) * G::CIN + cc]) * tab[(s * 3 + 1) * G::CIN + cc] + tab[(s * 3 + 2) * G::CIN + cc];
+            if (p.src.prologue == DMD_PROLOGUE_NORM_SILU) u = dmd_silu(u);
+            v[e] = u;
+          }
+        }
+      }
+      *(f32x4*)(patch + (size_t)pp2 * G::SB + 4 * q) = v;
+    }
+    // ---- stage dy (zero for a missing second subtile) ----
+#pragma unroll
+    for (int it = 0; it < (128 * CQO) / 256; ++it) {
+      const int id = it * 256 + tid;
+      const int q = id % CQO, pix = id / CQO;  // q == tid % CQO for every it
+      const int s = pix >> 6, r = pix & 63;
+      const SubTile t = s ? st[1] : st[0];
+      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (t.valid) v = *(const f32x4*)(p.dy + (((size_t)t.n * p.H + t.y0 + (r >> 3)) * p.W + t.x0 + (r & 7)) * G::COUT + 4 * q);
+      bsum += v;
+      *(f32x4*)(dyt + (size_t)pix * G::SA + 4 * q) = v;
+    }
+    __syncthreads();
+    // ---- 32 k-groups of 4 pixels ----
+#pragma unroll 2
+    for (int kq = 0; kq < 32; ++kq) {
+      const int s = kq >> 4, g = kq & 15;
+      const int row = g >> 1, col0 = (g & 1) * 4;
+      const float* ap = dyt + (size_t)(s * 64 + row * 8 + col0) * G::SA + aoff;
+      const float* bp = patch + (size_t)(s * G::PP + row * G::PW + col0) * G::SB;
+      float av[G::NCO], bv[G::CB];
+#pragma unroll
+      for (int a = 0; a < G::NCO; ++a) av[a] = ap[a * 16];
+#pragma unroll
+      for (int b = 0; b < G::CB; ++b) bv[b] = bp[boff[b]];
+#pragma unroll
+      for (int b = 0; b < G::CB; ++b)
+#pragma unroll
+        for (int a = 0; a < G::NCO; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+  }
+
+  // ---- partial results: [wg][NB][NCO][64 lanes][4] ----
+  float* part = p.workspace + (size_t)blockIdx.x * (G::NB * G::NCO * 256);
+#pragma unroll
+  for (int s = 0; s < G::CB; ++s) {
+    const int b = wave + 4 * s;
+    if (b < G::NB) {
+#pragma unroll
+      for (int a = 0; a < G::NCO; ++a) *(f32x4*)(part + ((size_t)(b * G::NCO + a) * 64 + lane) * 4) = acc[a][s];
+    }
+  }
+  // ---- bias partial: sum over threads with the same channel quad ----
+  __syncthreads();
+  f32x4* red = (f32x4*)smem;
+  red[tid] = bsum;
+  __syncthreads();
+  if (tid < CQO) {
+    f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < 256 / CQO; ++l) a += red[l * CQO + tid];
+    float* bpart = p.workspace + (size_t)gridDim.x * (G::NB * G::NCO * 256) + (size_t)blockIdx.x * G::COUT;
+    *(f32x4*)(bpart + 4 * tid) = a;
+  }
+}
+
+// partial element e of [NB][NCO][64][4] summed over workgroups -> OIHW gradient
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int num_wg, int NB, int NCO, int NCI, int taps, int cin_real,
+                                    float* __restrict__ dw, float* __restrict__ dbias) {
+  const int per = NB * NCO * 256;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < per) {
+    double s = 0.0;
+    for (int w = 0; w < num_wg; ++w) s += (double)ws[(size_t)w * per + idx];
+    const int r = idx & 3, lane = (idx >> 2) & 63;
+    const int blk = idx >> 8;
+    const int cob = blk % NCO, b = blk / NCO;
+    const int tap = b / NCI, cib = b - tap * NCI;
+    const int co = cob * 16 + 4 * (lane >> 4) + r;
+    const int ci = cib * 16 + (lane & 15);
+    if (ci < cin_real) dw[((size_t)co * cin_real + ci) * taps + tap] = (float)s;
+  } else if (dbias && idx < per + NCO * 16) {
+    const int co = idx - per;
+    const float* bp = ws + (size_t)num_wg * per;
+    double s = 0.0;
+    for (int w = 0; w < num_wg; ++w) s += (double)bp[(size_t)w * NCO * 16 + co];
+    dbias[co] = (float)s;
+  }
+}
+
+static int wgrad_plan(const dmd_wgrad_params* p, int* tiles, int* num_wg, int* tpw) {
+  const int sub = p->N * (p->H / 8) * (p->W / 8);
+  *tiles = (sub + 1) / 2;
+  int n = *tiles < 1024 ? *tiles : 1024;
+  *tpw = (*tiles + n - 1) / n;
+  *num_wg = (*tiles + *tpw - 1) / *tpw;
+  return 0;
+}
+
+extern "C" int64_t dmd_wgrad_workspace_floats(const dmd_wgrad_params* p) {
+  if (!p) return -1;
+  int tiles, num_wg, tpw;
+  wgrad_plan(p, &tiles, &num_wg, &tpw);
+  const int64_t NB = (int64_t)p->taps * (p->src.C / 16), NCO = p->Cout / 16;
+  return (int64_t)num_wg * (NB * NCO * 256 + p->Cout);
+}
+
+template <int NCO, int NCI, int TAPS>
+static int launch_wgrad(const dmd_wgrad_params& p, hipStream_t st) {
+  using G = WgradGeom<NCO, NCI, TAPS>;
+  int tiles, num_wg, tpw;
+  wgrad_plan(&p, &tiles, &num_wg, &tpw);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       G::SMEM_BYTES);
+    DMD_CHECK_ARG(e == hipSuccess, "wgrad: hipFuncSetAttribute(%d bytes): %s", G::SMEM_BYTES, hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wgrad_kernel<G>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
+  const int per = G::NB * NCO * 256 + NCO * 16;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((per + 255) / 256), dim3(256), 0, st, p.workspace, num_wg, G::NB, NCO, NCI, TAPS,
+                     p.cin_real, p.dw, p.dbias);
+  return 0;
+}
+
+extern "C" int dmd_conv2d_wgrad(const dmd_wgrad_params* p, dmd_stream_t stream) {
+  DMD_CHECK_ARG(p && p->src.x && p->dy && p->workspace && p->dw, "wgrad: null");
+  DMD_CHECK_ARG(p->N > 0 && p->H % 8 == 0 && p->W % 8 == 0, "wgrad: H, W must be multiples of 8 (%d x %d)", p->H, p->W);
+  DMD_CHECK_ARG(p->taps == 9 || p->taps == 1, "wgrad: taps");
+  DMD_CHECK_ARG(p->cin_real > 0 && p->cin_real <= p->src.C, "wgrad: cin_real");
+  if (p->src.prologue != DMD_PROLOGUE_NONE)
+    DMD_CHECK_ARG(p->src.norm.stats && p->src.norm.stat_tiles > 0, "wgrad: prologue without statistics");
+  hipStream_t st = (hipStream_t)stream;
+  const int nco = p->Cout / 16, nci = p->src.C / 16;
+  DMD_CHECK_ARG(p->Cout % 16 == 0 && p->src.C % 16 == 0, "wgrad: channels must be multiples of 16");
+  int rc = -1;
+  if (p->taps == 9) {
+    if (nco == 2 && nci == 1) rc = launch_wgrad<2, 1, 9>(*p, st);
+    else if (nco == 2 && nci == 2) rc = launch_wgrad<2, 2, 9>(*p, st);
+    else if (nco == 4 && nci == 2) rc = launch_wgrad<4, 2, 9>(*p, st);
+    else if (nco == 4 && nci == 4) rc = launch_wgrad<4, 4, 9>(*p, st);
+  } else {
+    if (nco == 4 && nci == 2) rc = launch_wgrad<4, 2, 1>(*p, st);
+    else if (nco == 2 && nci == 2) rc = launch_wgrad<2, 2, 1>(*p, st);
+    else if (nco == 4 && nci == 4) rc = launch_wgrad<4, 4, 1>(*p, st);
+  }
+  DMD_CHECK_ARG(rc >= 0, "wgrad: no kernel instance for Cin %d -> Cout %d, taps %d", p->src.C, p->Cout, p->taps);
+  if (rc) return rc;
+  DMD_LAUNCH_CHECK();
+  return 0;
+}

@@ -54,3 +54,16 @@ __device__ __forceinline__ double dmd_wave_sum(double v) {
   return v;
 }
 
+// per-channel affine of a GroupNorm(+FiLM): y = (x - mean) * a + add
+__device__ __forceinline__ void norm_entry(const dmd_norm& nm, int n, int c, int C, double count, float* mean,
+                                           float* a, float* add) {
+  const int G = C / DMD_GN_GROUP > 0 ? C / DMD_GN_GROUP : 1;
+  const int g = c / DMD_GN_GROUP;
+  float m, rstd;
+  dmd_finalize_stats(nm.stats + ((size_t)(n * G + g) * nm.stat_tiles) * 2, nm.stat_tiles, count, &m, &rstd);
+  float mul = nm.mul ? nm.mul[(size_t)n * nm.mul_stride + c] : 1.0f;
+  if (nm.mul_plus_one) mul = 1.0f + mul;
+  *mean = m;
+  *a = rstd * mul;
+  *add = nm.add ? nm.add[(size_t)n * nm.add_stride + c] : 0.0f;
+}

@@ -48,10 +48,23 @@ class LinearParams(C.Structure):
                 ("accumulate", C.c_int32), ("silu", C.c_int32)]
 
 
+class GnBwdParams(C.Structure):
+    _fields_ = [("N", C.c_int32), ("HW", C.c_int32), ("C", C.c_int32), ("reserved", C.c_int32), ("x", C.c_void_p),
+                ("norm", Norm), ("da", C.c_void_p), ("dskip", C.c_void_p), ("dx", C.c_void_p), ("workspace", C.c_void_p),
+                ("dmul", C.c_void_p), ("dadd", C.c_void_p)]
+
+
+class WgradParams(C.Structure):
+    _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cout", C.c_int32), ("taps", C.c_int32),
+                ("cin_real", C.c_int32), ("src", ConvSrc), ("dy", C.c_void_p), ("workspace", C.c_void_p), ("dw", C.c_void_p),
+                ("dbias", C.c_void_p)]
+
+
 EXPORTS = (
     "dmd_conv2d", "dmd_conv2d_naive", "dmd_conv_stat_tiles", "dmd_pack_conv_weight", "dmd_linear", "dmd_attention",
     "dmd_edm_pack_input", "dmd_cond_embed", "dmd_edm_denoised", "dmd_euler_step", "dmd_nchw_to_nhwc",
     "dmd_nhwc_to_nchw", "dmd_gn_stats", "dmd_maxpool2", "dmd_lstm_pointwise", "dmd_categorical_sample",
+    "dmd_maxpool2_bwd", "dmd_gn_bwd_workspace_bytes", "dmd_gn_silu_bwd", "dmd_wgrad_workspace_floats", "dmd_conv2d_wgrad",
     "dmd_last_error", "dmd_abi_version",
 )
 
@@ -89,6 +102,13 @@ def lib() -> C.CDLL:
         L.dmd_lstm_pointwise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.dmd_categorical_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.dmd_conv_stat_tiles.argtypes = [C.c_int, C.c_int]
+        L.dmd_maxpool2_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.dmd_gn_bwd_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.dmd_gn_bwd_workspace_bytes.restype = C.c_int64
+        L.dmd_gn_silu_bwd.argtypes = [C.POINTER(GnBwdParams), C.c_void_p]
+        L.dmd_wgrad_workspace_floats.argtypes = [C.POINTER(WgradParams)]
+        L.dmd_wgrad_workspace_floats.restype = C.c_int64
+        L.dmd_conv2d_wgrad.argtypes = [C.POINTER(WgradParams), C.c_void_p]
         _lib = L
     return _lib
 

@@ -145,6 +145,49 @@ int dmd_lstm_pointwise(const float* gates, const float* c_prev, float* h, float*
  * (env_loop.py:32, world_model_env.py:103-104). */
 int dmd_categorical_sample(const float* logits, const float* expo, int64_t* out, int N, int A, dmd_stream_t stream);
 
+/* ---- actor-critic encoder backward (what ATen autograd does for actor_critic.py:101-113 /
+ *      blocks.py:116-123 under loss.backward(), trainer.py:366) ------------------------------ */
+
+/* dx (N, H, W, C) <- scatter of dpooled (N, H/2, W/2, C) by the argmax dmd_maxpool2 saved */
+int dmd_maxpool2_bwd(const float* dpooled, const uint8_t* argmax, float* dx, int N, int H, int W, int C,
+                     dmd_stream_t stream);
+
+/* Backward of a = SiLU(GroupNorm(x) * mul' + add) (mul' = mul or 1 + mul, as in dmd_norm):
+ *   dx = d a / d x applied to da (+ dskip, the gradient of the residual branch around the block)
+ *   dmul[n][c] = sum_hw du * xhat,  dadd[n][c] = sum_hw du   (the caller sums over n for affine
+ *   parameters shared by the batch). */
+typedef struct dmd_gn_bwd_params {
+  int32_t N, HW, C;
+  int32_t reserved;
+  const float* x;      /* NHWC input of the GroupNorm                          */
+  dmd_norm norm;       /* its statistics + multiplicative/additive parameters  */
+  const float* da;     /* gradient w.r.t. the activated tensor                 */
+  const float* dskip;  /* NULL or NHWC, added to dx                            */
+  float* dx;
+  void* workspace;     /* dmd_gn_bwd_workspace_bytes(N, HW, C) bytes           */
+  float* dmul;         /* (N, C) */
+  float* dadd;         /* (N, C) */
+} dmd_gn_bwd_params;
+int64_t dmd_gn_bwd_workspace_bytes(int N, int HW, int C);
+int dmd_gn_silu_bwd(const dmd_gn_bwd_params* p, dmd_stream_t stream);
+
+/* Weight/bias gradient of a stride-1 dmd_conv2d (3x3 pad 1 or 1x1) with a single source:
+ *   dw[co][ci][ky][kx] = sum_{n,y,x} dy[n,y,x,co] * a[n, y+ky-1, x+kx-1, ci],  db[co] = sum dy,
+ * a = the conv's (prologue-activated) input, recomputed from src exactly as the forward does. */
+typedef struct dmd_wgrad_params {
+  int32_t N, H, W;
+  int32_t Cout;        /* multiple of 16 */
+  int32_t taps;        /* 9 | 1 */
+  int32_t cin_real;    /* input channels of the OIHW gradient (<= src.C, the padded count) */
+  dmd_conv_src src;
+  const float* dy;     /* NHWC (N, H, W, Cout) */
+  float* workspace;    /* dmd_wgrad_workspace_floats(p) floats */
+  float* dw;           /* OIHW (Cout, cin_real, k, k) */
+  float* dbias;        /* (Cout) or NULL */
+} dmd_wgrad_params;
+int64_t dmd_wgrad_workspace_floats(const dmd_wgrad_params* p);
+int dmd_conv2d_wgrad(const dmd_wgrad_params* p, dmd_stream_t stream);
+
 const char* dmd_last_error(void);
 int dmd_abi_version(void);
 

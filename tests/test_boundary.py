@@ -119,12 +119,14 @@ def test_struct_layouts_match_the_header():
     import tempfile
     from diamond_amd import native
 
-    src = '#include <stdio.h>\n#include "diamond_hip.h"\nint main(){printf("%zu %zu %zu %zu",sizeof(dmd_norm),' \
-          'sizeof(dmd_conv_src),sizeof(dmd_conv_params),sizeof(dmd_linear_params));return 0;}'
+    src = '#include <stdio.h>\n#include "diamond_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu",sizeof(dmd_norm),' \
+          'sizeof(dmd_conv_src),sizeof(dmd_conv_params),sizeof(dmd_linear_params),sizeof(dmd_gn_bwd_params),' \
+          'sizeof(dmd_wgrad_params));return 0;}'
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
         open(c, "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", os.path.join(d, "s")])
         sizes = [int(v) for v in subprocess.check_output([os.path.join(d, "s")]).split()]
-    mine = [ctypes.sizeof(t) for t in (native.Norm, native.ConvSrc, native.ConvParams, native.LinearParams)]
+    mine = [ctypes.sizeof(t) for t in (native.Norm, native.ConvSrc, native.ConvParams, native.LinearParams, native.GnBwdParams,
+                                     native.WgradParams)]
     assert sizes == mine

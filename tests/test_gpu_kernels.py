@@ -277,3 +277,108 @@ def test_maxpool_lstm_pointwise():
     c_ref = torch.sigmoid(f) * c0.double() + torch.sigmoid(i) * torch.tanh(gg)
     h_ref = torch.sigmoid(o) * torch.tanh(c_ref)
     assert rel_err(c, c_ref) < 1e-6 and rel_err(h, h_ref) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# actor-critic encoder backward kernels: truth = float64 torch-CPU autograd of the same op
+# ---------------------------------------------------------------------------------------------
+WGRAD_CASES = [
+    # name, N, H, W, Cin (padded), cin_real, Cout, taps, prologue
+    ("in16_3to32", 3, 16, 16, 16, 3, 32, 9, 0),
+    ("c32_32", 5, 16, 24, 32, 32, 32, 9, 1),
+    ("c32_64", 2, 16, 16, 32, 32, 64, 9, 1),
+    ("c64_64_8x8_odd", 3, 8, 8, 64, 64, 64, 9, 1),
+    ("skip1x1_32_64", 3, 16, 16, 32, 32, 64, 1, 0),
+    ("c32_32_many_tiles", 40, 64, 64, 32, 32, 32, 9, 1),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
+def test_conv_wgrad(case):
+    from diamond_amd import ac_native as A, engine as E
+
+    name, n, h, w, cin, cin_real, cout, taps, prologue = case
+    g = torch.Generator().manual_seed(len(name) * 7 + n)
+    k = 3 if taps == 9 else 1
+    x = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64) * 1.3 + 0.2
+    x[:, cin_real:] = 0
+    gamma = torch.randn(cin, generator=g, dtype=torch.float64) * 0.2 + 1
+    beta = torch.randn(cin, generator=g, dtype=torch.float64) * 0.2
+    dy = torch.randn(n, cout, h, w, generator=g, dtype=torch.float64)
+    wgt = torch.zeros(cout, cin_real, k, k, dtype=torch.float64, requires_grad=True)
+    bias = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    a = x
+    if prologue:
+        a = gn_ref(x, max(1, cin // 32)) * gamma[None, :, None, None] + beta[None, :, None, None]
+        a = a * torch.sigmoid(a)
+    out = F.conv2d(a[:, :cin_real], wgt, bias, padding=1 if k == 3 else 0)
+    out.backward(dy)
+    xa = make_act(x)
+    spec = E.NormSpec(mul=gamma.float().to(DEV), add=beta.float().to(DEV)) if prologue else None
+    dyd = to_nhwc(dy.float()).to(DEV)
+    dw, db = A._wgrad(xa, prologue, spec, dyd, taps, cin_real)
+    torch.cuda.synchronize()
+    assert rel_err(dw, wgt.grad) < 2e-5, f"{name}: dW rel err {rel_err(dw, wgt.grad):.3e}"
+    assert rel_err(db, bias.grad) < 2e-5, f"{name}: db rel err {rel_err(db, bias.grad):.3e}"
+
+
+@pytest.mark.parametrize("n,c,h,w,skip", [(3, 32, 16, 16, True), (2, 64, 8, 8, False), (2, 32, 64, 64, True), (2, 64, 24, 40, True)])
+def test_gn_silu_bwd(n, c, h, w, skip):
+    from diamond_amd import ac_native as A, engine as E
+
+    g = torch.Generator().manual_seed(n + c + h)
+    x = (torch.randn(n, c, h, w, generator=g, dtype=torch.float64) * 1.7 + 0.4).requires_grad_(True)
+    gamma = (torch.randn(c, generator=g, dtype=torch.float64) * 0.2 + 1).requires_grad_(True)
+    beta = (torch.randn(c, generator=g, dtype=torch.float64) * 0.2).requires_grad_(True)
+    da = torch.randn(n, c, h, w, generator=g, dtype=torch.float64)
+    dskip = torch.randn(n, c, h, w, generator=g, dtype=torch.float64) if skip else None
+    u = F.group_norm(x, c // 32, gamma, beta, eps=1e-5)
+    a = u * torch.sigmoid(u)
+    tot = (a * da).sum() + ((x * dskip).sum() if skip else 0)
+    tot.backward()
+    xa = make_act(x.detach())
+    spec = E.NormSpec(mul=gamma.detach().float().to(DEV), add=beta.detach().float().to(DEV))
+    dad = to_nhwc(da.float()).to(DEV)
+    dsd = to_nhwc(dskip.float()).to(DEV) if skip else None
+    dx, dmul, dadd = A._gn_silu_bwd(xa, spec, dad, dsd)
+    torch.cuda.synchronize()
+    assert rel_err(dx.permute(0, 3, 1, 2), x.grad) < 2e-5
+    assert rel_err(dmul.sum(0), gamma.grad) < 2e-5
+    assert rel_err(dadd.sum(0), beta.grad) < 2e-5
+
+
+def test_maxpool_bwd():
+    from diamond_amd import ac_native as A
+
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 32, 16, 24, generator=g).requires_grad_(True)
+    dp = torch.randn(3, 32, 8, 12, generator=g)
+    F.max_pool2d(x, 2).backward(dp)
+    pooled, arg = A._maxpool(to_nhwc(x.detach()).to(DEV))
+    dx = A._maxpool_bwd(to_nhwc(dp).to(DEV), arg)
+    assert torch.equal(dx.cpu().permute(0, 3, 1, 2), x.grad)
+
+
+def test_actor_critic_encoder_grads_vs_oracle():
+    """Whole encoder, forward + every parameter gradient, vs the CPU oracle under torch autograd (fp32);
+    tolerance 1e-4 relative (north_star)."""
+    import diamond_amd as D
+    from diamond_amd.testing import fill_module_, synthetic_frames
+    from oracle import diamond_oracle as O
+
+    agent = D.Agent(D.default_agent_config())
+    fill_module_(agent, 5)
+    ac = agent.actor_critic
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in ac.state_dict().items()}
+    g = torch.Generator().manual_seed(21)
+    obs = synthetic_frames(g, 5, 3, 64, 64)
+    wfeat = torch.randn(5, 1024, generator=g)
+    ref = O.ac_encoder(sd, O.ActorCriticSpec(), obs).flatten(1)
+    (ref * wfeat).sum().backward()
+    ac = ac.to(DEV)
+    feat = ac.encode(obs.to(DEV))
+    (feat * wfeat.to(DEV)).sum().backward()
+    assert rel_err(feat.detach(), ref.detach()) < 1e-4
+    for k, p in ac.named_parameters():
+        if k.startswith("encoder."):
+            assert rel_err(p.grad, sd[k].grad) < 1e-4, f"{k}: {rel_err(p.grad, sd[k].grad):.3e}"
