@@ -77,14 +77,27 @@ def build_agent(device, img_size, rank):
     return agent.to(device)
 
 
-def cpu_baseline(img_size):
-    """CPU oracle (oracle/diamond_oracle.py, torch-CPU fp32, all host threads) on a bounded
-    sample of the same workload: B=8, 2 imagined steps + actor-critic loss backward."""
+def usable_cores(cap=32):
+    """Host threads the CPU baseline may use: scheduler affinity, cgroup CPU quota, and a cap (a
+    256-thread oneDNN pool on a quota-limited container thrashes for minutes)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
+def cpu_baseline_worker(img_size, threads):
+    """CPU oracle (oracle/diamond_oracle.py, torch-CPU fp32) on a bounded sample of configs[0]
+    (B=16, 3 of its 15 imagined steps + actor-critic loss backward).  Runs in its own process."""
     from diamond_amd.testing import fill_state_dict_, initial_condition_batches
     from oracle import diamond_oracle as O
     import diamond_amd as D
 
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     agent = D.Agent(D.default_agent_config(num_actions=4, img_size=img_size))
     sd = agent.state_dict()
     fill_state_dict_(sd, 0)
@@ -92,7 +105,7 @@ def cpu_baseline(img_size):
     a = O.AgentSD(denoiser=sub("denoiser"), rew_end_model=sub("rew_end_model"), actor_critic=sub("actor_critic"),
                   aspec=O.ActorCriticSpec(img_size=img_size), rspec=O.RewEndSpec(img_size=img_size))
     a.actor_critic = {k: v.requires_grad_(True) for k, v in a.actor_critic.items()}
-    b, t = 8, 2
+    b, t = 16, 3
     draws = O.DrawSource(torch.Generator().manual_seed(1))
     env = O.ImaginationEnv(a, initial_condition_batches(5, b, 4, h=img_size, w=img_size), b, 15, draws, 1)
     state = (env.reset(), torch.zeros(b, 512), torch.zeros(b, 512))
@@ -102,8 +115,31 @@ def cpu_baseline(img_size):
     loss.backward()
     dt = time.perf_counter() - t0
     return {"value": b * t / dt, "unit": "imagined frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"B={b}, {t} imagined steps (3 Euler denoise + rew/end + actor-critic) + AC backward, "
-                      f"{img_size}x{img_size}, fp32 torch-CPU oracle, {dt:.1f}s"}
+            "sample": f"configs[0] shape, B={b}, {t} of 15 imagined steps (3 Euler denoise + rew/end + actor-critic) + AC "
+                      f"backward, {img_size}x{img_size}, fp32 torch-CPU oracle, {dt:.1f}s"}
+
+
+def cpu_baseline(img_size, timeout_s=240):
+    """Time the CPU oracle in a child process (own thread pool, hard timeout: the bench line must
+    never hang on the baseline)."""
+    import subprocess
+
+    threads = usable_cores()
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(threads), "--img-size", str(img_size)]
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, cwd=ROOT)
+    try:
+        out, _ = proc.communicate(timeout=timeout_s)
+        return json.loads(out.decode().strip().splitlines()[-1])
+    except subprocess.TimeoutExpired:
+        proc.kill()  # exactly the PID we started
+        proc.communicate()
+        return {"value": None, "unit": "imagined frames/s", "cores": threads, "kind": "port",
+                "sample": f"timed out after {timeout_s}s"}
+    except Exception as e:  # noqa: BLE001
+        return {"value": None, "unit": "imagined frames/s", "cores": threads, "kind": "port", "sample": f"failed: {e!r}"}
 
 
 def main():
@@ -117,8 +153,13 @@ def main():
     ap.add_argument("--img-size", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_worker:
+        print(json.dumps(cpu_baseline_worker(args.img_size, args.cpu_baseline_worker)))
+        return
 
+    t_start = time.perf_counter()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -162,9 +203,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def progress(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    progress("setup done")
     for _ in range(args.warmup):
         window()
     fence()
+    progress("warmup done")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         window()
@@ -175,6 +222,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    progress(f"timed region done: {elapsed:.2f}s for {args.steps} steps")
     frames = args.batch * world * args.horizon * args.steps
     fps = frames / elapsed
     line = {
@@ -208,15 +256,21 @@ def main():
             pmc = json.load(open(pmc_path)).get(key)
         line["roofline"] = {
             "kernel": key, "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc, "launches": d["launches"],
+            "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+            # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB units;
+            # tools/pmc_collect.sh -> profiles/pmc_traffic.json), next to the algorithmic bytes per launch
+            "traffic": None if pmc is None else pmc["hbm_bytes_per_launch"],
+            "algorithmic_bytes_per_launch": d["bytes"] / d["launches"], "launches": d["launches"],
             "avg_launch_ms": d["ms"] / d["launches"], "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
             "algorithmic_hbm_gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9,
             "frac_hbm_peak": d["bytes"] / (d["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "conv_share_of_window_ms": {k: v["ms"] for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])},
         }
 
+    progress("roofline window done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.img_size)
+        progress("cpu baseline done")
 
     if rank == 0:
         print(json.dumps(line))

@@ -24,21 +24,28 @@ def _worker(rank, world, port, q):
     if rank == 0:
         fill_module_(ac, 5)
     broadcast_parameters(ac)
-    ac.backend = "torch"  # CPU: the interim torch path only exercises the host-side collective logic
+    # The product's kernels need a GPU; this CPU test exercises the host-side collective logic only, so the
+    # gradients come from the CPU oracle (test infrastructure) evaluated on the module's own Parameters.
+    from oracle import diamond_oracle as O
+
+    def predict(model, x):
+        z = torch.zeros(x.size(0), model.lstm_dim)
+        logits, val, _ = O.ac_predict(dict(model.named_parameters()), O.ActorCriticSpec(), x, z, z)
+        return logits, val
+
     red = GradAllReducer(list(ac.parameters()))
     g = torch.Generator().manual_seed(40)
     obs_all = synthetic_frames(g, 4, 3, 64, 64)
     obs = obs_all[rank * 2:(rank + 1) * 2]
-    out = ac.predict_act_value(obs, None)
-    (out.logits_act.square().mean() + out.val.mean()).backward()
+    logits, val = predict(ac, obs)
+    (logits.square().mean() + val.mean()).backward()
     flat = red.all_reduce_mean().clone()
     if rank == 0:
         # single-process reference over the whole batch
         ac2 = D.ActorCritic(D.default_agent_config().actor_critic)
         fill_module_(ac2, 5)
-        ac2.backend = "torch"
-        o = ac2.predict_act_value(obs_all, None)
-        (o.logits_act.square().mean() + o.val.mean()).backward()
+        logits, val = predict(ac2, obs_all)
+        (logits.square().mean() + val.mean()).backward()
         ref = torch.cat([p.grad.reshape(-1) for p in ac2.parameters()])
         q.put(float((flat - ref).abs().max() / ref.abs().max()))
         q.put(all(p.grad.data_ptr() != 0 for p in ac.parameters()))
@@ -53,8 +60,17 @@ def test_grad_allreduce_world2_gloo():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    err = q.get(timeout=120)
-    ok = q.get(timeout=120)
+    import queue
+    import time
+
+    got, deadline = [], time.time() + 240
+    while len(got) < 2:
+        try:
+            got.append(q.get(timeout=2))
+        except queue.Empty:
+            assert time.time() < deadline, "timed out"
+            assert all(p.exitcode in (None, 0) for p in procs), "a rank died: " + str([p.exitcode for p in procs])
+    err, ok = got
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
