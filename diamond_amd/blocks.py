@@ -42,11 +42,18 @@ class RunCtx:
     GEMM -- they all consume the same cond vector, blocks.py:171-177)."""
 
     def __init__(self, cache: E.PackCache, film: Optional["FilmTable"] = None, table: Optional[Tensor] = None,
-                 naive: Optional[bool] = None):
+                 naive: Optional[bool] = None, precision: Optional[str] = None):
         self.cache = cache
         self.film = film
         self.table = table
         self.naive = naive
+        self.precision = precision or E.WORLD_MODEL_PRECISION
+
+    def w16(self, conv: nn.Conv2d) -> Optional[Tensor]:
+        """Split-fp16 weight pieces when this forward runs in "f16x2" precision (else None -> exact fp32)."""
+        if self.precision != "f16x2" or self.naive:
+            return None
+        return self.cache.conv_weight_f16x2(conv)
 
     def film_spec(self, norm: "AdaGroupNorm", c_start: int = 0) -> NormSpec:
         off = self.film.offset[id(norm)]
@@ -153,7 +160,7 @@ class Upsample(nn.Module):
     def run(self, ctx: RunCtx, x: Act) -> Act:
         # nearest x2 is folded into the conv's gather: in[y >> 1][x >> 1]
         return E.conv2d([(x, nv.PROLOGUE_NONE, None)], ctx.cache.conv_weight(self.conv), ctx.cache.conv_bias(self.conv),
-                        self.conv.out_channels, upsample=True, naive=ctx.naive)
+                        self.conv.out_channels, upsample=True, naive=ctx.naive, w_f16=ctx.w16(self.conv))
 
 
 class SmallResBlock(nn.Module):
@@ -189,9 +196,10 @@ class ResBlock(nn.Module):
         for a in xs:
             srcs.append((a, nv.PROLOGUE_NORM_SILU, ctx.film_spec(self.norm1, c0)))
             c0 += a.C
-        h = E.conv2d(srcs, ctx.cache.conv_weight(self.conv1), ctx.cache.conv_bias(self.conv1), cout, naive=ctx.naive)
+        h = E.conv2d(srcs, ctx.cache.conv_weight(self.conv1), ctx.cache.conv_bias(self.conv1), cout, naive=ctx.naive,
+                     w_f16=ctx.w16(self.conv1))
         h = E.conv2d([(h, nv.PROLOGUE_NORM_SILU, ctx.film_spec(self.norm2))], ctx.cache.conv_weight(self.conv2),
-                     ctx.cache.conv_bias(self.conv2), cout, residual=r, naive=ctx.naive)
+                     ctx.cache.conv_bias(self.conv2), cout, residual=r, naive=ctx.naive, w_f16=ctx.w16(self.conv2))
         if not isinstance(self.attn, nn.Identity):
             h = self.attn.run(ctx, h)
         return h

@@ -499,10 +499,14 @@ static void dispatch_wn(const dmd_conv_params& p, hipStream_t st) {
 
 extern "C" int dmd_conv_stat_tiles(int H, int W) { return (H / 8) * (W / ((W % 16) ? 8 : 16)); }
 
+int dmd_launch_conv_f16s(const dmd_conv_params& p, hipStream_t st);  // dmd_conv_f16.hip
+
 extern "C" int dmd_conv2d(const dmd_conv_params* p, dmd_stream_t stream) {
   if (int e = validate_conv(p)) return e;
   hipStream_t st = (hipStream_t)stream;
-  if (p->taps == 1)
+  if (dmd_conv2d_f16x2_eligible(p))
+    dmd_launch_conv_f16s(*p, st);
+  else if (p->taps == 1)
     dispatch_wn<1, 1>(*p, st);
   else if (p->stride == 2)
     dispatch_wn<9, 2>(*p, st);

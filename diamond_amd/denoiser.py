@@ -85,8 +85,9 @@ class Denoiser(nn.Module):
 
     @torch.no_grad()
     def compute_model_output(self, noisy_next_obs: Tensor, obs: Tensor, act: Tensor, sigma: Union[Tensor, float],
-                             naive: Optional[bool] = None) -> Tensor:
-        """F = inner_model(x * c_in, c_noise, obs / sigma_data, act)  (reference :74-77)."""
+                             naive: Optional[bool] = None, precision: Optional[str] = None) -> Tensor:
+        """F = inner_model(x * c_in, c_noise, obs / sigma_data, act)  (reference :74-77).
+        precision: None (engine.WORLD_MODEL_PRECISION) | "f32" | "f16x2"."""
         n, cx, h, w = noisy_next_obs.shape
         cobs = obs.shape[1]
         cond, stride = self.compute_conditioners(sigma)
@@ -99,7 +100,7 @@ class Denoiser(nn.Module):
         nv.check(nv.lib().dmd_edm_pack_input(nv.fptr(xc), nv.fptr(oc), nv.fptr(cond), stride, float(self.cfg.sigma_data),
                                              nv.fptr(packed), n, cx, cobs, h, w, cpad, nv.stream()), "dmd_edm_pack_input")
         cvec = self.inner_model.cond_vector(cond, stride, act)
-        return self.inner_model.run(packed, cvec, naive)
+        return self.inner_model.run(packed, cvec, naive, precision)
 
     @torch.no_grad()
     def wrap_model_output(self, noisy_next_obs: Tensor, model_output: Tensor, sigma: Union[Tensor, float]) -> Tensor:

@@ -16,6 +16,10 @@ from torch import Tensor, nn
 from . import native as nv
 
 _USE_NAIVE = os.environ.get("DIAMOND_CONV_IMPL", "mfma") == "naive"  # debugging aid only (still HIP)
+# Arithmetic of the no-grad world-model convolutions (denoiser / reward-end model):
+#   "f16x2": split-fp32 operands on the f16 matrix cores where dmd_conv2d_f16x2_eligible (default);
+#   "f32"  : exact fp32 MFMA everywhere.  The actor-critic (gradients) always runs exact fp32.
+WORLD_MODEL_PRECISION = os.environ.get("DIAMOND_CONV_PRECISION", "f16x2")
 
 
 class LaunchProfiler:
@@ -41,7 +45,9 @@ PROFILER: Optional[LaunchProfiler] = None
 
 
 def kernel_key(p) -> str:
-    """Name of the conv_mfma_kernel<ConvGeom<WN, CFGB, TAPS, STRIDE>> instantiation dmd_conv2d picks."""
+    """Name of the kernel instantiation dmd_conv2d picks for these parameters."""
+    if nv.lib().dmd_conv2d_f16x2_eligible(C.byref(p)):
+        return f"conv_f16s<{'B8' if p.W % 16 else 'A16'}>"
     wn = 4 if p.CoutPad % 64 == 0 else (2 if p.CoutPad % 32 == 0 else 1)
     return f"conv_mfma<WN{wn},{'B' if p.W % 16 else 'A'},taps{p.taps},s{p.stride}>"
 
@@ -97,6 +103,12 @@ class PackCache:
     def conv_weight(self, conv: nn.Conv2d, cout_padded: Optional[int] = None) -> Tensor:
         return self.get(conv.weight, f"convw{cout_padded}", lambda w: nv.pack_conv_weight(w, cout_padded))
 
+    def conv_weight_f16x2(self, conv: nn.Conv2d) -> Optional[Tensor]:
+        """Split-fp16 pieces of a 3x3, 64-output-channel weight (None for other shapes)."""
+        if conv.out_channels != 64 or conv.kernel_size != (3, 3) or conv.stride != (1, 1):
+            return None
+        return self.get(conv.weight, "convw_f16x2", nv.pack_conv_weight_f16x2)
+
     def conv_bias(self, conv: nn.Conv2d, cout_padded: Optional[int] = None) -> Optional[Tensor]:
         if conv.bias is None:
             return None
@@ -126,6 +138,7 @@ def conv2d(
     out_nchw: bool = False,
     cout_padded: Optional[int] = None,
     naive: Optional[bool] = None,
+    w_f16: Optional[Tensor] = None,
 ) -> Act:
     a0 = srcs[0][0]
     n, hs, ws, _ = a0.shape
@@ -147,6 +160,9 @@ def conv2d(
         if prologue != nv.PROLOGUE_NONE:
             p.src[i].norm = norm.to_native(a)
     p.w = nv.ptr(w_packed)
+    if w_f16 is not None:
+        p.w_f16 = nv.ptr(w_f16)
+        p.precision = nv.PRECISION_F16X2
     p.bias = nv.ptr(bias)
     if residual is not None:
         assert tuple(residual.shape) == (n, h, w, cout) and residual.t.is_contiguous()

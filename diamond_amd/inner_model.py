@@ -57,14 +57,14 @@ class InnerModel(nn.Module):
         y = E.linear(x, self._cache.f32(l0.weight), self._cache.f32(l0.bias), silu=True)
         return E.linear(y, self._cache.f32(l2.weight), self._cache.f32(l2.bias))
 
-    def run(self, packed_in: Tensor, cond: Tensor, naive: Optional[bool] = None) -> Tensor:
+    def run(self, packed_in: Tensor, cond: Tensor, naive: Optional[bool] = None, precision: Optional[str] = None) -> Tensor:
         """packed_in: NHWC16 [obs/sigma_data | noisy*c_in | 0]; returns F as NCHW (N,3,H,W)."""
         if self._film is None:
             self._film = FilmTable(self.unet)
         table = self._film.compute(cond)
-        ctx = RunCtx(self._cache, self._film, table, naive)
+        ctx = RunCtx(self._cache, self._film, table, naive, precision)
         x = E.conv2d([(E.Act(packed_in), nv.PROLOGUE_NONE, None)], self._cache.conv_weight(self.conv_in),
-                     self._cache.conv_bias(self.conv_in), self.conv_in.out_channels, naive=naive)
+                     self._cache.conv_bias(self.conv_in), self.conv_in.out_channels, naive=naive, w_f16=ctx.w16(self.conv_in))
         x = self.unet.run(ctx, x)
         return E.conv2d([(x, nv.PROLOGUE_NORM_SILU, self.norm_out.spec(ctx))], self._cache.conv_weight(self.conv_out),
                         self._cache.conv_bias(self.conv_out), self.conv_out.out_channels, want_stats=False, out_nchw=True,

@@ -18,6 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdiamond_hip.so")
 
 PROLOGUE_NONE, PROLOGUE_NORM_SILU, PROLOGUE_NORM = 0, 1, 2
+PRECISION_F32, PRECISION_F16X2 = 0, 1
 GN_GROUP = 32
 
 
@@ -38,8 +39,8 @@ class ConvParams(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cout", C.c_int32), ("CoutPad", C.c_int32),
                 ("taps", C.c_int32), ("stride", C.c_int32), ("upsample", C.c_int32), ("nsrc", C.c_int32),
                 ("src", ConvSrc * 2), ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p),
-                ("residual_norm", Norm), ("out", C.c_void_p), ("out_nchw", C.c_int32), ("reserved", C.c_int32),
-                ("out_stats", C.c_void_p)]
+                ("residual_norm", Norm), ("out", C.c_void_p), ("out_nchw", C.c_int32), ("precision", C.c_int32),
+                ("out_stats", C.c_void_p), ("w_f16", C.c_void_p)]
 
 
 class LinearParams(C.Structure):
@@ -61,7 +62,8 @@ class WgradParams(C.Structure):
 
 
 EXPORTS = (
-    "dmd_conv2d", "dmd_conv2d_naive", "dmd_conv_stat_tiles", "dmd_pack_conv_weight", "dmd_linear", "dmd_attention",
+    "dmd_conv2d", "dmd_conv2d_naive", "dmd_conv_stat_tiles", "dmd_pack_conv_weight", "dmd_conv2d_f16x2_eligible",
+    "dmd_pack_conv_weight_f16x2", "dmd_linear", "dmd_attention",
     "dmd_edm_pack_input", "dmd_cond_embed", "dmd_edm_denoised", "dmd_euler_step", "dmd_nchw_to_nhwc",
     "dmd_nhwc_to_nchw", "dmd_gn_stats", "dmd_maxpool2", "dmd_lstm_pointwise", "dmd_categorical_sample",
     "dmd_maxpool2_bwd", "dmd_gn_bwd_workspace_bytes", "dmd_gn_silu_bwd", "dmd_wgrad_workspace_floats", "dmd_conv2d_wgrad",
@@ -86,6 +88,8 @@ def lib() -> C.CDLL:
         L.dmd_conv2d_naive.argtypes = [C.POINTER(ConvParams), C.c_void_p]
         L.dmd_linear.argtypes = [C.POINTER(LinearParams), C.c_void_p]
         L.dmd_pack_conv_weight.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.dmd_pack_conv_weight_f16x2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.dmd_conv2d_f16x2_eligible.argtypes = [C.POINTER(ConvParams)]
         L.dmd_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.dmd_edm_pack_input.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -165,6 +169,17 @@ def pack_conv_weight(w_oihw: Tensor, cout_padded: Optional[int] = None) -> Tenso
     w = w_oihw.detach().contiguous().float()
     out = torch.empty(cinp // 16 * k * k * cp * 16, device=w.device, dtype=torch.float32)
     check(lib().dmd_pack_conv_weight(fptr(w), fptr(out), cout, cin, k, cp, cinp, stream()), "dmd_pack_conv_weight")
+    return out
+
+
+def pack_conv_weight_f16x2(w_oihw: Tensor) -> Tensor:
+    """OIHW (64, Cin, 3, 3) -> [CinPad/16][9][h|l][64][16] fp16 split pieces (w = h + l)."""
+    cout, cin, k, _ = w_oihw.shape
+    assert cout == 64 and k == 3, (cout, k)
+    cinp = (cin + 15) // 16 * 16
+    w = w_oihw.detach().contiguous().float()
+    out = torch.empty(cinp // 16 * 9 * 2 * 64 * 16, device=w.device, dtype=torch.float16)
+    check(lib().dmd_pack_conv_weight_f16x2(fptr(w), ptr(out), cout, cin, cinp, stream()), "dmd_pack_conv_weight_f16x2")
     return out
 
 

@@ -69,9 +69,22 @@ typedef struct dmd_conv_params {
   dmd_norm residual_norm; /* optional GroupNorm(+affine) applied to the residual        */
   float* out;        /* NHWC (N, H, W, Cout), or NCHW (N, Cout, H, W) if out_nchw       */
   int32_t out_nchw;
-  int32_t reserved;
+  int32_t precision; /* DMD_PRECISION_*: arithmetic of the contraction (see below)       */
   double* out_stats; /* (N, Cout/32, T, 2) partial sums of the output, or NULL          */
+  const void* w_f16; /* dmd_pack_conv_weight_f16x2 layout, or NULL (needed for F16X2)    */
 } dmd_conv_params;
+
+/* DMD_PRECISION_F32:   v_mfma_f32_16x16x4_f32, bit-for-bit a k-ordered fp32 fma chain.
+ * DMD_PRECISION_F16X2: fp32 operands split into two fp16 pieces each (x = h + l), three
+ *   v_mfma_f32_32x32x16_f16 per product into an fp32 accumulator: fp32-class accuracy
+ *   (representation error <= 2^-22 relative) for |x| < 65504, 16x the MFMA rate.  Honoured only
+ *   where dmd_conv2d_f16x2_eligible() says so (3x3 stride 1, Cout == 64, Cin <= 128, NHWC out);
+ *   everything else silently uses the exact kernel. */
+#define DMD_PRECISION_F32 0
+#define DMD_PRECISION_F16X2 1
+int dmd_conv2d_f16x2_eligible(const dmd_conv_params* p);
+/* OIHW (64, Cin, 3, 3) fp32 -> [CinPad/16][9][h|l][64][16] fp16 pieces */
+int dmd_pack_conv_weight_f16x2(const float* oihw, void* packed, int Cout, int Cin, int CinPad, dmd_stream_t stream);
 
 int dmd_conv2d(const dmd_conv_params* p, dmd_stream_t stream);
 /* number of GroupNorm stat tiles per image a dmd_conv2d with output (H, W) emits */

@@ -58,11 +58,15 @@ CONV_CASES = [
     ("c32to64", 2, 16, 16, [32], 64, 9, 1, False, 1, False, False),
     ("c32_down", 2, 16, 16, [32], 32, 9, 2, False, 0, False, False),
     ("rect_24x40", 1, 24, 40, [64], 64, 9, 1, False, 1, True, False),
+    ("c64_64x64", 2, 64, 64, [64], 64, 9, 1, False, 1, True, False),
+    ("cat128_16x16_n5", 5, 16, 16, [64, 64], 64, 9, 1, False, 1, True, False),
+    ("up_32to64", 1, 32, 32, [64], 64, 9, 1, True, 0, False, False),
+    ("c64_8x8_n6_noprologue", 6, 8, 8, [64], 64, 9, 1, False, 0, False, False),
 ]
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-@pytest.mark.parametrize("impl", ["mfma", "naive"])
+@pytest.mark.parametrize("impl", ["mfma", "naive", "f16x2"])
 def test_conv2d(case, impl):
     from diamond_amd import engine as E, native as nv
 
@@ -110,11 +114,17 @@ def test_conv2d(case, impl):
     bp = nv.pad_vector(bias.float().to(DEV), nv.cout_pad(cout))
     r_act = E.Act(to_nhwc(res.float()).to(DEV)) if res is not None else None
     want_stats = (cout % 32 == 0) and not nchw
+    w16 = None
+    if impl == "f16x2":
+        if not (cout == 64 and taps == 9 and stride == 1):
+            pytest.skip("shape not covered by the split-fp16 kernel (runs exact fp32)")
+        w16 = nv.pack_conv_weight_f16x2(wgt.float().to(DEV))
     out = E.conv2d(srcs, wp, bp, cout, taps=taps, stride=stride, upsample=up, residual=r_act, want_stats=want_stats,
-                   out_nchw=nchw, naive=(impl == "naive"))
+                   out_nchw=nchw, naive=(impl == "naive"), w_f16=w16)
     torch.cuda.synchronize()
     got = out.t if nchw else out.t.permute(0, 3, 1, 2)
     err = rel_err(got, ref)
+    print(f"{name}/{impl}: rel err {err:.3e}")
     assert err < 2e-5, f"{name}/{impl}: rel err {err:.3e}"
     if want_stats:
         st = out.stats.cpu().sum(dim=2)  # (N, G, 2)

@@ -86,12 +86,27 @@ def test_denoiser_not_further_from_fp64_than_cpu_fp32(agent):
     assert e_hip < 1e-4 and e_hip < 10 * e_cpu + 1e-6
 
 
+def test_denoiser_f16x2_vs_exact_fp32(agent):
+    """The split-fp16 MFMA path (default for the world model) against the exact-fp32 MFMA path of the same
+    network: the difference must be far inside the 1e-4 budget."""
+    gold = load_golden("denoiser_default.pt")
+    obs, act, noise = _denoiser_inputs(gold, 2)
+    for i, sigma in enumerate(gold["sigmas"][:-1]):
+        x = noise * sigma + obs[:, -3:] * 0.5
+        f32 = agent.denoiser.compute_model_output(x.to(DEV), obs.to(DEV), act.to(DEV), sigma, precision="f32")
+        f16 = agent.denoiser.compute_model_output(x.to(DEV), obs.to(DEV), act.to(DEV), sigma, precision="f16x2")
+        err = rel_err(f16, f32)
+        print(f"sigma#{i}: f16x2 vs f32 {err:.3e}; f32 vs golden {rel_err(f32, gold[f'model_output_{i}']):.3e}; "
+              f"f16x2 vs golden {rel_err(f16, gold[f'model_output_{i}']):.3e}")
+        assert err < 2e-5, err
+
+
 def test_denoiser_mfma_equals_naive_kernels(agent):
     gold = load_golden("denoiser_default.pt")
     obs, act, noise = _denoiser_inputs(gold, 2)
     sigma = gold["sigmas"][0]
     x = (noise * sigma + obs[:, -3:] * 0.5).to(DEV)
-    a = agent.denoiser.compute_model_output(x, obs.to(DEV), act.to(DEV), sigma)
+    a = agent.denoiser.compute_model_output(x, obs.to(DEV), act.to(DEV), sigma, precision="f32")
     b = agent.denoiser.compute_model_output(x, obs.to(DEV), act.to(DEV), sigma, naive=True)
     assert rel_err(a, b) < 2e-5
 
