@@ -504,9 +504,9 @@ int dmd_launch_conv_f16s(const dmd_conv_params& p, hipStream_t st);  // dmd_conv
 extern "C" int dmd_conv2d(const dmd_conv_params* p, dmd_stream_t stream) {
   if (int e = validate_conv(p)) return e;
   hipStream_t st = (hipStream_t)stream;
-  if (dmd_conv2d_f16x2_eligible(p))
-    dmd_launch_conv_f16s(*p, st);
-  else if (p->taps == 1)
+  if (dmd_conv2d_f16x2_eligible(p)) {
+    if (int e = dmd_launch_conv_f16s(*p, st)) return e;
+  } else if (p->taps == 1)
     dispatch_wn<1, 1>(*p, st);
   else if (p->stride == 2)
     dispatch_wn<9, 2>(*p, st);

@@ -23,9 +23,12 @@
 //   * K loop: 16 input channels per step (= MFMA K).  The halo'd patch of a chunk is staged once
 //     in LDS as [patch pixel][4 x 16 B]: {h[0:8], h[8:16], l[0:8], l[8:16]}, slot rotated by
 //     (px >> 1) -> conflict-free ds_read_b128 for every tap (tools/lds_sim.py rules); GroupNorm /
-//     FiLM + SiLU and the h/l split are applied while staging; double buffered.
-//   * weights: pre-split on the host side of the ABI (dmd_pack_conv_weight_f16x2), streamed from
-//     L2 into registers one (chunk, tap) step ahead: [chunk][tap][h|l][64 cout][16 cin] halfs.
+//     FiLM + SiLU (one fma + v_exp/v_rcp) and the h/l split are applied while staging.
+//   * weights: pre-split by dmd_pack_conv_weight_f16x2 into [chunk][tap][h|l][k group][64 cout][8 cin]
+//     halfs; the 36 KiB of a chunk are copied linearly into LDS next to the patch.  Both the next
+//     chunk's activations and its weights are prefetched into registers DURING the 9-tap MFMA loop,
+//     which itself contains no vmcnt wait (in-order vmcnt would otherwise serialise every tap's weight
+//     fetch behind the HBM-latency activation loads).
 #include "dmd_common.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -34,6 +37,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define F16S_CIN_MAX 128
+
+// Compile-time timing ablations (development only; results are WRONG when non-zero):
+//   1: no global stores / residual loads in the epilogue   2: no MFMA   4: no staging global loads
+//   8: no staging math (norm/SiLU)   16: no LDS fragment reads in the tap loop
+#ifndef F16S_ABL
+#define F16S_ABL 0
+#endif
 
 template <bool B8_>
 struct F16Geom {
@@ -44,6 +54,12 @@ struct F16Geom {
   static constexpr int PPS = PW * PW;
   static constexpr int NPP = SUB * PPS;
   static constexpr int ITEMS = (NPP * 4 + 255) / 256;
+  static constexpr int W_UNITS = 9 * 2 * 2 * 64;  // 16-byte units of one chunk's weights: [tap][h|l][g][64 cout]
+  static constexpr int OT_STRIDE = 68;                      // floats per pixel row of the epilogue's output tile
+  static constexpr int MAIN_BYTES = NPP * 64 + W_UNITS * 16;  // K loop: patch + weights
+  static constexpr int OT_BYTES = 256 * OT_STRIDE * 4;        // epilogue: [256 pixels][64 couts (+4 pad)] fp32
+  static constexpr int BODY_BYTES = MAIN_BYTES > OT_BYTES ? MAIN_BYTES : OT_BYTES;
+  static constexpr int SMEM_BYTES = BODY_BYTES + 2 * SUB * F16S_CIN_MAX * 4 + 256;
 };
 
 struct F16Tile {
@@ -66,14 +82,20 @@ __device__ __forceinline__ F16Tile f16_subtile(const dmd_conv_params& p, int til
   return t;
 }
 
-__device__ __forceinline__ float f16_clamp(float v) { return fminf(fmaxf(v, -65504.0f), 65504.0f); }
+// SiLU for the split-precision path: v_exp_f32 / v_rcp_f32 (1 ulp each, i.e. the same 2^-22 class as the
+// operand split itself) instead of the IEEE expf + division of the exact kernel.
+__device__ __forceinline__ float f16s_silu(float t) {
+  return t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * t));
+}
 
 template <class G>
 __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(const dmd_conv_params p) {
-  __shared__ u32x4 patch[2][G::NPP * 4];
-  __shared__ float tab_mean[G::SUB][F16S_CIN_MAX];
-  __shared__ float tab_a[G::SUB][F16S_CIN_MAX];
-  __shared__ float tab_add[G::SUB][F16S_CIN_MAX];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4* patch = (u32x4*)smem_raw;                               // [NPP][4] 16-byte slots
+  u32x4* wlds = patch + G::NPP * 4;                              // [9][2][2][64] 16-byte units
+  float* tab_a = (float*)(smem_raw + G::BODY_BYTES);             // [SUB][CIN_MAX]: t = v * a + b
+  float* tab_b = tab_a + G::SUB * F16S_CIN_MAX;
+  double* red = (double*)(tab_b + G::SUB * F16S_CIN_MAX);        // 32 doubles of scratch
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cb = wave & 1;   // 32-cout block == GroupNorm group
@@ -92,25 +114,67 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(const dmd_conv_params
   const int nch0 = C0 >> 4;
   const int nchunks = (C0 + C1) >> 4;
 
-  // ---- prologue tables ----
-  for (int c = tid; c < C0 + C1; c += 256) {
-    const int si = c < C0 ? 0 : 1;
-    const dmd_conv_src& sc = p.src[si];
-    const int cl = si ? c - C0 : c;
+  // ---- prologue tables: y = (x - mean) * rstd * mul' + add  ==  x * a + b ----
+  // group statistics first, one (sub-tile, source, group) per wave iteration: lanes fetch the producer's
+  // per-tile partial sums in parallel (fixed shuffle-tree order -> deterministic)
+  {
+    const int G0 = p.src[0].prologue != DMD_PROLOGUE_NONE ? C0 / DMD_GN_GROUP : 0;
+    const int G1 = (p.nsrc > 1 && p.src[1].prologue != DMD_PROLOGUE_NONE) ? C1 / DMD_GN_GROUP : 0;
+    const int GT = G0 + G1;  // <= 4
+    float* gms = (float*)red;  // [SUB][4][2] mean, rstd
+    const double count = (double)DMD_GN_GROUP * Hs * Ws;
+    for (int item = wave; item < G::SUB * GT; item += 4) {
+      const int s = item / GT, gi = item - s * GT;
+      const int si = gi < G0 ? 0 : 1;
+      const int gl = si ? gi - G0 : gi;
+      const dmd_norm& nm = p.src[si].norm;
+      const int Gs = p.src[si].C / DMD_GN_GROUP;
+      F16Tile t = ti[0];
 #pragma unroll
-    for (int s = 0; s < G::SUB; ++s) {
-      float m = 0.f, a = 1.f, ad = 0.f;
-      if (sc.prologue != DMD_PROLOGUE_NONE && ti[s].valid)
-        norm_entry(sc.norm, ti[s].n, cl, sc.C, (double)DMD_GN_GROUP * Hs * Ws, &m, &a, &ad);
-      tab_mean[s][c] = m;
-      tab_a[s][c] = a;
-      tab_add[s][c] = ad;
+      for (int k = 1; k < G::SUB; ++k)
+        if (s == k) t = ti[k];
+      const double* st = nm.stats + ((size_t)(t.n * Gs + gl) * nm.stat_tiles) * 2;
+      double a = 0.0, b = 0.0;
+      for (int tt = lane; tt < nm.stat_tiles; tt += 64) {
+        a += st[2 * tt];
+        b += st[2 * tt + 1];
+      }
+      a = dmd_wave_sum(a);
+      b = dmd_wave_sum(b);
+      if (lane == 0) {
+        const double m = a / count;
+        double var = b / count - m * m;
+        var = var < 0.0 ? 0.0 : var;
+        gms[(s * 4 + gi) * 2] = (float)m;
+        gms[(s * 4 + gi) * 2 + 1] = (float)(1.0 / sqrt(var + (double)DMD_GN_EPS));
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < C0 + C1; c += 256) {
+      const int si = c < C0 ? 0 : 1;
+      const dmd_conv_src& sc = p.src[si];
+      const int cl = si ? c - C0 : c;
+      const int gi = si ? G0 + cl / DMD_GN_GROUP : cl / DMD_GN_GROUP;
+#pragma unroll
+      for (int s = 0; s < G::SUB; ++s) {
+        float a = 1.f, b = 0.f;
+        if (sc.prologue != DMD_PROLOGUE_NONE && ti[s].valid) {
+          const dmd_norm& nm = sc.norm;
+          float mul = nm.mul ? nm.mul[(size_t)ti[s].n * nm.mul_stride + cl] : 1.0f;
+          if (nm.mul_plus_one) mul = 1.0f + mul;
+          const float add = nm.add ? nm.add[(size_t)ti[s].n * nm.add_stride + cl] : 0.0f;
+          a = gms[(s * 4 + gi) * 2 + 1] * mul;
+          b = add - gms[(s * 4 + gi) * 2] * a;
+        }
+        tab_a[s * F16S_CIN_MAX + c] = a;
+        tab_b[s * F16S_CIN_MAX + c] = b;
+      }
     }
   }
 
   // ---- staging items (chunk invariant): thread -> (patch pixel, channel quad q) ----
   int goff[G::ITEMS];  // source pixel index, -1: zero
-  int loff[G::ITEMS];  // 8-byte unit index of the h half-quad in a patch buffer, -1: no item
+  int loff[G::ITEMS];  // 8-byte unit index of the h half-quad in the patch, -1: no item
   int isub[G::ITEMS];
   const int q = tid & 3;
 #pragma unroll
@@ -135,7 +199,6 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(const dmd_conv_params
 
   // ---- B-operand addressing: lane = (pixel n31 of a 32-pixel block, k group g) ----
   int pixbase[4];
-  int col;
 #pragma unroll
   for (int blk = 0; blk < 4; ++blk) {
     if (G::B8) {
@@ -147,10 +210,12 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(const dmd_conv_params
       pixbase[blk] = row * G::PW + (n31 & 15);
     }
   }
-  col = G::B8 ? (n31 & 7) : (n31 & 15);
+  const int col = G::B8 ? (n31 & 7) : (n31 & 15);
   int posh[3];
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx) posh[dx] = (g + ((col + dx) >> 1)) & 3;
+  // A operand: unit ((tap * 2 + piece) * 2 + g) * 64 + cout
+  const int wunit = g * 64 + cb * 32 + n31;
 
   f32x16 acc[4];
 #pragma unroll
@@ -158,187 +223,257 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(const dmd_conv_params
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[blk][r] = 0.f;
 
-  // weights: [chunk][tap][piece][64][16] halfs; lane -> cout cb*32 + n31, k offset 8 g
-  const _Float16* wlane = (const _Float16*)p.w_f16 + (size_t)(cb * 32 + n31) * 16 + 8 * g;
-  constexpr size_t WPIECE = 64 * 16, WSTEP = 2 * WPIECE;
+  // global weights: [chunk][W_UNITS] 16-byte units, same order as the LDS copy
+  const u32x4* wglob = (const u32x4*)p.w_f16;
 
-  f32x4 stage[G::ITEMS];
-  auto load_chunk = [&](int ck) {
+  // Activations are prefetched TWO chunks ahead (two register sets): with one set the HBM latency of a chunk's
+  // loads (2-3 us under load) is longer than the chunk's own MFMA loop and every chunk stalls at its end.
+  f32x4 stage0[G::ITEMS], stage1[G::ITEMS];
+  u32x4 wstage[9];  // this thread's 9 units of the next chunk's weights
+  auto load_chunk = [&](int ck, f32x4 (&stage)[G::ITEMS]) {
     const int si = ck < nch0 ? 0 : 1;
     const dmd_conv_src& sc = p.src[si];
     const int c0 = (si ? ck - nch0 : ck) * 16 + 4 * q;
 #pragma unroll
     for (int it = 0; it < G::ITEMS; ++it) {
-      stage[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (goff[it] >= 0) stage[it] = *(const f32x4*)(sc.x + (size_t)goff[it] * sc.C + c0);
+      // branch-free: out-of-image / padding items read pixel 0 and are zeroed in store_chunk
+      const int go = goff[it] < 0 ? 0 : goff[it];
+#if F16S_ABL & 4
+      stage[it] = (f32x4){(float)go, 1.f, 2.f, (float)c0};
+#else
+      stage[it] = *(const f32x4*)(sc.x + (size_t)go * sc.C + c0);
+#endif
     }
   };
-  auto store_chunk = [&](int ck, int buf) {
+  auto store_chunk = [&](int ck, const f32x4 (&stage)[G::ITEMS]) {
     const int si = ck < nch0 ? 0 : 1;
     const int prologue = p.src[si].prologue;
     const int cc = ck * 16 + 4 * q;
-    uint2* pb = (uint2*)&patch[buf][0];
+    uint2* pb = (uint2*)patch;
 #pragma unroll
     for (int it = 0; it < G::ITEMS; ++it) {
       f32x4 v = stage[it];
-      if (prologue != DMD_PROLOGUE_NONE && goff[it] >= 0) {
-        const int s = isub[it];
+      if (prologue != DMD_PROLOGUE_NONE && !(F16S_ABL & 8)) {
+        const float* ta = tab_a + isub[it] * F16S_CIN_MAX + cc;
+        const float* tb = tab_b + isub[it] * F16S_CIN_MAX + cc;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float t = (v[e] - tab_mean[s][cc + e]) * tab_a[s][cc + e] + tab_add[s][cc + e];
-          if (prologue == DMD_PROLOGUE_NORM_SILU) t = dmd_silu(t);
+          float t = __builtin_fmaf(v[e], ta[e], tb[e]);
+          if (prologue == DMD_PROLOGUE_NORM_SILU) t = f16s_silu(t);
           v[e] = t;
         }
       }
       h4 hv, lv;
+      const bool zero = goff[it] < 0;  // conv zero padding is applied AFTER the activation (blocks.py:143-144)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float x = f16_clamp(v[e]);
+        const float x = zero ? 0.f : __builtin_amdgcn_fmed3f(v[e], -65504.0f, 65504.0f);
         const _Float16 h = (_Float16)x;
         hv[e] = h;
         lv[e] = (_Float16)(x - (float)h);
       }
       if (loff[it] >= 0) {
         pb[loff[it]] = __builtin_bit_cast(uint2, hv);
-        pb[loff[it] ^ 4] = __builtin_bit_cast(uint2, lv);  // l slots = h slot + 2 (mod 4): unit index bit 2
+        pb[loff[it] ^ 4] = __builtin_bit_cast(uint2, lv);  // l slot = h slot + 2 (mod 4): unit index bit 2
       }
     }
   };
 
+  load_chunk(0, stage0);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) wstage[k] = wglob[tid + 256 * k];
+  if (nchunks > 1) load_chunk(1, stage1);
   __syncthreads();  // tables visible
-  load_chunk(0);
-  store_chunk(0, 0);
-  h8 wh = *(const h8*)wlane;
-  h8 wl = *(const h8*)(wlane + WPIECE);
+  store_chunk(0, stage0);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) wlds[tid + 256 * k] = wstage[k];
   __syncthreads();
 
-  for (int ck = 0; ck < nchunks; ++ck) {
-    const int buf = ck & 1;
+  // one chunk: `hold` carries chunk ck + 1 (loaded a chunk ago), `recv` receives chunk ck + 2
+  auto chunk_body = [&](int ck, const f32x4 (&hold)[G::ITEMS], f32x4 (&recv)[G::ITEMS]) {
     const bool more = ck + 1 < nchunks;
-    if (more) load_chunk(ck + 1);
-    const u32x4* pbuf = &patch[buf][0];
+    if (more) {
+      // next chunk's weights first (L2, needed at the end of this chunk), then the activations of the chunk
+      // after it: the vmcnt wait before store_chunk can leave those youngest loads in flight
+      const u32x4* wnext = wglob + (size_t)(ck + 1) * G::W_UNITS + tid;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) wstage[k] = wnext[256 * k];
+    }
+    if (ck + 2 < nchunks) load_chunk(ck + 2, recv);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int dy = tap / 3, dx = tap % 3;
-      const h8 ah = wh, al = wl;
-      {
-        const int step = ck * 9 + tap + 1;
-        if (step < nchunks * 9) {
-          wh = *(const h8*)(wlane + (size_t)step * WSTEP);
-          wl = *(const h8*)(wlane + (size_t)step * WSTEP + WPIECE);
-        }
-      }
+      // LDS fragment reads are issued in the order the MFMAs consume them (LDS returns in order), two pixel
+      // blocks at a time: the first MFMAs start after 3 of the 10 reads have landed, the rest overlap.
       h8 bh[4], bl[4];
+      const int toff = dy * G::PW + dx;
+      const h8 ah = __builtin_bit_cast(h8, wlds[(tap * 2 + 0) * 128 + wunit]);
+      bh[0] = __builtin_bit_cast(h8, patch[(pixbase[0] + toff) * 4 + posh[dx]]);
+      bh[1] = __builtin_bit_cast(h8, patch[(pixbase[1] + toff) * 4 + posh[dx]]);
+      bl[0] = __builtin_bit_cast(h8, patch[(pixbase[0] + toff) * 4 + (posh[dx] ^ 2)]);
+      bl[1] = __builtin_bit_cast(h8, patch[(pixbase[1] + toff) * 4 + (posh[dx] ^ 2)]);
+      const h8 al = __builtin_bit_cast(h8, wlds[(tap * 2 + 1) * 128 + wunit]);
+      bh[2] = __builtin_bit_cast(h8, patch[(pixbase[2] + toff) * 4 + posh[dx]]);
+      bh[3] = __builtin_bit_cast(h8, patch[(pixbase[3] + toff) * 4 + posh[dx]]);
+      bl[2] = __builtin_bit_cast(h8, patch[(pixbase[2] + toff) * 4 + (posh[dx] ^ 2)]);
+      bl[3] = __builtin_bit_cast(h8, patch[(pixbase[3] + toff) * 4 + (posh[dx] ^ 2)]);
+#if F16S_ABL & 2
 #pragma unroll
-      for (int blk = 0; blk < 4; ++blk) {
-        const int pix = pixbase[blk] + dy * G::PW + dx;
-        bh[blk] = __builtin_bit_cast(h8, pbuf[pix * 4 + posh[dx]]);
-        bl[blk] = __builtin_bit_cast(h8, pbuf[pix * 4 + (posh[dx] ^ 2)]);
+      for (int blk = 0; blk < 4; ++blk) acc[blk][tap] += (float)(bh[blk][0] + bl[blk][1] + ah[0] + al[1]);
+#else
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const int b0 = 2 * pr, b1 = 2 * pr + 1;
+        acc[b0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[b0], acc[b0], 0, 0, 0);
+        acc[b1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[b1], acc[b1], 0, 0, 0);
+        acc[b0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[b0], acc[b0], 0, 0, 0);
+        acc[b1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[b1], acc[b1], 0, 0, 0);
+        acc[b0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[b0], acc[b0], 0, 0, 0);
+        acc[b1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[b1], acc[b1], 0, 0, 0);
       }
-#pragma unroll
-      for (int blk = 0; blk < 4; ++blk) acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[blk], acc[blk], 0, 0, 0);
-#pragma unroll
-      for (int blk = 0; blk < 4; ++blk) acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[blk], acc[blk], 0, 0, 0);
-#pragma unroll
-      for (int blk = 0; blk < 4; ++blk) acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[blk], acc[blk], 0, 0, 0);
+#endif
     }
-    if (more) store_chunk(ck + 1, buf ^ 1);
-    __syncthreads();
+    if (more) {
+      __syncthreads();  // every wave is done reading this chunk's patch and weights
+      store_chunk(ck + 1, hold);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) wlds[tid + 256 * k] = wstage[k];
+      __syncthreads();
+    }
+  };
+  for (int ck = 0; ck < nchunks; ck += 2) {
+    chunk_body(ck, stage1, stage0);
+    if (ck + 1 < nchunks) chunk_body(ck + 1, stage0, stage1);
   }
 
-  // ---- epilogue: lane owns couts cb*32 + 8 qd + 4 g + (0..3), qd = 0..3, of pixel n31 of each block ----
-  f32x4 bias[4];
-#pragma unroll
-  for (int qd = 0; qd < 4; ++qd) {
-    bias[qd] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bias[qd] = *(const f32x4*)(p.bias + cb * 32 + 8 * qd + 4 * g);
-  }
-  double ssum[2] = {0.0, 0.0}, ssq[2] = {0.0, 0.0};  // B8: [0] blocks 0-1, [1] blocks 2-3
-#pragma unroll
-  for (int blk = 0; blk < 4; ++blk) {
-    F16Tile t;
-    int oy, ox;
-    if (G::B8) {
-      const int s = ph * 2 + (blk >> 1);
-      t = ti[0];
-#pragma unroll
-      for (int k = 1; k < G::SUB; ++k)
-        if (s == k) t = ti[k];
-      oy = t.y0 + (blk & 1) * 4 + (n31 >> 3);
-      ox = t.x0 + (n31 & 7);
-    } else {
-      t = ti[0];
-      oy = t.y0 + ph * 8 + blk * 2 + (n31 >> 4);
-      ox = t.x0 + (n31 & 15);
-    }
-    if (!t.valid) continue;
-    const size_t pixel = ((size_t)t.n * p.H + oy) * p.W + ox;
-    float* op = p.out + pixel * 64 + cb * 32 + 4 * g;
-    const float* rp = p.residual ? p.residual + pixel * 64 + cb * 32 + 4 * g : nullptr;
-    const int slot = G::B8 ? (blk >> 1) : 0;
+  // ---- epilogue ----
+  // The MFMA result layout gives a lane 4 x 4 consecutive couts of ONE pixel: storing that directly writes 32-byte
+  // fragments at a 256-byte stride.  Instead the 256 x 64 tile is transposed through LDS so that every global
+  // access (residual read, output write) is a fully coalesced 1 KiB per wave instruction, and the GroupNorm
+  // partial sums are formed on the final values in the same pass.
+  __syncthreads();  // every wave is done with the patch / weights
+  float* otile = (float*)smem_raw;
+  {
+    f32x4 bias[4];
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
-      f32x4 v = (f32x4){acc[blk][4 * qd], acc[blk][4 * qd + 1], acc[blk][4 * qd + 2], acc[blk][4 * qd + 3]};
-      v += bias[qd];
-      if (rp) v += *(const f32x4*)(rp + 8 * qd);
-      *(f32x4*)(op + 8 * qd) = v;
+      bias[qd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bias[qd] = *(const f32x4*)(p.bias + cb * 32 + 8 * qd + 4 * g);
+    }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const double d = (double)v[e];
-        ssum[slot] += d;
-        ssq[slot] += d * d;
+    for (int blk = 0; blk < 4; ++blk) {
+      float* orow = otile + (ph * 128 + blk * 32 + n31) * G::OT_STRIDE + cb * 32 + 4 * g;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        f32x4 v = (f32x4){acc[blk][4 * qd], acc[blk][4 * qd + 1], acc[blk][4 * qd + 2], acc[blk][4 * qd + 3]};
+        *(f32x4*)(orow + 8 * qd) = v + bias[qd];
       }
     }
   }
-  if (p.out_stats) {
-    const int Gt = 2;  // Cout / 32
+  __syncthreads();
+  // wave w re-reads pixels [64 w, 64 w + 64) of the tile (raster order inside a sub-tile); lane = (pixel lane >> 4,
+  // channel quad lane & 15); GroupNorm group of the lane = (lane & 15) >> 3.
+  {
+    const int quad = lane & 15;
+    F16Tile t = ti[0];
+    if (G::B8) {
 #pragma unroll
-    for (int k = 0; k < (G::B8 ? 2 : 1); ++k) {
-      const double a = dmd_wave_sum(ssum[k]);
-      const double b = dmd_wave_sum(ssq[k]);
-      F16Tile t = ti[0];
-      int T, tt;
-      if (G::B8) {
-        const int s = ph * 2 + k;
+      for (int k = 1; k < G::SUB; ++k)
+        if (wave == k) t = ti[k];
+    }
+    double dsum = 0.0, dsq = 0.0;
+    if (t.valid) {
 #pragma unroll
-        for (int kk = 1; kk < G::SUB; ++kk)
-          if (s == kk) t = ti[kk];
-        const int tx8 = p.W / 8;
-        T = tx8 * (p.H / 8);
-        tt = (t.y0 / 8) * tx8 + t.x0 / 8;
-      } else {
-        const int tx16 = p.W / 16;
-        T = tx16 * (p.H / 8);
-        tt = (t.y0 / 8 + ph) * tx16 + t.x0 / 16;
+      for (int jj = 0; jj < 4; ++jj) {
+        float fs = 0.f, fq = 0.f;  // fp32 over 16 values, fp64 across (keeps E[x^2] - E[x]^2 accurate)
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+          const int pl = wave * 64 + (jj * 4 + j4) * 4 + (lane >> 4);
+          int oy, ox;
+          if (G::B8) {
+            const int r = pl & 63;
+            oy = t.y0 + (r >> 3);
+            ox = t.x0 + (r & 7);
+          } else {
+            oy = t.y0 + (pl >> 4);
+            ox = t.x0 + (pl & 15);
+          }
+          const size_t off = (((size_t)t.n * p.H + oy) * p.W + ox) * 64 + 4 * quad;
+          f32x4 v = *(const f32x4*)(otile + pl * G::OT_STRIDE + 4 * quad);
+#if F16S_ABL & 1
+          if (v[0] == 123.456f) *(f32x4*)(p.out + off) = v;
+#else
+          if (p.residual) v += *(const f32x4*)(p.residual + off);
+          *(f32x4*)(p.out + off) = v;
+#endif
+          fs += (v[0] + v[1]) + (v[2] + v[3]);
+          fq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+        dsum += (double)fs;
+        dsq += (double)fq;
       }
-      if (lane == 0 && t.valid) {
-        double* o = p.out_stats + ((size_t)(t.n * Gt + cb) * T + tt) * 2;
-        o[0] = a;
-        o[1] = b;
+    }
+    if (p.out_stats) {  // uniform
+      // lanes of one group: bits {0,1,2} (quad within the group) and {4,5} (pixel lane)
+#pragma unroll
+      for (int m = 1; m <= 32; m <<= 1) {
+        if (m == 8) continue;
+        dsum += __shfl_xor(dsum, m, 64);
+        dsq += __shfl_xor(dsq, m, 64);
+      }
+      if ((lane & 0x37) == 0) {  // lane 0 (group 0) and lane 8 (group 1)
+        red[(wave * 2 + (lane >> 3)) * 2] = dsum;
+        red[(wave * 2 + (lane >> 3)) * 2 + 1] = dsq;
+      }
+      __syncthreads();
+      if (G::B8) {
+        if (tid < 8) {  // (sub-tile, group)
+          const int s = tid >> 1, gg = tid & 1;
+          F16Tile ts = ti[0];
+#pragma unroll
+          for (int k = 1; k < G::SUB; ++k)
+            if (s == k) ts = ti[k];
+          if (ts.valid) {
+            const int tx8 = p.W / 8;
+            const int T = tx8 * (p.H / 8), tt = (ts.y0 / 8) * tx8 + ts.x0 / 8;
+            double* o = p.out_stats + ((size_t)(ts.n * 2 + gg) * T + tt) * 2;
+            o[0] = red[(s * 2 + gg) * 2];
+            o[1] = red[(s * 2 + gg) * 2 + 1];
+          }
+        }
+      } else if (tid < 4 && ti[0].valid) {  // (8-row half, group): waves 2h and 2h + 1
+        const int h = tid >> 1, gg = tid & 1;
+        const int tx16 = p.W / 16;
+        const int T = tx16 * (p.H / 8), tt = (ti[0].y0 / 8 + h) * tx16 + ti[0].x0 / 16;
+        double* o = p.out_stats + ((size_t)(ti[0].n * 2 + gg) * T + tt) * 2;
+        o[0] = red[((2 * h) * 2 + gg) * 2] + red[((2 * h + 1) * 2 + gg) * 2];
+        o[1] = red[((2 * h) * 2 + gg) * 2 + 1] + red[((2 * h + 1) * 2 + gg) * 2 + 1];
       }
     }
   }
 }
 
-// OIHW fp32 -> [CinPad/16][9][h|l][64][16] halfs
+// OIHW fp32 -> [CinPad/16][9][h|l][k group g = 0|1][64 cout][8 cin] halfs  (cin = 16 chunk + 8 g + e):
+// one chunk = 2304 contiguous 16-byte units, copied linearly into LDS by the kernel.
 __global__ void pack_weight_f16x2_kernel(const float* __restrict__ oihw, _Float16* __restrict__ packed, int Cout, int Cin,
                                          int CinPad) {
   const size_t total = (size_t)(CinPad / 16) * 9 * 64 * 16;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
-  const int ci = idx % 16;
-  const int co = (idx / 16) % 64;
-  const int tap = (idx / (16 * 64)) % 9;
-  const int chunk = idx / (16 * 64 * 9);
-  const int c = chunk * 16 + ci;
+  const int e = idx % 8;
+  const int co = (idx / 8) % 64;
+  const int g = (idx / (8 * 64)) % 2;
+  const int tap = (idx / (8 * 64 * 2)) % 9;
+  const int chunk = idx / (8 * 64 * 2 * 9);
+  const int c = chunk * 16 + g * 8 + e;
   float v = 0.f;
   if (co < Cout && c < Cin) v = oihw[((size_t)co * Cin + c) * 9 + tap];
   v = fminf(fmaxf(v, -65504.0f), 65504.0f);
   const _Float16 h = (_Float16)v;
   const _Float16 l = (_Float16)(v - (float)h);
-  const size_t base = (((size_t)chunk * 9 + tap) * 2) * (64 * 16) + (size_t)co * 16 + ci;
+  const size_t base = ((((size_t)chunk * 9 + tap) * 2 + 0) * 2 + g) * (64 * 8) + (size_t)co * 8 + e;
   packed[base] = h;
-  packed[base + 64 * 16] = l;
+  packed[base + 2 * 64 * 8] = l;
 }
 
 extern "C" int dmd_pack_conv_weight_f16x2(const float* oihw, void* packed, int Cout, int Cin, int CinPad, dmd_stream_t stream) {
@@ -353,7 +488,7 @@ extern "C" int dmd_pack_conv_weight_f16x2(const float* oihw, void* packed, int C
 
 // 1: the parameters can run on conv_f16s_kernel
 extern "C" int dmd_conv2d_f16x2_eligible(const dmd_conv_params* p) {
-  if (!p || p->precision != DMD_PRECISION_F16X2 || !p->w_f16) return 0;
+  if (!p || (p->precision & 0xff) != DMD_PRECISION_F16X2 || !p->w_f16) return 0;
   if (p->taps != 9 || p->stride != 1 || p->Cout != 64 || p->CoutPad != 64 || p->out_nchw) return 0;
   if (p->residual_norm.stats) return 0;
   int cin = 0;
@@ -364,14 +499,20 @@ extern "C" int dmd_conv2d_f16x2_eligible(const dmd_conv_params* p) {
   return (a16 || b8) ? 1 : 0;
 }
 
-int dmd_launch_conv_f16s(const dmd_conv_params& p, hipStream_t st) {
-  if (p.W % 16 != 0) {
-    using G = F16Geom<true>;
-    const int sub = p.N * (p.H / 8) * (p.W / 8);
-    hipLaunchKernelGGL((conv_f16s_kernel<G>), dim3((sub + 3) / 4), dim3(256), 0, st, p);
-  } else {
-    using G = F16Geom<false>;
-    hipLaunchKernelGGL((conv_f16s_kernel<G>), dim3(p.N * (p.H / 16) * (p.W / 16)), dim3(256), 0, st, p);
+template <class G>
+static int launch_f16s(const dmd_conv_params& p, int grid, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16s_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       G::SMEM_BYTES);
+    DMD_CHECK_ARG(e == hipSuccess, "conv_f16s: hipFuncSetAttribute(%d bytes): %s", G::SMEM_BYTES, hipGetErrorString(e));
+    attr_set = true;
   }
+  hipLaunchKernelGGL((conv_f16s_kernel<G>), dim3(grid), dim3(256), G::SMEM_BYTES, st, p);
   return 0;
+}
+
+int dmd_launch_conv_f16s(const dmd_conv_params& p, hipStream_t st) {
+  if (p.W % 16 != 0) return launch_f16s<F16Geom<true>>(p, (p.N * (p.H / 8) * (p.W / 8) + 3) / 4, st);
+  return launch_f16s<F16Geom<false>>(p, p.N * (p.H / 16) * (p.W / 16), st);
 }

@@ -15,7 +15,7 @@ import torch
 from torch import Tensor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdiamond_hip.so")
+LIB_PATH = os.environ.get("DIAMOND_LIB", os.path.join(_HERE, "libdiamond_hip.so"))  # override: development builds
 
 PROLOGUE_NONE, PROLOGUE_NORM_SILU, PROLOGUE_NORM = 0, 1, 2
 PRECISION_F32, PRECISION_F16X2 = 0, 1
