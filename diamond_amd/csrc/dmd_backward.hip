@@ -405,7 +405,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, in
   }
 
   // ---- partial results: [wg][NB][NCO][64 lanes][4] ----
-  float* part = p.workspace + (size_t)blockIdx.x * (G::NB * G::NCO * 256);
+  constexpr int PER_TOTAL = G::NB * G::NCO * 256 + G::COUT;  // [weights partial | bias partial] per workgroup
+  float* part = p.workspace + (size_t)blockIdx.x * PER_TOTAL;
 #pragma unroll
   for (int s = 0; s < G::CB; ++s) {
     const int b = wave + 4 * s;
@@ -422,19 +423,34 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, in
   if (tid < CQO) {
     f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int l = 0; l < 256 / CQO; ++l) a += red[l * CQO + tid];
-    float* bpart = p.workspace + (size_t)gridDim.x * (G::NB * G::NCO * 256) + (size_t)blockIdx.x * G::COUT;
+    float* bpart = part + G::NB * G::NCO * 256;
     *(f32x4*)(bpart + 4 * tid) = a;
   }
 }
 
-// partial element e of [NB][NCO][64][4] summed over workgroups -> OIHW gradient
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int num_wg, int NB, int NCO, int NCI, int taps, int cin_real,
-                                    float* __restrict__ dw, float* __restrict__ dbias) {
-  const int per = NB * NCO * 256;
+// Reduction of the per-workgroup partials, two deterministic passes:
+//   pass 1: grid (elements / 256, WGRAD_SLICES): slice s sums workgroups {s, s + S, ...} -> ws2[s][e]
+//   pass 2: element e of [NB][NCO][64][4] (+ bias) sums the S slices in order -> OIHW gradient
+#define WGRAD_SLICES 16
+
+__global__ void wgrad_reduce1_kernel(const float* __restrict__ ws, int num_wg, int per_total, float* __restrict__ ws2) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int sl = blockIdx.y;
+  if (idx >= per_total) return;
+  float s = 0.f;
+  for (int w = sl; w < num_wg; w += WGRAD_SLICES) s += ws[(size_t)w * per_total + idx];
+  ws2[(size_t)sl * per_total + idx] = s;
+}
+
+__global__ void wgrad_reduce2_kernel(const float* __restrict__ ws2, int NB, int NCO, int NCI, int taps, int cin_real,
+                                     float* __restrict__ dw, float* __restrict__ dbias) {
+  const int per = NB * NCO * 256;
+  const int per_total = per + NCO * 16;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= per_total) return;
+  double s = 0.0;
+  for (int sl = 0; sl < WGRAD_SLICES; ++sl) s += (double)ws2[(size_t)sl * per_total + idx];
   if (idx < per) {
-    double s = 0.0;
-    for (int w = 0; w < num_wg; ++w) s += (double)ws[(size_t)w * per + idx];
     const int r = idx & 3, lane = (idx >> 2) & 63;
     const int blk = idx >> 8;
     const int cob = blk % NCO, b = blk / NCO;
@@ -442,12 +458,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int num_wg, in
     const int co = cob * 16 + 4 * (lane >> 4) + r;
     const int ci = cib * 16 + (lane & 15);
     if (ci < cin_real) dw[((size_t)co * cin_real + ci) * taps + tap] = (float)s;
-  } else if (dbias && idx < per + NCO * 16) {
-    const int co = idx - per;
-    const float* bp = ws + (size_t)num_wg * per;
-    double s = 0.0;
-    for (int w = 0; w < num_wg; ++w) s += (double)bp[(size_t)w * NCO * 16 + co];
-    dbias[co] = (float)s;
+  } else if (dbias) {
+    dbias[idx - per] = (float)s;
   }
 }
 
@@ -465,7 +477,7 @@ extern "C" int64_t dmd_wgrad_workspace_floats(const dmd_wgrad_params* p) {
   int tiles, num_wg, tpw;
   wgrad_plan(p, &tiles, &num_wg, &tpw);
   const int64_t NB = (int64_t)p->taps * (p->src.C / 16), NCO = p->Cout / 16;
-  return (int64_t)num_wg * (NB * NCO * 256 + p->Cout);
+  return (int64_t)(num_wg + WGRAD_SLICES) * (NB * NCO * 256 + p->Cout);
 }
 
 template <int NCO, int NCI, int TAPS>
@@ -481,9 +493,12 @@ static int launch_wgrad(const dmd_wgrad_params& p, hipStream_t st) {
     attr_set = true;
   }
   hipLaunchKernelGGL((wgrad_kernel<G>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
-  const int per = G::NB * NCO * 256 + NCO * 16;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((per + 255) / 256), dim3(256), 0, st, p.workspace, num_wg, G::NB, NCO, NCI, TAPS,
-                     p.cin_real, p.dw, p.dbias);
+  const int per_total = G::NB * NCO * 256 + NCO * 16;
+  float* ws2 = p.workspace + (size_t)num_wg * per_total;
+  hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((per_total + 255) / 256, WGRAD_SLICES), dim3(256), 0, st, p.workspace, num_wg,
+                     per_total, ws2);
+  hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3((per_total + 255) / 256), dim3(256), 0, st, (const float*)ws2, G::NB, NCO, NCI,
+                     TAPS, p.cin_real, p.dw, p.dbias);
   return 0;
 }
 

@@ -102,8 +102,8 @@ class WorldModelEnv:
             obs_, act_, hx_, cx_ = [], [], [], []
             for _ in range(num_batches_to_preload):
                 batch = next(data_iterator)
-                obs = batch.obs.to(self.device)
-                act = batch.act.to(self.device)
+                obs = batch.obs.to(self.device, non_blocking=True)  # async when the loader pins its batches
+                act = batch.act.to(self.device, non_blocking=True)
                 *_, (hx, cx) = self.rew_end_model.predict_rew_end(obs[:, :-1], act[:, :-1], obs[:, 1:])
                 assert hx.size(0) == cx.size(0) == 1
                 obs_.append(obs)

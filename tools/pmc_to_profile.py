@@ -10,9 +10,13 @@ w = json.load(open(os.path.join(ROOT, "gpurun_out/pmc/WRITE_SIZE.json")))
 out = {}
 for name, fv in f.items():
     m = re.search(r"conv_mfma_kernel<ConvGeom<(\d+), (true|false), (\d+), (\d+)>", name)
-    if not m:
+    m2 = re.search(r"conv_f16s_kernel<F16Geom<(true|false)>", name)
+    if not m and not m2:
         continue
-    key = f"conv_mfma<WN{m.group(1)},{'B' if m.group(2) == 'true' else 'A'},taps{m.group(3)},s{m.group(4)}>"
+    if m2:
+        key = f"conv_f16s<{'B8' if m2.group(1) == 'true' else 'A16'}>"
+    else:
+        key = f"conv_mfma<WN{m.group(1)},{'B' if m.group(2) == 'true' else 'A'},taps{m.group(3)},s{m.group(4)}>"
     wv = w[name]
     out[key] = {"launches": fv["launches"], "fetch_bytes_per_launch": fv["mean"] * 2 * 1024,
                 "write_bytes_per_launch": wv["mean"] * 1024,

@@ -1,0 +1,30 @@
+"""GPU idle-gap analysis of a rocprofv3 kernel trace CSV (development aid).
+usage: python tools/trace_gaps.py kernel_trace.csv[.gz]"""
+import csv, gzip, sys
+from collections import defaultdict
+path = sys.argv[1]
+f = gzip.open(path, "rt") if path.endswith(".gz") else open(path)
+rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(f)]
+rows.sort()
+# restrict to the last 40 % of the trace (steady-state windows)
+t0 = rows[0][0] + int(0.6 * (rows[-1][1] - rows[0][0]))
+rows = [r for r in rows if r[0] >= t0]
+span = rows[-1][1] - rows[0][0]
+busy = sum(e - s for s, e, _ in rows)
+print(f"span {span/1e6:.1f} ms, kernel busy {busy/1e6:.1f} ms ({100*busy/span:.1f} %), {len(rows)} kernels")
+gaps = defaultdict(lambda: [0, 0])
+hist = defaultdict(lambda: [0, 0])
+prev_end, prev_name = rows[0][1], rows[0][2]
+for s, e, n in rows[1:]:
+    g = s - prev_end
+    if g > 0:
+        key = (prev_name[:50], n[:50])
+        gaps[key][0] += 1
+        gaps[key][1] += g
+        b = "<5us" if g < 5e3 else "<20us" if g < 2e4 else "<100us" if g < 1e5 else "<1ms" if g < 1e6 else ">=1ms"
+        hist[b][0] += 1
+        hist[b][1] += g
+    prev_end, prev_name = max(prev_end, e), n
+print("gap histogram:", {k: (v[0], round(v[1] / 1e6, 2)) for k, v in hist.items()})
+for (a, b), (c, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:25]:
+    print(f"{t/1e6:8.2f} ms  {c:6d}x  {a}  ->  {b}")
