@@ -23,6 +23,8 @@
 //     cin {4*k'+t}, k'=0..3 -- legal because A and B use the same map.
 //   * epilogue: + bias, + (optionally GroupNorm'ed) residual, store, and per-(image, group)
 //     fp64 partial (sum, sum^2) for the NEXT GroupNorm.
+#include <stdlib.h>
+
 #include "dmd_common.h"
 
 #define DMD_CIN_MAX 256
@@ -499,13 +501,16 @@ static void dispatch_wn(const dmd_conv_params& p, hipStream_t st) {
 
 extern "C" int dmd_conv_stat_tiles(int H, int W) { return (H / 8) * (W / ((W % 16) ? 8 : 16)); }
 
-int dmd_launch_conv_f16s(const dmd_conv_params& p, hipStream_t st);  // dmd_conv_f16.hip
+int dmd_launch_conv_f16s(const dmd_conv_params& p, hipStream_t st);   // dmd_conv_f16.hip
+int dmd_launch_conv_f16ws(const dmd_conv_params& p, hipStream_t st);  // dmd_conv_f16ws.hip (wave-specialised, persistent)
 
 extern "C" int dmd_conv2d(const dmd_conv_params* p, dmd_stream_t stream) {
   if (int e = validate_conv(p)) return e;
   hipStream_t st = (hipStream_t)stream;
   if (dmd_conv2d_f16x2_eligible(p)) {
-    if (int e = dmd_launch_conv_f16s(*p, st)) return e;
+    // DIAMOND_F16S_WS=0 selects the older uniform-role kernel (kept for A/B measurements)
+    static const int use_ws = getenv("DIAMOND_F16S_WS") ? atoi(getenv("DIAMOND_F16S_WS")) : 1;
+    if (int e = use_ws ? dmd_launch_conv_f16ws(*p, st) : dmd_launch_conv_f16s(*p, st)) return e;
   } else if (p->taps == 1)
     dispatch_wn<1, 1>(*p, st);
   else if (p->stride == 2)

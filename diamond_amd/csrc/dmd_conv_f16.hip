@@ -40,7 +40,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // Compile-time timing ablations (development only; results are WRONG when non-zero):
 //   1: no global stores / residual loads in the epilogue   2: no MFMA   4: no staging global loads
-//   8: no staging math (norm/SiLU)   16: no LDS fragment reads in the tap loop
+//   8: no staging math (norm/SiLU)   32: no tap loop at all (no fragment reads, no MFMA)
 #ifndef F16S_ABL
 #define F16S_ABL 0
 #endif
@@ -113,64 +113,6 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(const dmd_conv_params
   const int C1 = p.nsrc > 1 ? p.src[1].C : 0;
   const int nch0 = C0 >> 4;
   const int nchunks = (C0 + C1) >> 4;
-
-  // ---- prologue tables: y = (x - mean) * rstd * mul' + add  ==  x * a + b ----
-  // group statistics first, one (sub-tile, source, group) per wave iteration: lanes fetch the producer's
-  // per-tile partial sums in parallel (fixed shuffle-tree order -> deterministic)
-  {
-    const int G0 = p.src[0].prologue != DMD_PROLOGUE_NONE ? C0 / DMD_GN_GROUP : 0;
-    const int G1 = (p.nsrc > 1 && p.src[1].prologue != DMD_PROLOGUE_NONE) ? C1 / DMD_GN_GROUP : 0;
-    const int GT = G0 + G1;  // <= 4
-    float* gms = (float*)red;  // [SUB][4][2] mean, rstd
-    const double count = (double)DMD_GN_GROUP * Hs * Ws;
-    for (int item = wave; item < G::SUB * GT; item += 4) {
-      const int s = item / GT, gi = item - s * GT;
-      const int si = gi < G0 ? 0 : 1;
-      const int gl = si ? gi - G0 : gi;
-      const dmd_norm& nm = p.src[si].norm;
-      const int Gs = p.src[si].C / DMD_GN_GROUP;
-      F16Tile t = ti[0];
-#pragma unroll
-      for (int k = 1; k < G::SUB; ++k)
-        if (s == k) t = ti[k];
-      const double* st = nm.stats + ((size_t)(t.n * Gs + gl) * nm.stat_tiles) * 2;
-      double a = 0.0, b = 0.0;
-      for (int tt = lane; tt < nm.stat_tiles; tt += 64) {
-        a += st[2 * tt];
-        b += st[2 * tt + 1];
-      }
-      a = dmd_wave_sum(a);
-      b = dmd_wave_sum(b);
-      if (lane == 0) {
-        const double m = a / count;
-        double var = b / count - m * m;
-        var = var < 0.0 ? 0.0 : var;
-        gms[(s * 4 + gi) * 2] = (float)m;
-        gms[(s * 4 + gi) * 2 + 1] = (float)(1.0 / sqrt(var + (double)DMD_GN_EPS));
-      }
-    }
-    __syncthreads();
-    for (int c = tid; c < C0 + C1; c += 256) {
-      const int si = c < C0 ? 0 : 1;
-      const dmd_conv_src& sc = p.src[si];
-      const int cl = si ? c - C0 : c;
-      const int gi = si ? G0 + cl / DMD_GN_GROUP : cl / DMD_GN_GROUP;
-#pragma unroll
-      for (int s = 0; s < G::SUB; ++s) {
-        float a = 1.f, b = 0.f;
-        if (sc.prologue != DMD_PROLOGUE_NONE && ti[s].valid) {
-          const dmd_norm& nm = sc.norm;
-          float mul = nm.mul ? nm.mul[(size_t)ti[s].n * nm.mul_stride + cl] : 1.0f;
-          if (nm.mul_plus_one) mul = 1.0f + mul;
-          const float add = nm.add ? nm.add[(size_t)ti[s].n * nm.add_stride + cl] : 0.0f;
-          a = gms[(s * 4 + gi) * 2 + 1] * mul;
-          b = add - gms[(s * 4 + gi) * 2] * a;
-        }
-        tab_a[s * F16S_CIN_MAX + c] = a;
-        tab_b[s * F16S_CIN_MAX + c] = b;
-      }
-    }
-  }
 
   // ---- staging items (chunk invariant): thread -> (patch pixel, channel quad q) ----
   int goff[G::ITEMS];  // source pixel index, -1: zero
@@ -283,6 +225,80 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(const dmd_conv_params
 #pragma unroll
   for (int k = 0; k < 9; ++k) wstage[k] = wglob[tid + 256 * k];
   if (nchunks > 1) load_chunk(1, stage1);
+
+  // (the loads above are in flight while the normalisation tables are built: one exposed memory latency
+  // instead of three dependent ones per tile)
+  // ---- prologue tables: y = (x - mean) * rstd * mul' + add  ==  x * a + b ----
+  // group statistics first, one (sub-tile, source, group) per wave iteration: lanes fetch the producer's
+  // per-tile partial sums in parallel (fixed shuffle-tree order -> deterministic)
+  {
+    const int G0 = p.src[0].prologue != DMD_PROLOGUE_NONE ? C0 / DMD_GN_GROUP : 0;
+    const int G1 = (p.nsrc > 1 && p.src[1].prologue != DMD_PROLOGUE_NONE) ? C1 / DMD_GN_GROUP : 0;
+    const int GT = G0 + G1;  // <= 4
+    float* gms = (float*)red;  // [SUB][4][2] mean, rstd
+    const double count = (double)DMD_GN_GROUP * Hs * Ws;
+    // FiLM / affine parameters of this thread's channel: issued BEFORE the statistics reduction so that the two
+    // global-memory latencies overlap (C0 + C1 <= 128 < 256 threads: one channel per thread)
+    float pmul[G::SUB], padd[G::SUB];
+    {
+      const int c = tid < C0 + C1 ? tid : 0;
+      const int si = c < C0 ? 0 : 1;
+      const dmd_norm& nm = p.src[si].norm;
+      const int cl = si ? c - C0 : c;
+      const bool on = p.src[si].prologue != DMD_PROLOGUE_NONE;
+#pragma unroll
+      for (int s = 0; s < G::SUB; ++s) {
+        pmul[s] = (on && nm.mul) ? nm.mul[(size_t)ti[s].n * nm.mul_stride + cl] : 1.0f;
+        padd[s] = (on && nm.add) ? nm.add[(size_t)ti[s].n * nm.add_stride + cl] : 0.0f;
+      }
+    }
+    for (int item = wave; item < G::SUB * GT; item += 4) {
+      const int s = item / GT, gi = item - s * GT;
+      const int si = gi < G0 ? 0 : 1;
+      const int gl = si ? gi - G0 : gi;
+      const dmd_norm& nm = p.src[si].norm;
+      const int Gs = p.src[si].C / DMD_GN_GROUP;
+      F16Tile t = ti[0];
+#pragma unroll
+      for (int k = 1; k < G::SUB; ++k)
+        if (s == k) t = ti[k];
+      const double* st = nm.stats + ((size_t)(t.n * Gs + gl) * nm.stat_tiles) * 2;
+      double a = 0.0, b = 0.0;
+      for (int tt = lane; tt < nm.stat_tiles; tt += 64) {
+        a += st[2 * tt];
+        b += st[2 * tt + 1];
+      }
+      a = dmd_wave_sum(a);
+      b = dmd_wave_sum(b);
+      if (lane == 0) {
+        const double m = a / count;
+        double var = b / count - m * m;
+        var = var < 0.0 ? 0.0 : var;
+        gms[(s * 4 + gi) * 2] = (float)m;
+        gms[(s * 4 + gi) * 2 + 1] = (float)(1.0 / sqrt(var + (double)DMD_GN_EPS));
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < C0 + C1; c += 256) {
+      const int si = c < C0 ? 0 : 1;
+      const dmd_conv_src& sc = p.src[si];
+      const int cl = si ? c - C0 : c;
+      const int gi = si ? G0 + cl / DMD_GN_GROUP : cl / DMD_GN_GROUP;
+#pragma unroll
+      for (int s = 0; s < G::SUB; ++s) {
+        float a = 1.f, b = 0.f;
+        if (sc.prologue != DMD_PROLOGUE_NONE && ti[s].valid) {
+          float mul = pmul[s];
+          if (sc.norm.mul_plus_one) mul = 1.0f + mul;
+          a = gms[(s * 4 + gi) * 2 + 1] * mul;
+          b = padd[s] - gms[(s * 4 + gi) * 2] * a;
+        }
+        tab_a[s * F16S_CIN_MAX + c] = a;
+        tab_b[s * F16S_CIN_MAX + c] = b;
+      }
+    }
+  }
+
   __syncthreads();  // tables visible
   store_chunk(0, stage0);
 #pragma unroll
@@ -301,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(const dmd_conv_params
     }
     if (ck + 2 < nchunks) load_chunk(ck + 2, recv);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int tap = 0; tap < ((F16S_ABL & 32) ? 0 : 9); ++tap) {
       const int dy = tap / 3, dx = tap % 3;
       // LDS fragment reads are issued in the order the MFMAs consume them (LDS returns in order), two pixel
       // blocks at a time: the first MFMAs start after 3 of the 10 reads have landed, the rest overlap.

@@ -1,0 +1,447 @@
+// conv_f16ws_kernel -- wave-specialised, persistent form of the split-fp16 3x3 convolution
+// (same arithmetic and data layouts as dmd_conv_f16.hip: x = h + l fp16 pieces, 3 x
+// v_mfma_f32_32x32x16_f16 per product, fp32 accumulate).
+//
+// Why a second structure: in conv_f16s_kernel every wave alternates between the MFMA tap loop and
+// the staging work (global loads, GroupNorm/FiLM/SiLU, h/l split, LDS writes, weight copy); with
+// the 2 workgroups per CU that its registers allow, the matrix pipe idles whenever both are
+// staging, and per-tile fixed costs (first-chunk HBM latency, tables, epilogue) are paid on the
+// critical path of a K loop that is only 4-8 chunks long.  Here one 512-thread workgroup per CU
+// is split by ROLE:
+//   * waves 0-3 = CONSUMERS: nothing but LDS fragment reads + MFMAs (+ the epilogue of a finished
+//     tile); accumulators live only here.
+//   * waves 4-7 = PRODUCERS: everything else, running one chunk ahead of the consumers through a
+//     double-buffered {patch, weights} LDS pair, two chunks ahead for the activation loads.
+//   * the workgroup is persistent: it walks a contiguous range of tiles as ONE stream of chunks,
+//     so the producers prefetch the next tile's first chunks while the consumers finish the
+//     current tile -- no per-tile pipeline fill.
+// One s_barrier per chunk separates "consumers read buffer j, producers fill buffer j + 1".
+#include "dmd_common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define WS_CIN_MAX 128
+#define WS_TAB_SLOTS 4  // tiles whose tables can be alive at once (tile index & 3)
+
+template <bool B8_>
+struct WsGeom {
+  static constexpr bool B8 = B8_;
+  static constexpr int SUB = B8_ ? 4 : 1;
+  static constexpr int TS = B8_ ? 8 : 16;
+  static constexpr int PW = TS + 2;
+  static constexpr int PPS = PW * PW;
+  static constexpr int NPP = SUB * PPS;
+  static constexpr int ITEMS = (NPP * 4 + 255) / 256;
+  static constexpr int W_UNITS = 9 * 2 * 2 * 64;            // 16-byte units of one chunk's weights
+  static constexpr int BUF_UNITS = NPP * 4 + W_UNITS;       // one {patch, weights} buffer, 16-byte units
+  static constexpr int TAB_FLOATS = WS_TAB_SLOTS * SUB * WS_CIN_MAX;
+  static constexpr int SMEM_BYTES = 2 * BUF_UNITS * 16 + 2 * TAB_FLOATS * 4;
+};
+
+struct WsTile {
+  int n, y0, x0;
+  bool valid;
+};
+
+template <class G>
+__device__ __forceinline__ WsTile ws_subtile(const dmd_conv_params& p, int tile, int s) {
+  const int tx = p.W / G::TS, per_img = tx * (p.H / G::TS);
+  const int gs = tile * G::SUB + s;
+  WsTile t;
+  t.valid = gs < p.N * per_img;
+  const int g2 = t.valid ? gs : 0;
+  t.n = g2 / per_img;
+  const int r = g2 - t.n * per_img;
+  const int ty = r / tx;
+  t.y0 = ty * G::TS;
+  t.x0 = (r - ty * tx) * G::TS;
+  return t;
+}
+
+__device__ __forceinline__ float ws_silu(float t) {
+  return t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * t));
+}
+
+template <class G>
+__global__ __launch_bounds__(512, 2) void conv_f16ws_kernel(const dmd_conv_params p, int ntiles, int tiles_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4* bufs = (u32x4*)smem_raw;  // [2][BUF_UNITS]: patch [NPP][4] then weights [9][2][2][64]
+  float* tab_a = (float*)(bufs + 2 * G::BUF_UNITS);  // [slot][SUB][CIN_MAX]
+  float* tab_b = tab_a + G::TAB_FLOATS;
+
+  const int role = threadIdx.x >> 8;  // 0: consumer (MFMA), 1: producer (staging)
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int up = p.upsample;
+  const int Hs = p.H >> up, Ws = p.W >> up;
+  const int C0 = p.src[0].C;
+  const int C1 = p.nsrc > 1 ? p.src[1].C : 0;
+  const int nch0 = C0 >> 4;
+  const int nchunks = (C0 + C1) >> 4;
+  const int tile0 = blockIdx.x * tiles_per_wg;
+  const int nmy = min(tiles_per_wg, ntiles - tile0);
+  const int S = nmy * nchunks;  // chunk stream of this workgroup
+  // Workgroups walk their tile range from different starting points: with one image per workgroup all CUs would
+  // otherwise touch the same (row, column) offsets of 1 MiB-strided images at the same time (same low address
+  // bits -> the same HBM channels).
+  const int rot = (blockIdx.x * 7) % nmy;
+#define WS_TILE(k) (tile0 + (((k) + rot) >= nmy ? (k) + rot - nmy : (k) + rot))
+
+  if (role == 1) {
+    // =================================== PRODUCER ===================================
+    const int q = tid & 3;
+    int loff[G::ITEMS];  // 8-byte unit index of the h half-quad in a patch, -1: no item
+    int ipos[G::ITEMS];  // (sub << 16) | (py << 8) | px
+#pragma unroll
+    for (int it = 0; it < G::ITEMS; ++it) {
+      const int id = it * 256 + tid;
+      const int pp = id >> 2;
+      const bool ok = pp < G::NPP;
+      const int s = G::SUB == 1 ? 0 : (ok ? pp / G::PPS : 0);
+      const int rem = pp - s * G::PPS;
+      const int py = rem / G::PW, px = rem - py * G::PW;
+      loff[it] = ok ? (pp * 4 + (((q >> 1) + (px >> 1)) & 3)) * 2 + (q & 1) : -1;
+      ipos[it] = (s << 16) | (py << 8) | px;
+    }
+    int goff[G::ITEMS];  // source pixel index per item for tile `gk`, -1: zero
+    int gk = -1;
+    int tab_n = -1, tab_slot = -1;  // image whose tables are current (single-image tiles only) and their slot
+    const u32x4* wglob = (const u32x4*)p.w_f16;
+
+    auto setup_tile = [&](int k) {  // goff + normalisation tables of tile k (slot k & 3)
+      const int tile = WS_TILE(k);
+      WsTile ti[G::SUB];
+#pragma unroll
+      for (int s = 0; s < G::SUB; ++s) ti[s] = ws_subtile<G>(p, tile, s);
+#pragma unroll
+      for (int it = 0; it < G::ITEMS; ++it) {
+        const int s = ipos[it] >> 16, py = (ipos[it] >> 8) & 0xff, px = ipos[it] & 0xff;
+        WsTile t = ti[0];
+#pragma unroll
+        for (int kk = 1; kk < G::SUB; ++kk)
+          if (s == kk) t = ti[kk];
+        const int iy = t.y0 - 1 + py, ix = t.x0 - 1 + px;
+        const bool inb = loff[it] >= 0 && t.valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        goff[it] = inb ? ((t.n * Hs + (iy >> up)) * Ws + (ix >> up)) : -1;
+      }
+      // tables: all tiles of one image share them -- rebuild only when the image changes (A16; a B8 tile spans
+      // four images and its statistics are a single partial each)
+      const bool rebuild = G::SUB > 1 || ti[0].n != tab_n;
+      if (rebuild) {
+        tab_slot = (tab_slot + 1) & (WS_TAB_SLOTS - 1);
+        tab_n = ti[0].n;
+      }
+      if (rebuild && tid < C0 + C1) {  // one channel per thread; visible to the other producers after the next barrier
+        const int c = tid;
+        const int si = c < C0 ? 0 : 1;
+        const dmd_conv_src& sc = p.src[si];
+        const int cl = si ? c - C0 : c;
+        const int slot = tab_slot;
+#pragma unroll
+        for (int s = 0; s < G::SUB; ++s) {
+          float m = 0.f, a = 1.f, ad = 0.f;
+          if (sc.prologue != DMD_PROLOGUE_NONE && ti[s].valid)
+            norm_entry(sc.norm, ti[s].n, cl, sc.C, (double)DMD_GN_GROUP * Hs * Ws, &m, &a, &ad);
+          tab_a[(slot * G::SUB + s) * WS_CIN_MAX + c] = a;
+          tab_b[(slot * G::SUB + s) * WS_CIN_MAX + c] = ad - m * a;
+        }
+      }
+      gk = k;
+    };
+
+    // activation loads of stream element e into a register set (+ which items are conv zero padding)
+    auto issue_S = [&](int e, f32x4 (&st)[G::ITEMS], unsigned& zmask, int& slot_out) {
+      const int k = e / nchunks, ck = e - k * nchunks;
+      if (k != gk) setup_tile(k);
+      slot_out = tab_slot;
+      const int si = ck < nch0 ? 0 : 1;
+      const dmd_conv_src& sc = p.src[si];
+      const int c0 = (si ? ck - nch0 : ck) * 16 + 4 * q;
+      unsigned z = 0;
+#pragma unroll
+      for (int it = 0; it < G::ITEMS; ++it) {
+        const int go = goff[it] < 0 ? 0 : goff[it];
+        z |= (goff[it] < 0 ? 1u : 0u) << it;
+#if WS_ABL & 2
+        st[it] = (f32x4){(float)go, 1.f, 2.f, (float)c0};
+#elif WS_ABL & 8
+        // timing proxy (wrong data): same number of 16-byte loads, but 8 consecutive lanes cover one FULL 128-byte line
+        st[it] = *(const f32x4*)(sc.x + (size_t)(go & ~1) * sc.C + ((go & 1) * 16 + 4 * q + (c0 & 32)));
+#else
+        st[it] = *(const f32x4*)(sc.x + (size_t)go * sc.C + c0);
+#endif
+      }
+      zmask = z;
+    };
+    // normalise / activate / split element e from its register set into patch buffer e & 1
+    auto store_S = [&](int e, const f32x4 (&st)[G::ITEMS], unsigned zmask, int slot) {
+      const int ck = e % nchunks;
+      const int si = ck < nch0 ? 0 : 1;
+      const int prologue = p.src[si].prologue;
+      const int cc = ck * 16 + 4 * q;
+      uint2* pb = (uint2*)(bufs + (e & 1) * G::BUF_UNITS);
+#if WS_ABL & 4
+      if (e > 1) return;
+#endif
+#pragma unroll
+      for (int it = 0; it < G::ITEMS; ++it) {
+        f32x4 v = st[it];
+        if (prologue != DMD_PROLOGUE_NONE) {
+          const int s = ipos[it] >> 16;
+          const float* ta = tab_a + (slot * G::SUB + s) * WS_CIN_MAX + cc;
+          const float* tb = tab_b + (slot * G::SUB + s) * WS_CIN_MAX + cc;
+#pragma unroll
+          for (int el = 0; el < 4; ++el) {
+            float t = __builtin_fmaf(v[el], ta[el], tb[el]);
+            if (prologue == DMD_PROLOGUE_NORM_SILU) t = ws_silu(t);
+            v[el] = t;
+          }
+        }
+        h4 hv, lv;
+        const bool zero = (zmask >> it) & 1;  // conv zero padding is applied AFTER the activation (blocks.py:143-144)
+#pragma unroll
+        for (int el = 0; el < 4; ++el) {
+          const float x = zero ? 0.f : __builtin_amdgcn_fmed3f(v[el], -65504.0f, 65504.0f);
+          const _Float16 h = (_Float16)x;
+          hv[el] = h;
+          lv[el] = (_Float16)(x - (float)h);
+        }
+        if (loff[it] >= 0) {
+          pb[loff[it]] = __builtin_bit_cast(uint2, hv);
+          pb[loff[it] ^ 4] = __builtin_bit_cast(uint2, lv);
+        }
+      }
+    };
+
+    f32x4 stage0[G::ITEMS], stage1[G::ITEMS];
+    unsigned zm0 = 0, zm1 = 0;
+    int sl0 = 0, sl1 = 0;
+    u32x4 wst0[9], wst1[9];  // weights are fetched two steps ahead as well (L2 latency off the critical path)
+    auto load_W = [&](int e, u32x4 (&ws)[9]) {
+      const int ck = e % nchunks;
+      const u32x4* w = wglob + (size_t)ck * G::W_UNITS + tid;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) ws[i] = w[256 * i];
+    };
+    auto store_W = [&](int e, const u32x4 (&ws)[9]) {
+      u32x4* wl = bufs + (e & 1) * G::BUF_UNITS + G::NPP * 4;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) wl[tid + 256 * i] = ws[i];
+    };
+
+    // fill element 0; elements 1 and 2 in flight
+    issue_S(0, stage0, zm0, sl0);
+    load_W(0, wst0);
+    if (S > 1) {
+      issue_S(1, stage1, zm1, sl1);
+      load_W(1, wst1);
+    }
+    __syncthreads();  // B(-1): the tables written by setup_tile are visible to all producers
+    store_S(0, stage0, zm0, sl0);
+    if (S > 2) issue_S(2, stage0, zm0, sl0);
+    store_W(0, wst0);
+    if (S > 2) load_W(2, wst0);
+    __syncthreads();  // B0: buffer 0 = element 0
+    // step j: consumers compute element j, producers fill element j + 1 (register set (j + 1) & 1)
+#ifndef WS_ABL
+#define WS_ABL 0  // development only: 1 = producers idle in steady state, 2 = no activation loads, 4 = no store_S math/writes
+#endif
+    for (int j = 0; j < S; j += 2) {
+#if WS_ABL & 1
+      __syncthreads();
+      if (j + 1 < S) __syncthreads();
+      continue;
+#endif
+      if (j + 1 < S) {
+        store_S(j + 1, stage1, zm1, sl1);
+        if (j + 3 < S) issue_S(j + 3, stage1, zm1, sl1);
+        store_W(j + 1, wst1);
+        if (j + 3 < S) load_W(j + 3, wst1);
+      }
+      __syncthreads();
+      if (j + 1 < S) {
+        if (j + 2 < S) {
+          store_S(j + 2, stage0, zm0, sl0);
+          if (j + 4 < S) issue_S(j + 4, stage0, zm0, sl0);
+          store_W(j + 2, wst0);
+          if (j + 4 < S) load_W(j + 4, wst0);
+        }
+        __syncthreads();
+      }
+    }
+  } else {
+    // =================================== CONSUMER ===================================
+#ifndef WS_CONSUMER_PRIO
+#define WS_CONSUMER_PRIO 3
+#endif
+    // static priority: the MFMA waves win issue arbitration against the co-resident staging wave of their SIMD
+    __builtin_amdgcn_s_setprio(WS_CONSUMER_PRIO);
+    const int cb = wave & 1;   // 32-cout block == GroupNorm group
+    const int ph = wave >> 1;  // pixel half of the tile
+    const int n31 = lane & 31, g = lane >> 5;
+    int pixbase[4];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+      if (G::B8) {
+        const int s = ph * 2 + (blk >> 1);
+        const int row = (blk & 1) * 4 + (n31 >> 3);
+        pixbase[blk] = s * G::PPS + row * G::PW + (n31 & 7);
+      } else {
+        const int row = ph * 8 + blk * 2 + (n31 >> 4);
+        pixbase[blk] = row * G::PW + (n31 & 15);
+      }
+    }
+    const int col = G::B8 ? (n31 & 7) : (n31 & 15);
+    int posh[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) posh[dx] = (g + ((col + dx) >> 1)) & 3;
+    const int wunit = G::NPP * 4 + g * 64 + cb * 32 + n31;  // weights follow the patch inside a buffer
+
+    f32x16 acc[4];
+    f32x4 bias[4];
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      bias[qd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bias[qd] = *(const f32x4*)(p.bias + cb * 32 + 8 * qd + 4 * g);
+    }
+
+    __syncthreads();  // B(-1)
+    __syncthreads();  // B0
+    int k = 0, ck = 0;
+    for (int j = 0; j < S; ++j) {
+      if (ck == 0) {
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[blk][r] = 0.f;
+      }
+      const u32x4* buf = bufs + (j & 1) * G::BUF_UNITS;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap % 3;
+        h8 bh[4], bl[4];
+        const int toff = dy * G::PW + dx;
+        const h8 ah = __builtin_bit_cast(h8, buf[(tap * 2 + 0) * 128 + wunit]);
+        bh[0] = __builtin_bit_cast(h8, buf[(pixbase[0] + toff) * 4 + posh[dx]]);
+        bh[1] = __builtin_bit_cast(h8, buf[(pixbase[1] + toff) * 4 + posh[dx]]);
+        bl[0] = __builtin_bit_cast(h8, buf[(pixbase[0] + toff) * 4 + (posh[dx] ^ 2)]);
+        bl[1] = __builtin_bit_cast(h8, buf[(pixbase[1] + toff) * 4 + (posh[dx] ^ 2)]);
+        const h8 al = __builtin_bit_cast(h8, buf[(tap * 2 + 1) * 128 + wunit]);
+        bh[2] = __builtin_bit_cast(h8, buf[(pixbase[2] + toff) * 4 + posh[dx]]);
+        bh[3] = __builtin_bit_cast(h8, buf[(pixbase[3] + toff) * 4 + posh[dx]]);
+        bl[2] = __builtin_bit_cast(h8, buf[(pixbase[2] + toff) * 4 + (posh[dx] ^ 2)]);
+        bl[3] = __builtin_bit_cast(h8, buf[(pixbase[3] + toff) * 4 + (posh[dx] ^ 2)]);
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const int b0 = 2 * pr, b1 = 2 * pr + 1;
+          acc[b0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[b0], acc[b0], 0, 0, 0);
+          acc[b1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[b1], acc[b1], 0, 0, 0);
+          acc[b0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[b0], acc[b0], 0, 0, 0);
+          acc[b1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[b1], acc[b1], 0, 0, 0);
+          acc[b0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[b0], acc[b0], 0, 0, 0);
+          acc[b1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[b1], acc[b1], 0, 0, 0);
+        }
+      }
+      if (ck == nchunks - 1) {
+        // ---- epilogue of tile k: lane owns couts cb*32 + 8 qd + 4 g + (0..3) of pixel n31 of each block ----
+        const int tile = WS_TILE(k);
+        WsTile ti[G::SUB];
+#pragma unroll
+        for (int s = 0; s < G::SUB; ++s) ti[s] = ws_subtile<G>(p, tile, s);
+        double ssum[2] = {0.0, 0.0}, ssq[2] = {0.0, 0.0};  // B8: [0] blocks 0-1, [1] blocks 2-3
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+          WsTile t = ti[0];
+          int oy, ox;
+          if (G::B8) {
+            const int s = ph * 2 + (blk >> 1);
+#pragma unroll
+            for (int kk = 1; kk < G::SUB; ++kk)
+              if (s == kk) t = ti[kk];
+            oy = t.y0 + (blk & 1) * 4 + (n31 >> 3);
+            ox = t.x0 + (n31 & 7);
+          } else {
+            oy = t.y0 + ph * 8 + blk * 2 + (n31 >> 4);
+            ox = t.x0 + (n31 & 15);
+          }
+          if (!t.valid) continue;
+          const size_t pixel = ((size_t)t.n * p.H + oy) * p.W + ox;
+          float* op = p.out + pixel * 64 + cb * 32 + 4 * g;
+          const float* rp = p.residual ? p.residual + pixel * 64 + cb * 32 + 4 * g : nullptr;
+          f32x4 rv[4];
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) rv[qd] = rp ? *(const f32x4*)(rp + 8 * qd) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          float fs = 0.f, fq = 0.f;  // fp32 over the lane's 16 values of this block, fp64 across
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            f32x4 v = (f32x4){acc[blk][4 * qd], acc[blk][4 * qd + 1], acc[blk][4 * qd + 2], acc[blk][4 * qd + 3]};
+            v += bias[qd];
+            v += rv[qd];
+            *(f32x4*)(op + 8 * qd) = v;
+            fs += (v[0] + v[1]) + (v[2] + v[3]);
+            fq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+          }
+          const int slot = G::B8 ? (blk >> 1) : 0;
+          ssum[slot] += (double)fs;
+          ssq[slot] += (double)fq;
+        }
+        if (p.out_stats) {
+#pragma unroll
+          for (int kk = 0; kk < (G::B8 ? 2 : 1); ++kk) {
+            const double a = dmd_wave_sum(ssum[kk]);
+            const double b = dmd_wave_sum(ssq[kk]);
+            WsTile t = ti[0];
+            int T, tt;
+            if (G::B8) {
+              const int s = ph * 2 + kk;
+#pragma unroll
+              for (int k2 = 1; k2 < G::SUB; ++k2)
+                if (s == k2) t = ti[k2];
+              const int tx8 = p.W / 8;
+              T = tx8 * (p.H / 8);
+              tt = (t.y0 / 8) * tx8 + t.x0 / 8;
+            } else {
+              const int tx16 = p.W / 16;
+              T = tx16 * (p.H / 8);
+              tt = (t.y0 / 8 + ph) * tx16 + t.x0 / 16;
+            }
+            if (lane == 0 && t.valid) {
+              double* o = p.out_stats + ((size_t)(t.n * 2 + cb) * T + tt) * 2;
+              o[0] = a;
+              o[1] = b;
+            }
+          }
+        }
+        ck = -1;
+        ++k;
+      }
+      ++ck;
+      __syncthreads();  // B(j + 1)
+    }
+  }
+}
+
+template <class G>
+static int launch_f16ws(const dmd_conv_params& p, int ntiles, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16ws_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       G::SMEM_BYTES);
+    DMD_CHECK_ARG(e == hipSuccess, "conv_f16ws: hipFuncSetAttribute(%d bytes): %s", G::SMEM_BYTES, hipGetErrorString(e));
+    attr_set = true;
+  }
+  // persistent: one 512-thread workgroup per CU (LDS-limited), contiguous tile ranges (neighbouring tiles share
+  // halo rows and, inside one image, the normalisation statistics)
+  const int ncu = 256;
+  const int tpw = (ntiles + ncu - 1) / ncu;
+  const int nwg = (ntiles + tpw - 1) / tpw;
+  hipLaunchKernelGGL((conv_f16ws_kernel<G>), dim3(nwg), dim3(512), G::SMEM_BYTES, st, p, ntiles, tpw);
+  return 0;
+}
+
+int dmd_launch_conv_f16ws(const dmd_conv_params& p, hipStream_t st) {
+  if (p.W % 16 != 0) return launch_f16ws<WsGeom<true>>(p, (p.N * (p.H / 8) * (p.W / 8) + 3) / 4, st);
+  return launch_f16ws<WsGeom<false>>(p, p.N * (p.H / 16) * (p.W / 16), st);
+}
