@@ -8,9 +8,12 @@
 // staging, and per-tile fixed costs (first-chunk HBM latency, tables, epilogue) are paid on the
 // critical path of a K loop that is only 4-8 chunks long.  Here one 512-thread workgroup per CU
 // is split by ROLE:
-//   * waves 0-3 = CONSUMERS: nothing but LDS fragment reads + MFMAs (+ the epilogue of a finished
-//     tile); accumulators live only here.
-//   * waves 4-7 = PRODUCERS: everything else, running one chunk ahead of the consumers through a
+//   * waves 0-3 and 4-7 = two CONSUMER groups that take alternate tiles: the group whose tile is
+//     current does nothing but LDS fragment reads + MFMAs; the other group meanwhile writes its
+//     finished tile out (bias, residual, store, GroupNorm partial sums), one 32-pixel block per
+//     chunk step.  A CU can only store ~10 B/clk, so a 64 KiB tile takes longer to write than a
+//     chunk takes to compute: with a single consumer group that write sits on the critical path.
+//   * waves 8-11 = PRODUCERS: everything else, running one chunk ahead of the consumers through a
 //     double-buffered {patch, weights} LDS pair, two chunks ahead for the activation loads.
 //   * the workgroup is persistent: it walks a contiguous range of tiles as ONE stream of chunks,
 //     so the producers prefetch the next tile's first chunks while the consumers finish the
@@ -66,13 +69,16 @@ __device__ __forceinline__ float ws_silu(float t) {
 }
 
 template <class G>
-__global__ __launch_bounds__(512, 2) void conv_f16ws_kernel(const dmd_conv_params p, int ntiles, int tiles_per_wg) {
+__global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_params p, int ntiles, int tiles_per_wg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4* bufs = (u32x4*)smem_raw;  // [2][BUF_UNITS]: patch [NPP][4] then weights [9][2][2][64]
   float* tab_a = (float*)(bufs + 2 * G::BUF_UNITS);  // [slot][SUB][CIN_MAX]
   float* tab_b = tab_a + G::TAB_FLOATS;
 
-  const int role = threadIdx.x >> 8;  // 0: consumer (MFMA), 1: producer (staging)
+#ifndef WS_ABL
+#define WS_ABL 0  // development only: 1 = producers idle in steady state, 2 = no activation loads, 4 = no store_S, 16 = no MFMA loop
+#endif
+  const int role = threadIdx.x >> 8;  // 0, 1: consumer groups (even / odd tiles), 2: producer (staging)
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int up = p.upsample;
   const int Hs = p.H >> up, Ws = p.W >> up;
@@ -89,11 +95,12 @@ __global__ __launch_bounds__(512, 2) void conv_f16ws_kernel(const dmd_conv_param
   const int rot = (blockIdx.x * 7) % nmy;
 #define WS_TILE(k) (tile0 + (((k) + rot) >= nmy ? (k) + rot - nmy : (k) + rot))
 
-  if (role == 1) {
+  if (role == 2) {
     // =================================== PRODUCER ===================================
     const int q = tid & 3;
-    int loff[G::ITEMS];  // 8-byte unit index of the h half-quad in a patch, -1: no item
-    int ipos[G::ITEMS];  // (sub << 16) | (py << 8) | px
+    int ipos[G::ITEMS];  // (sub << 16) | (py << 8) | px; -1: no item (beyond the patch)
+    // 8-byte unit index of the h half-quad of item `it` in a patch (recomputed where needed: registers are scarce)
+    auto loff_of = [&](int it) { return ((it * 64 + (tid >> 2)) * 4 + (((q >> 1) + ((ipos[it] & 0xff) >> 1)) & 3)) * 2 + (q & 1); };
 #pragma unroll
     for (int it = 0; it < G::ITEMS; ++it) {
       const int id = it * 256 + tid;
@@ -102,8 +109,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16ws_kernel(const dmd_conv_param
       const int s = G::SUB == 1 ? 0 : (ok ? pp / G::PPS : 0);
       const int rem = pp - s * G::PPS;
       const int py = rem / G::PW, px = rem - py * G::PW;
-      loff[it] = ok ? (pp * 4 + (((q >> 1) + (px >> 1)) & 3)) * 2 + (q & 1) : -1;
-      ipos[it] = (s << 16) | (py << 8) | px;
+      ipos[it] = ok ? ((s << 16) | (py << 8) | px) : -1;
     }
     int goff[G::ITEMS];  // source pixel index per item for tile `gk`, -1: zero
     int gk = -1;
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16ws_kernel(const dmd_conv_param
         for (int kk = 1; kk < G::SUB; ++kk)
           if (s == kk) t = ti[kk];
         const int iy = t.y0 - 1 + py, ix = t.x0 - 1 + px;
-        const bool inb = loff[it] >= 0 && t.valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const bool inb = ipos[it] >= 0 && t.valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         goff[it] = inb ? ((t.n * Hs + (iy >> up)) * Ws + (ix >> up)) : -1;
       }
       // tables: all tiles of one image share them -- rebuild only when the image changes (A16; a B8 tile spans
@@ -208,9 +214,10 @@ __global__ __launch_bounds__(512, 2) void conv_f16ws_kernel(const dmd_conv_param
           hv[el] = h;
           lv[el] = (_Float16)(x - (float)h);
         }
-        if (loff[it] >= 0) {
-          pb[loff[it]] = __builtin_bit_cast(uint2, hv);
-          pb[loff[it] ^ 4] = __builtin_bit_cast(uint2, lv);
+        if (ipos[it] >= 0) {
+          const int lo = loff_of(it);
+          pb[lo] = __builtin_bit_cast(uint2, hv);
+          pb[lo ^ 4] = __builtin_bit_cast(uint2, lv);
         }
       }
     };
@@ -218,36 +225,29 @@ __global__ __launch_bounds__(512, 2) void conv_f16ws_kernel(const dmd_conv_param
     f32x4 stage0[G::ITEMS], stage1[G::ITEMS];
     unsigned zm0 = 0, zm1 = 0;
     int sl0 = 0, sl1 = 0;
-    u32x4 wst0[9], wst1[9];  // weights are fetched two steps ahead as well (L2 latency off the critical path)
-    auto load_W = [&](int e, u32x4 (&ws)[9]) {
+    u32x4 wst[9];
+    auto load_W = [&](int e) {
       const int ck = e % nchunks;
       const u32x4* w = wglob + (size_t)ck * G::W_UNITS + tid;
 #pragma unroll
-      for (int i = 0; i < 9; ++i) ws[i] = w[256 * i];
+      for (int i = 0; i < 9; ++i) wst[i] = w[256 * i];
     };
-    auto store_W = [&](int e, const u32x4 (&ws)[9]) {
+    auto store_W = [&](int e) {
       u32x4* wl = bufs + (e & 1) * G::BUF_UNITS + G::NPP * 4;
 #pragma unroll
-      for (int i = 0; i < 9; ++i) wl[tid + 256 * i] = ws[i];
+      for (int i = 0; i < 9; ++i) wl[tid + 256 * i] = wst[i];
     };
 
     // fill element 0; elements 1 and 2 in flight
     issue_S(0, stage0, zm0, sl0);
-    load_W(0, wst0);
-    if (S > 1) {
-      issue_S(1, stage1, zm1, sl1);
-      load_W(1, wst1);
-    }
+    load_W(0);
+    if (S > 1) issue_S(1, stage1, zm1, sl1);
     __syncthreads();  // B(-1): the tables written by setup_tile are visible to all producers
     store_S(0, stage0, zm0, sl0);
     if (S > 2) issue_S(2, stage0, zm0, sl0);
-    store_W(0, wst0);
-    if (S > 2) load_W(2, wst0);
+    store_W(0);
     __syncthreads();  // B0: buffer 0 = element 0
     // step j: consumers compute element j, producers fill element j + 1 (register set (j + 1) & 1)
-#ifndef WS_ABL
-#define WS_ABL 0  // development only: 1 = producers idle in steady state, 2 = no activation loads, 4 = no store_S math/writes
-#endif
     for (int j = 0; j < S; j += 2) {
 #if WS_ABL & 1
       __syncthreads();
@@ -255,18 +255,18 @@ __global__ __launch_bounds__(512, 2) void conv_f16ws_kernel(const dmd_conv_param
       continue;
 #endif
       if (j + 1 < S) {
+        load_W(j + 1);
         store_S(j + 1, stage1, zm1, sl1);
         if (j + 3 < S) issue_S(j + 3, stage1, zm1, sl1);
-        store_W(j + 1, wst1);
-        if (j + 3 < S) load_W(j + 3, wst1);
+        store_W(j + 1);
       }
       __syncthreads();
       if (j + 1 < S) {
         if (j + 2 < S) {
+          load_W(j + 2);
           store_S(j + 2, stage0, zm0, sl0);
           if (j + 4 < S) issue_S(j + 4, stage0, zm0, sl0);
-          store_W(j + 2, wst0);
-          if (j + 4 < S) load_W(j + 4, wst0);
+          store_W(j + 2);
         }
         __syncthreads();
       }
@@ -300,79 +300,77 @@ __global__ __launch_bounds__(512, 2) void conv_f16ws_kernel(const dmd_conv_param
     const int wunit = G::NPP * 4 + g * 64 + cb * 32 + n31;  // weights follow the patch inside a buffer
 
     f32x16 acc[4];
-    f32x4 bias[4];
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      bias[qd] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (p.bias) bias[qd] = *(const f32x4*)(p.bias + cb * 32 + 8 * qd + 4 * g);
-    }
 
-    __syncthreads();  // B(-1)
-    __syncthreads();  // B0
-    int k = 0, ck = 0;
-    for (int j = 0; j < S; ++j) {
-      if (ck == 0) {
+    // ---- write-out state of this group's finished tile ----
+    // lane owns couts cb*32 + 8 qd + 4 g + (0..3), qd = 0..3, of pixel n31 of each 32-pixel block
+    int pixoff[4];     // 16-byte unit offset of (pixel, cb*32 + 4 g) per block, -1: sub-tile outside the tensor
+    int stat_slot[2];  // out_stats slot per statistics tile of this wave, -1: none
+    double ssum[2], ssq[2];
+    int pending = 0;   // next block of the finished tile to write (4 = nothing pending)
+    pending = 4;
+    auto epi_begin = [&](int k) {
+      const int tile = WS_TILE(k);
+      WsTile ti[G::SUB];
 #pragma unroll
-        for (int blk = 0; blk < 4; ++blk)
+      for (int s = 0; s < G::SUB; ++s) ti[s] = ws_subtile<G>(p, tile, s);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[blk][r] = 0.f;
-      }
-      const u32x4* buf = bufs + (j & 1) * G::BUF_UNITS;
+      for (int blk = 0; blk < 4; ++blk) {
+        WsTile t = ti[0];
+        int oy, ox;
+        if (G::B8) {
+          const int s = ph * 2 + (blk >> 1);
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int dy = tap / 3, dx = tap % 3;
-        h8 bh[4], bl[4];
-        const int toff = dy * G::PW + dx;
-        const h8 ah = __builtin_bit_cast(h8, buf[(tap * 2 + 0) * 128 + wunit]);
-        bh[0] = __builtin_bit_cast(h8, buf[(pixbase[0] + toff) * 4 + posh[dx]]);
-        bh[1] = __builtin_bit_cast(h8, buf[(pixbase[1] + toff) * 4 + posh[dx]]);
-        bl[0] = __builtin_bit_cast(h8, buf[(pixbase[0] + toff) * 4 + (posh[dx] ^ 2)]);
-        bl[1] = __builtin_bit_cast(h8, buf[(pixbase[1] + toff) * 4 + (posh[dx] ^ 2)]);
-        const h8 al = __builtin_bit_cast(h8, buf[(tap * 2 + 1) * 128 + wunit]);
-        bh[2] = __builtin_bit_cast(h8, buf[(pixbase[2] + toff) * 4 + posh[dx]]);
-        bh[3] = __builtin_bit_cast(h8, buf[(pixbase[3] + toff) * 4 + posh[dx]]);
-        bl[2] = __builtin_bit_cast(h8, buf[(pixbase[2] + toff) * 4 + (posh[dx] ^ 2)]);
-        bl[3] = __builtin_bit_cast(h8, buf[(pixbase[3] + toff) * 4 + (posh[dx] ^ 2)]);
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-          const int b0 = 2 * pr, b1 = 2 * pr + 1;
-          acc[b0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[b0], acc[b0], 0, 0, 0);
-          acc[b1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[b1], acc[b1], 0, 0, 0);
-          acc[b0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[b0], acc[b0], 0, 0, 0);
-          acc[b1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[b1], acc[b1], 0, 0, 0);
-          acc[b0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[b0], acc[b0], 0, 0, 0);
-          acc[b1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[b1], acc[b1], 0, 0, 0);
+          for (int kk = 1; kk < G::SUB; ++kk)
+            if (s == kk) t = ti[kk];
+          oy = t.y0 + (blk & 1) * 4 + (n31 >> 3);
+          ox = t.x0 + (n31 & 7);
+        } else {
+          oy = t.y0 + ph * 8 + blk * 2 + (n31 >> 4);
+          ox = t.x0 + (n31 & 15);
         }
+        pixoff[blk] = t.valid ? (((t.n * p.H + oy) * p.W + ox) * 16 + cb * 8 + g) : -1;  // < 2^31 units = 32 GiB
       }
-      if (ck == nchunks - 1) {
-        // ---- epilogue of tile k: lane owns couts cb*32 + 8 qd + 4 g + (0..3) of pixel n31 of each block ----
-        const int tile = WS_TILE(k);
-        WsTile ti[G::SUB];
 #pragma unroll
-        for (int s = 0; s < G::SUB; ++s) ti[s] = ws_subtile<G>(p, tile, s);
-        double ssum[2] = {0.0, 0.0}, ssq[2] = {0.0, 0.0};  // B8: [0] blocks 0-1, [1] blocks 2-3
+      for (int kk = 0; kk < 2; ++kk) {
+        WsTile t = ti[0];
+        int T, tt;
+        if (G::B8) {
+          const int s = ph * 2 + kk;
 #pragma unroll
-        for (int blk = 0; blk < 4; ++blk) {
-          WsTile t = ti[0];
-          int oy, ox;
-          if (G::B8) {
-            const int s = ph * 2 + (blk >> 1);
+          for (int k2 = 1; k2 < G::SUB; ++k2)
+            if (s == k2) t = ti[k2];
+          const int tx8 = p.W / 8;
+          T = tx8 * (p.H / 8);
+          tt = (t.y0 / 8) * tx8 + t.x0 / 8;
+        } else {
+          const int tx16 = p.W / 16;
+          T = tx16 * (p.H / 8);
+          tt = (t.y0 / 8 + ph) * tx16 + t.x0 / 16;
+        }
+        stat_slot[kk] = (t.valid && (G::B8 || kk == 0)) ? ((t.n * 2 + cb) * T + tt) : -1;
+        ssum[kk] = 0.0;
+        ssq[kk] = 0.0;
+      }
+      pending = 0;
+    };
+    // blocks [pending, pending + count) of the finished tile: bias, residual, store, statistics
+    auto epi_blocks = [&](int count) {
+      const int first = pending, last = min(4, pending + count);
+      f32x4 bias[4];  // re-read per call (L1/L2 resident): not worth 16 registers across the MFMA loop
 #pragma unroll
-            for (int kk = 1; kk < G::SUB; ++kk)
-              if (s == kk) t = ti[kk];
-            oy = t.y0 + (blk & 1) * 4 + (n31 >> 3);
-            ox = t.x0 + (n31 & 7);
-          } else {
-            oy = t.y0 + ph * 8 + blk * 2 + (n31 >> 4);
-            ox = t.x0 + (n31 & 15);
-          }
-          if (!t.valid) continue;
-          const size_t pixel = ((size_t)t.n * p.H + oy) * p.W + ox;
-          float* op = p.out + pixel * 64 + cb * 32 + 4 * g;
-          const float* rp = p.residual ? p.residual + pixel * 64 + cb * 32 + 4 * g : nullptr;
+      for (int qd = 0; qd < 4; ++qd) {
+        bias[qd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bias[qd] = *(const f32x4*)(p.bias + cb * 32 + 8 * qd + 4 * g);
+      }
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) {
+        if (blk < first || blk >= last) continue;  // uniform; keeps acc[] statically indexed
+        if (pixoff[blk] >= 0) {
+          float* op = p.out + (size_t)pixoff[blk] * 4;
           f32x4 rv[4];
 #pragma unroll
-          for (int qd = 0; qd < 4; ++qd) rv[qd] = rp ? *(const f32x4*)(rp + 8 * qd) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int qd = 0; qd < 4; ++qd)
+            rv[qd] = p.residual ? *(const f32x4*)(p.residual + (size_t)pixoff[blk] * 4 + 8 * qd) : (f32x4){0.f, 0.f, 0.f, 0.f};
           float fs = 0.f, fq = 0.f;  // fp32 over the lane's 16 values of this block, fp64 across
 #pragma unroll
           for (int qd = 0; qd < 4; ++qd) {
@@ -387,39 +385,74 @@ __global__ __launch_bounds__(512, 2) void conv_f16ws_kernel(const dmd_conv_param
           ssum[slot] += (double)fs;
           ssq[slot] += (double)fq;
         }
-        if (p.out_stats) {
+      }
+      pending = last;
+      if (last == 4 && first < 4 && p.out_stats) {
 #pragma unroll
-          for (int kk = 0; kk < (G::B8 ? 2 : 1); ++kk) {
-            const double a = dmd_wave_sum(ssum[kk]);
-            const double b = dmd_wave_sum(ssq[kk]);
-            WsTile t = ti[0];
-            int T, tt;
-            if (G::B8) {
-              const int s = ph * 2 + kk;
-#pragma unroll
-              for (int k2 = 1; k2 < G::SUB; ++k2)
-                if (s == k2) t = ti[k2];
-              const int tx8 = p.W / 8;
-              T = tx8 * (p.H / 8);
-              tt = (t.y0 / 8) * tx8 + t.x0 / 8;
-            } else {
-              const int tx16 = p.W / 16;
-              T = tx16 * (p.H / 8);
-              tt = (t.y0 / 8 + ph) * tx16 + t.x0 / 16;
-            }
-            if (lane == 0 && t.valid) {
-              double* o = p.out_stats + ((size_t)(t.n * 2 + cb) * T + tt) * 2;
-              o[0] = a;
-              o[1] = b;
-            }
+        for (int kk = 0; kk < (G::B8 ? 2 : 1); ++kk) {
+          const double a = dmd_wave_sum(ssum[kk]);
+          const double b = dmd_wave_sum(ssq[kk]);
+          if (lane == 0 && stat_slot[kk] >= 0) {
+            double* o = p.out_stats + (size_t)stat_slot[kk] * 2;
+            o[0] = a;
+            o[1] = b;
           }
         }
-        ck = -1;
-        ++k;
       }
-      ++ck;
-      __syncthreads();  // B(j + 1)
+    };
+    const int blocks_per_step = nchunks >= 4 ? 1 : (nchunks >= 2 ? 2 : 4);
+
+    __syncthreads();  // B(-1)
+    __syncthreads();  // B0
+    int j = 0;
+    for (int k = 0; k < nmy; ++k) {
+      if ((k & 1) == role) {
+        // ---- this group's tile: MFMA only ----
+        if (pending < 4) epi_blocks(4);  // (only if the other group's tile had too few steps to finish the write-out)
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[blk][r] = 0.f;
+        for (int ck = 0; ck < nchunks; ++ck, ++j) {
+          const u32x4* buf = bufs + (j & 1) * G::BUF_UNITS;
+#pragma unroll
+          for (int tap = 0; tap < ((WS_ABL & 16) ? 0 : 9); ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+            h8 bh[4], bl[4];
+            const int toff = dy * G::PW + dx;
+            const h8 ah = __builtin_bit_cast(h8, buf[(tap * 2 + 0) * 128 + wunit]);
+            bh[0] = __builtin_bit_cast(h8, buf[(pixbase[0] + toff) * 4 + posh[dx]]);
+            bh[1] = __builtin_bit_cast(h8, buf[(pixbase[1] + toff) * 4 + posh[dx]]);
+            bl[0] = __builtin_bit_cast(h8, buf[(pixbase[0] + toff) * 4 + (posh[dx] ^ 2)]);
+            bl[1] = __builtin_bit_cast(h8, buf[(pixbase[1] + toff) * 4 + (posh[dx] ^ 2)]);
+            const h8 al = __builtin_bit_cast(h8, buf[(tap * 2 + 1) * 128 + wunit]);
+            bh[2] = __builtin_bit_cast(h8, buf[(pixbase[2] + toff) * 4 + posh[dx]]);
+            bh[3] = __builtin_bit_cast(h8, buf[(pixbase[3] + toff) * 4 + posh[dx]]);
+            bl[2] = __builtin_bit_cast(h8, buf[(pixbase[2] + toff) * 4 + (posh[dx] ^ 2)]);
+            bl[3] = __builtin_bit_cast(h8, buf[(pixbase[3] + toff) * 4 + (posh[dx] ^ 2)]);
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+              const int b0 = 2 * pr, b1 = 2 * pr + 1;
+              acc[b0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[b0], acc[b0], 0, 0, 0);
+              acc[b1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[b1], acc[b1], 0, 0, 0);
+              acc[b0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[b0], acc[b0], 0, 0, 0);
+              acc[b1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[b1], acc[b1], 0, 0, 0);
+              acc[b0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[b0], acc[b0], 0, 0, 0);
+              acc[b1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[b1], acc[b1], 0, 0, 0);
+            }
+          }
+          __syncthreads();  // B(j + 1)
+        }
+        epi_begin(k);  // written out while the other group computes the next tile
+      } else {
+        // ---- the other group's tile: write our finished tile out, a slice per chunk step ----
+        for (int ck = 0; ck < nchunks; ++ck, ++j) {
+          if (pending < 4) epi_blocks(blocks_per_step);
+          __syncthreads();  // B(j + 1)
+        }
+      }
     }
+    if (pending < 4) epi_blocks(4);  // tail: the last tile(s) of the range
   }
 }
 
@@ -432,12 +465,12 @@ static int launch_f16ws(const dmd_conv_params& p, int ntiles, hipStream_t st) {
     DMD_CHECK_ARG(e == hipSuccess, "conv_f16ws: hipFuncSetAttribute(%d bytes): %s", G::SMEM_BYTES, hipGetErrorString(e));
     attr_set = true;
   }
-  // persistent: one 512-thread workgroup per CU (LDS-limited), contiguous tile ranges (neighbouring tiles share
+  // persistent: one 768-thread workgroup per CU (LDS-limited), contiguous tile ranges (neighbouring tiles share
   // halo rows and, inside one image, the normalisation statistics)
   const int ncu = 256;
   const int tpw = (ntiles + ncu - 1) / ncu;
   const int nwg = (ntiles + tpw - 1) / tpw;
-  hipLaunchKernelGGL((conv_f16ws_kernel<G>), dim3(nwg), dim3(512), G::SMEM_BYTES, st, p, ntiles, tpw);
+  hipLaunchKernelGGL((conv_f16ws_kernel<G>), dim3(nwg), dim3(768), G::SMEM_BYTES, st, p, ntiles, tpw);
   return 0;
 }
 
