@@ -48,6 +48,8 @@ class RunCtx:
         self.table = table
         self.naive = naive
         self.precision = precision or E.WORLD_MODEL_PRECISION
+        # cheaper (1-ulp v_exp/v_rcp) prologue math also for the shapes the split kernel does not cover
+        self.fast_math = self.precision == "f16x2" and not naive
 
     def w16(self, conv: nn.Conv2d) -> Optional[Tensor]:
         """Split-fp16 weight pieces when this forward runs in "f16x2" precision (else None -> exact fp32)."""
@@ -197,9 +199,10 @@ class ResBlock(nn.Module):
             srcs.append((a, nv.PROLOGUE_NORM_SILU, ctx.film_spec(self.norm1, c0)))
             c0 += a.C
         h = E.conv2d(srcs, ctx.cache.conv_weight(self.conv1), ctx.cache.conv_bias(self.conv1), cout, naive=ctx.naive,
-                     w_f16=ctx.w16(self.conv1))
+                     w_f16=ctx.w16(self.conv1), fast_math=ctx.fast_math)
         h = E.conv2d([(h, nv.PROLOGUE_NORM_SILU, ctx.film_spec(self.norm2))], ctx.cache.conv_weight(self.conv2),
-                     ctx.cache.conv_bias(self.conv2), cout, residual=r, naive=ctx.naive, w_f16=ctx.w16(self.conv2))
+                     ctx.cache.conv_bias(self.conv2), cout, residual=r, naive=ctx.naive, w_f16=ctx.w16(self.conv2),
+                     fast_math=ctx.fast_math)
         if not isinstance(self.attn, nn.Identity):
             h = self.attn.run(ctx, h)
         return h

@@ -32,6 +32,10 @@ void dmd_set_error(const char* fmt, ...);
 // F.silu = x * sigmoid(x).  Accurate expf and IEEE division on purpose (no fast-math): the
 // conv kernels are MFMA-bound, the prologue VALU work is hidden.
 __device__ __forceinline__ float dmd_silu(float v) { return v / (1.0f + expf(-v)); }
+// v_exp_f32 / v_rcp_f32 form (1 ulp each): used where DMD_PRECISION_F16X2 is requested
+__device__ __forceinline__ float dmd_silu_fast(float t) {
+  return t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * t));
+}
 __device__ __forceinline__ float dmd_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
 
 // mean / rstd of a GroupNorm group from T per-tile fp64 partial sums (fixed order).

@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const dmd_conv_params
       if (goff[it] >= 0) stage[it] = *(const f32x4*)(sc.x + (size_t)goff[it] * sc.C + c0);
     }
   };
+  const bool fast_math = p.precision != DMD_PRECISION_F32;
   auto store_chunk = [&](int ck, int buf) {
     const int si = ck < nch0 ? 0 : 1;
     const int prologue = p.src[si].prologue;
@@ -210,7 +211,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const dmd_conv_params
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float t = (v[e] - tab_mean[s][cc + e]) * tab_a[s][cc + e] + tab_add[s][cc + e];
-          if (prologue == DMD_PROLOGUE_NORM_SILU) t = dmd_silu(t);
+          // precision != F32 (no-grad world-model launches that fall back to this kernel): v_exp/v_rcp SiLU,
+          // 1 ulp each, instead of IEEE expf + division -- the staging VALU work bounds the small-Cout layers
+          if (prologue == DMD_PROLOGUE_NORM_SILU) t = fast_math ? dmd_silu_fast(t) : dmd_silu(t);
           v[e] = t;
         }
       }

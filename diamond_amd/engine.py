@@ -139,6 +139,7 @@ def conv2d(
     cout_padded: Optional[int] = None,
     naive: Optional[bool] = None,
     w_f16: Optional[Tensor] = None,
+    fast_math: bool = False,
 ) -> Act:
     a0 = srcs[0][0]
     n, hs, ws, _ = a0.shape
@@ -162,7 +163,8 @@ def conv2d(
     p.w = nv.ptr(w_packed)
     if w_f16 is not None:
         p.w_f16 = nv.ptr(w_f16)
-        p.precision = nv.PRECISION_F16X2
+    if w_f16 is not None or fast_math:
+        p.precision = nv.PRECISION_F16X2  # shapes the split kernel does not cover still get its cheaper prologue math
     p.bias = nv.ptr(bias)
     if residual is not None:
         assert tuple(residual.shape) == (n, h, w, cout) and residual.t.is_contiguous()

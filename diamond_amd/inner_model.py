@@ -68,4 +68,4 @@ class InnerModel(nn.Module):
         x = self.unet.run(ctx, x)
         return E.conv2d([(x, nv.PROLOGUE_NORM_SILU, self.norm_out.spec(ctx))], self._cache.conv_weight(self.conv_out),
                         self._cache.conv_bias(self.conv_out), self.conv_out.out_channels, want_stats=False, out_nchw=True,
-                        naive=naive).t
+                        naive=naive, fast_math=ctx.fast_math).t

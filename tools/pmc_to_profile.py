@@ -10,7 +10,7 @@ w = json.load(open(os.path.join(ROOT, "gpurun_out/pmc/WRITE_SIZE.json")))
 out = {}
 for name, fv in f.items():
     m = re.search(r"conv_mfma_kernel<ConvGeom<(\d+), (true|false), (\d+), (\d+)>", name)
-    m2 = re.search(r"conv_f16s_kernel<F16Geom<(true|false)>", name)
+    m2 = re.search(r"conv_f16w?s_kernel<(?:F16|Ws)Geom<(true|false)>", name)
     if not m and not m2:
         continue
     if m2:
