@@ -17,6 +17,7 @@ torch ops (rocBLAS/hipBLASLt) under ordinary autograd.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -81,9 +82,33 @@ def _gn_silu_bwd(x: Act, spec: NormSpec, da: Tensor, dskip: Optional[Tensor]) ->
     return dx, dmul, dadd
 
 
+# Arithmetic of the encoder's forward and dgrad convolutions: "f16x2" = split-fp32 on the f16 matrix cores where the
+# shape is covered (fp32-class accuracy, see dmd_conv_f16ws.hip), "f32" = exact fp32 MFMA.  The weight gradient
+# (contraction over pixels) always runs on the exact fp32 MFMA kernel.
+AC_PRECISION = os.environ.get("DIAMOND_AC_PRECISION", "f16x2")
+
+
+def _transposed(w: Tensor) -> Tensor:
+    return w.detach().flip(2, 3).transpose(0, 1).contiguous()
+
+
 def _dgrad_weight(cache: E.PackCache, conv: nn.Conv2d) -> Tensor:
     """Packed weight of the transposed convolution: w_t[ci][co][ky][kx] = w[co][ci][2-ky][2-kx]."""
-    return cache.get(conv.weight, "dgradw", lambda w: nv.pack_conv_weight(w.detach().flip(2, 3).transpose(0, 1).contiguous()))
+    return cache.get(conv.weight, "dgradw", lambda w: nv.pack_conv_weight(_transposed(w)))
+
+
+def _w16(cache: E.PackCache, conv: nn.Conv2d) -> Optional[Tensor]:
+    return cache.conv_weight_f16x2(conv) if AC_PRECISION == "f16x2" else None
+
+
+def _dgrad_w16(cache: E.PackCache, conv: nn.Conv2d) -> Optional[Tensor]:
+    """Split-fp16 pieces of the transposed weight (its output channels = conv.in_channels)."""
+    if AC_PRECISION != "f16x2" or conv.kernel_size != (3, 3) or conv.stride != (1, 1):
+        return None
+    cout_t, cin_t = conv.in_channels, conv.out_channels
+    if cout_t not in (32, 64) or cin_t > (128 if cout_t == 64 else 64):
+        return None
+    return cache.get(conv.weight, "dgradw_f16x2", lambda w: nv.pack_conv_weight_f16x2(_transposed(w)))
 
 
 class _Plan:
@@ -118,7 +143,8 @@ class _EncoderFn(torch.autograd.Function):
         n, cimg = obs.shape[:2]
         x16 = E.nchw_to_nhwc(obs.detach().float(), 16)
         ci = plan.conv_in
-        x = E.conv2d([(Act(x16), nv.PROLOGUE_NONE, None)], cache.conv_weight(ci), cache.conv_bias(ci), ci.out_channels)
+        x = E.conv2d([(Act(x16), nv.PROLOGUE_NONE, None)], cache.conv_weight(ci), cache.conv_bias(ci), ci.out_channels,
+                     w_f16=_w16(cache, ci))
         saved = []
         for blk, pool in plan.blocks:
             gn, conv = blk.f[0].norm, blk.f[2]
@@ -130,7 +156,7 @@ class _EncoderFn(torch.autograd.Function):
                 r = E.conv2d([(x, nv.PROLOGUE_NONE, None)], cache.conv_weight(sp), cache.conv_bias(sp), sp.out_channels, taps=1,
                              want_stats=False)
             y = E.conv2d([(x, nv.PROLOGUE_NORM_SILU, spec)], cache.conv_weight(conv), cache.conv_bias(conv), conv.out_channels,
-                         residual=r, want_stats=not pool)
+                         residual=r, want_stats=not pool, w_f16=_w16(cache, conv))
             arg = None
             nxt = y
             if pool:
@@ -158,7 +184,7 @@ class _EncoderFn(torch.autograd.Function):
             dy = _maxpool_bwd(dcur, arg) if pool else dcur
             dw, db = _wgrad(x, nv.PROLOGUE_NORM_SILU, spec, dy, 9, conv.in_channels)
             da = E.conv2d([(Act(dy), nv.PROLOGUE_NONE, None)], _dgrad_weight(cache, conv), None, conv.in_channels,
-                          want_stats=False).t
+                          want_stats=False, w_f16=_dgrad_w16(cache, conv)).t
             sp = blk.skip_projection
             g_skip: List[Optional[Tensor]] = []
             if isinstance(sp, nn.Identity):

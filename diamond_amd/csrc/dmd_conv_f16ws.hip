@@ -26,22 +26,30 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-#define WS_CIN_MAX 128
-#define WS_TAB_SLOTS 4  // tiles whose tables can be alive at once (tile index & 3)
+#define WS_TAB_SLOTS 4  // images whose tables can be alive at once
 
-template <bool B8_>
+// NCB = 32-output-channel blocks of the convolution (2: Cout = 64, the U-Net; 1: Cout = 32, the reward/end model and
+// the first actor-critic blocks).  The workgroup's consumer group is always 4 waves = NCB cout blocks x NPH pixel
+// halves of 128 pixels, so a Cout = 32 tile is 512 pixels (two 16x16 patches / eight 8x8 patches).
+template <bool B8_, int NCB_>
 struct WsGeom {
   static constexpr bool B8 = B8_;
-  static constexpr int SUB = B8_ ? 4 : 1;
+  static constexpr int NCB = NCB_;
+  static constexpr int COUT = 32 * NCB_;
+  static constexpr int NPH = 4 / NCB_;
+  static constexpr int SUB = B8_ ? 2 * NPH : NPH / 2;
   static constexpr int TS = B8_ ? 8 : 16;
   static constexpr int PW = TS + 2;
   static constexpr int PPS = PW * PW;
   static constexpr int NPP = SUB * PPS;
   static constexpr int ITEMS = (NPP * 4 + 255) / 256;
-  static constexpr int W_UNITS = 9 * 2 * 2 * 64;            // 16-byte units of one chunk's weights
+  static constexpr int W_UNITS = 9 * 2 * 2 * COUT;          // 16-byte units of one chunk's weights
+  static constexpr int WU = (W_UNITS + 255) / 256;          // units per producer thread
   static constexpr int BUF_UNITS = NPP * 4 + W_UNITS;       // one {patch, weights} buffer, 16-byte units
-  static constexpr int TAB_FLOATS = WS_TAB_SLOTS * SUB * WS_CIN_MAX;
+  static constexpr int CIN_MAX = NCB_ == 2 ? 128 : 64;
+  static constexpr int TAB_FLOATS = WS_TAB_SLOTS * SUB * CIN_MAX;
   static constexpr int SMEM_BYTES = 2 * BUF_UNITS * 16 + 2 * TAB_FLOATS * 4;
+  static constexpr bool DOUBLE_STAGE = NCB_ == 2;           // two activation register sets only where they fit
 };
 
 struct WsTile {
@@ -113,7 +121,10 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     }
     int goff[G::ITEMS];  // source pixel index per item for tile `gk`, -1: zero
     int gk = -1;
-    int tab_n = -1, tab_slot = -1;  // image whose tables are current (single-image tiles only) and their slot
+    int tab_n[G::SUB];  // images whose tables are current, and their slot
+#pragma unroll
+    for (int s2 = 0; s2 < G::SUB; ++s2) tab_n[s2] = -1;
+    int tab_slot = -1;
     const u32x4* wglob = (const u32x4*)p.w_f16;
 
     auto setup_tile = [&](int k) {  // goff + normalisation tables of tile k (slot k & 3)
@@ -132,13 +143,15 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         const bool inb = ipos[it] >= 0 && t.valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         goff[it] = inb ? ((t.n * Hs + (iy >> up)) * Ws + (ix >> up)) : -1;
       }
-      // tables: all tiles of one image share them -- rebuild only when the image changes (A16; a B8 tile spans
-      // four images and its statistics are a single partial each)
-      const bool rebuild = G::SUB > 1 || ti[0].n != tab_n;
-      if (rebuild) {
-        tab_slot = (tab_slot + 1) & (WS_TAB_SLOTS - 1);
-        tab_n = ti[0].n;
+      // tables: all tiles of one image share them -- rebuild only when an image of the tile changes
+      bool rebuild = false;
+#pragma unroll
+      for (int s2 = 0; s2 < G::SUB; ++s2) {
+        const int nn = ti[s2].valid ? ti[s2].n : -2;
+        rebuild |= nn != tab_n[s2];
+        tab_n[s2] = nn;
       }
+      if (rebuild) tab_slot = (tab_slot + 1) & (WS_TAB_SLOTS - 1);
       if (rebuild && tid < C0 + C1) {  // one channel per thread; visible to the other producers after the next barrier
         const int c = tid;
         const int si = c < C0 ? 0 : 1;
@@ -150,15 +163,15 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           float m = 0.f, a = 1.f, ad = 0.f;
           if (sc.prologue != DMD_PROLOGUE_NONE && ti[s].valid)
             norm_entry(sc.norm, ti[s].n, cl, sc.C, (double)DMD_GN_GROUP * Hs * Ws, &m, &a, &ad);
-          tab_a[(slot * G::SUB + s) * WS_CIN_MAX + c] = a;
-          tab_b[(slot * G::SUB + s) * WS_CIN_MAX + c] = ad - m * a;
+          tab_a[(slot * G::SUB + s) * G::CIN_MAX + c] = a;
+          tab_b[(slot * G::SUB + s) * G::CIN_MAX + c] = ad - m * a;
         }
       }
       gk = k;
     };
 
     // activation loads of stream element e into a register set (+ which items are conv zero padding)
-    auto issue_S = [&](int e, f32x4 (&st)[G::ITEMS], unsigned& zmask, int& slot_out) {
+    auto issue_S = [&](int e, auto& st, unsigned& zmask, int& slot_out) {
       const int k = e / nchunks, ck = e - k * nchunks;
       if (k != gk) setup_tile(k);
       slot_out = tab_slot;
@@ -182,7 +195,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       zmask = z;
     };
     // normalise / activate / split element e from its register set into patch buffer e & 1
-    auto store_S = [&](int e, const f32x4 (&st)[G::ITEMS], unsigned zmask, int slot) {
+    auto store_S = [&](int e, const auto& st, unsigned zmask, int slot) {
       const int ck = e % nchunks;
       const int si = ck < nch0 ? 0 : 1;
       const int prologue = p.src[si].prologue;
@@ -196,8 +209,8 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         f32x4 v = st[it];
         if (prologue != DMD_PROLOGUE_NONE) {
           const int s = ipos[it] >> 16;
-          const float* ta = tab_a + (slot * G::SUB + s) * WS_CIN_MAX + cc;
-          const float* tb = tab_b + (slot * G::SUB + s) * WS_CIN_MAX + cc;
+          const float* ta = tab_a + (slot * G::SUB + s) * G::CIN_MAX + cc;
+          const float* tb = tab_b + (slot * G::SUB + s) * G::CIN_MAX + cc;
 #pragma unroll
           for (int el = 0; el < 4; ++el) {
             float t = __builtin_fmaf(v[el], ta[el], tb[el]);
@@ -222,51 +235,73 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       }
     };
 
-    f32x4 stage0[G::ITEMS], stage1[G::ITEMS];
+    f32x4 stage0[G::ITEMS], stage1[G::DOUBLE_STAGE ? G::ITEMS : 1];
     unsigned zm0 = 0, zm1 = 0;
     int sl0 = 0, sl1 = 0;
-    u32x4 wst[9];
+    u32x4 wst[G::WU];
     auto load_W = [&](int e) {
       const int ck = e % nchunks;
       const u32x4* w = wglob + (size_t)ck * G::W_UNITS + tid;
 #pragma unroll
-      for (int i = 0; i < 9; ++i) wst[i] = w[256 * i];
+      for (int i = 0; i < G::WU; ++i)
+        if (G::W_UNITS % 256 == 0 || tid + 256 * i < G::W_UNITS) wst[i] = w[256 * i];
     };
     auto store_W = [&](int e) {
       u32x4* wl = bufs + (e & 1) * G::BUF_UNITS + G::NPP * 4;
 #pragma unroll
-      for (int i = 0; i < 9; ++i) wl[tid + 256 * i] = wst[i];
+      for (int i = 0; i < G::WU; ++i)
+        if (G::W_UNITS % 256 == 0 || tid + 256 * i < G::W_UNITS) wl[tid + 256 * i] = wst[i];
     };
 
-    // fill element 0; elements 1 and 2 in flight
-    issue_S(0, stage0, zm0, sl0);
-    load_W(0);
-    if (S > 1) issue_S(1, stage1, zm1, sl1);
-    __syncthreads();  // B(-1): the tables written by setup_tile are visible to all producers
-    store_S(0, stage0, zm0, sl0);
-    if (S > 2) issue_S(2, stage0, zm0, sl0);
-    store_W(0);
-    __syncthreads();  // B0: buffer 0 = element 0
-    // step j: consumers compute element j, producers fill element j + 1 (register set (j + 1) & 1)
-    for (int j = 0; j < S; j += 2) {
+    if (G::DOUBLE_STAGE) {
+      // fill element 0; elements 1 and 2 in flight
+      issue_S(0, stage0, zm0, sl0);
+      load_W(0);
+      if (S > 1) issue_S(1, stage1, zm1, sl1);
+      __syncthreads();  // B(-1): the tables written by setup_tile are visible to all producers
+      store_S(0, stage0, zm0, sl0);
+      if (S > 2) issue_S(2, stage0, zm0, sl0);
+      store_W(0);
+      __syncthreads();  // B0: buffer 0 = element 0
+      // step j: consumers compute element j, producers fill element j + 1 (register set (j + 1) & 1)
+      for (int j = 0; j < S; j += 2) {
 #if WS_ABL & 1
-      __syncthreads();
-      if (j + 1 < S) __syncthreads();
-      continue;
+        __syncthreads();
+        if (j + 1 < S) __syncthreads();
+        continue;
 #endif
-      if (j + 1 < S) {
-        load_W(j + 1);
-        store_S(j + 1, stage1, zm1, sl1);
-        if (j + 3 < S) issue_S(j + 3, stage1, zm1, sl1);
-        store_W(j + 1);
+        if (j + 1 < S) {
+          load_W(j + 1);
+          store_S(j + 1, stage1, zm1, sl1);
+          if (j + 3 < S) issue_S(j + 3, stage1, zm1, sl1);
+          store_W(j + 1);
+        }
+        __syncthreads();
+        if (j + 1 < S) {
+          if (j + 2 < S) {
+            load_W(j + 2);
+            store_S(j + 2, stage0, zm0, sl0);
+            if (j + 4 < S) issue_S(j + 4, stage0, zm0, sl0);
+            store_W(j + 2);
+          }
+          __syncthreads();
+        }
       }
-      __syncthreads();
-      if (j + 1 < S) {
-        if (j + 2 < S) {
-          load_W(j + 2);
-          store_S(j + 2, stage0, zm0, sl0);
-          if (j + 4 < S) issue_S(j + 4, stage0, zm0, sl0);
-          store_W(j + 2);
+    } else {
+      // one register set: activations are fetched one step ahead only
+      issue_S(0, stage0, zm0, sl0);
+      load_W(0);
+      __syncthreads();  // B(-1)
+      store_S(0, stage0, zm0, sl0);
+      if (S > 1) issue_S(1, stage0, zm0, sl0);
+      store_W(0);
+      __syncthreads();  // B0
+      for (int j = 0; j < S; ++j) {
+        if (j + 1 < S) {
+          load_W(j + 1);
+          store_S(j + 1, stage0, zm0, sl0);
+          if (j + 2 < S) issue_S(j + 2, stage0, zm0, sl0);
+          store_W(j + 1);
         }
         __syncthreads();
       }
@@ -278,8 +313,8 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
 #endif
     // static priority: the MFMA waves win issue arbitration against the co-resident staging wave of their SIMD
     __builtin_amdgcn_s_setprio(WS_CONSUMER_PRIO);
-    const int cb = wave & 1;   // 32-cout block == GroupNorm group
-    const int ph = wave >> 1;  // pixel half of the tile
+    const int cb = wave % G::NCB;  // 32-cout block == GroupNorm group
+    const int ph = wave / G::NCB;  // 128-pixel part of the tile
     const int n31 = lane & 31, g = lane >> 5;
     int pixbase[4];
 #pragma unroll
@@ -289,15 +324,15 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         const int row = (blk & 1) * 4 + (n31 >> 3);
         pixbase[blk] = s * G::PPS + row * G::PW + (n31 & 7);
       } else {
-        const int row = ph * 8 + blk * 2 + (n31 >> 4);
-        pixbase[blk] = row * G::PW + (n31 & 15);
+        const int row = (ph & 1) * 8 + blk * 2 + (n31 >> 4);
+        pixbase[blk] = (ph >> 1) * G::PPS + row * G::PW + (n31 & 15);
       }
     }
     const int col = G::B8 ? (n31 & 7) : (n31 & 15);
     int posh[3];
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) posh[dx] = (g + ((col + dx) >> 1)) & 3;
-    const int wunit = G::NPP * 4 + g * 64 + cb * 32 + n31;  // weights follow the patch inside a buffer
+    const int wunit = G::NPP * 4 + g * G::COUT + cb * 32 + n31;  // weights follow the patch inside a buffer
 
     f32x16 acc[4];
 
@@ -325,10 +360,13 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           oy = t.y0 + (blk & 1) * 4 + (n31 >> 3);
           ox = t.x0 + (n31 & 7);
         } else {
-          oy = t.y0 + ph * 8 + blk * 2 + (n31 >> 4);
+#pragma unroll
+          for (int kk = 1; kk < G::SUB; ++kk)
+            if ((ph >> 1) == kk) t = ti[kk];
+          oy = t.y0 + (ph & 1) * 8 + blk * 2 + (n31 >> 4);
           ox = t.x0 + (n31 & 15);
         }
-        pixoff[blk] = t.valid ? (((t.n * p.H + oy) * p.W + ox) * 16 + cb * 8 + g) : -1;  // < 2^31 units = 32 GiB
+        pixoff[blk] = t.valid ? (((t.n * p.H + oy) * p.W + ox) * (G::COUT / 4) + cb * 8 + g) : -1;  // 16-byte units
       }
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -343,11 +381,14 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           T = tx8 * (p.H / 8);
           tt = (t.y0 / 8) * tx8 + t.x0 / 8;
         } else {
+#pragma unroll
+          for (int k2 = 1; k2 < G::SUB; ++k2)
+            if ((ph >> 1) == k2) t = ti[k2];
           const int tx16 = p.W / 16;
           T = tx16 * (p.H / 8);
-          tt = (t.y0 / 8 + ph) * tx16 + t.x0 / 16;
+          tt = (t.y0 / 8 + (ph & 1)) * tx16 + t.x0 / 16;
         }
-        stat_slot[kk] = (t.valid && (G::B8 || kk == 0)) ? ((t.n * 2 + cb) * T + tt) : -1;
+        stat_slot[kk] = (t.valid && (G::B8 || kk == 0)) ? ((t.n * G::NCB + cb) * T + tt) : -1;
         ssum[kk] = 0.0;
         ssq[kk] = 0.0;
       }
@@ -420,12 +461,12 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
             const int dy = tap / 3, dx = tap % 3;
             h8 bh[4], bl[4];
             const int toff = dy * G::PW + dx;
-            const h8 ah = __builtin_bit_cast(h8, buf[(tap * 2 + 0) * 128 + wunit]);
+            const h8 ah = __builtin_bit_cast(h8, buf[(tap * 2 + 0) * 2 * G::COUT + wunit]);
             bh[0] = __builtin_bit_cast(h8, buf[(pixbase[0] + toff) * 4 + posh[dx]]);
             bh[1] = __builtin_bit_cast(h8, buf[(pixbase[1] + toff) * 4 + posh[dx]]);
             bl[0] = __builtin_bit_cast(h8, buf[(pixbase[0] + toff) * 4 + (posh[dx] ^ 2)]);
             bl[1] = __builtin_bit_cast(h8, buf[(pixbase[1] + toff) * 4 + (posh[dx] ^ 2)]);
-            const h8 al = __builtin_bit_cast(h8, buf[(tap * 2 + 1) * 128 + wunit]);
+            const h8 al = __builtin_bit_cast(h8, buf[(tap * 2 + 1) * 2 * G::COUT + wunit]);
             bh[2] = __builtin_bit_cast(h8, buf[(pixbase[2] + toff) * 4 + posh[dx]]);
             bh[3] = __builtin_bit_cast(h8, buf[(pixbase[3] + toff) * 4 + posh[dx]]);
             bl[2] = __builtin_bit_cast(h8, buf[(pixbase[2] + toff) * 4 + (posh[dx] ^ 2)]);
@@ -475,6 +516,11 @@ static int launch_f16ws(const dmd_conv_params& p, int ntiles, hipStream_t st) {
 }
 
 int dmd_launch_conv_f16ws(const dmd_conv_params& p, hipStream_t st) {
-  if (p.W % 16 != 0) return launch_f16ws<WsGeom<true>>(p, (p.N * (p.H / 8) * (p.W / 8) + 3) / 4, st);
-  return launch_f16ws<WsGeom<false>>(p, p.N * (p.H / 16) * (p.W / 16), st);
+  const bool b8 = p.W % 16 != 0;
+  if (p.Cout == 64) {
+    if (b8) return launch_f16ws<WsGeom<true, 2>>(p, (p.N * (p.H / 8) * (p.W / 8) + 3) / 4, st);
+    return launch_f16ws<WsGeom<false, 2>>(p, p.N * (p.H / 16) * (p.W / 16), st);
+  }
+  if (b8) return launch_f16ws<WsGeom<true, 1>>(p, (p.N * (p.H / 8) * (p.W / 8) + 7) / 8, st);
+  return launch_f16ws<WsGeom<false, 1>>(p, (p.N * (p.H / 16) * (p.W / 16) + 1) / 2, st);
 }

@@ -47,7 +47,7 @@ PROFILER: Optional[LaunchProfiler] = None
 def kernel_key(p) -> str:
     """Name of the kernel instantiation dmd_conv2d picks for these parameters."""
     if nv.lib().dmd_conv2d_f16x2_eligible(C.byref(p)):
-        return f"conv_f16s<{'B8' if p.W % 16 else 'A16'}>"
+        return f"conv_f16s<{'B8' if p.W % 16 else 'A16'},c{p.Cout}>"
     wn = 4 if p.CoutPad % 64 == 0 else (2 if p.CoutPad % 32 == 0 else 1)
     return f"conv_mfma<WN{wn},{'B' if p.W % 16 else 'A'},taps{p.taps},s{p.stride}>"
 
@@ -104,8 +104,10 @@ class PackCache:
         return self.get(conv.weight, f"convw{cout_padded}", lambda w: nv.pack_conv_weight(w, cout_padded))
 
     def conv_weight_f16x2(self, conv: nn.Conv2d) -> Optional[Tensor]:
-        """Split-fp16 pieces of a 3x3, 64-output-channel weight (None for other shapes)."""
-        if conv.out_channels != 64 or conv.kernel_size != (3, 3) or conv.stride != (1, 1):
+        """Split-fp16 pieces of a 3x3 stride-1 weight with 32 or 64 output channels (None for other shapes)."""
+        if conv.out_channels not in (32, 64) or conv.kernel_size != (3, 3) or conv.stride != (1, 1):
+            return None
+        if conv.in_channels > (128 if conv.out_channels == 64 else 64):
             return None
         return self.get(conv.weight, "convw_f16x2", nv.pack_conv_weight_f16x2)
 

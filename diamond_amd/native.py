@@ -173,12 +173,12 @@ def pack_conv_weight(w_oihw: Tensor, cout_padded: Optional[int] = None) -> Tenso
 
 
 def pack_conv_weight_f16x2(w_oihw: Tensor) -> Tensor:
-    """OIHW (64, Cin, 3, 3) -> [CinPad/16][9][h|l][64][16] fp16 split pieces (w = h + l)."""
+    """OIHW (Cout in {32, 64}, Cin, 3, 3) -> [CinPad/16][9][h|l][2][Cout][8] fp16 split pieces (w = h + l)."""
     cout, cin, k, _ = w_oihw.shape
-    assert cout == 64 and k == 3, (cout, k)
+    assert cout in (32, 64) and k == 3, (cout, k)
     cinp = (cin + 15) // 16 * 16
     w = w_oihw.detach().contiguous().float()
-    out = torch.empty(cinp // 16 * 9 * 2 * 64 * 16, device=w.device, dtype=torch.float16)
+    out = torch.empty(cinp // 16 * 9 * 2 * cout * 16, device=w.device, dtype=torch.float16)
     check(lib().dmd_pack_conv_weight_f16x2(fptr(w), ptr(out), cout, cin, cinp, stream()), "dmd_pack_conv_weight_f16x2")
     return out
 

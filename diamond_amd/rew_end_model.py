@@ -60,7 +60,7 @@ class RewEndEncoder(nn.Module):
 
     def run(self, ctx: RunCtx, x_nhwc16: Tensor) -> E.Act:
         x = E.conv2d([(E.Act(x_nhwc16), nv.PROLOGUE_NONE, None)], ctx.cache.conv_weight(self.conv_in),
-                     ctx.cache.conv_bias(self.conv_in), self.conv_in.out_channels, naive=ctx.naive)
+                     ctx.cache.conv_bias(self.conv_in), self.conv_in.out_channels, naive=ctx.naive, w_f16=ctx.w16(self.conv_in))
         for blocks, down in zip(self.blocks, self.downsamples):
             if not isinstance(down, nn.Identity):
                 x = down.run(ctx, x)

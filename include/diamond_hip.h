@@ -83,7 +83,7 @@ typedef struct dmd_conv_params {
 #define DMD_PRECISION_F32 0
 #define DMD_PRECISION_F16X2 1
 int dmd_conv2d_f16x2_eligible(const dmd_conv_params* p);
-/* OIHW (64, Cin, 3, 3) fp32 -> [CinPad/16][9][h|l][64][16] fp16 pieces */
+/* OIHW (Cout in {32, 64}, Cin, 3, 3) fp32 -> [CinPad/16][9][h|l][2][Cout][8] fp16 pieces */
 int dmd_pack_conv_weight_f16x2(const float* oihw, void* packed, int Cout, int Cin, int CinPad, dmd_stream_t stream);
 
 int dmd_conv2d(const dmd_conv_params* p, dmd_stream_t stream);

@@ -250,3 +250,26 @@ def test_full_window_vs_reference_golden():
         for k, p in ac.named_parameters():
             n = float(w["grad_norms"][k])
             assert abs(float(p.grad.norm()) - n) <= 2e-2 * n + 1e-6, k
+
+
+def test_denoiser_256x256_attention_vs_oracle():
+    """BASELINE configs[4] shape (256x256x3, attention on the two deepest levels -> 1024 / 4096-token flash
+    attention, 16 x 16 tiles of 16 x 16 pixels per image): HIP path vs the CPU oracle on one frame."""
+    from diamond_amd.testing import synthetic_actions, synthetic_frames
+    from oracle import diamond_oracle as O
+
+    attn = (0, 0, 1, 1)
+    ag = make_agent(attn)
+    oa = make_oracle_agent(attn_depths=attn)
+    g = torch.Generator().manual_seed(77)
+    obs = synthetic_frames(g, 1, 12, 256, 256)
+    act = synthetic_actions(g, 4, 1, 4)
+    noise = torch.randn(1, 3, 256, 256, generator=g)
+    sigma = torch.tensor(0.9)
+    x = noise * sigma + obs[:, -3:] * 0.5
+    ref = O.model_output(oa.denoiser, oa.dspec, x, sigma, obs, act)
+    for prec in ("f32", "f16x2"):
+        f = ag.denoiser.compute_model_output(x.to(DEV), obs.to(DEV), act.to(DEV), sigma, precision=prec)
+        err = rel_err(f, ref)
+        print(f"256x256 {prec}: model_output rel err {err:.3e}")
+        assert err < 1e-4, (prec, err)
