@@ -513,7 +513,7 @@ extern "C" int dmd_conv2d(const dmd_conv_params* p, dmd_stream_t stream) {
   if (dmd_conv2d_f16x2_eligible(p)) {
     // DIAMOND_F16S_WS=0 selects the older uniform-role kernel (kept for A/B measurements)
     static const int use_ws = getenv("DIAMOND_F16S_WS") ? atoi(getenv("DIAMOND_F16S_WS")) : 1;
-    if (int e = (use_ws || p->Cout != 64) ? dmd_launch_conv_f16ws(*p, st) : dmd_launch_conv_f16s(*p, st)) return e;
+    if (int e = (use_ws || p->CoutPad != 64) ? dmd_launch_conv_f16ws(*p, st) : dmd_launch_conv_f16s(*p, st)) return e;
   } else if (p->taps == 1)
     dispatch_wn<1, 1>(*p, st);
   else if (p->stride == 2)

@@ -506,11 +506,13 @@ extern "C" int dmd_pack_conv_weight_f16x2(const float* oihw, void* packed, int C
 // 1: the parameters can run on the split-fp16 kernels (Cout = 64: both kernels; Cout = 32: conv_f16ws only)
 extern "C" int dmd_conv2d_f16x2_eligible(const dmd_conv_params* p) {
   if (!p || (p->precision & 0xff) != DMD_PRECISION_F16X2 || !p->w_f16) return 0;
-  if (p->taps != 9 || p->stride != 1 || (p->Cout != 64 && p->Cout != 32) || p->CoutPad != p->Cout || p->out_nchw) return 0;
-  if (p->residual_norm.stats) return 0;
+  if (p->taps != 9 || p->stride != 1 || p->residual_norm.stats) return 0;
+  // few-channel NCHW head (conv_out): Cout <= 4 zero-padded to 32, no residual / statistics
+  const bool head = p->out_nchw && p->Cout <= 4 && p->CoutPad == 32 && !p->residual && !p->out_stats;
+  if (!head && ((p->Cout != 64 && p->Cout != 32) || p->CoutPad != p->Cout || p->out_nchw)) return 0;
   int cin = 0;
   for (int i = 0; i < p->nsrc; ++i) cin += p->src[i].C;
-  if (cin > (p->Cout == 64 ? F16S_CIN_MAX : 64)) return 0;
+  if (cin > (p->CoutPad == 64 ? F16S_CIN_MAX : 64)) return 0;
   const bool a16 = p->H % 16 == 0 && p->W % 16 == 0;
   const bool b8 = p->W % 16 != 0;
   return (a16 || b8) ? 1 : 0;

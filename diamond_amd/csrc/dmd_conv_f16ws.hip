@@ -406,6 +406,19 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
 #pragma unroll
       for (int blk = 0; blk < 4; ++blk) {
         if (blk < first || blk >= last) continue;  // uniform; keeps acc[] statically indexed
+        if (G::NCB == 1 && p.out_nchw) {
+          // few-channel NCHW output (conv_out: 64 -> 3, weights zero-padded to 32 couts): the real channels are
+          // couts 0..3 = quad 0 of the k-group-0 lanes; consecutive lanes = consecutive pixels of a plane
+          if (pixoff[blk] >= 0 && g == 0) {
+            const int pixel = pixoff[blk] >> 3;  // cb == 0, g == 0
+            const int HW = p.H * p.W;
+            const int n = pixel / HW, rem = pixel - n * HW;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (c < p.Cout) p.out[((size_t)n * p.Cout + c) * HW + rem] = acc[blk][c] + bias[0][c];
+          }
+          continue;
+        }
         if (pixoff[blk] >= 0) {
           float* op = p.out + (size_t)pixoff[blk] * 4;
           f32x4 rv[4];
@@ -517,7 +530,7 @@ static int launch_f16ws(const dmd_conv_params& p, int ntiles, hipStream_t st) {
 
 int dmd_launch_conv_f16ws(const dmd_conv_params& p, hipStream_t st) {
   const bool b8 = p.W % 16 != 0;
-  if (p.Cout == 64) {
+  if (p.CoutPad == 64) {
     if (b8) return launch_f16ws<WsGeom<true, 2>>(p, (p.N * (p.H / 8) * (p.W / 8) + 3) / 4, st);
     return launch_f16ws<WsGeom<false, 2>>(p, p.N * (p.H / 16) * (p.W / 16), st);
   }

@@ -47,7 +47,7 @@ PROFILER: Optional[LaunchProfiler] = None
 def kernel_key(p) -> str:
     """Name of the kernel instantiation dmd_conv2d picks for these parameters."""
     if nv.lib().dmd_conv2d_f16x2_eligible(C.byref(p)):
-        return f"conv_f16s<{'B8' if p.W % 16 else 'A16'},c{p.Cout}>"
+        return f"conv_f16s<{'B8' if p.W % 16 else 'A16'},c{p.CoutPad}>"
     wn = 4 if p.CoutPad % 64 == 0 else (2 if p.CoutPad % 32 == 0 else 1)
     return f"conv_mfma<WN{wn},{'B' if p.W % 16 else 'A'},taps{p.taps},s{p.stride}>"
 
@@ -110,6 +110,18 @@ class PackCache:
         if conv.in_channels > (128 if conv.out_channels == 64 else 64):
             return None
         return self.get(conv.weight, "convw_f16x2", nv.pack_conv_weight_f16x2)
+
+    def conv_weight_f16x2_head(self, conv: nn.Conv2d) -> Optional[Tensor]:
+        """Split-fp16 pieces of a few-output-channel 3x3 head (conv_out: 64 -> 3), zero-padded to 32 couts."""
+        if conv.out_channels > 4 or conv.kernel_size != (3, 3) or conv.stride != (1, 1) or conv.in_channels > 64:
+            return None
+
+        def pack(w: Tensor) -> Tensor:
+            wp = torch.zeros(32, *w.shape[1:], device=w.device, dtype=torch.float32)
+            wp[: w.shape[0]] = w.detach().float()
+            return nv.pack_conv_weight_f16x2(wp)
+
+        return self.get(conv.weight, "convw_f16x2_head", pack)
 
     def conv_bias(self, conv: nn.Conv2d, cout_padded: Optional[int] = None) -> Optional[Tensor]:
         if conv.bias is None:

@@ -66,6 +66,9 @@ class InnerModel(nn.Module):
         x = E.conv2d([(E.Act(packed_in), nv.PROLOGUE_NONE, None)], self._cache.conv_weight(self.conv_in),
                      self._cache.conv_bias(self.conv_in), self.conv_in.out_channels, naive=naive, w_f16=ctx.w16(self.conv_in))
         x = self.unet.run(ctx, x)
-        return E.conv2d([(x, nv.PROLOGUE_NORM_SILU, self.norm_out.spec(ctx))], self._cache.conv_weight(self.conv_out),
-                        self._cache.conv_bias(self.conv_out), self.conv_out.out_channels, want_stats=False, out_nchw=True,
-                        naive=naive, fast_math=ctx.fast_math).t
+        co = self.conv_out
+        w16 = self._cache.conv_weight_f16x2_head(co) if (ctx.precision == "f16x2" and not naive) else None
+        cpad = 32 if w16 is not None else None  # the split kernel's 32-cout instance, real channels stored as NCHW
+        return E.conv2d([(x, nv.PROLOGUE_NORM_SILU, self.norm_out.spec(ctx))], self._cache.conv_weight(co, cpad),
+                        self._cache.conv_bias(co, cpad), co.out_channels, want_stats=False, out_nchw=True, naive=naive,
+                        fast_math=ctx.fast_math, w_f16=w16, cout_padded=cpad).t

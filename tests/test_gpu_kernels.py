@@ -138,6 +138,31 @@ def test_conv2d(case, impl):
         assert rel_err(st[..., 1], refg.square().sum(-1)) < 2e-5
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 16, 16), (3, 64, 64), (5, 8, 8)])
+def test_conv_head_nchw_f16x2(n, h, w):
+    """conv_out (64 -> 3, GroupNorm + SiLU prologue, NCHW output) on the 32-cout split-fp16 instance."""
+    from diamond_amd import engine as E, native as nv
+
+    g = torch.Generator().manual_seed(n * 31 + h)
+    x = torch.randn(n, 64, h, w, generator=g, dtype=torch.float64) * 1.5 + 0.3
+    wgt = torch.randn(3, 64, 3, 3, generator=g, dtype=torch.float64) / 24
+    bias = torch.randn(3, generator=g, dtype=torch.float64) * 0.1
+    gamma = torch.randn(64, generator=g, dtype=torch.float64) * 0.2 + 1
+    beta = torch.randn(64, generator=g, dtype=torch.float64) * 0.2
+    a = gn_ref(x, 2) * gamma[None, :, None, None] + beta[None, :, None, None]
+    ref = F.conv2d(a * torch.sigmoid(a), wgt, bias, padding=1)
+    wp32 = torch.zeros(32, 64, 3, 3)
+    wp32[:3] = wgt.float()
+    spec = E.NormSpec(mul=gamma.float().to(DEV), add=beta.float().to(DEV))
+    out = E.conv2d([(make_act(x), nv.PROLOGUE_NORM_SILU, spec)], nv.pack_conv_weight(wgt.float().to(DEV), 32),
+                   nv.pad_vector(bias.float().to(DEV), 32), 3, want_stats=False, out_nchw=True, cout_padded=32,
+                   w_f16=nv.pack_conv_weight_f16x2(wp32.to(DEV)))
+    torch.cuda.synchronize()
+    assert tuple(out.t.shape) == (n, 3, h, w)
+    err = rel_err(out.t, ref)
+    assert err < 2e-5, err
+
+
 def test_conv_residual_norm():
     """out = conv1x1(y) + GN_affine(x): the attention block's `x_normed + out_proj(y)` (blocks.py:72)."""
     from diamond_amd import engine as E, native as nv
