@@ -105,6 +105,9 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
 
   if (role == 2) {
     // =================================== PRODUCER ===================================
+#ifdef WS_PRODUCER_PRIO
+    __builtin_amdgcn_s_setprio(WS_PRODUCER_PRIO);
+#endif
     const int q = tid & 3;
     int ipos[G::ITEMS];  // (sub << 16) | (py << 8) | px; -1: no item (beyond the patch)
     // 8-byte unit index of the h half-quad of item `it` in a patch (recomputed where needed: registers are scarce)
