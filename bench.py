@@ -69,11 +69,11 @@ class _Loader:
             yield SimpleNamespace(obs=obs, act=act)
 
 
-def build_agent(device, img_size, rank):
+def build_agent(device, img_size, rank, attn_depths=(0, 0, 0, 0)):
     import diamond_amd as D
     from diamond_amd.testing import fill_module_
 
-    agent = D.Agent(D.default_agent_config(num_actions=4, img_size=img_size))
+    agent = D.Agent(D.default_agent_config(num_actions=4, img_size=img_size, denoiser_attn_depths=tuple(attn_depths)))
     fill_module_(agent, 0)
     with torch.no_grad():
         # Synthetic weights would terminate ~half of the imagined episodes at every step; bias
@@ -162,6 +162,8 @@ def main():
     ap.add_argument("--horizon", type=int, default=15)
     ap.add_argument("--denoise-steps", type=int, default=3)
     ap.add_argument("--img-size", type=int, default=64)
+    ap.add_argument("--attn-depths", type=str, default="0,0,0,0",
+                    help="denoiser attention per level; BASELINE configs[4] (256x256) uses 0,0,1,1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
@@ -186,7 +188,8 @@ def main():
     from diamond_amd.dist import GradAllReducer
 
     torch.manual_seed(1234 + rank)
-    agent = build_agent(device, args.img_size, rank)
+    attn = tuple(int(v) for v in args.attn_depths.split(","))
+    agent = build_agent(device, args.img_size, rank, attn)
     env = D.WorldModelEnv(agent.denoiser, agent.rew_end_model, _Loader(args.batch, 100 + rank, args.img_size),
                           D.WorldModelEnvConfig(horizon=args.horizon, num_batches_to_preload=2,
                                                 diffusion_sampler=D.DiffusionSamplerConfig(
@@ -234,6 +237,9 @@ def main():
         elapsed = float(tt.item())
 
     progress(f"timed region done: {elapsed:.2f}s for {args.steps} steps")
+    is_cfg1 = (args.img_size, args.batch, args.horizon, args.denoise_steps, attn) == (64, 256, 15, 3, (0, 0, 0, 0))
+    cfg_name = ("configs[1] (Breakout-shaped)" if world == 1 else "configs[2] (Breakout-shaped, sharded)") if is_cfg1 else \
+        f"custom (attn_depths {args.attn_depths})"
     frames = args.batch * world * args.horizon * args.steps
     fps = frames / elapsed
     line = {
@@ -242,7 +248,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (world-model 3x3 convs: fp32 operands split into 2 x fp16 pieces on v_mfma_f32_32x32x16_f16, fp32 accumulate, "
                  "fp32-class accuracy; everything else incl. actor-critic fwd/bwd: exact fp32 v_mfma_f32_16x16x4_f32)", "data": "synthetic",
-        "config": {"workload": f"configs[1]: Breakout-shaped {args.img_size}x{args.img_size}x3, batch {args.batch}/GPU, "
+        "config": {"workload": f"{cfg_name}: {args.img_size}x{args.img_size}x3 frames, batch {args.batch}/GPU, "
                                f"horizon {args.horizon}, {args.denoise_steps} Euler denoise steps; step = "
                                "ActorCritic.forward()+backward+all-reduce+clip+AdamW over one 15-step imagined window",
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (batch-sharded envs, flat-bucket "
