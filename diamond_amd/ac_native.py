@@ -154,7 +154,7 @@ class _EncoderFn(torch.autograd.Function):
                 r = x
             else:
                 r = E.conv2d([(x, nv.PROLOGUE_NONE, None)], cache.conv_weight(sp), cache.conv_bias(sp), sp.out_channels, taps=1,
-                             want_stats=False)
+                             want_stats=False, w_f16=_w16(cache, sp))
             y = E.conv2d([(x, nv.PROLOGUE_NORM_SILU, spec)], cache.conv_weight(conv), cache.conv_bias(conv), conv.out_channels,
                          residual=r, want_stats=not pool, w_f16=_w16(cache, conv))
             arg = None

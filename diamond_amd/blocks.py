@@ -193,7 +193,8 @@ class ResBlock(nn.Module):
             r = xs[0]
         else:
             r = E.conv2d([(a, nv.PROLOGUE_NONE, None) for a in xs], ctx.cache.conv_weight(self.proj),
-                         ctx.cache.conv_bias(self.proj), cout, taps=1, want_stats=False, naive=ctx.naive)
+                         ctx.cache.conv_bias(self.proj), cout, taps=1, want_stats=False, naive=ctx.naive,
+                         w_f16=ctx.w16(self.proj))
         srcs, c0 = [], 0
         for a in xs:
             srcs.append((a, nv.PROLOGUE_NORM_SILU, ctx.film_spec(self.norm1, c0)))

@@ -506,14 +506,19 @@ extern "C" int dmd_conv_stat_tiles(int H, int W) { return (H / 8) * (W / ((W % 1
 
 int dmd_launch_conv_f16s(const dmd_conv_params& p, hipStream_t st);   // dmd_conv_f16.hip
 int dmd_launch_conv_f16ws(const dmd_conv_params& p, hipStream_t st);  // dmd_conv_f16ws.hip (wave-specialised, persistent)
+int dmd_launch_conv1x1_stream(const dmd_conv_params& p, hipStream_t st);  // dmd_conv1x1.hip (streaming 1x1, exact fp32)
+extern "C" int dmd_conv1x1_stream_eligible(const dmd_conv_params* p);
 
 extern "C" int dmd_conv2d(const dmd_conv_params* p, dmd_stream_t stream) {
   if (int e = validate_conv(p)) return e;
   hipStream_t st = (hipStream_t)stream;
-  if (dmd_conv2d_f16x2_eligible(p)) {
+  static const int use_1x1 = getenv("DIAMOND_CONV1X1_STREAM") ? atoi(getenv("DIAMOND_CONV1X1_STREAM")) : 1;
+  if (use_1x1 && dmd_conv1x1_stream_eligible(p)) {
+    dmd_launch_conv1x1_stream(*p, st);
+  } else if (dmd_conv2d_f16x2_eligible(p)) {
     // DIAMOND_F16S_WS=0 selects the older uniform-role kernel (kept for A/B measurements)
     static const int use_ws = getenv("DIAMOND_F16S_WS") ? atoi(getenv("DIAMOND_F16S_WS")) : 1;
-    if (int e = (use_ws || p->CoutPad != 64) ? dmd_launch_conv_f16ws(*p, st) : dmd_launch_conv_f16s(*p, st)) return e;
+    if (int e = (use_ws || p->CoutPad != 64 || p->taps != 9) ? dmd_launch_conv_f16ws(*p, st) : dmd_launch_conv_f16s(*p, st)) return e;
   } else if (p->taps == 1)
     dispatch_wn<1, 1>(*p, st);
   else if (p->stride == 2)

@@ -472,33 +472,35 @@ __global__ __launch_bounds__(256, 2) void conv_f16s_kernel(const dmd_conv_params
 // OIHW fp32 -> [CinPad/16][9][h|l][k group g = 0|1][Cout][8 cin] halfs  (cin = 16 chunk + 8 g + e), Cout in {32, 64}:
 // one chunk = 36 * Cout contiguous 16-byte units, copied linearly into LDS by the kernels.
 __global__ void pack_weight_f16x2_kernel(const float* __restrict__ oihw, _Float16* __restrict__ packed, int Cout, int Cin,
-                                         int CinPad) {
-  const size_t total = (size_t)(CinPad / 16) * 9 * Cout * 16;
+                                         int CinPad, int taps) {
+  const size_t total = (size_t)(CinPad / 16) * taps * Cout * 16;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int e = idx % 8;
   const int co = (idx / 8) % Cout;
   const int g = (idx / (8 * (size_t)Cout)) % 2;
-  const int tap = (idx / (8 * (size_t)Cout * 2)) % 9;
-  const int chunk = idx / (8 * (size_t)Cout * 2 * 9);
+  const int tap = (idx / (8 * (size_t)Cout * 2)) % taps;
+  const int chunk = idx / (8 * (size_t)Cout * 2 * taps);
   const int c = chunk * 16 + g * 8 + e;
   float v = 0.f;
-  if (c < Cin) v = oihw[((size_t)co * Cin + c) * 9 + tap];
+  if (c < Cin) v = oihw[((size_t)co * Cin + c) * taps + tap];
   v = fminf(fmaxf(v, -65504.0f), 65504.0f);
   const _Float16 h = (_Float16)v;
   const _Float16 l = (_Float16)(v - (float)h);
-  const size_t base = ((((size_t)chunk * 9 + tap) * 2 + 0) * 2 + g) * ((size_t)Cout * 8) + (size_t)co * 8 + e;
+  const size_t base = ((((size_t)chunk * taps + tap) * 2 + 0) * 2 + g) * ((size_t)Cout * 8) + (size_t)co * 8 + e;
   packed[base] = h;
   packed[base + 2 * (size_t)Cout * 8] = l;
 }
 
-extern "C" int dmd_pack_conv_weight_f16x2(const float* oihw, void* packed, int Cout, int Cin, int CinPad, dmd_stream_t stream) {
+extern "C" int dmd_pack_conv_weight_f16x2(const float* oihw, void* packed, int Cout, int Cin, int k, int CinPad,
+                                          dmd_stream_t stream) {
   DMD_CHECK_ARG(oihw && packed, "pack_f16x2: null");
-  DMD_CHECK_ARG((Cout == 64 || Cout == 32) && CinPad >= Cin && CinPad % 16 == 0,
-                "pack_f16x2: needs Cout in {32, 64} (got %d), CinPad %% 16 == 0", Cout);
-  const size_t total = (size_t)(CinPad / 16) * 9 * Cout * 16;
+  DMD_CHECK_ARG((Cout == 64 || Cout == 32) && (k == 3 || k == 1) && CinPad >= Cin && CinPad % 16 == 0,
+                "pack_f16x2: needs Cout in {32, 64} (got %d), k in {1, 3}, CinPad %% 16 == 0", Cout);
+  const int taps = k * k;
+  const size_t total = (size_t)(CinPad / 16) * taps * Cout * 16;
   hipLaunchKernelGGL(pack_weight_f16x2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, oihw,
-                     (_Float16*)packed, Cout, Cin, CinPad);
+                     (_Float16*)packed, Cout, Cin, CinPad, taps);
   DMD_LAUNCH_CHECK();
   return 0;
 }
@@ -506,7 +508,8 @@ extern "C" int dmd_pack_conv_weight_f16x2(const float* oihw, void* packed, int C
 // 1: the parameters can run on the split-fp16 kernels (Cout = 64: both kernels; Cout = 32: conv_f16ws only)
 extern "C" int dmd_conv2d_f16x2_eligible(const dmd_conv_params* p) {
   if (!p || (p->precision & 0xff) != DMD_PRECISION_F16X2 || !p->w_f16) return 0;
-  if (p->taps != 9 || p->stride != 1 || p->residual_norm.stats) return 0;
+  if (p->stride != 1 || p->residual_norm.stats || (p->taps != 9 && p->taps != 1)) return 0;
+  if (p->taps == 1 && p->upsample) return 0;
   // few-channel NCHW head (conv_out): Cout <= 4 zero-padded to 32, no residual / statistics
   const bool head = p->out_nchw && p->Cout <= 4 && p->CoutPad == 32 && !p->residual && !p->out_stats;
   if (!head && ((p->Cout != 64 && p->Cout != 32) || p->CoutPad != p->Cout || p->out_nchw)) return 0;

@@ -31,10 +31,12 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // NCB = 32-output-channel blocks of the convolution (2: Cout = 64, the U-Net; 1: Cout = 32, the reward/end model and
 // the first actor-critic blocks).  The workgroup's consumer group is always 4 waves = NCB cout blocks x NPH pixel
 // halves of 128 pixels, so a Cout = 32 tile is 512 pixels (two 16x16 patches / eight 8x8 patches).
-template <bool B8_, int NCB_>
+// TAPS = 9 (3x3, pad 1) or 1 (1x1: the same halo'd patch geometry, only the centre window is loaded and read).
+template <bool B8_, int NCB_, int TAPS_ = 9>
 struct WsGeom {
   static constexpr bool B8 = B8_;
   static constexpr int NCB = NCB_;
+  static constexpr int TAPS = TAPS_;
   static constexpr int COUT = 32 * NCB_;
   static constexpr int NPH = 4 / NCB_;
   static constexpr int SUB = B8_ ? 2 * NPH : NPH / 2;
@@ -43,7 +45,7 @@ struct WsGeom {
   static constexpr int PPS = PW * PW;
   static constexpr int NPP = SUB * PPS;
   static constexpr int ITEMS = (NPP * 4 + 255) / 256;
-  static constexpr int W_UNITS = 9 * 2 * 2 * COUT;          // 16-byte units of one chunk's weights
+  static constexpr int W_UNITS = TAPS_ * 2 * 2 * COUT;      // 16-byte units of one chunk's weights
   static constexpr int WU = (W_UNITS + 255) / 256;          // units per producer thread
   static constexpr int BUF_UNITS = NPP * 4 + W_UNITS;       // one {patch, weights} buffer, 16-byte units
   static constexpr int CIN_MAX = NCB_ == 2 ? 128 : 64;
@@ -143,7 +145,8 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         for (int kk = 1; kk < G::SUB; ++kk)
           if (s == kk) t = ti[kk];
         const int iy = t.y0 - 1 + py, ix = t.x0 - 1 + px;
-        const bool inb = ipos[it] >= 0 && t.valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const bool window = G::TAPS == 9 || (py >= 1 && py <= G::TS && px >= 1 && px <= G::TS);  // 1x1: no halo needed
+        const bool inb = ipos[it] >= 0 && window && t.valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         goff[it] = inb ? ((t.n * Hs + (iy >> up)) * Ws + (ix >> up)) : -1;
       }
       // tables: all tiles of one image share them -- rebuild only when an image of the tile changes
@@ -473,8 +476,10 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         for (int ck = 0; ck < nchunks; ++ck, ++j) {
           const u32x4* buf = bufs + (j & 1) * G::BUF_UNITS;
 #pragma unroll
-          for (int tap = 0; tap < ((WS_ABL & 16) ? 0 : 9); ++tap) {
-            const int dy = tap / 3, dx = tap % 3;
+          for (int tt = 0; tt < ((WS_ABL & 16) ? 0 : G::TAPS); ++tt) {
+            const int tap = tt;                       // index into the chunk's weights
+            const int win = G::TAPS == 9 ? tt : 4;    // window of the 3x3 patch geometry (4 = centre)
+            const int dy = win / 3, dx = win % 3;
             h8 bh[4], bl[4];
             const int toff = dy * G::PW + dx;
             const h8 ah = __builtin_bit_cast(h8, buf[(tap * 2 + 0) * 2 * G::COUT + wunit]);
@@ -533,10 +538,11 @@ static int launch_f16ws(const dmd_conv_params& p, int ntiles, hipStream_t st) {
 
 int dmd_launch_conv_f16ws(const dmd_conv_params& p, hipStream_t st) {
   const bool b8 = p.W % 16 != 0;
-  if (p.CoutPad == 64) {
-    if (b8) return launch_f16ws<WsGeom<true, 2>>(p, (p.N * (p.H / 8) * (p.W / 8) + 3) / 4, st);
-    return launch_f16ws<WsGeom<false, 2>>(p, p.N * (p.H / 16) * (p.W / 16), st);
+  const int sub8 = p.N * (p.H / 8) * (p.W / 8), t16 = p.N * (p.H / 16) * (p.W / 16);
+  if (p.taps == 9) {
+    if (p.CoutPad == 64) return b8 ? launch_f16ws<WsGeom<true, 2, 9>>(p, (sub8 + 3) / 4, st) : launch_f16ws<WsGeom<false, 2, 9>>(p, t16, st);
+    return b8 ? launch_f16ws<WsGeom<true, 1, 9>>(p, (sub8 + 7) / 8, st) : launch_f16ws<WsGeom<false, 1, 9>>(p, (t16 + 1) / 2, st);
   }
-  if (b8) return launch_f16ws<WsGeom<true, 1>>(p, (p.N * (p.H / 8) * (p.W / 8) + 7) / 8, st);
-  return launch_f16ws<WsGeom<false, 1>>(p, (p.N * (p.H / 16) * (p.W / 16) + 1) / 2, st);
+  if (p.CoutPad == 64) return b8 ? launch_f16ws<WsGeom<true, 2, 1>>(p, (sub8 + 3) / 4, st) : launch_f16ws<WsGeom<false, 2, 1>>(p, t16, st);
+  return b8 ? launch_f16ws<WsGeom<true, 1, 1>>(p, (sub8 + 7) / 8, st) : launch_f16ws<WsGeom<false, 1, 1>>(p, (t16 + 1) / 2, st);
 }

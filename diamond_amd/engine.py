@@ -46,8 +46,10 @@ PROFILER: Optional[LaunchProfiler] = None
 
 def kernel_key(p) -> str:
     """Name of the kernel instantiation dmd_conv2d picks for these parameters."""
+    if nv.lib().dmd_conv1x1_stream_eligible(C.byref(p)):
+        return f"conv1x1_stream<cin{sum(p.src[i].C for i in range(p.nsrc))}{',f16x2' if p.precision else ''}>"
     if nv.lib().dmd_conv2d_f16x2_eligible(C.byref(p)):
-        return f"conv_f16s<{'B8' if p.W % 16 else 'A16'},c{p.CoutPad}>"
+        return f"conv_f16s<{'B8' if p.W % 16 else 'A16'},c{p.CoutPad}{',1x1' if p.taps == 1 else ''}>"
     wn = 4 if p.CoutPad % 64 == 0 else (2 if p.CoutPad % 32 == 0 else 1)
     return f"conv_mfma<WN{wn},{'B' if p.W % 16 else 'A'},taps{p.taps},s{p.stride}>"
 
@@ -104,8 +106,8 @@ class PackCache:
         return self.get(conv.weight, f"convw{cout_padded}", lambda w: nv.pack_conv_weight(w, cout_padded))
 
     def conv_weight_f16x2(self, conv: nn.Conv2d) -> Optional[Tensor]:
-        """Split-fp16 pieces of a 3x3 stride-1 weight with 32 or 64 output channels (None for other shapes)."""
-        if conv.out_channels not in (32, 64) or conv.kernel_size != (3, 3) or conv.stride != (1, 1):
+        """Split-fp16 pieces of a 3x3 / 1x1 stride-1 weight with 32 or 64 output channels (None for other shapes)."""
+        if conv.out_channels not in (32, 64) or conv.kernel_size not in ((3, 3), (1, 1)) or conv.stride != (1, 1):
             return None
         if conv.in_channels > (128 if conv.out_channels == 64 else 64):
             return None

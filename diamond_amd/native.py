@@ -63,6 +63,7 @@ class WgradParams(C.Structure):
 
 EXPORTS = (
     "dmd_conv2d", "dmd_conv2d_naive", "dmd_conv_stat_tiles", "dmd_pack_conv_weight", "dmd_conv2d_f16x2_eligible",
+    "dmd_conv1x1_stream_eligible",
     "dmd_pack_conv_weight_f16x2", "dmd_linear", "dmd_attention",
     "dmd_edm_pack_input", "dmd_cond_embed", "dmd_edm_denoised", "dmd_euler_step", "dmd_nchw_to_nhwc",
     "dmd_nhwc_to_nchw", "dmd_gn_stats", "dmd_maxpool2", "dmd_lstm_pointwise", "dmd_categorical_sample",
@@ -88,8 +89,9 @@ def lib() -> C.CDLL:
         L.dmd_conv2d_naive.argtypes = [C.POINTER(ConvParams), C.c_void_p]
         L.dmd_linear.argtypes = [C.POINTER(LinearParams), C.c_void_p]
         L.dmd_pack_conv_weight.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-        L.dmd_pack_conv_weight_f16x2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.dmd_pack_conv_weight_f16x2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.dmd_conv2d_f16x2_eligible.argtypes = [C.POINTER(ConvParams)]
+        L.dmd_conv1x1_stream_eligible.argtypes = [C.POINTER(ConvParams)]
         L.dmd_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.dmd_edm_pack_input.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -173,13 +175,13 @@ def pack_conv_weight(w_oihw: Tensor, cout_padded: Optional[int] = None) -> Tenso
 
 
 def pack_conv_weight_f16x2(w_oihw: Tensor) -> Tensor:
-    """OIHW (Cout in {32, 64}, Cin, 3, 3) -> [CinPad/16][9][h|l][2][Cout][8] fp16 split pieces (w = h + l)."""
+    """OIHW (Cout in {32, 64}, Cin, k, k), k in {1, 3} -> [CinPad/16][k*k][h|l][2][Cout][8] fp16 split pieces (w = h + l)."""
     cout, cin, k, _ = w_oihw.shape
-    assert cout in (32, 64) and k == 3, (cout, k)
+    assert cout in (32, 64) and k in (1, 3), (cout, k)
     cinp = (cin + 15) // 16 * 16
     w = w_oihw.detach().contiguous().float()
-    out = torch.empty(cinp // 16 * 9 * 2 * cout * 16, device=w.device, dtype=torch.float16)
-    check(lib().dmd_pack_conv_weight_f16x2(fptr(w), ptr(out), cout, cin, cinp, stream()), "dmd_pack_conv_weight_f16x2")
+    out = torch.empty(cinp // 16 * k * k * 2 * cout * 16, device=w.device, dtype=torch.float16)
+    check(lib().dmd_pack_conv_weight_f16x2(fptr(w), ptr(out), cout, cin, k, cinp, stream()), "dmd_pack_conv_weight_f16x2")
     return out
 
 

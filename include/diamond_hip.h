@@ -83,8 +83,11 @@ typedef struct dmd_conv_params {
 #define DMD_PRECISION_F32 0
 #define DMD_PRECISION_F16X2 1
 int dmd_conv2d_f16x2_eligible(const dmd_conv_params* p);
-/* OIHW (Cout in {32, 64}, Cin, 3, 3) fp32 -> [CinPad/16][9][h|l][2][Cout][8] fp16 pieces */
-int dmd_pack_conv_weight_f16x2(const float* oihw, void* packed, int Cout, int Cin, int CinPad, dmd_stream_t stream);
+/* 1: dmd_conv2d runs these parameters on the streaming 1x1 kernel (exact fp32; taps == 1, Cout == 64, no
+ * prologue / residual / statistics, Cin in {32, 64, 128}): blocks.py:120,133 skip projections */
+int dmd_conv1x1_stream_eligible(const dmd_conv_params* p);
+/* OIHW (Cout in {32, 64}, Cin, k, k) fp32, k in {1, 3} -> [CinPad/16][k*k][h|l][2][Cout][8] fp16 pieces */
+int dmd_pack_conv_weight_f16x2(const float* oihw, void* packed, int Cout, int Cin, int k, int CinPad, dmd_stream_t stream);
 
 int dmd_conv2d(const dmd_conv_params* p, dmd_stream_t stream);
 /* number of GroupNorm stat tiles per image a dmd_conv2d with output (H, W) emits */

@@ -67,6 +67,9 @@ CONV_CASES = [
     ("c32_32x32", 1, 32, 32, [32], 32, 9, 1, False, 1, True, False),
     ("c32_8x8_n11", 11, 8, 8, [32], 32, 9, 1, False, 1, True, False),
     ("c64to32_16x16", 2, 16, 16, [64], 32, 9, 1, False, 0, False, False),
+    ("proj1x1_cat_64x64", 2, 64, 64, [64, 64], 64, 1, 1, False, 0, False, False),
+    ("skip1x1_32to64_16x16", 3, 16, 16, [32], 64, 1, 1, False, 0, False, False),
+    ("proj1x1_prologue_res", 2, 16, 16, [64], 64, 1, 1, False, 1, True, False),
 ]
 
 
@@ -121,7 +124,8 @@ def test_conv2d(case, impl):
     want_stats = (cout % 32 == 0) and not nchw
     w16 = None
     if impl == "f16x2":
-        if not (taps == 9 and stride == 1 and not nchw and ((cout == 64 and cin <= 128) or (cout == 32 and cin <= 64))):
+        if not (stride == 1 and not nchw and not (taps == 1 and up) and
+                ((cout == 64 and cin <= 128) or (cout == 32 and cin <= 64))):
             pytest.skip("shape not covered by the split-fp16 kernel (runs exact fp32)")
         w16 = nv.pack_conv_weight_f16x2(wgt.float().to(DEV))
     out = E.conv2d(srcs, wp, bp, cout, taps=taps, stride=stride, upsample=up, residual=r_act, want_stats=want_stats,

@@ -10,11 +10,11 @@ w = json.load(open(os.path.join(ROOT, "gpurun_out/pmc/WRITE_SIZE.json")))
 out = {}
 for name, fv in f.items():
     m = re.search(r"conv_mfma_kernel<ConvGeom<(\d+), (true|false), (\d+), (\d+)>", name)
-    m2 = re.search(r"conv_f16w?s_kernel<(?:F16|Ws)Geom<(true|false)(?:, (\d))?>", name)
+    m2 = re.search(r"conv_f16w?s_kernel<(?:F16|Ws)Geom<(true|false)(?:, (\d))?(?:, (\d))?>", name)
     if not m and not m2:
         continue
     if m2:
-        key = f"conv_f16s<{'B8' if m2.group(1) == 'true' else 'A16'},c{32 * int(m2.group(2) or 2)}>"
+        key = f"conv_f16s<{'B8' if m2.group(1) == 'true' else 'A16'},c{32 * int(m2.group(2) or 2)}{',1x1' if m2.group(3) == '1' else ''}>"
     else:
         key = f"conv_mfma<WN{m.group(1)},{'B' if m.group(2) == 'true' else 'A'},taps{m.group(3)},s{m.group(4)}>"
     wv = w[name]
