@@ -214,7 +214,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       for (int it = 0; it < G::ITEMS; ++it) {
         f32x4 v = st[it];
         if (prologue != DMD_PROLOGUE_NONE) {
-          const int s = ipos[it] >> 16;
+          const int s = G::SUB == 1 ? 0 : (ipos[it] >> 16);  // SUB == 1: the table rows are item-invariant -> hoisted
           const float* ta = tab_a + (slot * G::SUB + s) * G::CIN_MAX + cc;
           const float* tb = tab_b + (slot * G::SUB + s) * G::CIN_MAX + cc;
 #pragma unroll
