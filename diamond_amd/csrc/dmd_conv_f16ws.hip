@@ -19,6 +19,8 @@
 //     so the producers prefetch the next tile's first chunks while the consumers finish the
 //     current tile -- no per-tile pipeline fill.
 // One s_barrier per chunk separates "consumers read buffer j, producers fill buffer j + 1".
+#include <type_traits>
+
 #include "dmd_common.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -201,26 +203,33 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       zmask = z;
     };
     // normalise / activate / split element e from its register set into patch buffer e & 1
-    auto store_S = [&](int e, const auto& st, unsigned zmask, int slot) {
+    // mode (wave-uniform, hoisted out of the item loop as a compile-time tag): 0 = no prologue, 1 = norm, 2 = norm + SiLU
+    auto store_S_mode = [&](auto mode_tag, int e, const auto& st, unsigned zmask, int slot) {
+      constexpr int MODE = decltype(mode_tag)::value;
       const int ck = e % nchunks;
-      const int si = ck < nch0 ? 0 : 1;
-      const int prologue = p.src[si].prologue;
       const int cc = ck * 16 + 4 * q;
       uint2* pb = (uint2*)(bufs + (e & 1) * G::BUF_UNITS);
-#if WS_ABL & 4
-      if (e > 1) return;
-#endif
+      // single-image tiles: the (a, b) rows of this thread's channel quad are the same for every item -> ONE pair of
+      // LDS reads per chunk instead of one (with its lgkmcnt stall) per item
+      f32x4 ta0 = (f32x4){1.f, 1.f, 1.f, 1.f}, tb0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (MODE != 0 && G::SUB == 1) {
+        ta0 = *(const f32x4*)(tab_a + slot * G::CIN_MAX + cc);
+        tb0 = *(const f32x4*)(tab_b + slot * G::CIN_MAX + cc);
+      }
 #pragma unroll
       for (int it = 0; it < G::ITEMS; ++it) {
         f32x4 v = st[it];
-        if (prologue != DMD_PROLOGUE_NONE) {
-          const int s = G::SUB == 1 ? 0 : (ipos[it] >> 16);  // SUB == 1: the table rows are item-invariant -> hoisted
-          const float* ta = tab_a + (slot * G::SUB + s) * G::CIN_MAX + cc;
-          const float* tb = tab_b + (slot * G::SUB + s) * G::CIN_MAX + cc;
+        if (MODE != 0) {
+          f32x4 ta = ta0, tb = tb0;
+          if (G::SUB > 1) {
+            const int s = ipos[it] >> 16;
+            ta = *(const f32x4*)(tab_a + (slot * G::SUB + s) * G::CIN_MAX + cc);
+            tb = *(const f32x4*)(tab_b + (slot * G::SUB + s) * G::CIN_MAX + cc);
+          }
 #pragma unroll
           for (int el = 0; el < 4; ++el) {
             float t = __builtin_fmaf(v[el], ta[el], tb[el]);
-            if (prologue == DMD_PROLOGUE_NORM_SILU) t = ws_silu(t);
+            if (MODE == 2) t = ws_silu(t);
             v[el] = t;
           }
         }
@@ -239,6 +248,19 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           pb[lo ^ 4] = __builtin_bit_cast(uint2, lv);
         }
       }
+    };
+    auto store_S = [&](int e, const auto& st, unsigned zmask, int slot) {
+#if WS_ABL & 4
+      if (e > 1) return;
+#endif
+      const int ck = e % nchunks;
+      const int prologue = p.src[ck < nch0 ? 0 : 1].prologue;
+      if (prologue == DMD_PROLOGUE_NORM_SILU)
+        store_S_mode(std::integral_constant<int, 2>{}, e, st, zmask, slot);
+      else if (prologue == DMD_PROLOGUE_NORM)
+        store_S_mode(std::integral_constant<int, 1>{}, e, st, zmask, slot);
+      else
+        store_S_mode(std::integral_constant<int, 0>{}, e, st, zmask, slot);
     };
 
     f32x4 stage0[G::ITEMS], stage1[G::DOUBLE_STAGE ? G::ITEMS : 1];
