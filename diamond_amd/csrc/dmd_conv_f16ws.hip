@@ -126,7 +126,8 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       const int py = rem / G::PW, px = rem - py * G::PW;
       ipos[it] = ok ? ((s << 16) | (py << 8) | px) : -1;
     }
-    int goff[G::ITEMS];  // source pixel index per item for tile `gk`, -1: zero
+    int goff[G::ITEMS];   // source pixel index per item for tile `gk` (0 for items outside the image)
+    unsigned gzero = 0;   // bit it: item is conv zero padding / outside the tensor for tile `gk`
     int gk = -1;
     int tab_n[G::SUB];  // images whose tables are current, and their slot
 #pragma unroll
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       WsTile ti[G::SUB];
 #pragma unroll
       for (int s = 0; s < G::SUB; ++s) ti[s] = ws_subtile<G>(p, tile, s);
+      unsigned gz = 0;
 #pragma unroll
       for (int it = 0; it < G::ITEMS; ++it) {
         const int s = ipos[it] >> 16, py = (ipos[it] >> 8) & 0xff, px = ipos[it] & 0xff;
@@ -149,8 +151,10 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         const int iy = t.y0 - 1 + py, ix = t.x0 - 1 + px;
         const bool window = G::TAPS == 9 || (py >= 1 && py <= G::TS && px >= 1 && px <= G::TS);  // 1x1: no halo needed
         const bool inb = ipos[it] >= 0 && window && t.valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        goff[it] = inb ? ((t.n * Hs + (iy >> up)) * Ws + (ix >> up)) : -1;
+        goff[it] = inb ? ((t.n * Hs + (iy >> up)) * Ws + (ix >> up)) : 0;
+        gz |= (inb ? 0u : 1u) << it;
       }
+      gzero = gz;
       // tables: all tiles of one image share them -- rebuild only when an image of the tile changes
       bool rebuild = false;
 #pragma unroll
@@ -186,21 +190,21 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       const int si = ck < nch0 ? 0 : 1;
       const dmd_conv_src& sc = p.src[si];
       const int c0 = (si ? ck - nch0 : ck) * 16 + 4 * q;
-      unsigned z = 0;
+      const f32x4* base4 = (const f32x4*)sc.x + (c0 >> 2);  // 16-byte units: index = pixel * (C / 4)
+      const unsigned cq = (unsigned)sc.C >> 2;
 #pragma unroll
       for (int it = 0; it < G::ITEMS; ++it) {
-        const int go = goff[it] < 0 ? 0 : goff[it];
-        z |= (goff[it] < 0 ? 1u : 0u) << it;
+        const int go = goff[it];
 #if WS_ABL & 2
         st[it] = (f32x4){(float)go, 1.f, 2.f, (float)c0};
 #elif WS_ABL & 8
         // timing proxy (wrong data): same number of 16-byte loads, but 8 consecutive lanes cover one FULL 128-byte line
         st[it] = *(const f32x4*)(sc.x + (size_t)(go & ~1) * sc.C + ((go & 1) * 16 + 4 * q + (c0 & 32)));
 #else
-        st[it] = *(const f32x4*)(sc.x + (size_t)go * sc.C + c0);
+        st[it] = base4[(unsigned)go * cq];
 #endif
       }
-      zmask = z;
+      zmask = gzero;
     };
     // normalise / activate / split element e from its register set into patch buffer e & 1
     // mode (wave-uniform, hoisted out of the item loop as a compile-time tag): 0 = no prologue, 1 = norm, 2 = norm + SiLU
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           hv[el] = h;
           lv[el] = (_Float16)(x - (float)h);
         }
-        if (ipos[it] >= 0) {
+        if ((it + 1) * 256 <= G::NPP * 4 || ipos[it] >= 0) {  // only the last item row can fall beyond the patch
           const int lo = loff_of(it);
           pb[lo] = __builtin_bit_cast(uint2, hv);
           pb[lo ^ 4] = __builtin_bit_cast(uint2, lv);
