@@ -1,21 +1,22 @@
 """bench.py -- imagined frames/s of DIAMOND's imagined-rollout hot path on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W                      (BASELINE configs[1], the headline metric)
+    python bench.py --config 3 --steps 1 --warmup 1                    (configs[3]: 50-step Heun sampler)
+    python bench.py --config 4 --steps 2 --warmup 1                    (configs[4]: 256x256, attention, 8 envs per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one complete actor-critic BPTT window, exactly what `Trainer.train_component
 ("actor_critic")` does per optimiser step (reference trainer.py:363-382): ActorCritic.forward()
-(15 imagined env steps: policy forward -> action sample -> 3-step Euler diffusion sampling ->
-reward/end model -> bookkeeping/resets) + loss.backward() + gradient all-reduce (N > 1) +
-clip_grad_norm_ + AdamW step.  Workload = BASELINE.json configs[1]: Breakout-shaped 64x64x3
-frames, batch 256 per GPU, horizon 15, 3 denoising steps, fp32, synthetic weights/inputs.
-value = B_global * 15 / (max-over-ranks seconds per step).
+(15 imagined env steps: policy forward -> action sample -> diffusion sampling -> reward/end model ->
+bookkeeping/resets) + loss.backward() + gradient all-reduce (N > 1) + clip_grad_norm_ + AdamW step.
+Default workload = BASELINE.json configs[1]: Breakout-shaped 64x64x3 frames, batch 256 per GPU, horizon 15,
+3 Euler denoising steps, synthetic weights/inputs.  value = B_global * 15 / (max-over-ranks seconds per step).
 
-Extra objects on the JSON line: `roofline` for the dominant kernel (the 64-channel 3x3
-implicit-GEMM conv, MFMA-fp32 bound), measured with HIP events in a dedicated instrumented
-window after the timed region, and `cpu_baseline` = the CPU oracle timed on this box's host
-cores on a bounded sample (rank 0, N=1 only).
+Extra objects on the JSON line: `roofline` for the dominant kernel (found by measured time; HIP events around
+every dmd_conv2d launch in a dedicated instrumented window after the timed region), `exact_fp32` = the same window
+with every convolution on the exact-fp32 MFMA kernels (configs[1] only), and `cpu_baseline` = the CPU oracle
+timed on this box's host cores on one whole window of configs[0] (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -31,10 +32,29 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_* = fp32 vector peak
-F16_MFMA_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak (same guide); conv_f16s executes 3 f16 MACs per fp32 MAC
+F16_MFMA_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak (same guide); the split kernels execute 3 f16 MACs per fp32 MAC
 HBM_PEAK_GBS = 8000.0
-FLOP_PER_FRAME = 19.080e9  # algorithmic, SURVEY.md §8(d): 3 x 6.0909 denoiser + 0.4477 rew/end + 0.3597 AC fwd+bwd
-BYTES_PER_FRAME = 168.8e6  # algorithmic NHWC fp32 conv traffic model, SURVEY.md §8(d)
+
+# BASELINE.json configs -> (img_size, batch per GPU, horizon, denoise steps, sampler order, denoiser attn_depths)
+CONFIGS = {
+    1: dict(img_size=64, batch=256, horizon=15, denoise_steps=3, order=1, attn_depths="0,0,0,0"),
+    3: dict(img_size=64, batch=256, horizon=15, denoise_steps=50, order=2, attn_depths="0,0,0,0"),
+    4: dict(img_size=256, batch=8, horizon=15, denoise_steps=3, order=1, attn_depths="0,0,1,1"),
+}
+
+
+def algorithmic_work(img_size, denoise_steps, order, attn):
+    """(FLOP, bytes) per imagined frame, SURVEY.md §8(d) / BASELINE.md §2 (MAC = 2; NHWC fp32, every conv reads its
+    input once and writes its output once)."""
+    calls = denoise_steps if order == 1 else 2 * denoise_steps - 1  # Heun skips the 2nd evaluation of the last step
+    s = (img_size / 64) ** 2
+    if img_size == 256 and attn == (0, 0, 1, 1):
+        den_flop, den_bytes = 121.555e9, 827.25 * 2 ** 20
+    else:
+        den_flop, den_bytes = 6.0909e9 * s, 51.757e6 * s
+    rest_flop = (0.4477e9 + 0.3597e9) * s
+    rest_bytes = (7.22e6 + 3 * 2.11e6) * s
+    return calls * den_flop + rest_flop, calls * den_bytes + rest_bytes, calls
 
 
 class _Loader:
@@ -69,6 +89,11 @@ class _Loader:
             yield SimpleNamespace(obs=obs, act=act)
 
 
+END_LOGIT_BIAS_NOTE = ("end-logits of the synthetic reward/end model are biased so that episodes end by horizon truncation "
+                       "(as a trained world model's do) instead of ~50 % of the envs dying at every step: all 256 envs reset "
+                       "+ burn in together at the window boundary, no mid-window resets; same kernels and FLOPs per frame")
+
+
 def build_agent(device, img_size, rank, attn_depths=(0, 0, 0, 0)):
     import diamond_amd as D
     from diamond_amd.testing import fill_module_
@@ -78,7 +103,7 @@ def build_agent(device, img_size, rank, attn_depths=(0, 0, 0, 0)):
     with torch.no_grad():
         # Synthetic weights would terminate ~half of the imagined episodes at every step; bias
         # the end logits (through one saturated hidden unit) so episodes end by horizon
-        # truncation like a trained world model's do.  Pure workload shaping, same FLOPs.
+        # truncation like a trained world model's do.  Disclosed in config.workload (END_LOGIT_BIAS_NOTE).
         head = agent.rew_end_model.head
         head[0].bias[0] = 50.0
         head[2].weight[3].zero_()
@@ -101,9 +126,15 @@ def usable_cores(cap=32):
     return max(1, min(n, cap))
 
 
+REFERENCE_MEASURED = {"value": 6.2, "unit": "imagined frames/s", "cores": 8, "kind": "reference",
+                      "where": "the reference itself (src/ imported with stubs), configs[0], 2nd window, build container, "
+                               "8 threads, torch-CPU fp32 -- BASELINE.md §3; it cannot travel to the GPU box"}
+
+
 def cpu_baseline_worker(img_size, threads):
-    """CPU oracle (oracle/diamond_oracle.py, torch-CPU fp32) on a bounded sample of configs[0]
-    (B=16, 3 of its 15 imagined steps + actor-critic loss backward).  Runs in its own process."""
+    """CPU oracle (oracle/diamond_oracle.py, torch-CPU fp32) on ONE WHOLE WINDOW of configs[0]: B=16, reset
+    (pool preload + reward/end burn-in) + 15 imagined steps (3 Euler denoise + rew/end + actor-critic each) +
+    actor-critic loss backward.  Runs in its own process."""
     from diamond_amd.testing import fill_state_dict_, initial_condition_batches
     from oracle import diamond_oracle as O
     import diamond_amd as D
@@ -116,18 +147,20 @@ def cpu_baseline_worker(img_size, threads):
     a = O.AgentSD(denoiser=sub("denoiser"), rew_end_model=sub("rew_end_model"), actor_critic=sub("actor_critic"),
                   aspec=O.ActorCriticSpec(img_size=img_size), rspec=O.RewEndSpec(img_size=img_size))
     a.actor_critic = {k: v.requires_grad_(True) for k, v in a.actor_critic.items()}
-    b, t = 16, 3
+    b, t = 16, 15
     draws = O.DrawSource(torch.Generator().manual_seed(1))
+    t0 = time.perf_counter()
     env = O.ImaginationEnv(a, initial_condition_batches(5, b, 4, h=img_size, w=img_size), b, 15, draws, 1)
     state = (env.reset(), torch.zeros(b, 512), torch.zeros(b, 512))
-    t0 = time.perf_counter()
     (obs, act, rew, end, trunc, logits, val, vb), state = O.rollout(a, env, state, t, draws)
     loss, _ = O.ac_loss(logits, val, act, rew, end, trunc, vb, O.LossSpec(backup_every=t))
     loss.backward()
     dt = time.perf_counter() - t0
     return {"value": b * t / dt, "unit": "imagined frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"configs[0] shape, B={b}, {t} of 15 imagined steps (3 Euler denoise + rew/end + actor-critic) + AC "
-                      f"backward, {img_size}x{img_size}, fp32 torch-CPU oracle, {dt:.1f}s"}
+            "sample": f"configs[0]: one whole window, B={b}, reset + {t} imagined steps (3 Euler denoise + rew/end + actor-critic) "
+                      f"+ AC backward, {img_size}x{img_size}, fp32 torch-CPU oracle (unbiased synthetic end-logits: includes "
+                      f"mid-window resets / burn-in), {dt:.1f}s",
+            "reference_measured": REFERENCE_MEASURED}
 
 
 def cpu_baseline(img_size, timeout_s=240):
@@ -141,33 +174,52 @@ def cpu_baseline(img_size, timeout_s=240):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, cwd=ROOT)
+    fail = {"value": None, "unit": "imagined frames/s", "cores": threads, "kind": "port", "reference_measured": REFERENCE_MEASURED}
     try:
         out, _ = proc.communicate(timeout=timeout_s)
         return json.loads(out.decode().strip().splitlines()[-1])
     except subprocess.TimeoutExpired:
         proc.kill()  # exactly the PID we started
         proc.communicate()
-        return {"value": None, "unit": "imagined frames/s", "cores": threads, "kind": "port",
-                "sample": f"timed out after {timeout_s}s"}
+        return dict(fail, sample=f"timed out after {timeout_s}s")
     except Exception as e:  # noqa: BLE001
-        return {"value": None, "unit": "imagined frames/s", "cores": threads, "kind": "port", "sample": f"failed: {e!r}"}
+        return dict(fail, sample=f"failed: {e!r}")
+
+
+def precision_label(E, ac_native):
+    wm = ("world-model stride-1 3x3/1x1 convs: fp32 operands split into 2 x fp16 pieces, 3 x v_mfma_f32_*_f16 per product, fp32 "
+          "accumulate (fp32-class, 22-bit operands); other world-model convs, attention, linears: exact fp32 v_mfma_f32_16x16x4_f32"
+          if E.WORLD_MODEL_PRECISION == "f16x2" else "world model: exact fp32 v_mfma_f32_16x16x4_f32")
+    ac = ("actor-critic encoder forward + dgrad convs: same split-fp16 form, weight gradients exact fp32 MFMA"
+          if ac_native.AC_PRECISION == "f16x2" else "actor-critic encoder fwd/bwd: exact fp32 MFMA")
+    short = "f32" if (E.WORLD_MODEL_PRECISION, ac_native.AC_PRECISION) == ("f32", "f32") else "f32 via split-f16 MFMA"
+    return f"{short} ({wm}; {ac}; LSTM cells / heads: fp32 rocBLAS GEMMs)"
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=256, help="imagination batch PER GPU")
-    ap.add_argument("--horizon", type=int, default=15)
-    ap.add_argument("--denoise-steps", type=int, default=3)
-    ap.add_argument("--img-size", type=int, default=64)
-    ap.add_argument("--attn-depths", type=str, default="0,0,0,0",
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="BASELINE.json configs[] index (1, 3 or 4)")
+    ap.add_argument("--batch", type=int, default=None, help="imagination batch PER GPU")
+    ap.add_argument("--horizon", type=int, default=None)
+    ap.add_argument("--denoise-steps", type=int, default=None)
+    ap.add_argument("--order", type=int, default=None, choices=(1, 2))
+    ap.add_argument("--img-size", type=int, default=None)
+    ap.add_argument("--attn-depths", type=str, default=None,
                     help="denoiser attention per level; BASELINE configs[4] (256x256) uses 0,0,1,1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-exact-fp32", action="store_true")
     ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    preset = CONFIGS[args.config]
+    for k, v in preset.items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
+    if args.steps is None:
+        args.steps = 3 if args.config == 1 else (1 if args.config == 3 else 2)
     if args.cpu_baseline_worker:
         print(json.dumps(cpu_baseline_worker(args.img_size, args.cpu_baseline_worker)))
         return
@@ -184,16 +236,19 @@ def main():
         dist.init_process_group("nccl", device_id=device)  # "nccl" == RCCL on ROCm
 
     import diamond_amd as D
+    from diamond_amd import ac_native
     from diamond_amd import engine as E
-    from diamond_amd.dist import GradAllReducer
+    from diamond_amd.dist import GradAllReducer, broadcast_parameters, parameter_checksum
 
     torch.manual_seed(1234 + rank)
     attn = tuple(int(v) for v in args.attn_depths.split(","))
     agent = build_agent(device, args.img_size, rank, attn)
+    if world > 1:
+        broadcast_parameters(agent, src=0)  # what the DDP constructor does in the reference (utils.py:106)
     env = D.WorldModelEnv(agent.denoiser, agent.rew_end_model, _Loader(args.batch, 100 + rank, args.img_size),
                           D.WorldModelEnvConfig(horizon=args.horizon, num_batches_to_preload=2,
                                                 diffusion_sampler=D.DiffusionSamplerConfig(
-                                                    num_steps_denoising=args.denoise_steps)))
+                                                    num_steps_denoising=args.denoise_steps, order=args.order)))
     agent.setup_training(D.SigmaDistributionConfig(-0.4, 1.2, 2e-3, 20),
                          D.ActorCriticLossConfig(backup_every=args.horizon, gamma=0.985, lambda_=0.95,
                                                  weight_value_loss=1.0, weight_entropy_loss=0.001), env)
@@ -235,28 +290,43 @@ def main():
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # replicas must still hold identical actor-critic parameters after the all-reduced steps
+        cs = torch.tensor([parameter_checksum(ac)], device=device, dtype=torch.float64)
+        gathered = [torch.zeros_like(cs) for _ in range(world)]
+        dist.all_gather(gathered, cs)
+        assert all(float(g) == float(gathered[0]) for g in gathered), f"replicas diverged: {[float(g) for g in gathered]}"
 
     progress(f"timed region done: {elapsed:.2f}s for {args.steps} steps")
-    is_cfg1 = (args.img_size, args.batch, args.horizon, args.denoise_steps, attn) == (64, 256, 15, 3, (0, 0, 0, 0))
-    cfg_name = ("configs[1] (Breakout-shaped)" if world == 1 else "configs[2] (Breakout-shaped, sharded)") if is_cfg1 else \
-        f"custom (attn_depths {args.attn_depths})"
+    custom = any(getattr(args, k) != v for k, v in preset.items())
+    cfg_idx = args.config if world == 1 or args.config != 1 else 2
+    cfg_name = f"configs[{cfg_idx}]" + (" (modified by flags)" if custom else "") + \
+        (" (sharded over the GPUs)" if world > 1 else "")
+    sampler = f"{args.denoise_steps} Euler denoise steps" if args.order == 1 else \
+        f"{args.denoise_steps}-step 2nd-order Heun ({2 * args.denoise_steps - 1} denoiser calls per frame)"
+    flop_pf, bytes_pf, den_calls = algorithmic_work(args.img_size, args.denoise_steps, args.order, attn)
     frames = args.batch * world * args.horizon * args.steps
     fps = frames / elapsed
+    sz = f"{args.img_size}x{args.img_size}"
+    metric = {1: "imagined frames/sec (64x64, 3 denoise steps, batch 256)",
+              3: "imagined frames/sec (64x64, 50-step 2nd-order Heun, batch 256)",
+              4: "imagined frames/sec (256x256, 3 denoise steps, 8 envs per GPU, attention [0,0,1,1])"}[args.config]
     line = {
-        "metric": "imagined frames/sec (64x64, 3 denoise steps, batch 256)", "value": fps, "unit": "frames/s",
+        "metric": metric, "value": fps, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (world-model 3x3 convs: fp32 operands split into 2 x fp16 pieces on v_mfma_f32_32x32x16_f16, fp32 accumulate, "
-                 "fp32-class accuracy; everything else incl. actor-critic fwd/bwd: exact fp32 v_mfma_f32_16x16x4_f32)", "data": "synthetic",
-        "config": {"workload": f"{cfg_name}: {args.img_size}x{args.img_size}x3 frames, batch {args.batch}/GPU, "
-                               f"horizon {args.horizon}, {args.denoise_steps} Euler denoise steps; step = "
-                               "ActorCritic.forward()+backward+all-reduce+clip+AdamW over one 15-step imagined window",
+        "dtype": precision_label(E, ac_native), "data": "synthetic",
+        "config": {"workload": f"{cfg_name}: {sz}x3 frames, batch {args.batch}/GPU, horizon {args.horizon}, {sampler}"
+                               f"{', denoiser attention at levels ' + args.attn_depths if any(attn) else ''}; step = "
+                               f"ActorCritic.forward()+backward+all-reduce+clip+AdamW over one {args.horizon}-step imagined window; "
+                               + END_LOGIT_BIAS_NOTE,
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (batch-sharded envs, flat-bucket "
-                   "RCCL all-reduce of actor-critic grads)", "actor_critic_backend": ac.backend},
-        "whole_step_algorithmic": {"tflops": fps * FLOP_PER_FRAME / 1e12 / world,
-                                   "frac_fp32_peak": fps * FLOP_PER_FRAME / 1e12 / world / FP32_MFMA_PEAK_TFLOPS,
-                                   "hbm_gbs": fps * BYTES_PER_FRAME / 1e9 / world,
-                                   "frac_hbm_peak": fps * BYTES_PER_FRAME / 1e9 / world / HBM_PEAK_GBS},
+                   "RCCL all-reduce of actor-critic grads)", "actor_critic_backend": ac.backend,
+                   "world_model_precision": E.WORLD_MODEL_PRECISION, "actor_critic_precision": ac_native.AC_PRECISION},
+        "whole_step_algorithmic": {"gflop_per_frame": flop_pf / 1e9, "mb_per_frame": bytes_pf / 1e6,
+                                   "tflops": fps * flop_pf / 1e12 / world,
+                                   "frac_fp32_peak": fps * flop_pf / 1e12 / world / FP32_MFMA_PEAK_TFLOPS,
+                                   "hbm_gbs": fps * bytes_pf / 1e9 / world,
+                                   "frac_hbm_peak": fps * bytes_pf / 1e9 / world / HBM_PEAK_GBS},
     }
 
     if not args.no_roofline:
@@ -268,17 +338,18 @@ def main():
         key = max(summ, key=lambda k: summ[k]["ms"])
         d = summ[key]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        split = key.startswith("conv_f16s")
+        split = key.startswith("conv_f16ws") or (key.startswith("conv1x1_stream") and key.endswith("true>"))
         peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
-        pmc = None
+        pmc, pmc_set = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path)).get(key)
+        if os.path.exists(pmc_path) and args.config == 1 and world == 1:
+            pmc = json.load(open(pmc_path)).get(key)  # keyed by the rocprofv3 kernel name (tools/pmc_to_profile.py)
         line["roofline"] = {
             "kernel": key, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB units;
-            # tools/pmc_collect.sh -> profiles/pmc_traffic.json), next to the algorithmic bytes per launch
+            # tools/pmc_collect.sh -> tools/pmc_to_profile.py -> profiles/<set>_pmc_traffic.json), next to the algorithmic bytes
             "traffic": None if pmc is None else pmc["hbm_bytes_per_launch"],
+            "traffic_source": None if pmc is None else f"profiles/pmc_traffic.json [{pmc.get('profile_set')}]: {pmc.get('workload')}",
             "algorithmic_bytes_per_launch": d["bytes"] / d["launches"], "launches": d["launches"],
             "avg_launch_ms": d["ms"] / d["launches"], "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
             "algorithmic_hbm_gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9,
@@ -291,10 +362,30 @@ def main():
             "frac_of_fp32_direct_conv_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
             "conv_share_of_window_ms": {k: v["ms"] for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])},
         }
+        progress("roofline window done")
 
-    progress("roofline window done")
+    if args.config == 1 and not args.no_exact_fp32 and not custom:
+        # the same window with every convolution on the exact-fp32 MFMA kernels (reported next to `value`, never as it)
+        saved = (E.WORLD_MODEL_PRECISION, ac_native.AC_PRECISION)
+        E.WORLD_MODEL_PRECISION, ac_native.AC_PRECISION = "f32", "f32"
+        window()
+        fence()
+        t1 = time.perf_counter()
+        window()
+        fence()
+        dt = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        E.WORLD_MODEL_PRECISION, ac_native.AC_PRECISION = saved
+        line["exact_fp32"] = {"value": args.batch * world * args.horizon / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt, "steps": 1,
+                              "dtype": "f32 (every convolution on v_mfma_f32_16x16x4_f32: DIAMOND_CONV_PRECISION=f32 "
+                                       "DIAMOND_AC_PRECISION=f32)"}
+        progress("exact-fp32 window done")
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(args.img_size)
+        line["cpu_baseline"] = cpu_baseline(64)
         progress("cpu baseline done")
 
     if rank == 0:

@@ -79,7 +79,8 @@ class FilmTable:
         self._packed: Optional[Tuple[Tuple[int, ...], Tensor, Tensor]] = None
 
     def weights(self) -> Tuple[Tensor, Tensor]:
-        ver = tuple(m.linear.weight._version + m.linear.bias._version for m in self.norms)
+        ver = tuple((m.linear.weight._version, m.linear.weight.data_ptr(), m.linear.bias._version, m.linear.bias.data_ptr())
+                    for m in self.norms)
         dev = self.norms[0].linear.weight.device
         if self._packed is None or self._packed[0] != ver or self._packed[1].device != dev:
             w = torch.cat([m.linear.weight.detach().float() for m in self.norms], dim=0).contiguous()
@@ -242,9 +243,11 @@ class UNet(nn.Module):
         self.upsamples = nn.ModuleList([nn.Identity()] + [Upsample(c) for c in reversed(channels[:-1])])
 
     def run(self, ctx: RunCtx, x: Act) -> Act:
-        m = 2 ** self._num_down
-        assert x.shape[1] % max(8, m) == 0 and x.shape[2] % max(8, m) == 0, \
-            "the native U-Net needs H, W multiples of 8 (the reference pads to 2**num_down, blocks.py:227-229)"
+        m = 8 * 2 ** self._num_down  # every level must itself be a multiple of the kernels' 8-pixel tile
+        assert x.shape[1] % m == 0 and x.shape[2] % m == 0, \
+            (f"the native U-Net needs H, W multiples of {m} (8 x 2**num_down: every level is tiled in 8x8 pixel blocks); got "
+             f"{x.shape[1]}x{x.shape[2]}.  The reference pads to a multiple of 2**num_down and crops (blocks.py:227-229,247): "
+             "sizes that are not multiples of 8 at every level are not supported by this implementation")
         skips: List[List[Act]] = []
         for blocks, down in zip(self.d_blocks, self.downsamples):
             if not isinstance(down, nn.Identity):

@@ -504,7 +504,6 @@ static void dispatch_wn(const dmd_conv_params& p, hipStream_t st) {
 
 extern "C" int dmd_conv_stat_tiles(int H, int W) { return (H / 8) * (W / ((W % 16) ? 8 : 16)); }
 
-int dmd_launch_conv_f16s(const dmd_conv_params& p, hipStream_t st);   // dmd_conv_f16.hip
 int dmd_launch_conv_f16ws(const dmd_conv_params& p, hipStream_t st);  // dmd_conv_f16ws.hip (wave-specialised, persistent)
 int dmd_launch_conv1x1_stream(const dmd_conv_params& p, hipStream_t st);  // dmd_conv1x1.hip (streaming 1x1, exact fp32)
 extern "C" int dmd_conv1x1_stream_eligible(const dmd_conv_params* p);
@@ -516,9 +515,7 @@ extern "C" int dmd_conv2d(const dmd_conv_params* p, dmd_stream_t stream) {
   if (use_1x1 && dmd_conv1x1_stream_eligible(p)) {
     dmd_launch_conv1x1_stream(*p, st);
   } else if (dmd_conv2d_f16x2_eligible(p)) {
-    // DIAMOND_F16S_WS=0 selects the older uniform-role kernel (kept for A/B measurements)
-    static const int use_ws = getenv("DIAMOND_F16S_WS") ? atoi(getenv("DIAMOND_F16S_WS")) : 1;
-    if (int e = (use_ws || p->CoutPad != 64 || p->taps != 9) ? dmd_launch_conv_f16ws(*p, st) : dmd_launch_conv_f16s(*p, st)) return e;
+    if (int e = dmd_launch_conv_f16ws(*p, st)) return e;
   } else if (p->taps == 1)
     dispatch_wn<1, 1>(*p, st);
   else if (p->stride == 2)
@@ -526,6 +523,28 @@ extern "C" int dmd_conv2d(const dmd_conv_params* p, dmd_stream_t stream) {
   else
     dispatch_wn<9, 1>(*p, st);
   DMD_LAUNCH_CHECK();
+  return 0;
+}
+
+// Name of the kernel instantiation dmd_conv2d launches for these parameters, spelled like rocprofv3's kernel trace
+// (without the "void " prefix and the argument list), so that bench.py's per-kernel records, profiles/*_kernel_stats.csv
+// and the PMC tables share one key.
+extern "C" int dmd_conv2d_kernel_name(const dmd_conv_params* p, char* buf, int buf_len) {
+  if (int e = validate_conv(p)) return e;
+  DMD_CHECK_ARG(buf && buf_len > 0, "kernel_name: buffer");
+  static const int use_1x1 = getenv("DIAMOND_CONV1X1_STREAM") ? atoi(getenv("DIAMOND_CONV1X1_STREAM")) : 1;
+  const bool b8 = p->W % 16 != 0;
+  if (use_1x1 && dmd_conv1x1_stream_eligible(p)) {
+    int cin = 0;
+    for (int i = 0; i < p->nsrc; ++i) cin += p->src[i].C;
+    snprintf(buf, buf_len, "conv1x1_stream_kernel<%d, %d, %s>", cin / 16, cin == 128 ? 2 : 4,
+             (p->precision & 0xff) == DMD_PRECISION_F16X2 ? "true" : "false");
+  } else if (dmd_conv2d_f16x2_eligible(p)) {
+    snprintf(buf, buf_len, "conv_f16ws_kernel<WsGeom<%s, %d, %d>>", b8 ? "true" : "false", p->CoutPad == 64 ? 2 : 1, p->taps);
+  } else {
+    const int wn = p->CoutPad % 64 == 0 ? 4 : (p->CoutPad % 32 == 0 ? 2 : 1);
+    snprintf(buf, buf_len, "conv_mfma_kernel<ConvGeom<%d, %s, %d, %d>>", wn, b8 ? "true" : "false", p->taps, p->stride);
+  }
   return 0;
 }
 

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const dmd_conv_para
       h4 hh, ll;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float x = __builtin_amdgcn_fmed3f(wv[e], -65504.0f, 65504.0f);
+        const float x = wv[e];
         hh[e] = (_Float16)x;
         ll[e] = (_Float16)(x - (float)hh[e]);
       }
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const dmd_conv_para
         for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float x = __builtin_amdgcn_fmed3f(xf[ks][pb][e], -65504.0f, 65504.0f);
+            const float x = xf[ks][pb][e];  // no clamp: see the range contract in dmd_conv_f16ws.hip
             const _Float16 h = (_Float16)x;
             xh[ks][pb][e] = h;
             xl[ks][pb][e] = (_Float16)(x - (float)h);

@@ -1,20 +1,30 @@
-// conv_f16ws_kernel -- wave-specialised, persistent form of the split-fp16 3x3 convolution
-// (same arithmetic and data layouts as dmd_conv_f16.hip: x = h + l fp16 pieces, 3 x
-// v_mfma_f32_32x32x16_f16 per product, fp32 accumulate).
+// conv_f16ws_kernel -- the stride-1 3x3 / 1x1 convolutions with 32 or 64 output channels (92 % of the denoiser's
+// FLOPs) on the f16 matrix cores with SPLIT fp32 operands, wave-specialised and persistent.
 //
-// Why a second structure: in conv_f16s_kernel every wave alternates between the MFMA tap loop and
-// the staging work (global loads, GroupNorm/FiLM/SiLU, h/l split, LDS writes, weight copy); with
-// the 2 workgroups per CU that its registers allow, the matrix pipe idles whenever both are
-// staging, and per-tile fixed costs (first-chunk HBM latency, tables, epilogue) are paid on the
-// critical path of a K loop that is only 4-8 chunks long.  Here one 512-thread workgroup per CU
-// is split by ROLE:
+// Arithmetic (DMD_PRECISION_F16X2).  Exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, dmd_conv.hip) runs at the fp32 vector
+// rate (157 TFLOP/s chip peak); the f16 MFMA is 16x faster.  Every fp32 operand x is split as
+//     x = h + l + e,   h = fp16(x),  l = fp16(x - h),   |e| <= max(2^-22 |x|, 2^-25)
+// (gfx950's MFMA honours fp16 subnormals, tools/probe/mfma_f16_probe.hip, so l needs no scaling) and a product is
+// evaluated as  w_h*x_h + w_h*x_l + w_l*x_h  -- three v_mfma_f32_32x32x16_f16 into ONE fp32 accumulator; the
+// dropped w_l*x_l term is 2^-22 relative.  Result: fp32-class accuracy (measured 3-8e-7 of the output scale per
+// conv) at an effective peak of 2.5 PFLOP/s / 3.
+// Range contract: finite operands must satisfy |x| < 65520 (the fp16 range).  Nothing is clamped: an operand beyond
+// the range becomes h = +-inf, l = -+inf and every output it touches is NaN -- an out-of-range activation fails
+// LOUDLY instead of silently saturating, and NaN / Inf inputs stay non-finite exactly where F.conv2d's would
+// (tests/test_gpu_precision.py).  Operands below 2^-25 in magnitude are flushed (absolute floor): tensors whose scale
+// is far below 1 (gradients) are pre-scaled by a power of two by the caller (ac_native._EncoderFn.backward).
+//
+// Structure.  One 768-thread workgroup per CU is split by ROLE:
 //   * waves 0-3 and 4-7 = two CONSUMER groups that take alternate tiles: the group whose tile is
 //     current does nothing but LDS fragment reads + MFMAs; the other group meanwhile writes its
 //     finished tile out (bias, residual, store, GroupNorm partial sums), one 32-pixel block per
 //     chunk step.  A CU can only store ~10 B/clk, so a 64 KiB tile takes longer to write than a
 //     chunk takes to compute: with a single consumer group that write sits on the critical path.
-//   * waves 8-11 = PRODUCERS: everything else, running one chunk ahead of the consumers through a
-//     double-buffered {patch, weights} LDS pair, two chunks ahead for the activation loads.
+//   * waves 8-11 = PRODUCERS: global loads, GroupNorm/FiLM (one fma) + SiLU (v_exp/v_rcp) + h/l split, LDS
+//     writes of the halo'd patch [patch pixel][4 x 16 B] = {h[0:8], h[8:16], l[0:8], l[8:16]} (slot rotated by
+//     (px >> 1) -> conflict-free ds_read_b128 for every tap, tools/lds_sim.py) and the linear copy of the chunk's
+//     pre-split weights; they run one chunk ahead of the consumers through a double-buffered {patch, weights}
+//     LDS pair, two chunks ahead for the activation loads.
 //   * the workgroup is persistent: it walks a contiguous range of tiles as ONE stream of chunks,
 //     so the producers prefetch the next tile's first chunks while the consumers finish the
 //     current tile -- no per-tile pipeline fill.
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         const bool zero = (zmask >> it) & 1;  // conv zero padding is applied AFTER the activation (blocks.py:143-144)
 #pragma unroll
         for (int el = 0; el < 4; ++el) {
-          const float x = zero ? 0.f : __builtin_amdgcn_fmed3f(v[el], -65504.0f, 65504.0f);
+          const float x = zero ? 0.f : v[el];  // no clamp: out-of-range operands turn into NaN outputs (header)
           const _Float16 h = (_Float16)x;
           hv[el] = h;
           lv[el] = (_Float16)(x - (float)h);
@@ -572,3 +582,55 @@ int dmd_launch_conv_f16ws(const dmd_conv_params& p, hipStream_t st) {
   if (p.CoutPad == 64) return b8 ? launch_f16ws<WsGeom<true, 2, 1>>(p, (sub8 + 3) / 4, st) : launch_f16ws<WsGeom<false, 2, 1>>(p, t16, st);
   return b8 ? launch_f16ws<WsGeom<true, 1, 1>>(p, (sub8 + 7) / 8, st) : launch_f16ws<WsGeom<false, 1, 1>>(p, (t16 + 1) / 2, st);
 }
+
+// OIHW fp32 -> [CinPad/16][9][h|l][k group g = 0|1][Cout][8 cin] halfs  (cin = 16 chunk + 8 g + e), Cout in {32, 64}:
+// one chunk = 36 * Cout contiguous 16-byte units, copied linearly into LDS by the kernels.
+__global__ void pack_weight_f16x2_kernel(const float* __restrict__ oihw, _Float16* __restrict__ packed, int Cout, int Cin,
+                                         int CinPad, int taps) {
+  const size_t total = (size_t)(CinPad / 16) * taps * Cout * 16;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int e = idx % 8;
+  const int co = (idx / 8) % Cout;
+  const int g = (idx / (8 * (size_t)Cout)) % 2;
+  const int tap = (idx / (8 * (size_t)Cout * 2)) % taps;
+  const int chunk = idx / (8 * (size_t)Cout * 2 * taps);
+  const int c = chunk * 16 + g * 8 + e;
+  float v = 0.f;
+  if (c < Cin) v = oihw[((size_t)co * Cin + c) * taps + tap];
+  const _Float16 h = (_Float16)v;
+  const _Float16 l = (_Float16)(v - (float)h);
+  const size_t base = ((((size_t)chunk * taps + tap) * 2 + 0) * 2 + g) * ((size_t)Cout * 8) + (size_t)co * 8 + e;
+  packed[base] = h;
+  packed[base + 2 * (size_t)Cout * 8] = l;
+}
+
+extern "C" int dmd_pack_conv_weight_f16x2(const float* oihw, void* packed, int Cout, int Cin, int k, int CinPad,
+                                          dmd_stream_t stream) {
+  DMD_CHECK_ARG(oihw && packed, "pack_f16x2: null");
+  DMD_CHECK_ARG((Cout == 64 || Cout == 32) && (k == 3 || k == 1) && CinPad >= Cin && CinPad % 16 == 0,
+                "pack_f16x2: needs Cout in {32, 64} (got %d), k in {1, 3}, CinPad %% 16 == 0", Cout);
+  const int taps = k * k;
+  const size_t total = (size_t)(CinPad / 16) * taps * Cout * 16;
+  hipLaunchKernelGGL(pack_weight_f16x2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, oihw,
+                     (_Float16*)packed, Cout, Cin, CinPad, taps);
+  DMD_LAUNCH_CHECK();
+  return 0;
+}
+
+// 1: the parameters run on conv_f16ws_kernel
+extern "C" int dmd_conv2d_f16x2_eligible(const dmd_conv_params* p) {
+  if (!p || (p->precision & 0xff) != DMD_PRECISION_F16X2 || !p->w_f16) return 0;
+  if (p->stride != 1 || p->residual_norm.stats || (p->taps != 9 && p->taps != 1)) return 0;
+  if (p->taps == 1 && p->upsample) return 0;
+  // few-channel NCHW head (conv_out): Cout <= 4 zero-padded to 32, no residual / statistics
+  const bool head = p->out_nchw && p->Cout <= 4 && p->CoutPad == 32 && !p->residual && !p->out_stats;
+  if (!head && ((p->Cout != 64 && p->Cout != 32) || p->CoutPad != p->Cout || p->out_nchw)) return 0;
+  int cin = 0;
+  for (int i = 0; i < p->nsrc; ++i) cin += p->src[i].C;
+  if (cin > (p->CoutPad == 64 ? 128 : 64)) return 0;
+  const bool a16 = p->H % 16 == 0 && p->W % 16 == 0;
+  const bool b8 = p->W % 16 != 0;
+  return (a16 || b8) ? 1 : 0;
+}
+

@@ -7,37 +7,46 @@
 #include "dmd_common.h"
 
 // ---- cat(obs / sigma_data, x * c_in) : NCHW -> NHWC(CPad) ------------------------------------
-// One thread per pixel; NCHW reads are coalesced across threads (consecutive pixels), the
-// NHWC writes are CPad*4 = 64 contiguous bytes per thread.
+// One thread per (pixel, channel quad): the NCHW reads of a wave are 16 consecutive pixels of 4 x 4 planes (64-byte
+// segments), the NHWC writes of a wave are 1 KiB contiguous (16 bytes per lane, consecutive lanes).
+// The conditioning frames may live in a RING of T frames of Cobs / T channels each: logical frame t is stored at
+// physical slot (head + t) % T (WorldModelEnv keeps its context that way instead of rolling it every step,
+// world_model_env.py:74-75); T = 1, head = 0 is a plain (N, Cobs, H, W) tensor.
 __global__ void edm_pack_input_kernel(const float* __restrict__ x, const float* __restrict__ obs,
                                       const float* __restrict__ cond, int cond_stride, float sd,
-                                      float* __restrict__ out, int N, int Cx, int Cobs, int HW, int CPad) {
+                                      float* __restrict__ out, int N, int Cx, int Cobs, int HW, int CPad, int T, int head) {
+  const int Q = CPad >> 2;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (size_t)N * HW) return;
-  const int n = idx / HW;
-  const int pix = idx - (size_t)n * HW;
+  if (idx >= (size_t)N * HW * Q) return;
+  const int qd = idx % Q;
+  const size_t np = idx / Q;
+  const int n = np / HW;
+  const int pix = np - (size_t)n * HW;
   const float c_in = cond[(size_t)n * cond_stride + 0];
-  float* o = out + idx * CPad;
-  for (int ch = 0; ch < CPad; ch += 4) {
-    f32x4 v;
+  const int cimg = Cobs / T;
+  f32x4 v;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int cc = ch + e;
-      float t = 0.f;
-      if (cc < Cobs)
-        t = obs[((size_t)n * Cobs + cc) * HW + pix] / sd;  // rescaled_obs = obs / sigma_data, denoiser.py:75
-      else if (cc < Cobs + Cx)
-        t = x[((size_t)n * Cx + (cc - Cobs)) * HW + pix] * c_in;  // denoiser.py:76
-      v[e] = t;
+  for (int e = 0; e < 4; ++e) {
+    const int cc = qd * 4 + e;
+    float t = 0.f;
+    if (cc < Cobs) {
+      const int fr = cc / cimg, ci = cc - fr * cimg;
+      int slot = fr + head;
+      slot = slot >= T ? slot - T : slot;
+      t = obs[((size_t)n * Cobs + slot * cimg + ci) * HW + pix] / sd;  // rescaled_obs = obs / sigma_data, denoiser.py:75
+    } else if (cc < Cobs + Cx) {
+      t = x[((size_t)n * Cx + (cc - Cobs)) * HW + pix] * c_in;  // denoiser.py:76
     }
-    *(f32x4*)(o + ch) = v;
+    v[e] = t;
   }
+  *(f32x4*)(out + np * CPad + qd * 4) = v;
 }
 
 // ---- cond input: [cos(f) | sin(f)] + flatten(Embedding(act)),  f = 2 pi c_noise w -----------
 __global__ void cond_embed_kernel(const float* __restrict__ cond, int cond_stride,
                                   const float* __restrict__ fw, const int64_t* __restrict__ act,
-                                  const float* __restrict__ emb, float* __restrict__ out, int N, int half, int T, int E) {
+                                  const float* __restrict__ emb, float* __restrict__ out, int N, int half, int T, int E,
+                                  int act_head, int A) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int D = 2 * half;
   if (idx >= N * D) return;
@@ -49,7 +58,11 @@ __global__ void cond_embed_kernel(const float* __restrict__ cond, int cond_strid
   const float f = two_pi_c * fw[k];
   float v = jj < half ? cosf(f) : sinf(f);
   const int t = jj / E, e = jj - t * E;  // flatten (T, E) -> T*E == D
-  v += emb[(size_t)act[(size_t)n * T + t] * E + e];
+  int slot = t + act_head;  // logical step t of a ring of T actions starting at act_head
+  slot = slot >= T ? slot - T : slot;
+  int64_t a = act[(size_t)n * T + slot];
+  a = a < 0 ? 0 : (a >= A ? A - 1 : a);  // memory safety only: nn.Embedding raises on an out-of-range index, the host checks it in debug mode
+  v += emb[(size_t)a * E + e];
   out[idx] = v;
 }
 
@@ -84,19 +97,71 @@ __global__ void euler_step_kernel(const float* __restrict__ x, const float* __re
   xo[idx] = xv + d * dt;                        // :49
 }
 
+// Heun (2nd order) update, diffusion_sampler.py:52-56, same fp32 op order:
+//   d = (x - D) / sigma_hat;  d_2 = (x_2 - D_2) / sigma_next;  x_out = x + ((d + d_2) / 2) * dt
+__global__ void heun_step_kernel(const float* __restrict__ x, const float* __restrict__ den, const float* __restrict__ x2,
+                                 const float* __restrict__ den2, float sigma_hat, float sigma_next, float dt,
+                                 float* __restrict__ xo, int64_t n) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const float xv = x[idx];
+  const float d = (xv - den[idx]) / sigma_hat;
+  const float d2 = (x2[idx] - den2[idx]) / sigma_next;
+  const float dp = (d + d2) / 2.0f;
+  xo[idx] = xv + dp * dt;
+}
+
 // ---- NCHW <-> NHWC(CPad) ---------------------------------------------------------------------
+// one thread per (pixel, channel quad): 1 KiB contiguous NHWC writes per wave
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int C, int HW, int CPad) {
+  const int Q = CPad >> 2;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (size_t)N * HW) return;
-  const int n = idx / HW;
-  const int pix = idx - (size_t)n * HW;
-  float* o = out + idx * CPad;
-  for (int ch = 0; ch < CPad; ch += 4) {
-    f32x4 v;
+  if (idx >= (size_t)N * HW * Q) return;
+  const int qd = idx % Q;
+  const size_t np = idx / Q;
+  const int n = np / HW;
+  const int pix = np - (size_t)n * HW;
+  f32x4 v;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (ch + e) < C ? in[((size_t)n * C + ch + e) * HW + pix] : 0.f;
-    *(f32x4*)(o + ch) = v;
-  }
+  for (int e = 0; e < 4; ++e) v[e] = (qd * 4 + e) < C ? in[((size_t)n * C + qd * 4 + e) * HW + pix] : 0.f;
+  *(f32x4*)(out + np * CPad + qd * 4) = v;
+}
+
+// ---- uint8 frame pool (episode frames are uint8 on disk, data/episode.py:36-50) ----------------
+// u8 = round((x + 1) / 2 * 255) of frames in [-1, 1]; *off_grid is set when a value is not exactly the
+// dequantisation of its level (such a pool must stay fp32).
+__global__ void quantize_u8_kernel(const float* __restrict__ x, uint8_t* __restrict__ q, int* __restrict__ off_grid, int64_t n) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const float v = x[idx];
+  const float lv = rintf((v + 1.0f) / 2.0f * 255.0f);
+  const float lc = fminf(fmaxf(lv, 0.0f), 255.0f);
+  q[idx] = (uint8_t)lc;
+  const float back = (lc / 255.0f) * 2.0f - 1.0f;  // Episode.load: .div(255).mul(2).sub(1)
+  if (!(back == v)) *off_grid = 1;                 // benign race: every writer stores 1
+}
+
+// dst[row[i]] frames (logical order, ring slot (head + t) % T) <- dequantised pool frames src[idx[i]]
+// per_frame = C * H * W; one thread per 4 consecutive values
+__global__ void dequant_gather_kernel(const uint8_t* __restrict__ pool, const int64_t* __restrict__ idx,
+                                      const int64_t* __restrict__ rows, float* __restrict__ dst, int M, int T,
+                                      int64_t per_frame, int head) {
+  const int64_t q4 = per_frame >> 2;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)M * T * q4) return;
+  const int64_t e4 = gid % q4;
+  const int64_t mt = gid / q4;
+  const int t = mt % T;
+  const int m = mt / T;
+  const int64_t src = idx ? idx[m] : m;
+  const int64_t row = rows ? rows[m] : m;
+  int slot = t + head;
+  slot = slot >= T ? slot - T : slot;
+  const uint32_t pk = *(const uint32_t*)(pool + (src * T + t) * per_frame + e4 * 4);
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = ((float)((pk >> (8 * e)) & 0xff) / 255.0f) * 2.0f - 1.0f;
+  *(f32x4*)(dst + (row * T + slot) * per_frame + e4 * 4) = v;
 }
 
 __global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int C, int HW, int CPad) {
@@ -230,21 +295,25 @@ __global__ void categorical_sample_kernel(const float* __restrict__ logits, cons
 static inline unsigned nblk(size_t n, int b) { return (unsigned)((n + b - 1) / b); }
 
 extern "C" int dmd_edm_pack_input(const float* x, const float* obs, const float* cond, int cond_stride, float sigma_data,
-                                  float* out, int N, int Cx, int Cobs, int H, int W, int CPad, dmd_stream_t stream) {
+                                  float* out, int N, int Cx, int Cobs, int H, int W, int CPad, int T, int head,
+                                  dmd_stream_t stream) {
   DMD_CHECK_ARG(x && obs && cond && out, "edm_pack_input: null");
   DMD_CHECK_ARG(CPad % 4 == 0 && CPad >= Cx + Cobs, "edm_pack_input: CPad");
-  hipLaunchKernelGGL(edm_pack_input_kernel, dim3(nblk((size_t)N * H * W, 256)), dim3(256), 0, (hipStream_t)stream, x, obs,
-                     cond, cond_stride, sigma_data, out, N, Cx, Cobs, H * W, CPad);
+  DMD_CHECK_ARG(T >= 1 && Cobs % T == 0 && head >= 0 && head < T, "edm_pack_input: ring T %d head %d Cobs %d", T, head, Cobs);
+  hipLaunchKernelGGL(edm_pack_input_kernel, dim3(nblk((size_t)N * H * W * (CPad / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                     x, obs, cond, cond_stride, sigma_data, out, N, Cx, Cobs, H * W, CPad, T, head);
   DMD_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int dmd_cond_embed(const float* cond, int cond_stride, const float* fw, const int64_t* act,
-                              const float* emb, float* out, int N, int half, int T, int E, dmd_stream_t stream) {
+                              const float* emb, float* out, int N, int half, int T, int E, int act_head, int A,
+                              dmd_stream_t stream) {
   DMD_CHECK_ARG(cond && fw && act && emb && out, "cond_embed: null");
   DMD_CHECK_ARG(T * E == 2 * half, "cond_embed: T*E (%d) != cond channels (%d)", T * E, 2 * half);
+  DMD_CHECK_ARG(act_head >= 0 && act_head < T && A > 0, "cond_embed: act_head %d outside [0, %d) or A %d", act_head, T, A);
   hipLaunchKernelGGL(cond_embed_kernel, dim3(nblk((size_t)N * 2 * half, 256)), dim3(256), 0, (hipStream_t)stream, cond,
-                     cond_stride, fw, act, emb, out, N, half, T, E);
+                     cond_stride, fw, act, emb, out, N, half, T, E, act_head, A);
   DMD_LAUNCH_CHECK();
   return 0;
 }
@@ -267,10 +336,37 @@ extern "C" int dmd_euler_step(const float* x, const float* den, float sigma_hat,
   return 0;
 }
 
+extern "C" int dmd_heun_step(const float* x, const float* den, const float* x2, const float* den2, float sigma_hat,
+                             float sigma_next, float dt, float* xo, int64_t n, dmd_stream_t stream) {
+  DMD_CHECK_ARG(x && den && x2 && den2 && xo, "heun_step: null");
+  hipLaunchKernelGGL(heun_step_kernel, dim3(nblk((size_t)n, 256)), dim3(256), 0, (hipStream_t)stream, x, den, x2, den2,
+                     sigma_hat, sigma_next, dt, xo, n);
+  DMD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dmd_quantize_u8(const float* x, uint8_t* q, int* off_grid, int64_t n, dmd_stream_t stream) {
+  DMD_CHECK_ARG(x && q && off_grid, "quantize_u8: null");
+  hipLaunchKernelGGL(quantize_u8_kernel, dim3(nblk((size_t)n, 256)), dim3(256), 0, (hipStream_t)stream, x, q, off_grid, n);
+  DMD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dmd_dequant_gather(const uint8_t* pool, const int64_t* idx, const int64_t* rows, float* dst, int M, int T,
+                                  int64_t per_frame, int head, dmd_stream_t stream) {
+  DMD_CHECK_ARG(pool && dst, "dequant_gather: null");
+  DMD_CHECK_ARG(per_frame % 4 == 0 && T >= 1 && head >= 0 && head < T, "dequant_gather: per_frame %% 4, ring");
+  if (M == 0) return 0;
+  hipLaunchKernelGGL(dequant_gather_kernel, dim3(nblk((size_t)M * T * (per_frame / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                     pool, idx, rows, dst, M, T, per_frame, head);
+  DMD_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int dmd_nchw_to_nhwc(const float* in, float* out, int N, int C, int H, int W, int CPad, dmd_stream_t stream) {
   DMD_CHECK_ARG(in && out && CPad % 4 == 0 && CPad >= C, "nchw_to_nhwc: args");
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(nblk((size_t)N * H * W, 256)), dim3(256), 0, (hipStream_t)stream, in, out, N, C,
-                     H * W, CPad);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(nblk((size_t)N * H * W * (CPad / 4), 256)), dim3(256), 0, (hipStream_t)stream, in,
+                     out, N, C, H * W, CPad);
   DMD_LAUNCH_CHECK();
   return 0;
 }

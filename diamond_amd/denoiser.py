@@ -85,10 +85,19 @@ class Denoiser(nn.Module):
 
     @torch.no_grad()
     def compute_model_output(self, noisy_next_obs: Tensor, obs: Tensor, act: Tensor, sigma: Union[Tensor, float],
-                             naive: Optional[bool] = None, precision: Optional[str] = None) -> Tensor:
+                             naive: Optional[bool] = None, precision: Optional[str] = None,
+                             ring: Optional[Tuple[int, int]] = None) -> Tensor:
         """F = inner_model(x * c_in, c_noise, obs / sigma_data, act)  (reference :74-77).
-        precision: None (engine.WORLD_MODEL_PRECISION) | "f32" | "f16x2"."""
+        precision: None (engine.WORLD_MODEL_PRECISION) | "f32" | "f16x2".
+        ring = (obs_head, act_head): `obs` is then the PHYSICAL ring (N, T, C, H, W) of conditioning frames and `act`
+        the physical (N, T) ring of actions of a WorldModelEnv (logical step t at slot (head + t) % T); the ring
+        order is resolved inside dmd_edm_pack_input / dmd_cond_embed, nothing is rolled or copied."""
         n, cx, h, w = noisy_next_obs.shape
+        t_ring, obs_head, act_head = 1, 0, 0
+        if ring is not None:
+            assert obs.ndim == 5, "ring mode takes the (N, T, C, H, W) context buffer"
+            t_ring, (obs_head, act_head) = obs.shape[1], ring
+            obs = obs.reshape(n, -1, h, w)
         cobs = obs.shape[1]
         cond, stride = self.compute_conditioners(sigma)
         assert stride == 0 or cond.shape[0] == n, "sigma must be a scalar or one value per sample"
@@ -98,8 +107,9 @@ class Denoiser(nn.Module):
         # argument list would be freed (and its block re-used) before the kernel is even launched.
         xc, oc = noisy_next_obs.contiguous(), obs.contiguous()
         nv.check(nv.lib().dmd_edm_pack_input(nv.fptr(xc), nv.fptr(oc), nv.fptr(cond), stride, float(self.cfg.sigma_data),
-                                             nv.fptr(packed), n, cx, cobs, h, w, cpad, nv.stream()), "dmd_edm_pack_input")
-        cvec = self.inner_model.cond_vector(cond, stride, act)
+                                             nv.fptr(packed), n, cx, cobs, h, w, cpad, t_ring, obs_head, nv.stream()),
+                 "dmd_edm_pack_input")
+        cvec = self.inner_model.cond_vector(cond, stride, act, act_head)
         return self.inner_model.run(packed, cvec, naive, precision)
 
     @torch.no_grad()
@@ -115,8 +125,9 @@ class Denoiser(nn.Module):
         return out
 
     @torch.no_grad()
-    def denoise(self, noisy_next_obs: Tensor, sigma: Union[Tensor, float], obs: Tensor, act: Tensor) -> Tensor:
-        f = self.compute_model_output(noisy_next_obs, obs, act, sigma)
+    def denoise(self, noisy_next_obs: Tensor, sigma: Union[Tensor, float], obs: Tensor, act: Tensor,
+                ring: Optional[Tuple[int, int]] = None) -> Tensor:
+        f = self.compute_model_output(noisy_next_obs, obs, act, sigma, ring=ring)
         return self.wrap_model_output(noisy_next_obs, f, sigma)
 
     def forward(self, batch):

@@ -56,9 +56,17 @@ class DiffusionSampler:
 
     @torch.no_grad()
     def sample(self, prev_obs: Tensor, prev_act: Tensor) -> Tuple[Tensor, List[Tensor]]:
-        device = prev_obs.device
-        b, t, c, h, w = prev_obs.size()
-        obs = prev_obs.reshape(b, t * c, h, w)
+        """Reference entry point (diffusion_sampler.py:30-58): prev_obs (B, T, C, H, W), prev_act (B, T)."""
+        return self.sample_ring(prev_obs, prev_act, 0, 0)
+
+    @torch.no_grad()
+    def sample_ring(self, ctx_obs: Tensor, ctx_act: Tensor, obs_head: int, act_head: int) -> Tuple[Tensor, List[Tensor]]:
+        """`sample` over ring-indexed context buffers (logical step t at slot (head + t) % T): what WorldModelEnv
+        calls every step, so its context is never rolled (world_model_env.py:74-75)."""
+        device = ctx_obs.device
+        b, t, c, h, w = ctx_obs.size()
+        ctx_obs = ctx_obs.contiguous()
+        ring = (obs_head, act_head)
         sig = self._host_sigmas
         gamma_ = min(self.cfg.s_churn / (len(sig) - 1), 2 ** 0.5 - 1)
         x = self._randn((b, c, h, w), device)
@@ -69,7 +77,7 @@ class DiffusionSampler:
             if gamma > 0:
                 eps = self._randn(x.shape, device) * self.cfg.s_noise
                 x = x + eps * float((sigma_hat ** 2 - sigma ** 2) ** 0.5)
-            denoised = self.denoiser.denoise(x, sigma, obs, prev_act)  # sigma, not sigma_hat: reference :44
+            denoised = self.denoiser.denoise(x, sigma, ctx_obs, ctx_act, ring=ring)  # sigma, not sigma_hat: reference :44
             dt = next_sigma - sigma_hat  # fp32 subtraction like the reference
             if self.cfg.order == 1 or next_sigma == 0:
                 x = self._euler(x, denoised, float(sigma_hat), float(dt))
@@ -77,10 +85,8 @@ class DiffusionSampler:
                 x_2 = self._euler(x, denoised, float(sigma_hat), float(dt))
                 # the reference passes next_sigma as a (B,) tensor of equal values (:53); one scalar
                 # yields the same per-sample conditioners without a per-sample array
-                denoised_2 = self.denoiser.denoise(x_2, next_sigma, obs, prev_act)
-                d = (x - denoised) / float(sigma_hat)
-                d_2 = (x_2 - denoised_2) / float(next_sigma)
-                x = x + (d + d_2) / 2 * float(dt)
+                denoised_2 = self.denoiser.denoise(x_2, next_sigma, ctx_obs, ctx_act, ring=ring)
+                x = self._heun(x, denoised, x_2, denoised_2, float(sigma_hat), float(next_sigma), float(dt))
             trajectory.append(x)
         return x, trajectory
 
@@ -90,4 +96,14 @@ class DiffusionSampler:
         out = torch.empty_like(x)
         nv.check(nv.lib().dmd_euler_step(nv.fptr(x), nv.fptr(denoised), sigma_hat, dt, nv.fptr(out), x.numel(),
                                          nv.stream()), "dmd_euler_step")
+        return out
+
+    @staticmethod
+    def _heun(x: Tensor, denoised: Tensor, x_2: Tensor, denoised_2: Tensor, sigma_hat: float, sigma_next: float,
+              dt: float) -> Tensor:
+        """x + ((x - D)/sigma_hat + (x_2 - D_2)/sigma_next) / 2 * dt  (reference :52-56), one fused kernel."""
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        nv.check(nv.lib().dmd_heun_step(nv.fptr(x), nv.fptr(denoised), nv.fptr(x_2), nv.fptr(denoised_2), sigma_hat,
+                                        sigma_next, dt, nv.fptr(out), x.numel(), nv.stream()), "dmd_heun_step")
         return out

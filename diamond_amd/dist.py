@@ -54,9 +54,30 @@ class GradAllReducer:
 
 
 def broadcast_parameters(module: nn.Module, src: int = 0, group=None) -> None:
-    """Startup parameter/buffer broadcast (what the DDP constructor does, utils.py:106)."""
+    """Startup parameter/buffer broadcast (what the DDP constructor does, utils.py:106): ONE flat message per dtype
+    (xGMI is point-to-point: a single large broadcast instead of hundreds of latency-bound small ones), copied back
+    with `copy_` -- c10d collectives write through the storage without bumping `Tensor._version`, and the packed
+    kernel-layout copies (engine.PackCache / FilmTable) are cached per parameter version."""
     if not (dist.is_available() and dist.is_initialized()):
         return
     with torch.no_grad():
-        for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src=src, group=group)
+        tensors = list(module.parameters()) + list(module.buffers())
+        for dtype in sorted({t.dtype for t in tensors}, key=str):
+            group_t = [t for t in tensors if t.dtype == dtype]
+            flat = torch.cat([t.detach().reshape(-1) for t in group_t])
+            dist.broadcast(flat, src=src, group=group)
+            off = 0
+            for t in group_t:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view_as(t))  # in-place on the tensor itself: bumps _version
+                off += n
+
+
+@torch.no_grad()
+def parameter_checksum(module: nn.Module) -> float:
+    """Order-dependent fp64 checksum of all parameters: equal on every rank iff the replicas hold the same values
+    (bench.py asserts it after the timed steps)."""
+    total = torch.zeros((), dtype=torch.float64, device=next(module.parameters()).device)
+    for i, p in enumerate(module.parameters()):
+        total += p.detach().double().sum() * (1.0 + (i % 7) * 0.125)
+    return float(total)

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -18,7 +19,9 @@ from . import native as nv
 _USE_NAIVE = os.environ.get("DIAMOND_CONV_IMPL", "mfma") == "naive"  # debugging aid only (still HIP)
 # Arithmetic of the no-grad world-model convolutions (denoiser / reward-end model):
 #   "f16x2": split-fp32 operands on the f16 matrix cores where dmd_conv2d_f16x2_eligible (default);
-#   "f32"  : exact fp32 MFMA everywhere.  The actor-critic (gradients) always runs exact fp32.
+#   "f32"  : exact fp32 MFMA everywhere.
+# The actor-critic encoder has its own switch (ac_native.AC_PRECISION, DIAMOND_AC_PRECISION, default "f16x2" for its
+# forward and dgrad convolutions; its weight gradients always run on the exact fp32 MFMA kernel).
 WORLD_MODEL_PRECISION = os.environ.get("DIAMOND_CONV_PRECISION", "f16x2")
 
 
@@ -45,13 +48,11 @@ PROFILER: Optional[LaunchProfiler] = None
 
 
 def kernel_key(p) -> str:
-    """Name of the kernel instantiation dmd_conv2d picks for these parameters."""
-    if nv.lib().dmd_conv1x1_stream_eligible(C.byref(p)):
-        return f"conv1x1_stream<cin{sum(p.src[i].C for i in range(p.nsrc))}{',f16x2' if p.precision else ''}>"
-    if nv.lib().dmd_conv2d_f16x2_eligible(C.byref(p)):
-        return f"conv_f16s<{'B8' if p.W % 16 else 'A16'},c{p.CoutPad}{',1x1' if p.taps == 1 else ''}>"
-    wn = 4 if p.CoutPad % 64 == 0 else (2 if p.CoutPad % 32 == 0 else 1)
-    return f"conv_mfma<WN{wn},{'B' if p.W % 16 else 'A'},taps{p.taps},s{p.stride}>"
+    """Name of the kernel instantiation dmd_conv2d launches for these parameters, spelled like rocprofv3's kernel
+    trace (so bench.py's records, profiles/*_kernel_stats.csv and profiles/*pmc*.json share one key)."""
+    buf = C.create_string_buffer(128)
+    nv.check(nv.lib().dmd_conv2d_kernel_name(C.byref(p), buf, len(buf)), "dmd_conv2d_kernel_name")
+    return buf.value.decode()
 
 
 @dataclass
@@ -91,16 +92,22 @@ class PackCache:
     layouts so checkpoints stay interchangeable (agent.py:48-62)."""
 
     def __init__(self) -> None:
-        self._store: Dict[Tuple[int, str], Tuple[int, Tensor]] = {}
+        self._store: Dict[Tuple[int, str], Tuple[Tuple, "weakref.ref", Tensor]] = {}
+
+    def invalidate(self) -> None:
+        """Drop every packed copy.  Needed after writes that do not bump `Tensor._version` (anything done through
+        `p.data`: `.data.copy_`, `.data.fill_`, collectives on `.data`)."""
+        self._store.clear()
 
     def get(self, p: Tensor, kind: str, fn):
         key = (id(p), kind)
         hit = self._store.get(key)
-        ver = p._version
-        if hit is None or hit[0] != ver or hit[1].device != p.device:
-            hit = (ver, fn(p))
+        # storage pointer: catches `p.data = other`; weakref: an id() re-used by a new tensor is not a hit
+        stamp = (p._version, p.data_ptr(), p.device)
+        if hit is None or hit[0] != stamp or hit[1]() is not p:
+            hit = (stamp, weakref.ref(p), fn(p))
             self._store[key] = hit
-        return hit[1]
+        return hit[2]
 
     def conv_weight(self, conv: nn.Conv2d, cout_padded: Optional[int] = None) -> Tensor:
         return self.get(conv.weight, f"convw{cout_padded}", lambda w: nv.pack_conv_weight(w, cout_padded))

@@ -1,6 +1,7 @@
 """U-Net wrapper of the EDM denoiser (reference models/diffusion/inner_model.py:23-49), native."""
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -10,6 +11,8 @@ from torch import Tensor, nn
 from . import engine as E
 from . import native as nv
 from .blocks import FilmTable, FourierFeatures, GroupNorm, RunCtx, UNet, conv3x3
+
+_DEBUG_CHECKS = os.environ.get("DIAMOND_DEBUG", "0") == "1"  # extra host-side validation (adds device syncs)
 
 
 @dataclass
@@ -42,17 +45,23 @@ class InnerModel(nn.Module):
         self._film: Optional[FilmTable] = None
 
     # -- native pieces -------------------------------------------------------------------
-    def cond_vector(self, cond: Tensor, cond_stride: int, act: Tensor) -> Tensor:
+    def cond_vector(self, cond: Tensor, cond_stride: int, act: Tensor, act_head: int = 0) -> Tensor:
         """cond_proj(noise_emb(c_noise) + act_emb(act))  (reference :45); c_noise is entry 3 of
-        the per-sample conditioner array (Denoiser.compute_conditioners)."""
+        the per-sample conditioner array (Denoiser.compute_conditioners).  `act` (N, T) int64 may be a ring
+        whose logical step 0 is column `act_head` (WorldModelEnv keeps its action context that way)."""
+        assert act.dtype == torch.long and act.ndim == 2, f"act must be an int64 (N, T) tensor, got {act.dtype} {tuple(act.shape)}"
         n, t = act.shape
         emb = self.act_emb[0].weight
+        if _DEBUG_CHECKS:  # nn.Embedding raises on an out-of-range index; the kernel only clamps (one host sync)
+            lo, hi = int(act.min()), int(act.max())
+            if lo < 0 or hi >= emb.shape[0]:
+                raise IndexError(f"action index out of range [0, {emb.shape[0]}): min {lo}, max {hi}")
         half = self.noise_emb.weight.shape[1]
         x = torch.empty(n, 2 * half, device=act.device, dtype=torch.float32)
         act = act.contiguous()
         fw, ew = self._cache.f32(self.noise_emb.weight), self._cache.f32(emb)
         nv.check(nv.lib().dmd_cond_embed(nv.fptr(cond), cond_stride, nv.fptr(fw), nv.ptr(act), nv.fptr(ew), nv.fptr(x), n,
-                                         half, t, emb.shape[1], nv.stream()), "dmd_cond_embed")
+                                         half, t, emb.shape[1], act_head, emb.shape[0], nv.stream()), "dmd_cond_embed")
         l0, l2 = self.cond_proj[0], self.cond_proj[2]
         y = E.linear(x, self._cache.f32(l0.weight), self._cache.f32(l0.bias), silu=True)
         return E.linear(y, self._cache.f32(l2.weight), self._cache.f32(l2.bias))

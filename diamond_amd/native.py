@@ -62,10 +62,11 @@ class WgradParams(C.Structure):
 
 
 EXPORTS = (
-    "dmd_conv2d", "dmd_conv2d_naive", "dmd_conv_stat_tiles", "dmd_pack_conv_weight", "dmd_conv2d_f16x2_eligible",
+    "dmd_conv2d", "dmd_conv2d_kernel_name", "dmd_conv2d_naive", "dmd_conv_stat_tiles", "dmd_pack_conv_weight", "dmd_conv2d_f16x2_eligible",
     "dmd_conv1x1_stream_eligible",
     "dmd_pack_conv_weight_f16x2", "dmd_linear", "dmd_attention",
-    "dmd_edm_pack_input", "dmd_cond_embed", "dmd_edm_denoised", "dmd_euler_step", "dmd_nchw_to_nhwc",
+    "dmd_edm_pack_input", "dmd_cond_embed", "dmd_edm_denoised", "dmd_euler_step", "dmd_heun_step", "dmd_quantize_u8",
+    "dmd_dequant_gather", "dmd_nchw_to_nhwc",
     "dmd_nhwc_to_nchw", "dmd_gn_stats", "dmd_maxpool2", "dmd_lstm_pointwise", "dmd_categorical_sample",
     "dmd_maxpool2_bwd", "dmd_gn_bwd_workspace_bytes", "dmd_gn_silu_bwd", "dmd_wgrad_workspace_floats", "dmd_conv2d_wgrad",
     "dmd_last_error", "dmd_abi_version",
@@ -87,6 +88,7 @@ def lib() -> C.CDLL:
             getattr(L, name)  # AttributeError if the ABI is incomplete
         L.dmd_conv2d.argtypes = [C.POINTER(ConvParams), C.c_void_p]
         L.dmd_conv2d_naive.argtypes = [C.POINTER(ConvParams), C.c_void_p]
+        L.dmd_conv2d_kernel_name.argtypes = [C.POINTER(ConvParams), C.c_char_p, C.c_int]
         L.dmd_linear.argtypes = [C.POINTER(LinearParams), C.c_void_p]
         L.dmd_pack_conv_weight.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.dmd_pack_conv_weight_f16x2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -94,9 +96,14 @@ def lib() -> C.CDLL:
         L.dmd_conv1x1_stream_eligible.argtypes = [C.POINTER(ConvParams)]
         L.dmd_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.dmd_edm_pack_input.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_int,
-                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.dmd_cond_embed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                     C.c_int, C.c_int, C.c_int, C.c_void_p]
+                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.dmd_heun_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
+                                    C.c_void_p, C.c_int64, C.c_void_p]
+        L.dmd_quantize_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.dmd_dequant_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64,
+                                         C.c_int, C.c_void_p]
         L.dmd_edm_denoised.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64,
                                        C.c_void_p]
         L.dmd_euler_step.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]

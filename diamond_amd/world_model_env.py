@@ -1,19 +1,33 @@
-"""Batched imagination environment (reference envs/world_model_env.py:25-139).
+"""Batched imagination environment with a ring-indexed context and a device-resident uint8 pool of
+initial conditions.
 
-Same constructor / attributes / step contract as the reference so src/trainer.py and
-src/play.py can use it unchanged; `predict_next_obs` and `predict_rew_end` are plain
-instance-assignable callables (trainer.py:182-184 overwrites them).
+Contract = the reference's `WorldModelEnv` (envs/world_model_env.py:25-139): constructor, `num_envs`,
+`horizon`, `device`, `sampler`, `reset(**kw) -> (obs, {})`, `step(act) -> (obs, rew, end, trunc, info)` with
+`info["final_observation"]` / `info["burnin_obs"]` / `info["denoising_trajectory"]`, and the two re-assignable
+callables `predict_next_obs()` / `predict_rew_end(next_obs)` (trainer.py:182-184 overwrites them).  The data
+structures behind it are designed for the GPU instead of transcribed:
+
+* context ring -- the T = 4 conditioning frames and actions of every env live in ONE (B, T, C, H, W) fp32 /
+  (B, T) int64 buffer that is never rolled (the reference copies the whole buffer every step, :74-75).  Logical
+  step t sits at physical slot (head + t) % T; a step overwrites the oldest slot and advances `head`.  The ring
+  order is resolved inside `dmd_edm_pack_input` / `dmd_cond_embed` (C ABI: `T, head` arguments).
+* initial-condition pool -- preloaded batches are quantised back to the uint8 levels they were decoded from
+  (data/episode.py:36-50: `x.div(255).mul(2).sub(1)`) by `dmd_quantize_u8` and stay on the device as uint8
+  (4x smaller than the reference's python lists of fp32 rows, :128-131); a reset gathers + dequantises the rows it
+  needs straight into the ring slots of the dead envs (`dmd_dequant_gather`).  A loader that yields frames off the
+  256-level grid (detected by the quantiser) keeps an fp32 pool: results never change.
 """
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Any, Callable, Dict, Generator, List, Optional, Tuple
+from typing import Any, Callable, Dict, Iterator, List, Optional, Tuple
 
 import torch
 from torch import Tensor
 
+from . import native as nv
 from .diffusion_sampler import DiffusionSampler, DiffusionSamplerConfig
-from .env_loop import coroutine, sample_categorical
+from .env_loop import sample_categorical
 
 
 @dataclass
@@ -21,6 +35,83 @@ class WorldModelEnvConfig:
     horizon: int
     num_batches_to_preload: int
     diffusion_sampler: DiffusionSamplerConfig
+
+
+class InitialConditionPool:
+    """Device-resident queue of (context frames, context actions, burnt-in reward/end LSTM state).
+
+    Same serving rule as the reference generator (:133-139): requests are served in order from the preloaded
+    batches; when fewer rows are left than a request needs, the remainder is dropped and fresh batches are
+    preloaded (each one burns the reward/end LSTM in on its first T-1 transitions, :123-124)."""
+
+    def __init__(self, rew_end_model, data_loader, num_batches: int, device_fn: Callable[[], torch.device]) -> None:
+        self._model = rew_end_model
+        self._loader = data_loader
+        self._iter: Optional[Iterator] = None
+        self._num_batches = num_batches
+        self._device_fn = device_fn
+        self.frames_u8: Optional[Tensor] = None   # (P, T, C, H, W) uint8, or
+        self.frames_f32: Optional[Tensor] = None  # (P, T, C, H, W) fp32 when the loader's frames are off the uint8 grid
+        self.act: Optional[Tensor] = None         # (P, T) int64
+        self.hx: Optional[Tensor] = None          # (P, lstm_dim)
+        self.cx: Optional[Tensor] = None
+        self._cursor = 0
+
+    @property
+    def size(self) -> int:
+        return 0 if self.act is None else self.act.shape[0]
+
+    @torch.no_grad()
+    def _preload(self) -> None:
+        if self._iter is None:
+            self._iter = iter(self._loader)
+        dev = self._device_fn()
+        q_, f_, act_, hx_, cx_ = [], [], [], [], []
+        off_grid = torch.zeros(1, dtype=torch.int32, device=dev)
+        for _ in range(self._num_batches):
+            batch = next(self._iter)
+            obs = batch.obs.to(dev, non_blocking=True).float().contiguous()  # async when the loader pins its batches
+            act = batch.act.to(dev, non_blocking=True)
+            *_, (hx, cx) = self._model.predict_rew_end(obs[:, :-1], act[:, :-1], obs[:, 1:])
+            assert hx.size(0) == cx.size(0) == 1
+            q = torch.empty(obs.shape, dtype=torch.uint8, device=dev)
+            nv.check(nv.lib().dmd_quantize_u8(nv.fptr(obs), nv.ptr(q), nv.ptr(off_grid), obs.numel(), nv.stream()),
+                     "dmd_quantize_u8")
+            q_.append(q)
+            f_.append(obs)
+            act_.append(act)
+            hx_.append(hx[0])
+            cx_.append(cx[0])
+        if int(off_grid.item()) == 0:  # one sync per preload round
+            self.frames_u8, self.frames_f32 = torch.cat(q_), None
+        else:
+            self.frames_u8, self.frames_f32 = None, torch.cat(f_)
+        self.act, self.hx, self.cx = torch.cat(act_), torch.cat(hx_), torch.cat(cx_)
+        self._cursor = 0
+
+    def take(self, count: int) -> Tensor:
+        """Device index vector of the next `count` pool rows (preloading when the pool runs short)."""
+        if self.size == 0:
+            self._preload()
+        while self._cursor + count > self.size:
+            assert count <= self._num_batches * self._loader.batch_sampler.batch_size, \
+                "more simultaneous resets than one preload round holds"
+            self._preload()
+        idx = torch.arange(self._cursor, self._cursor + count, device=self.act.device)
+        self._cursor += count
+        return idx
+
+    def scatter_frames(self, idx: Tensor, rows: Optional[Tensor], ring: Tensor, head: int) -> None:
+        """ring[rows[i]] <- pool frames idx[i] in logical order (slot (head + t) % T); rows None = all rows."""
+        b, t = ring.shape[:2]
+        per_frame = ring[0, 0].numel()
+        if self.frames_u8 is not None:
+            nv.check(nv.lib().dmd_dequant_gather(nv.ptr(self.frames_u8), nv.ptr(idx), nv.ptr(rows), nv.fptr(ring),
+                                                 idx.numel(), t, per_frame, head, nv.stream()), "dmd_dequant_gather")
+        else:  # fp32 pool (off-grid frames): plain indexed copy
+            cols = (head + torch.arange(t, device=ring.device)) % t
+            r = rows if rows is not None else torch.arange(b, device=ring.device)
+            ring[r[:, None], cols[None, :]] = self.frames_f32[idx]
 
 
 class WorldModelEnv:
@@ -31,7 +122,10 @@ class WorldModelEnv:
         self.horizon = cfg.horizon
         self.return_denoising_trajectory = return_denoising_trajectory
         self.num_envs = data_loader.batch_sampler.batch_size
-        self.generator_init = self.make_generator_init(data_loader, cfg.num_batches_to_preload)
+        self.pool = InitialConditionPool(rew_end_model, data_loader, cfg.num_batches_to_preload, lambda: self.device)
+        self._ctx: Optional[Tensor] = None  # (B, T, C, H, W) fp32 context ring
+        self._act: Optional[Tensor] = None  # (B, T) int64 action ring
+        self._head = 0                      # physical slot of logical step 0 (both rings advance together)
         # test hook: injected exponential draws for the reward / end samples (host RNG parity)
         self.expo_fn: Optional[Callable[[Tensor], Tensor]] = None
 
@@ -39,81 +133,92 @@ class WorldModelEnv:
     def device(self) -> torch.device:
         return self.sampler.denoiser.device
 
+    # -- ring bookkeeping ------------------------------------------------------------------------
+    def _slot(self, t: int) -> int:
+        """Physical slot of logical step t (negative t counts from the newest step)."""
+        steps = self._ctx.shape[1]
+        return (self._head + (t % steps)) % steps
+
+    def _cols(self) -> Tensor:
+        steps = self._ctx.shape[1]
+        return (self._head + torch.arange(steps, device=self._ctx.device)) % steps
+
+    @property
+    def obs_buffer(self) -> Tensor:
+        """The context in the reference's logical layout (B, T, C, H, W) -- a COPY, for inspection."""
+        return self._ctx[:, self._cols()]
+
+    @property
+    def act_buffer(self) -> Tensor:
+        return self._act[:, self._cols()]
+
+    # -- gym-style API ---------------------------------------------------------------------------
     @torch.no_grad()
     def reset(self, **kwargs) -> Tuple[Tensor, Dict[str, Any]]:
-        obs, act, (hx, cx) = self.generator_init.send(self.num_envs)
-        self.obs_buffer, self.act_buffer = obs, act
-        self.hx_rew_end, self.cx_rew_end = hx, cx
-        self.ep_len = torch.zeros(self.num_envs, dtype=torch.long, device=obs.device)
-        return self.obs_buffer[:, -1], {}
+        idx = self.pool.take(self.num_envs)
+        dev = idx.device
+        frames = self.pool.frames_u8 if self.pool.frames_u8 is not None else self.pool.frames_f32
+        self._ctx = torch.empty((self.num_envs,) + tuple(frames.shape[1:]), dtype=torch.float32, device=dev)
+        self._head = 0
+        self.pool.scatter_frames(idx, None, self._ctx, 0)
+        self._act = self.pool.act[idx].clone()
+        self.hx_rew_end = self.pool.hx[idx].unsqueeze(0).clone()
+        self.cx_rew_end = self.pool.cx[idx].unsqueeze(0).clone()
+        self.ep_len = torch.zeros(self.num_envs, dtype=torch.long, device=dev)
+        return self._ctx[:, self._slot(-1)].clone(), {}  # a copy: ring slots are overwritten T steps later
 
     @torch.no_grad()
-    def reset_dead(self, dead: Tensor) -> None:
-        obs, act, (hx, cx) = self.generator_init.send(int(dead.sum().item()))
-        self.obs_buffer[dead] = obs
-        self.act_buffer[dead] = act
-        self.hx_rew_end[:, dead] = hx
-        self.cx_rew_end[:, dead] = cx
-        self.ep_len[dead] = 0
+    def reset_dead(self, dead: Tensor) -> Tensor:
+        """Replace the context / action ring / reward-end LSTM state of the dead envs by fresh pool rows;
+        returns the dead row indices."""
+        rows = dead.nonzero(as_tuple=True)[0]
+        idx = self.pool.take(int(rows.numel()))
+        self.pool.scatter_frames(idx, rows, self._ctx, self._head)
+        self._act[rows[:, None], self._cols()[None, :]] = self.pool.act[idx]
+        self.hx_rew_end[0, rows] = self.pool.hx[idx]
+        self.cx_rew_end[0, rows] = self.pool.cx[idx]
+        self.ep_len[rows] = 0
+        return rows
 
     @torch.no_grad()
     def step(self, act: Tensor):
-        self.act_buffer[:, -1] = act
+        newest = self._slot(-1)
+        self._act[:, newest] = act
         next_obs, denoising_trajectory = self.predict_next_obs()
         rew, end = self.predict_rew_end(next_obs.unsqueeze(1))
 
         self.ep_len += 1
         trunc = (self.ep_len >= self.horizon).long()
-        self.obs_buffer = self.obs_buffer.roll(-1, dims=1)
-        self.act_buffer = self.act_buffer.roll(-1, dims=1)
-        self.obs_buffer[:, -1] = next_obs
+        # advance the rings: the oldest slot becomes the newest and receives the imagined frame (its action slot is
+        # written by the next step, exactly when the reference writes act_buffer[:, -1])
+        oldest = self._head
+        self._head = (self._head + 1) % self._ctx.shape[1]
+        self._ctx[:, oldest] = next_obs
         dead = torch.logical_or(end, trunc)
 
         info: Dict[str, Any] = {}
         if self.return_denoising_trajectory:
             info["denoising_trajectory"] = torch.stack(denoising_trajectory, dim=1)
+        obs = next_obs  # a fresh tensor every step: never aliases the ring
         if dead.any():
-            self.reset_dead(dead)
-            info["final_observation"] = next_obs[dead]
-            info["burnin_obs"] = self.obs_buffer[dead, :-1]
-        return self.obs_buffer[:, -1], rew, end, trunc, info
+            rows = self.reset_dead(dead)
+            info["final_observation"] = next_obs[rows]
+            cols = self._cols()
+            info["burnin_obs"] = self._ctx[rows[:, None], cols[None, :-1]]
+            obs = self._ctx[:, self._slot(-1)].clone()  # dead envs now show the newest frame of their new episode
+        return obs, rew, end, trunc, info
 
     @torch.no_grad()
     def predict_next_obs(self) -> Tuple[Tensor, List[Tensor]]:
-        return self.sampler.sample(self.obs_buffer, self.act_buffer)
+        return self.sampler.sample_ring(self._ctx, self._act, self._head, self._head)
 
     @torch.no_grad()
     def predict_rew_end(self, next_obs: Tensor) -> Tuple[Tensor, Tensor]:
+        newest = self._slot(-1)
         logits_rew, logits_end, (self.hx_rew_end, self.cx_rew_end) = self.rew_end_model.predict_rew_end(
-            self.obs_buffer[:, -1:], self.act_buffer[:, -1:], next_obs, (self.hx_rew_end, self.cx_rew_end))
+            self._ctx[:, newest:newest + 1], self._act[:, newest:newest + 1], next_obs, (self.hx_rew_end, self.cx_rew_end))
         e_rew = None if self.expo_fn is None else self.expo_fn(logits_rew)
         e_end = None if self.expo_fn is None else self.expo_fn(logits_end)
         rew = sample_categorical(logits_rew, e_rew).squeeze(1) - 1.0  # {-1, 0, 1}
         end = sample_categorical(logits_end, e_end).squeeze(1)
         return rew, end
-
-    @coroutine
-    def make_generator_init(self, data_loader, num_batches_to_preload: int) -> Generator:
-        """Pool of initial conditions (reference :107-139): preload batches, burn the rew/end
-        LSTM in on their first T-1 transitions, then serve `num_dead` samples per request."""
-        num_dead = yield
-        data_iterator = iter(data_loader)
-        while True:
-            obs_, act_, hx_, cx_ = [], [], [], []
-            for _ in range(num_batches_to_preload):
-                batch = next(data_iterator)
-                obs = batch.obs.to(self.device, non_blocking=True)  # async when the loader pins its batches
-                act = batch.act.to(self.device, non_blocking=True)
-                *_, (hx, cx) = self.rew_end_model.predict_rew_end(obs[:, :-1], act[:, :-1], obs[:, 1:])
-                assert hx.size(0) == cx.size(0) == 1
-                obs_.append(obs)
-                act_.append(act)
-                hx_.append(hx[0])
-                cx_.append(cx[0])
-            # one device-resident pool tensor per field (the reference keeps python lists of rows)
-            obs_p, act_p, hx_p, cx_p = torch.cat(obs_), torch.cat(act_), torch.cat(hx_), torch.cat(cx_)
-            c = 0
-            while c + num_dead <= obs_p.size(0):
-                sl = slice(c, c + num_dead)
-                c += num_dead
-                num_dead = yield obs_p[sl].clone(), act_p[sl].clone(), (hx_p[sl].unsqueeze(0).clone(), cx_p[sl].unsqueeze(0).clone())

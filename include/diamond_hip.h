@@ -77,9 +77,11 @@ typedef struct dmd_conv_params {
 /* DMD_PRECISION_F32:   v_mfma_f32_16x16x4_f32, bit-for-bit a k-ordered fp32 fma chain.
  * DMD_PRECISION_F16X2: fp32 operands split into two fp16 pieces each (x = h + l), three
  *   v_mfma_f32_32x32x16_f16 per product into an fp32 accumulator: fp32-class accuracy
- *   (representation error <= 2^-22 relative) for |x| < 65504, 16x the MFMA rate.  Honoured only
- *   where dmd_conv2d_f16x2_eligible() says so (3x3 stride 1, Cout == 64, Cin <= 128, NHWC out);
- *   everything else silently uses the exact kernel. */
+ *   (representation error <= max(2^-22 |x|, 2^-25)), 16x the MFMA rate.  Range contract: finite operands must
+ *   be inside the fp16 range (|x| < 65520); nothing is clamped, an operand beyond it makes every output it
+ *   touches NaN (loud, never a silently wrong finite value), NaN / Inf inputs stay non-finite.  Honoured only
+ *   where dmd_conv2d_f16x2_eligible() says so (3x3 / 1x1 stride 1, Cout in {32, 64}, Cin <= 128 / 64, NHWC
+ *   out, or the few-channel NCHW head); everything else uses the exact kernel. */
 #define DMD_PRECISION_F32 0
 #define DMD_PRECISION_F16X2 1
 int dmd_conv2d_f16x2_eligible(const dmd_conv_params* p);
@@ -90,6 +92,9 @@ int dmd_conv1x1_stream_eligible(const dmd_conv_params* p);
 int dmd_pack_conv_weight_f16x2(const float* oihw, void* packed, int Cout, int Cin, int k, int CinPad, dmd_stream_t stream);
 
 int dmd_conv2d(const dmd_conv_params* p, dmd_stream_t stream);
+/* name of the kernel instantiation dmd_conv2d launches for these parameters, spelled like rocprofv3's kernel trace
+ * (e.g. "conv_f16ws_kernel<WsGeom<false, 2, 9>>"): measurement plumbing for bench.py / profiles */
+int dmd_conv2d_kernel_name(const dmd_conv_params* p, char* buf, int buf_len);
 /* number of GroupNorm stat tiles per image a dmd_conv2d with output (H, W) emits */
 int dmd_conv_stat_tiles(int H, int W);
 /* OIHW (Cout, Cin, k, k) fp32 -> packed layout; Cin padded to 16, Cout padded to CoutPad. */
@@ -126,19 +131,38 @@ int dmd_attention(const float* qkv, float* out, int N, int T, int C, int head_di
  * cond[n * cond_stride + {0: c_in, 1: c_out, 2: c_skip, 3: c_noise}], cond_stride in {0, 4}. */
 
 /* cat(obs / sigma_data, x * c_in) -> NHWC with CPad channels (zero padded).
- * x (N, Cx, H, W), obs (N, Cobs, H, W) NCHW. */
+ * x (N, Cx, H, W), obs (N, Cobs, H, W) NCHW.  obs may be a RING of T conditioning frames (N, T, Cobs / T, H, W):
+ * logical frame t is stored at slot (head + t) % T, so that WorldModelEnv.step never rolls its context
+ * (world_model_env.py:74-75).  T = 1, head = 0: plain tensor. */
 int dmd_edm_pack_input(const float* x, const float* obs, const float* cond, int cond_stride, float sigma_data,
-                       float* out_nhwc, int N, int Cx, int Cobs, int H, int W, int CPad, dmd_stream_t stream);
-/* cond input: fourier(c_noise) + flatten(embedding(act))  (blocks.py:84-87, inner_model.py:27-30,45) */
+                       float* out_nhwc, int N, int Cx, int Cobs, int H, int W, int CPad, int T, int head,
+                       dmd_stream_t stream);
+/* cond input: fourier(c_noise) + flatten(embedding(act))  (blocks.py:84-87, inner_model.py:27-30,45);
+ * act is a ring of T actions per sample starting at act_head (0: plain (N, T) tensor); A = rows of act_emb
+ * (indices are clamped to [0, A) for memory safety -- validating them is the caller's job) */
 int dmd_cond_embed(const float* cond, int cond_stride, const float* fourier_w /*[half]*/,
                    const int64_t* act /*(N, T)*/, const float* act_emb /*(A, E)*/, float* out /*(N, 2*half)*/, int N,
-                   int half, int T, int E, dmd_stream_t stream);
+                   int half, int T, int E, int act_head, int A, dmd_stream_t stream);
 /* denoised = quantise(c_skip * x + c_out * F)  (denoiser.py:81-83); all NCHW, elementwise */
 int dmd_edm_denoised(const float* x, const float* model_out, const float* cond, int cond_stride,
                      float* denoised, int N, int64_t per_sample, dmd_stream_t stream);
 /* x_out = x + ((x - denoised) / sigma_hat) * dt   (diffusion_sampler.py:45-49) */
 int dmd_euler_step(const float* x, const float* denoised, float sigma_hat, float dt, float* x_out, int64_t n,
                    dmd_stream_t stream);
+/* Heun combine, diffusion_sampler.py:52-56: d = (x - D) / sigma_hat, d_2 = (x_2 - D_2) / sigma_next,
+ * x_out = x + ((d + d_2) / 2) * dt   (same fp32 op order as the reference) */
+int dmd_heun_step(const float* x, const float* denoised, const float* x_2, const float* denoised_2, float sigma_hat,
+                  float sigma_next, float dt, float* x_out, int64_t n, dmd_stream_t stream);
+
+/* ---- device-resident uint8 pool of initial conditions (world_model_env.py:107-139; frames are uint8 on disk,
+ *      data/episode.py:36-50, and `x.div(255).mul(2).sub(1)` when loaded) ------------------------------------- */
+/* q = round((x + 1) / 2 * 255); *off_grid (device int, zeroed by the caller) becomes 1 if some x is not exactly the
+ * dequantisation of its level -- such a pool cannot be kept as uint8 without changing results. */
+int dmd_quantize_u8(const float* x, uint8_t* q, int* off_grid, int64_t n, dmd_stream_t stream);
+/* dst ring row rows[i] (NULL: i), slot (head + t) % T  <-  (pool[idx[i]][t] / 255) * 2 - 1   for i < M, t < T.
+ * pool (P, T, per_frame) uint8, dst (B, T, per_frame) fp32, per_frame = C * H * W (multiple of 4). */
+int dmd_dequant_gather(const uint8_t* pool, const int64_t* idx, const int64_t* rows, float* dst, int M, int T,
+                       int64_t per_frame, int head, dmd_stream_t stream);
 
 /* NCHW (N, C, H, W) -> NHWC (N, H, W, CPad), zero padded channels */
 int dmd_nchw_to_nhwc(const float* in, float* out, int N, int C, int H, int W, int CPad, dmd_stream_t stream);

@@ -188,7 +188,76 @@ def gen_window():
     save("window.pt", out)
 
 
+def gen_window_teacher_forced():
+    """The same two windows as gen_window(), with everything the reference's env handed to env_loop recorded per
+    step (observations as uint8 levels -- they are on the 256-level grid up to one ulp --, rewards, ends, truncs,
+    final observations, burn-in frames).  tests/test_gpu_models.py replays that stream into this repo's
+    env_loop + ActorCritic (teacher forcing: no quantisation flip can feed back), which pins logits / values /
+    loss / gradients of a whole window at the 1e-4 tolerance."""
+    from envs import WorldModelEnv, WorldModelEnvConfig
+    from models.actor_critic import ActorCriticLossConfig, compute_lambda_returns
+    from models.diffusion import DiffusionSamplerConfig, SigmaDistributionConfig
+    from torch.distributions.categorical import Categorical
+    import torch.nn.functional as F
+
+    u8 = lambda x: x.add(1).div(2).mul(255).round().to(torch.uint8)
+    agent = ref_agent()
+    b, horizon, t = 4, 4, 6
+    env = WorldModelEnv(agent.denoiser, agent.rew_end_model, _FakeLoader(b, seed=21),
+                        WorldModelEnvConfig(horizon=horizon, num_batches_to_preload=2,
+                                            diffusion_sampler=DiffusionSamplerConfig(num_steps_denoising=3)))
+    log = {"reset_obs_u8": None, "steps": []}
+    orig_reset, orig_step = env.reset, env.step
+
+    def reset(**kw):
+        obs, info = orig_reset(**kw)
+        log["reset_obs_u8"] = u8(obs)
+        return obs, info
+
+    def step(act):
+        obs, rew, end, trunc, info = orig_step(act)
+        rec = {"obs_u8": u8(obs), "rew": rew.clone(), "end": end.clone(), "trunc": trunc.clone(), "act": act.clone()}
+        if "final_observation" in info:
+            rec["final_observation_u8"] = u8(info["final_observation"])
+            rec["burnin_obs_u8"] = u8(info["burnin_obs"])
+        log["steps"].append(rec)
+        return obs, rew, end, trunc, info
+
+    env.reset, env.step = reset, step
+    agent.setup_training(SigmaDistributionConfig(-0.4, 1.2, 2e-3, 20),
+                         ActorCriticLossConfig(backup_every=t, gamma=0.985, lambda_=0.95, weight_value_loss=1.0,
+                                               weight_entropy_loss=0.001), env)
+    torch.manual_seed(1234)
+    random.seed(0)
+    out = {"b": b, "horizon": horizon, "backup_every": t, "rng_seed": 1234, "windows": []}
+    ac = agent.actor_critic
+    for _ in range(2):
+        ac.zero_grad()
+        n0 = len(log["steps"])
+        all_obs, act, rew, end, trunc, logits_act, val, val_bootstrap, _ = ac.env_loop.send(t)
+        c = ac.loss_cfg
+        d = Categorical(logits=logits_act)
+        lam = compute_lambda_returns(rew, end, trunc, val_bootstrap, c.gamma, c.lambda_)
+        loss = (-d.log_prob(act) * (lam - val).detach()).mean() + c.weight_value_loss * F.mse_loss(val, lam) \
+            - c.weight_entropy_loss * d.entropy().mean()
+        loss.backward()
+        grads = {k: p.grad.clone() for k, p in ac.named_parameters()}
+        out["windows"].append({
+            "steps": log["steps"][n0:], "act": act, "logits_act": logits_act.detach(), "val": val.detach(),
+            "val_bootstrap": val_bootstrap, "loss": loss.detach(),
+            "grad_norms": {k: v.norm() for k, v in grads.items()},
+            # whole tensors up to 40k elements (all conv / GroupNorm / head parameters), every 97th element of the LSTM matrices
+            "grads": {k: (v if v.numel() <= 40000 else v.flatten()[::97].clone()) for k, v in grads.items()},
+        })
+        print("teacher-forced window: loss", float(loss), "resets", sum("burnin_obs_u8" in s for s in log["steps"][n0:]))
+    out["reset_obs_u8"] = log["reset_obs_u8"]
+    save("window_tf.pt", out)
+
+
 def main():
+    if "--window-tf" in sys.argv:  # add this fixture without regenerating the others
+        gen_window_teacher_forced()
+        return
     agent = ref_agent()
     save("state_dict_keys.pt", {k: tuple(v.shape) for k, v in agent.state_dict().items()})
     gen_denoiser(agent, "default")
@@ -196,6 +265,7 @@ def main():
     gen_rew_end(agent)
     gen_actor_critic(agent)
     gen_window()
+    gen_window_teacher_forced()
     # attention at 16x16 and 8x8 inside the U-Net (BASELINE config 5 uses attn_depths=[0,0,1,1])
     gen_denoiser(ref_agent(denoiser_attn_depths=(0, 0, 1, 1)), "attn0011", b=1)
 

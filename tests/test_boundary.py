@@ -109,7 +109,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     for sym in sorted(declared):
         assert hasattr(lib, sym), f"{sym} declared in include/diamond_hip.h but not exported"
     assert set(native.EXPORTS) == declared
-    assert lib.dmd_abi_version() == 2
+    assert lib.dmd_abi_version() == 3
     assert lib.dmd_conv_stat_tiles(64, 64) == 32 and lib.dmd_conv_stat_tiles(8, 8) == 1
 
 
@@ -130,3 +130,43 @@ def test_struct_layouts_match_the_header():
     mine = [ctypes.sizeof(t) for t in (native.Norm, native.ConvSrc, native.ConvParams, native.LinearParams, native.GnBwdParams,
                                      native.WgradParams)]
     assert sizes == mine
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="the reference tree only exists in the build container")
+def test_reference_configure_opt_and_agent_load_accept_our_modules(tmp_path):
+    """The reference's OWN `utils.configure_opt` (utils.py:129-166) groups every parameter of our three models, and the
+    reference's own `Agent.load` reads a checkpoint written from our state dict (and vice versa) -- run in a child
+    process so that the reference's top-level module names (`agent`, `utils`, `models`, ...) stay out of this one."""
+    import subprocess
+    import sys
+
+    script = f"""
+import sys, torch
+sys.dont_write_bytecode = True
+sys.path.insert(0, {os.path.join(ROOT, 'tests', 'golden')!r}); sys.path.insert(0, {ROOT!r})
+import _refimport as R
+R.install()
+import diamond_amd as D
+from diamond_amd.testing import fill_module_
+from utils import configure_opt            # the reference's
+from agent import Agent as RefAgent        # the reference's
+mine = D.Agent(D.default_agent_config())
+fill_module_(mine, 3)
+for m in (mine.denoiser, mine.rew_end_model, mine.actor_critic):
+    opt = configure_opt(m, lr=1e-4, weight_decay=1e-2, eps=1e-8)
+    n = sum(p.numel() for g in opt.param_groups for p in g['params'])
+    assert n == sum(p.numel() for p in m.parameters())
+path = {str(tmp_path / 'ckpt.pt')!r}
+torch.save(mine.state_dict(), path)
+ref = RefAgent(R.default_agent_config(num_actions=4))
+ref.load(path)                             # reference Agent.load on OUR checkpoint
+assert all(torch.equal(a, b) for a, b in zip(ref.state_dict().values(), mine.state_dict().values()))
+fill_module_(ref, 9)
+torch.save(ref.state_dict(), path)
+mine.load(path)                            # our Agent.load on the REFERENCE's checkpoint
+assert all(torch.equal(a, b) for a, b in zip(ref.state_dict().values(), mine.state_dict().values()))
+print('ok')
+"""
+    out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-3000:]

@@ -1,5 +1,7 @@
-"""world_size-2 gloo test of the gradient all-reduce path (CPU): the mean of the two ranks'
-actor-critic gradients equals the gradient of the mean loss over the concatenated batch."""
+"""world_size-2 and -4 gloo tests of the data-parallel path (CPU): parameter broadcast (and that it invalidates the
+packed-weight caches), the flat-bucket gradient all-reduce -- the mean of the ranks' actor-critic gradients equals the
+gradient of the mean loss over the concatenated batch --, bucket views surviving zero_grad(set_to_none=True), and
+the replica checksum bench.py asserts."""
 import os
 import sys
 
@@ -19,11 +21,20 @@ def _worker(rank, world, port, q):
     from diamond_amd.dist import GradAllReducer, broadcast_parameters
     from diamond_amd.testing import fill_module_, synthetic_frames
 
+    from diamond_amd.dist import parameter_checksum
+
     torch.manual_seed(rank)  # different default init per rank: broadcast must fix it
     ac = D.ActorCritic(D.default_agent_config().actor_critic)
     if rank == 0:
         fill_module_(ac, 5)
+    versions = [p._version for p in ac.parameters()]
     broadcast_parameters(ac)
+    # the broadcast must bump Tensor._version: packed kernel-layout copies are cached per parameter version
+    bumped = all(p._version > v for p, v in zip(ac.parameters(), versions))
+    cs = torch.tensor([parameter_checksum(ac)], dtype=torch.float64)
+    all_cs = [torch.zeros_like(cs) for _ in range(world)]
+    dist.all_gather(all_cs, cs)
+    same_params = all(float(c) == float(all_cs[0]) for c in all_cs)
     # The product's kernels need a GPU; this CPU test exercises the host-side collective logic only, so the
     # gradients come from the CPU oracle (test infrastructure) evaluated on the module's own Parameters.
     from oracle import diamond_oracle as O
@@ -35,11 +46,17 @@ def _worker(rank, world, port, q):
 
     red = GradAllReducer(list(ac.parameters()))
     g = torch.Generator().manual_seed(40)
-    obs_all = synthetic_frames(g, 4, 3, 64, 64)
+    obs_all = synthetic_frames(g, 2 * world, 3, 64, 64)
     obs = obs_all[rank * 2:(rank + 1) * 2]
+    # a first backward, then zero_grad(set_to_none=True): the reducer must re-attach its bucket views
     logits, val = predict(ac, obs)
     (logits.square().mean() + val.mean()).backward()
+    ac.zero_grad(set_to_none=True)
+    logits, val = predict(ac, obs)
+    (logits.square().mean() + val.mean()).backward()  # autograd allocates fresh .grad tensors outside the bucket
     flat = red.all_reduce_mean().clone()
+    views_ok = all(p.grad.data_ptr() >= red.bucket.data_ptr() and
+                   p.grad.data_ptr() < red.bucket.data_ptr() + red.bucket.numel() * 4 for p in ac.parameters())
     if rank == 0:
         # single-process reference over the whole batch
         ac2 = D.ActorCritic(D.default_agent_config().actor_critic)
@@ -48,16 +65,20 @@ def _worker(rank, world, port, q):
         (logits.square().mean() + val.mean()).backward()
         ref = torch.cat([p.grad.reshape(-1) for p in ac2.parameters()])
         q.put(float((flat - ref).abs().max() / ref.abs().max()))
-        q.put(all(p.grad.data_ptr() != 0 for p in ac.parameters()))
+        q.put(bool(views_ok and bumped and same_params))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_grad_allreduce_world2_gloo():
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_grad_allreduce_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 1000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() + 17 * world) % 1000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     import queue

@@ -1,0 +1,125 @@
+"""WorldModelEnv's device data structures on a real MI355X: the uint8 initial-condition pool (quantise /
+gather-dequantise kernels) and the ring-indexed context, checked against a roll-based shadow that follows the
+reference's bookkeeping (envs/world_model_env.py:64-89) on the same imagined frames."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from tests.conftest import WEIGHT_SEED
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_quantize_u8_and_dequant_gather_bit_exact():
+    from diamond_amd import native as nv
+    from diamond_amd.testing import synthetic_frames
+
+    g = torch.Generator().manual_seed(0)
+    u8 = torch.randint(0, 256, (6, 4, 3, 16, 24), generator=g, dtype=torch.uint8)
+    frames = u8.float().div(255).mul(2).sub(1)  # Episode.load (data/episode.py:36-41)
+    fd = frames.to(DEV)
+    q = torch.empty(frames.shape, dtype=torch.uint8, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    nv.check(nv.lib().dmd_quantize_u8(nv.fptr(fd), nv.ptr(q), nv.ptr(flag), fd.numel(), nv.stream()), "quantize")
+    assert torch.equal(q.cpu(), u8) and int(flag.item()) == 0
+    # off-grid detection
+    fd2 = fd.clone()
+    fd2[3, 2, 1, 5, 7] += 1e-3
+    nv.check(nv.lib().dmd_quantize_u8(nv.fptr(fd2), nv.ptr(q), nv.ptr(flag), fd2.numel(), nv.stream()), "quantize")
+    assert int(flag.item()) == 1
+    # gather rows [4, 1, 5] of the pool into ring rows [2, 0, 3] with head 3: logical frame t -> slot (3 + t) % 4
+    nv.check(nv.lib().dmd_quantize_u8(nv.fptr(fd), nv.ptr(q), nv.ptr(flag), fd.numel(), nv.stream()), "quantize")
+    ring = torch.full((5, 4, 3, 16, 24), 7.0, device=DEV)
+    idx = torch.tensor([4, 1, 5], device=DEV)
+    rows = torch.tensor([2, 0, 3], device=DEV)
+    nv.check(nv.lib().dmd_dequant_gather(nv.ptr(q), nv.ptr(idx), nv.ptr(rows), nv.fptr(ring), 3, 4, 3 * 16 * 24, 3, nv.stream()),
+             "gather")
+    ring = ring.cpu()
+    for i, r in zip((4, 1, 5), (2, 0, 3)):
+        for t in range(4):
+            assert torch.equal(ring[r, (3 + t) % 4], frames[i, t])
+    assert float(ring[1].min()) == 7.0 and float(ring[4].min()) == 7.0  # untouched rows
+
+
+class _Loader:
+    def __init__(self, b, batches):
+        self.batch_sampler = SimpleNamespace(batch_size=b)
+        self._batches = batches
+
+    def __iter__(self):
+        i = 0
+        while True:
+            obs, act = self._batches[i % len(self._batches)]
+            i += 1
+            yield SimpleNamespace(obs=obs, act=act)
+
+
+@pytest.mark.parametrize("on_grid", [True, False])
+def test_ring_context_matches_roll_based_shadow(on_grid):
+    """Drive the env for 9 steps (horizon 3 -> every env resets, at different times once `end` fires) and keep a
+    shadow that rolls / overwrites like the reference does, fed with the env's own imagined frames: contexts,
+    action buffers, returned observations, final observations and burn-in frames must be identical."""
+    import diamond_amd as D
+    from diamond_amd.testing import fill_module_, synthetic_actions, synthetic_frames
+
+    agent = D.Agent(D.default_agent_config())
+    fill_module_(agent, WEIGHT_SEED)
+    agent = agent.to(DEV).eval()
+    b = 3
+    g = torch.Generator().manual_seed(5)
+    batches = []
+    for _ in range(4):
+        obs = synthetic_frames(g, b, 4, 3, 64, 64)
+        if not on_grid:
+            obs = (obs + (torch.rand(obs.shape, generator=g) - 0.5) * 1e-3).clamp(-1, 1)
+        batches.append((obs, synthetic_actions(g, 4, b, 4)))
+    env = D.WorldModelEnv(agent.denoiser, agent.rew_end_model, _Loader(b, batches),
+                          D.WorldModelEnvConfig(horizon=3, num_batches_to_preload=2,
+                                                diffusion_sampler=D.DiffusionSamplerConfig(num_steps_denoising=1)))
+    obs0, _ = env.reset()
+    assert (env.pool.frames_u8 is not None) == on_grid
+    pool_obs = torch.cat([batches[0][0], batches[1][0]]).to(DEV)
+    pool_act = torch.cat([batches[0][1], batches[1][1]]).to(DEV)
+    cursor = b
+    sh_obs, sh_act = pool_obs[:b].clone(), pool_act[:b].clone()
+    assert torch.equal(obs0, sh_obs[:, -1]) and torch.equal(env.obs_buffer, sh_obs) and torch.equal(env.act_buffer, sh_act)
+    captured = {}
+    inner = env.predict_next_obs
+
+    def spy():
+        out = inner()
+        captured["next_obs"] = out[0]
+        return out
+
+    env.predict_next_obs = spy  # also checks that the callable is re-assignable (trainer.py:182-184)
+    pools_seen = 1
+    for step in range(9):
+        act = torch.randint(0, 4, (b,), generator=g).to(DEV)
+        obs, rew, end, trunc, info = env.step(act)
+        nxt = captured["next_obs"]
+        # ---- shadow: the reference's bookkeeping
+        sh_act[:, -1] = act
+        sh_obs, sh_act = sh_obs.roll(-1, dims=1), sh_act.roll(-1, dims=1)
+        sh_obs[:, -1] = nxt
+        dead = torch.logical_or(end, trunc)
+        if dead.any():
+            nd = int(dead.sum())
+            if cursor + nd > pool_obs.shape[0]:  # pool exhausted: the next preload round replaces it
+                pool_obs = torch.cat([batches[(2 * pools_seen) % 4][0], batches[(2 * pools_seen + 1) % 4][0]]).to(DEV)
+                pool_act = torch.cat([batches[(2 * pools_seen) % 4][1], batches[(2 * pools_seen + 1) % 4][1]]).to(DEV)
+                pools_seen += 1
+                cursor = 0
+            sh_obs[dead] = pool_obs[cursor:cursor + nd]
+            sh_act[dead] = pool_act[cursor:cursor + nd]
+            cursor += nd
+            assert torch.equal(info["final_observation"], nxt[dead])
+            assert torch.equal(info["burnin_obs"], sh_obs[dead, :-1])
+        else:
+            assert "final_observation" not in info
+        assert torch.equal(obs, sh_obs[:, -1]), f"step {step}: returned observation"
+        assert torch.equal(env.obs_buffer, sh_obs), f"step {step}: context ring != rolled shadow"
+        # the newest action slot is written by the NEXT step (like the reference's act_buffer[:, -1])
+        assert torch.equal(env.act_buffer[:, :-1], sh_act[:, :-1]), f"step {step}: action ring"
+    assert pools_seen >= 1

@@ -240,9 +240,19 @@ def test_edm_pointwise_bit_exact():
         # pack
         packed = torch.empty(n, h, w, 16, device=DEV)
         nv.check(nv.lib().dmd_edm_pack_input(nv.fptr(xd), nv.fptr(obsd), nv.fptr(cond), stride, 0.5,
-                                             nv.fptr(packed), n, 3, 12, h, w, 16, nv.stream()), "pack")
+                                             nv.fptr(packed), n, 3, 12, h, w, 16, 1, 0, nv.stream()), "pack")
         ref = torch.cat((obs / 0.5, x * c_in, torch.zeros(n, 1, h, w)), 1).permute(0, 2, 3, 1)
         assert torch.equal(packed.cpu(), ref), "edm_pack_input is not bit-exact"
+        # ring-indexed context: physical slot (head + t) % T holds logical frame t
+        for head in (1, 3):
+            ring = torch.empty(n, 4, 3, h, w)
+            for t in range(4):
+                ring[:, (head + t) % 4] = obs.reshape(n, 4, 3, h, w)[:, t]
+            ringd = ring.to(DEV)
+            packed2 = torch.empty(n, h, w, 16, device=DEV)
+            nv.check(nv.lib().dmd_edm_pack_input(nv.fptr(xd), nv.fptr(ringd), nv.fptr(cond), stride, 0.5,
+                                                 nv.fptr(packed2), n, 3, 12, h, w, 16, 4, head, nv.stream()), "pack ring")
+            assert torch.equal(packed2.cpu(), ref), f"ring-indexed edm_pack_input (head {head}) is not bit-exact"
         # denoised
         den = torch.empty(n, 3, h, w, device=DEV)
         nv.check(nv.lib().dmd_edm_denoised(nv.fptr(xd), nv.fptr(fd), nv.fptr(cond), stride, nv.fptr(den), n,
@@ -259,6 +269,16 @@ def test_edm_pointwise_bit_exact():
                                      x.numel(), nv.stream()), "euler")
     ref_x = x + (x - den) / s * (nx - s)
     assert torch.equal(out.cpu(), ref_x), "euler_step is not bit-exact"
+    # heun combine (diffusion_sampler.py:52-56), same op order
+    den2 = O.quantize_frame(torch.randn(n, 3, h, w, generator=g))
+    d = (x - den) / s
+    d_2 = (ref_x - den2) / nx
+    ref_h = x + (d + d_2) / 2 * (nx - s)
+    out_h = torch.empty(n, 3, h, w, device=DEV)
+    x2d, den2d = ref_x.to(DEV), den2.to(DEV)
+    nv.check(nv.lib().dmd_heun_step(nv.fptr(xd), nv.fptr(dend), nv.fptr(x2d), nv.fptr(den2d), float(s), float(nx),
+                                    float(nx - s), nv.fptr(out_h), x.numel(), nv.stream()), "heun")
+    assert torch.equal(out_h.cpu(), ref_h), "heun_step is not bit-exact"
 
 
 def test_cond_embed():
@@ -278,8 +298,18 @@ def test_cond_embed():
     cond[:, 3] = c_noise
     cd, fwd, actd, embd = cond.to(DEV), fw.to(DEV), act.to(DEV), emb.to(DEV)
     nv.check(nv.lib().dmd_cond_embed(nv.fptr(cd), 4, nv.fptr(fwd), nv.ptr(actd),
-                                     nv.fptr(embd), nv.fptr(out), n, 128, 4, 64, nv.stream()), "cond")
+                                     nv.fptr(embd), nv.fptr(out), n, 128, 4, 64, 0, 4, nv.stream()), "cond")
     assert float((out.cpu() - ref).abs().max()) < 2e-6
+    # ring-indexed actions: logical step t at column (head + t) % T
+    head = 2
+    ring = torch.empty_like(act)
+    for t in range(4):
+        ring[:, (head + t) % 4] = act[:, t]
+    out2 = torch.empty(n, 256, device=DEV)
+    ringd = ring.to(DEV)
+    nv.check(nv.lib().dmd_cond_embed(nv.fptr(cd), 4, nv.fptr(fwd), nv.ptr(ringd), nv.fptr(embd), nv.fptr(out2), n, 128, 4,
+                                     64, head, 4, nv.stream()), "cond ring")
+    assert torch.equal(out2, out)
 
 
 def test_categorical_sample_bit_exact():

@@ -190,11 +190,15 @@ def test_actor_critic_vs_golden(agent):
                       (o2.hx_cx[0], "hx2"), (o2.hx_cx[1], "cx2")):
         assert rel_err(mine.detach(), gold[key]) < 1e-4, key
     assert rel_err(loss.detach(), gold["loss"]) < 1e-4
+    errs = {}
     for k, p in ac.named_parameters():
         n = float(gold["grad_norms"][k])
-        assert abs(float(p.grad.norm()) - n) <= 2e-4 * n + 1e-6, k
+        errs[k + " |norm|"] = abs(float(p.grad.norm()) - n) / (n + 1e-30)
     for k, gr in gold["grads_small"].items():
-        assert rel_err(dict(ac.named_parameters())[k].grad, gr) < 2e-4, k
+        errs[k] = rel_err(dict(ac.named_parameters())[k].grad, gr)
+    print("actor-critic gradient rel errs:", {k: f"{v:.2e}" for k, v in errs.items()})
+    bad = {k: v for k, v in errs.items() if v >= 1e-4}  # north_star tolerance
+    assert not bad, bad
 
 
 class _Loader:
@@ -253,6 +257,77 @@ def test_full_window_vs_reference_golden():
         for k, p in ac.named_parameters():
             n = float(w["grad_norms"][k])
             assert abs(float(p.grad.norm()) - n) <= 2e-2 * n + 1e-6, k
+
+
+class _ReplayEnv:
+    """Teacher forcing: replays what the REFERENCE's WorldModelEnv handed to env_loop (tests/golden/window_tf.pt),
+    consuming the default CPU generator exactly like the reference's env did so that the
+    action draws of env_loop stay aligned with the stream the reference consumed."""
+
+    def __init__(self, gold):
+        self.num_envs = gold["b"]
+        self._steps = [s for w in gold["windows"] for s in w["steps"]]
+        self._reset_obs = gold["reset_obs_u8"]
+        self._i = 0
+        self.acts = []
+
+    @staticmethod
+    def _f(u):
+        return u.float().div(255).mul(2).sub(1).to(DEV)
+
+    def reset(self, **kw):
+        return self._f(self._reset_obs), {}
+
+    def step(self, act):
+        rec = self._steps[self._i]
+        self._i += 1
+        self.acts.append(act.cpu())
+        b = self.num_envs
+        torch.randn(b, 3, 64, 64)                    # diffusion_sampler.py:36
+        torch.empty(b, 1, 3).exponential_(1)         # world_model_env.py:103
+        torch.empty(b, 1, 2).exponential_(1)         # :104
+        info = {}
+        if "final_observation_u8" in rec:
+            info["final_observation"] = self._f(rec["final_observation_u8"])
+            info["burnin_obs"] = self._f(rec["burnin_obs_u8"])
+        return self._f(rec["obs_u8"]), rec["rew"].to(DEV), rec["end"].to(DEV), rec["trunc"].to(DEV), info
+
+
+def test_window_teacher_forced_vs_reference_golden_1e4():
+    """Two whole BPTT windows of env_loop + ActorCritic (resets, burn-in with grad, dead-env bootstrap) fed with the
+    REFERENCE's frames: logits, values, bootstrap values, loss and every gradient within 1e-4 (north_star), sampled
+    actions bit-exact."""
+    import random
+    import diamond_amd as D
+    from diamond_amd.actor_critic import actor_critic_loss
+
+    gold = load_golden("window_tf.pt")
+    ag = make_agent()
+    env = _ReplayEnv(gold)
+    ac = ag.actor_critic
+    ac.setup_training(env, D.ActorCriticLossConfig(backup_every=gold["backup_every"], gamma=0.985, lambda_=0.95,
+                                                   weight_value_loss=1.0, weight_entropy_loss=0.001))
+    torch.manual_seed(gold["rng_seed"])
+    random.seed(0)
+    ac.expo_fn = lambda logits: torch.empty(logits.shape, dtype=torch.float32).exponential_(1)
+    for wi, w in enumerate(gold["windows"]):
+        ac.zero_grad()
+        _, act, rew, end, trunc, logits_act, val, vb, _ = ac.env_loop.send(gold["backup_every"])
+        assert torch.equal(act.cpu(), w["act"]), "sampled actions differ from the reference"
+        errs = {"logits_act": rel_err(logits_act.detach(), w["logits_act"]), "val": rel_err(val.detach(), w["val"]),
+                "val_bootstrap": rel_err(vb, w["val_bootstrap"])}
+        loss, _ = actor_critic_loss(logits_act, val, act, rew, end, trunc, vb, ac.loss_cfg)
+        errs["loss"] = rel_err(loss.detach(), w["loss"])
+        loss.backward()
+        for k, p in ac.named_parameters():
+            gref = w["grads"][k]
+            mine = p.grad if gref.shape == p.grad.shape else p.grad.flatten()[::97]
+            errs["grad " + k] = rel_err(mine, gref)
+            n = float(w["grad_norms"][k])
+            errs["|grad| " + k] = abs(float(p.grad.norm()) - n) / (n + 1e-30)
+        print(f"window {wi}:", {k: f"{v:.2e}" for k, v in errs.items()})
+        bad = {k: v for k, v in errs.items() if v >= 1e-4}
+        assert not bad, (wi, bad)
 
 
 def test_denoiser_256x256_attention_vs_oracle():

@@ -1,0 +1,255 @@
+"""Parity of the PRODUCTION launch configurations (BASELINE configs[1]: batch 256) on a real MI355X.
+
+The persistent conv kernels give each of the 256 workgroups `tiles_per_wg = ceil(tiles / 256)` tiles; the
+per-kernel cases of test_gpu_kernels.py all have `tiles_per_wg == 1`.  The cases here drive every
+`WsGeom` instance of conv_f16ws and conv1x1_stream with `tiles_per_wg >= 2` (tpw in the test ids): alternating
+consumer groups, sliced write-out under the other group's MFMAs, rotated tile walk, table-slot rotation
+across images.  Checks per case:
+  (1) a sampled subset of images against the float64 torch-CPU evaluation of the same op (2e-5 relative);
+  (2) the same images run as an N=2 launch (tiles_per_wg == 1) must be BITWISE identical, including the
+      GroupNorm partial statistics -- the result of an image may not depend on where its tiles fall in the walk.
+Model level: Denoiser / RewEndModel / ActorCritic encoder (+ backward) at batch 256 against the CPU oracle on
+sampled envs (convolutions and GroupNorm are per image, so the oracle only needs those images).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.conftest import WEIGHT_SEED, load_golden, make_oracle_agent
+from tests.test_gpu_kernels import gn_ref, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+NCU = 256
+
+
+def _tiles(n, ho, wo, cout_pad, taps, stream_1x1):
+    """tiles and tiles_per_wg of the launch dmd_conv2d picks (mirrors dmd_launch_conv_f16ws / launch1x1s)."""
+    if stream_1x1:
+        return None
+    b8 = wo % 16 != 0
+    if cout_pad == 64:
+        tiles = (n * (ho // 8) * (wo // 8) + 3) // 4 if b8 else n * (ho // 16) * (wo // 16)
+    else:
+        tiles = (n * (ho // 8) * (wo // 8) + 7) // 8 if b8 else (n * (ho // 16) * (wo // 16) + 1) // 2
+    return tiles, (tiles + NCU - 1) // NCU
+
+
+TPW_CASES = [
+    # name, N, H, W (input spatial), [Cin...], Cout, taps, upsample, prologue, residual, head(NCHW 3-channel)
+    ("tpw16_c64_64x64_N256_res", 256, 64, 64, [64], 64, 9, False, 1, True, False),
+    ("tpw3_cat128_64x64_N41_odd", 41, 64, 64, [64, 64], 64, 9, False, 1, False, False),
+    ("tpw4_cat128_32x32_N256_res", 256, 32, 32, [64, 64], 64, 9, False, 1, True, False),
+    ("tpw16_up_32to64_N256", 256, 32, 32, [64], 64, 9, True, 0, False, False),
+    ("tpw2_c64_16x16_N300", 300, 16, 16, [64], 64, 9, False, 1, True, False),
+    ("tpw2_c64_8x8_N1100_B8", 1100, 8, 8, [64], 64, 9, False, 1, True, False),
+    ("tpw2_cat128_8x8_N1031_B8_odd", 1031, 8, 8, [64, 64], 64, 9, False, 1, False, False),
+    ("tpw8_c32_64x64_N256_res", 256, 64, 64, [32], 32, 9, False, 1, True, False),
+    ("tpw2_c32_16x16_N768_burnin", 768, 16, 16, [32], 32, 9, False, 1, True, False),
+    ("tpw2_c32_8x8_N2100_B8", 2100, 8, 8, [32], 32, 9, False, 1, True, False),
+    ("tpw8_c16to32_64x64_N256_convin", 256, 64, 64, [16], 32, 9, False, 0, False, False),
+    ("tpw16_c16to64_64x64_N256_convin", 256, 64, 64, [16], 64, 9, False, 0, False, False),
+    ("tpw8_head64to3_nchw_64x64_N256", 256, 64, 64, [64], 3, 9, False, 1, False, True),
+    ("tpw4_c64to32_32x32_N511_odd", 511, 32, 32, [64], 32, 9, False, 0, False, False),
+    ("tpw4_1x1ws_c64_32x32_N256_prologue_res", 256, 32, 32, [64], 64, 1, False, 1, True, False),
+    ("tpw2_1x1ws_c32to64_16x16_N300", 300, 16, 16, [32], 64, 1, False, 1, False, False),
+    ("stream1x1_cat128_64x64_N256", 256, 64, 64, [64, 64], 64, 1, False, 0, False, False),
+    ("stream1x1_c64_32x32_N300", 300, 32, 32, [64], 64, 1, False, 0, False, False),
+    ("stream1x1_c32_32x32_N257_odd", 257, 32, 32, [32], 64, 1, False, 0, False, False),
+]
+
+
+def _run(E, nv, xs, prologue, mul, add, cin, wgt, bias, cout, taps, up, res, head, precision_f16):
+    srcs, c0 = [], 0
+    for x in xs:
+        c = x.shape[3]
+        a = E.gn_stats(x) if (prologue and c % 32 == 0) else E.Act(x)
+        spec = E.NormSpec(mul=mul[:, c0:], add=add[:, c0:], mul_stride=cin, add_stride=cin, plus_one=True) if prologue else None
+        srcs.append((a, prologue, spec))
+        c0 += c
+    if head:
+        wp32 = torch.zeros(32, cin, 3, 3, device=DEV)
+        wp32[:cout] = wgt
+        return E.conv2d(srcs, nv.pack_conv_weight(wgt, 32), nv.pad_vector(bias, 32), cout, want_stats=False, out_nchw=True,
+                        cout_padded=32, w_f16=nv.pack_conv_weight_f16x2(wp32))
+    r_act = E.Act(res) if res is not None else None
+    stream = taps == 1 and prologue == 0 and res is None
+    w16 = None if stream else nv.pack_conv_weight_f16x2(wgt)
+    return E.conv2d(srcs, nv.pack_conv_weight(wgt), nv.pad_vector(bias, nv.cout_pad(cout)), cout, taps=taps, upsample=up,
+                    residual=r_act, want_stats=(cout % 32 == 0) and not stream, w_f16=w16, fast_math=precision_f16)
+
+
+@pytest.mark.parametrize("case", TPW_CASES, ids=[c[0] for c in TPW_CASES])
+@pytest.mark.parametrize("precision", ["f16x2", "f32"])
+def test_conv2d_production_tiles_per_wg(case, precision):
+    from diamond_amd import engine as E, native as nv
+
+    name, n, h, w, cins, cout, taps, up, prologue, use_res, head = case
+    stream = taps == 1 and prologue == 0 and not use_res
+    if precision == "f32" and not stream:
+        pytest.skip("exact-fp32 arm only exists for the streaming 1x1 kernel here (conv_mfma is not persistent)")
+    cin = sum(cins)
+    k = 3 if taps == 9 else 1
+    ho, wo = (2 * h, 2 * w) if up else (h, w)
+    info = _tiles(n, ho, wo, 32 if head else cout, taps, stream)
+    if info is not None:
+        assert info[1] >= 2, f"{name}: case does not reach tiles_per_wg >= 2 ({info})"
+    g = torch.Generator(device=DEV).manual_seed(sum(map(ord, name)))
+    xs = [torch.randn(n, h, w, c, device=DEV, generator=g) * 1.5 + 0.3 for c in cins]
+    wgt = torch.randn(cout, cin, k, k, device=DEV, generator=g) / math.sqrt(cin * k * k)
+    bias = torch.randn(cout, device=DEV, generator=g) * 0.1
+    mul = torch.randn(n, cin, device=DEV, generator=g) * 0.3
+    add = torch.randn(n, cin, device=DEV, generator=g) * 0.3
+    res = torch.randn(n, ho, wo, cout, device=DEV, generator=g) if use_res else None
+    f16 = precision == "f16x2"
+    out = _run(E, nv, xs, prologue, mul, add, cin, wgt, bias, cout, taps, up, res, head, f16)
+    torch.cuda.synchronize()
+
+    sample = sorted({0, 1, n // 3, n // 2, n - 2, n - 1})
+    # ---- (1) float64 truth on the sampled images
+    idx = torch.tensor(sample, device=DEV)
+    parts, c0 = [], 0
+    for x, c in zip(xs, cins):
+        y = x[idx].double().cpu().permute(0, 3, 1, 2)
+        if prologue:
+            sc, sh = mul[idx, c0:c0 + c].double().cpu(), add[idx, c0:c0 + c].double().cpu()
+            y = gn_ref(y, max(1, c // 32)) * (1 + sc[:, :, None, None]) + sh[:, :, None, None]
+            if prologue == 1:
+                y = y * torch.sigmoid(y)
+        parts.append(y)
+        c0 += c
+    xin = torch.cat(parts, 1)
+    if up:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, wgt.double().cpu(), bias.double().cpu(), padding=1 if k == 3 else 0)
+    if res is not None:
+        ref = ref + res[idx].double().cpu().permute(0, 3, 1, 2)
+    got = out.t[idx] if head else out.t[idx].permute(0, 3, 1, 2)
+    err = rel_err(got, ref)
+    print(f"{name}/{precision}: tiles/tpw {info}, rel err vs fp64 on images {sample}: {err:.3e}")
+    assert err < 2e-5, f"{name}: rel err {err:.3e}"
+    if out.stats is not None:
+        st = out.stats[idx].cpu().sum(dim=2)
+        refg = ref.reshape(len(sample), cout // 32, -1)
+        assert rel_err(st[..., 1], refg.square().sum(-1)) < 2e-5
+
+    # ---- (2) bitwise against the same images launched as N = 2 (tiles_per_wg == 1)
+    for pair in ((sample[0], sample[-1]), (sample[2], sample[3])):
+        pi = torch.tensor(pair, device=DEV)
+        small = _run(E, nv, [x[pi].contiguous() for x in xs], prologue, mul[pi].contiguous(), add[pi].contiguous(), cin, wgt, bias,
+                     cout, taps, up, None if res is None else res[pi].contiguous(), head, f16)
+        torch.cuda.synchronize()
+        assert torch.equal(out.t[pi], small.t), f"{name}: images {pair} differ between the N={n} and the N=2 launch"
+        if out.stats is not None:
+            assert torch.equal(out.stats[pi], small.stats), f"{name}: statistics of images {pair} differ"
+
+
+# ------------------------------------------------------------------------------------------------------------
+# model level, batch 256
+# ------------------------------------------------------------------------------------------------------------
+SAMPLED_ENVS = [0, 77, 130, 255]
+
+
+def _agent():
+    import diamond_amd as D
+    from diamond_amd.testing import fill_module_
+
+    agent = D.Agent(D.default_agent_config())
+    fill_module_(agent, WEIGHT_SEED)
+    return agent.to(DEV).eval()
+
+
+def test_denoiser_batch256_tpw16_vs_oracle_sampled_envs():
+    """Denoiser.compute_model_output + denoise at B=256 (every 64x64-level conv walks 16 tiles per workgroup),
+    oracle on 4 sampled envs: 1e-4 relative on the pre-quantisation output, quantised frames on the oracle's
+    uint8 level except <= 3e-4 of the pixels one level off."""
+    from diamond_amd.testing import synthetic_actions, synthetic_frames
+    from oracle import diamond_oracle as O
+    from tests.test_gpu_models import check_quantised, u8
+
+    ag = _agent()
+    oa = make_oracle_agent()
+    g = torch.Generator().manual_seed(256)
+    b = 256
+    obs = synthetic_frames(g, b, 12, 64, 64)
+    act = synthetic_actions(g, 4, b, 4)
+    noise = torch.randn(b, 3, 64, 64, generator=g)
+    sigmas = O.build_sigmas(O.SamplerSpec())
+    s = torch.tensor(SAMPLED_ENVS)
+    for sigma in (sigmas[0], sigmas[2]):
+        x = noise * sigma + obs[:, -3:] * 0.5
+        f = ag.denoiser.compute_model_output(x.to(DEV), obs.to(DEV), act.to(DEV), sigma)
+        ref = O.model_output(oa.denoiser, oa.dspec, x[s], sigma, obs[s], act[s])
+        err = rel_err(f[s.to(DEV)], ref)
+        print(f"B=256 denoiser, sigma {float(sigma):.4f}: model_output rel err on envs {SAMPLED_ENVS}: {err:.3e}")
+        assert err < 1e-4, err
+        d = ag.denoiser.denoise(x.to(DEV), sigma, obs.to(DEV), act.to(DEV))
+        dref = O.denoise(oa.denoiser, oa.dspec, x[s], sigma, obs[s], act[s])
+        check_quantised(u8(d[s.to(DEV)]), u8(dref), max_frac=3e-4)
+        # the same envs as a B=4 launch (tiles_per_wg == 1 everywhere): same result within rounding of the FiLM GEMM
+        f4 = ag.denoiser.compute_model_output(x[s].to(DEV), obs[s].to(DEV), act[s].to(DEV), sigma)
+        assert rel_err(f[s.to(DEV)], f4) < 2e-6
+
+
+def test_rew_end_batch256_tpw_vs_oracle_sampled_envs():
+    """predict_rew_end at B=256: burn-in form (T=3 -> 768 images per conv launch) then the per-step form with the
+    carried LSTM state; oracle on 4 sampled envs (the model is per-env), 1e-4."""
+    from diamond_amd.testing import synthetic_actions, synthetic_frames
+    from oracle import diamond_oracle as O
+
+    ag = _agent()
+    oa = make_oracle_agent()
+    g = torch.Generator().manual_seed(257)
+    b = 256
+    obs = synthetic_frames(g, b, 4, 3, 64, 64)
+    act = synthetic_actions(g, 4, b, 4)
+    nxt = synthetic_frames(g, b, 1, 3, 64, 64)
+    m = ag.rew_end_model
+    od, ad = obs.to(DEV), act.to(DEV)
+    lr, le, hc = m.predict_rew_end(od[:, :-1], ad[:, :-1], od[:, 1:])
+    lr2, le2, hc2 = m.predict_rew_end(od[:, -1:], ad[:, -1:], nxt.to(DEV), hc)
+    s = torch.tensor(SAMPLED_ENVS)
+    rr, re_, rhc = O.rew_end_predict(oa.rew_end_model, oa.rspec, obs[s, :-1], act[s, :-1], obs[s, 1:])
+    rr2, re2, rhc2 = O.rew_end_predict(oa.rew_end_model, oa.rspec, obs[s, -1:], act[s, -1:], nxt[s], rhc)
+    sd = s.to(DEV)
+    for mine, ref, key in ((lr[sd], rr, "logits_rew"), (le[sd], re_, "logits_end"), (hc[0][:, sd], rhc[0], "hx"),
+                           (hc[1][:, sd], rhc[1], "cx"), (lr2[sd], rr2, "logits_rew_step"), (le2[sd], re2, "logits_end_step"),
+                           (hc2[0][:, sd], rhc2[0], "hx_step"), (hc2[1][:, sd], rhc2[1], "cx_step")):
+        e = rel_err(mine, ref)
+        print(f"B=256 rew/end {key}: {e:.3e}")
+        assert e < 1e-4, (key, e)
+
+
+def test_actor_critic_encoder_batch256_tpw_fwd_bwd_vs_oracle():
+    """ActorCritic.encode forward + every encoder parameter gradient at B=256 (the 64x64 convs walk 8 tiles per
+    workgroup, wgrad reduces over 256 images) against the CPU oracle under torch autograd on ALL 256 images;
+    upstream gradient at the scale the real loss produces (mean over B*T: ~1e-6)."""
+    import diamond_amd as D
+    from diamond_amd.testing import fill_module_, synthetic_frames
+    from oracle import diamond_oracle as O
+
+    agent = D.Agent(D.default_agent_config())
+    fill_module_(agent, 5)
+    ac = agent.actor_critic
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in ac.state_dict().items()}
+    g = torch.Generator().manual_seed(258)
+    b = 256
+    obs = synthetic_frames(g, b, 3, 64, 64)
+    wfeat = torch.randn(b, 1024, generator=g) / (b * 15)
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    ref = O.ac_encoder(sd, O.ActorCriticSpec(), obs).flatten(1)
+    (ref * wfeat).sum().backward()
+    ac = ac.to(DEV)
+    feat = ac.encode(obs.to(DEV))
+    (feat * wfeat.to(DEV)).sum().backward()
+    assert rel_err(feat.detach(), ref.detach()) < 1e-4
+    worst = {}
+    for k, p in ac.named_parameters():
+        if k.startswith("encoder."):
+            worst[k] = rel_err(p.grad, sd[k].grad)
+    print("B=256 encoder gradient rel errs:", {k: f"{v:.2e}" for k, v in worst.items()})
+    bad = {k: v for k, v in worst.items() if v >= 1e-4}
+    assert not bad, bad

@@ -1,30 +1,67 @@
-"""gpurun_out/pmc/{FETCH,WRITE}_SIZE.json -> profiles/pmc_traffic.json (bytes per launch per conv kernel).
+"""gpurun_out/pmc/{FETCH,WRITE}_SIZE.json -> profiles/<tag>_pmc_traffic.json and profiles/pmc_traffic.json
+(HBM bytes per launch per kernel, keyed by the rocprofv3 kernel name normalised exactly like
+dmd_conv2d_kernel_name() spells it, so bench.py finds its dominant kernel by name).
 
-Corrections (MI355X_MICROARCH.md, HBM section; re-checked here on a 1 GiB copy): FETCH_SIZE and
-WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads ->
-x2; WRITE_SIZE matched the known byte count 1:1."""
-import json, os, re, sys
+    python tools/pmc_to_profile.py r02a        (after `bash tools/pmc_collect.sh` on the GPU box)
+
+Corrections (MI355X_MICROARCH.md, HBM section; re-checked by the calibration copy in tools/pmc_target.py):
+FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads -> x2;
+WRITE_SIZE matches a known byte count 1:1.  The measured calibration factors are stored under "_calibration"."""
+import json
+import os
+import shutil
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-f = json.load(open(os.path.join(ROOT, "gpurun_out/pmc/FETCH_SIZE.json")))
-w = json.load(open(os.path.join(ROOT, "gpurun_out/pmc/WRITE_SIZE.json")))
-out = {}
-for name, fv in f.items():
-    m = re.search(r"conv_mfma_kernel<ConvGeom<(\d+), (true|false), (\d+), (\d+)>", name)
-    m2 = re.search(r"conv_f16w?s_kernel<(?:F16|Ws)Geom<(true|false)(?:, (\d))?(?:, (\d))?>", name)
-    if not m and not m2:
-        continue
-    if m2:
-        key = f"conv_f16s<{'B8' if m2.group(1) == 'true' else 'A16'},c{32 * int(m2.group(2) or 2)}{',1x1' if m2.group(3) == '1' else ''}>"
-    else:
-        key = f"conv_mfma<WN{m.group(1)},{'B' if m.group(2) == 'true' else 'A'},taps{m.group(3)},s{m.group(4)}>"
-    wv = w[name]
-    out[key] = {"launches": fv["launches"], "fetch_bytes_per_launch": fv["mean"] * 2 * 1024,
-                "write_bytes_per_launch": wv["mean"] * 1024,
-                "hbm_bytes_per_launch": fv["mean"] * 2 * 1024 + wv["mean"] * 1024,
-                "workload": "2 x Denoiser.denoise at B=256, 64x64 (tools/pmc_target.py), separate --pmc passes"}
-cp = "__amd_rocclr_copyBuffer"
-out["_calibration"] = {"kernel": cp, "known_bytes_read": 2 * 2 ** 30, "known_bytes_written": 2 * 2 ** 30,
-                       "FETCH_SIZE_total_KiB": f[cp]["total"], "WRITE_SIZE_total_KiB": w[cp]["total"],
-                       "fetch_factor": 2 * 2 ** 30 / (f[cp]["total"] * 1024), "write_factor": 2 * 2 ** 30 / (w[cp]["total"] * 1024)}
-json.dump(out, open(os.path.join(ROOT, "profiles/pmc_traffic.json"), "w"), indent=1)
-print(json.dumps(out, indent=1))
+
+
+def normalise(name: str) -> str:
+    """'void conv_f16ws_kernel<WsGeom<false, 2, 9> >(dmd_conv_params, int, int)' -> 'conv_f16ws_kernel<WsGeom<false, 2, 9>>'"""
+    n = name.strip()
+    if n.startswith("void "):
+        n = n[5:]
+    depth, cut = 0, len(n)
+    for i, ch in enumerate(n):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            cut = i
+            break
+    n = n[:cut].strip()
+    while "> >" in n:
+        n = n.replace("> >", ">>")
+    return n
+
+
+def main() -> None:
+    tag = sys.argv[1] if len(sys.argv) > 1 else "latest"
+    src = os.path.join(ROOT, "gpurun_out", "pmc")
+    f = json.load(open(os.path.join(src, "FETCH_SIZE.json")))
+    w = json.load(open(os.path.join(src, "WRITE_SIZE.json")))
+    out = {}
+    for name, fv in f.items():
+        if name not in w or not any(s in name for s in ("conv", "wgrad", "attention", "linear", "edm_", "gn_")):
+            continue
+        wv = w[name]
+        out[normalise(name)] = {
+            "launches": fv["launches"], "fetch_bytes_per_launch": fv["mean"] * 2 * 1024, "write_bytes_per_launch": wv["mean"] * 1024,
+            "hbm_bytes_per_launch": fv["mean"] * 2 * 1024 + wv["mean"] * 1024,
+            "workload": "2 x Denoiser.denoise at B=256, 64x64 (tools/pmc_target.py), separate --pmc passes", "profile_set": tag}
+    cp = "__amd_rocclr_copyBuffer"
+    if cp in f and cp in w:
+        out["_calibration"] = {"kernel": cp, "known_bytes_read": 2 * 2 ** 30, "known_bytes_written": 2 * 2 ** 30,
+                               "FETCH_SIZE_total_KiB": f[cp]["total"], "WRITE_SIZE_total_KiB": w[cp]["total"],
+                               "fetch_factor": 2 * 2 ** 30 / (f[cp]["total"] * 1024),
+                               "write_factor": 2 * 2 ** 30 / (w[cp]["total"] * 1024)}
+    dst = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
+    json.dump(out, open(dst, "w"), indent=1)
+    shutil.copyfile(dst, os.path.join(ROOT, "profiles", "pmc_traffic.json"))
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        shutil.copyfile(os.path.join(src, f"{c}.json"), os.path.join(ROOT, "profiles", f"{tag}_pmc_{c}.json"))
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
