@@ -90,6 +90,44 @@ __device__ __forceinline__ float ws_silu(float t) {
   return t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * t));
 }
 
+#ifndef WS_PIPE
+#define WS_PIPE 0  // 1: tap-level software pipeline of the fragment reads. Measured r02b: 5 % SLOWER than the compiler's tap-by-tap order (367 vs 350 us on the 64x64 residual conv)
+#endif
+
+// one tap's MFMA operands of a consumer wave: weight pieces (A) and the 4 pixel blocks' activation pieces (B)
+struct WsFrag {
+  h8 ah, al, bh[4], bl[4];
+};
+
+template <class G>
+__device__ __forceinline__ void ws_load_frag(const u32x4* buf, int tt, int wunit, const int (&pixbase)[4], const int (&posh)[3],
+                                             WsFrag& f) {
+  const int tap = tt;                     // index into the chunk's weights
+  const int win = G::TAPS == 9 ? tt : 4;  // window of the 3x3 patch geometry (4 = centre)
+  const int dy = win / 3, dx = win % 3;
+  const int toff = dy * G::PW + dx;
+  f.ah = __builtin_bit_cast(h8, buf[(tap * 2 + 0) * 2 * G::COUT + wunit]);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) f.bh[b] = __builtin_bit_cast(h8, buf[(pixbase[b] + toff) * 4 + posh[dx]]);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) f.bl[b] = __builtin_bit_cast(h8, buf[(pixbase[b] + toff) * 4 + (posh[dx] ^ 2)]);
+  f.al = __builtin_bit_cast(h8, buf[(tap * 2 + 1) * 2 * G::COUT + wunit]);
+}
+
+__device__ __forceinline__ void ws_mfma_frag(const WsFrag& f, f32x16 (&acc)[4]) {
+#pragma unroll
+  for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.bh[b], acc[b], 0, 0, 0);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah, f.bl[b], acc[b], 0, 0, 0);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al, f.bh[b], acc[b], 0, 0, 0);
+}
+
+// phase fence of the tap pipeline: nothing is scheduled across it, so the reads of tap t + 1 stay in the phase whose MFMAs
+// are tap t's (left alone, the scheduler sinks every read to just before its first use to save registers and the wave
+// stalls on each LDS round trip)
+__device__ __forceinline__ void ws_sched_tap(bool) { __builtin_amdgcn_sched_barrier(0); }
+
 template <class G>
 __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_params p, int ntiles, int tiles_per_wg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -475,7 +513,15 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
             v += rv[qd];
             *(f32x4*)(op + 8 * qd) = v;
             fs += (v[0] + v[1]) + (v[2] + v[3]);
-            fq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            // Sum of squares as an fma chain into its own register, NOT as in-place squares of v: with the squares
+            // written over v's registers (`v_mul_f32 v48, v48, v48` right behind the `global_store_dwordx4 v[48:51]`),
+            // a slice executed while the other consumer group's MFMAs run on the same SIMD lost one lane's
+            // contribution of a block now and then (sum and stored outputs exact, sum of squares short by ~16 values)
+            // -- found by tests/test_gpu_tpw.py (tiles_per_wg >= 2), reproduced and bisected in tools/debug/r02*.
+            fq = __builtin_fmaf(v[0], v[0], fq);
+            fq = __builtin_fmaf(v[1], v[1], fq);
+            fq = __builtin_fmaf(v[2], v[2], fq);
+            fq = __builtin_fmaf(v[3], v[3], fq);
           }
           const int slot = G::B8 ? (blk >> 1) : 0;
           ssum[slot] += (double)fs;
@@ -511,6 +557,27 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           for (int r = 0; r < 16; ++r) acc[blk][r] = 0.f;
         for (int ck = 0; ck < nchunks; ++ck, ++j) {
           const u32x4* buf = bufs + (j & 1) * G::BUF_UNITS;
+#if WS_PIPE
+          // Software pipeline over the taps: the 10 fragment reads of tap t + 1 are issued between the 12 MFMAs of tap t
+          // (two fragment sets), so an LDS round trip (100+ cycles under the producers' write bursts) is covered by a
+          // whole tap of matrix work (384 cycles) instead of stalling the wave before every MFMA group.  Per
+          // accumulator the products are still added in the order ah*bh, ah*bl, al*bh, tap by tap: results are
+          // bit-identical to the unpipelined loop.
+          constexpr int NT = (WS_ABL & 16) ? 0 : G::TAPS;
+          WsFrag fa, fb;
+          if (NT > 0) ws_load_frag<G>(buf, 0, wunit, pixbase, posh, fa);
+#pragma unroll
+          for (int tt = 0; tt < NT; tt += 2) {
+            if (tt + 1 < NT) ws_load_frag<G>(buf, tt + 1, wunit, pixbase, posh, fb);
+            ws_mfma_frag(fa, acc);
+            ws_sched_tap(tt + 1 < NT);
+            if (tt + 1 < NT) {
+              if (tt + 2 < NT) ws_load_frag<G>(buf, tt + 2, wunit, pixbase, posh, fa);
+              ws_mfma_frag(fb, acc);
+              ws_sched_tap(tt + 2 < NT);
+            }
+          }
+#else
 #pragma unroll
           for (int tt = 0; tt < ((WS_ABL & 16) ? 0 : G::TAPS); ++tt) {
             const int tap = tt;                       // index into the chunk's weights
@@ -539,6 +606,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
               acc[b1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[b1], acc[b1], 0, 0, 0);
             }
           }
+#endif
           __syncthreads();  // B(j + 1)
         }
         epi_begin(k);  // written out while the other group computes the next tile

@@ -119,7 +119,8 @@ def gen_actor_critic(agent):
     save("actor_critic.pt", {
         "seed": 14, "logits1": o1.logits_act.detach(), "val1": o1.val.detach(), "logits2": o2.logits_act.detach(),
         "val2": o2.val.detach(), "hx2": o2.hx_cx[0].detach(), "cx2": o2.hx_cx[1].detach(), "loss": loss.detach(),
-        "grad_norms": {k: v.norm() for k, v in grads.items()},
+        # norms accumulated in fp64: an fp32 norm over the 2M-element LSTM matrices is itself only good to ~1e-4
+        "grad_norms": {k: v.double().norm() for k, v in grads.items()},
         "grads_small": {k: v for k, v in grads.items() if v.numel() <= 20000},
     })
 
@@ -245,7 +246,7 @@ def gen_window_teacher_forced():
         out["windows"].append({
             "steps": log["steps"][n0:], "act": act, "logits_act": logits_act.detach(), "val": val.detach(),
             "val_bootstrap": val_bootstrap, "loss": loss.detach(),
-            "grad_norms": {k: v.norm() for k, v in grads.items()},
+            "grad_norms": {k: v.double().norm() for k, v in grads.items()},  # fp64 accumulation
             # whole tensors up to 40k elements (all conv / GroupNorm / head parameters), every 97th element of the LSTM matrices
             "grads": {k: (v if v.numel() <= 40000 else v.flatten()[::97].clone()) for k, v in grads.items()},
         })
@@ -255,8 +256,11 @@ def gen_window_teacher_forced():
 
 
 def main():
-    if "--window-tf" in sys.argv:  # add this fixture without regenerating the others
-        gen_window_teacher_forced()
+    if "--window-tf" in sys.argv or "--actor-critic" in sys.argv:  # (re)generate single fixtures
+        if "--window-tf" in sys.argv:
+            gen_window_teacher_forced()
+        if "--actor-critic" in sys.argv:
+            gen_actor_critic(ref_agent())
         return
     agent = ref_agent()
     save("state_dict_keys.pt", {k: tuple(v.shape) for k, v in agent.state_dict().items()})

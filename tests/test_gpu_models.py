@@ -193,7 +193,7 @@ def test_actor_critic_vs_golden(agent):
     errs = {}
     for k, p in ac.named_parameters():
         n = float(gold["grad_norms"][k])
-        errs[k + " |norm|"] = abs(float(p.grad.norm()) - n) / (n + 1e-30)
+        errs[k + " |norm|"] = abs(float(p.grad.double().norm()) - n) / (n + 1e-30)
     for k, gr in gold["grads_small"].items():
         errs[k] = rel_err(dict(ac.named_parameters())[k].grad, gr)
     print("actor-critic gradient rel errs:", {k: f"{v:.2e}" for k, v in errs.items()})
@@ -324,7 +324,7 @@ def test_window_teacher_forced_vs_reference_golden_1e4():
             mine = p.grad if gref.shape == p.grad.shape else p.grad.flatten()[::97]
             errs["grad " + k] = rel_err(mine, gref)
             n = float(w["grad_norms"][k])
-            errs["|grad| " + k] = abs(float(p.grad.norm()) - n) / (n + 1e-30)
+            errs["|grad| " + k] = abs(float(p.grad.double().norm()) - n) / (n + 1e-30)
         print(f"window {wi}:", {k: f"{v:.2e}" for k, v in errs.items()})
         bad = {k: v for k, v in errs.items() if v >= 1e-4}
         assert not bad, (wi, bad)

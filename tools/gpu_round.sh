@@ -10,7 +10,7 @@ mkdir -p $O
 cd $R
 export TMPDIR=/tmp
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
-  timeout 900 python -m pytest tests -m gpu -q -s -p no:cacheprovider ${PYTEST_ARGS:-} > $O/tests.log 2>&1
+  timeout 1100 python -m pytest tests -m gpu -q -s -p no:cacheprovider ${PYTEST_ARGS:-} > $O/tests.log 2>&1
   echo "pytest rc=$?" >> $O/tests.log
   tail -3 $O/tests.log
 fi
