@@ -38,19 +38,24 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-#define WS_TAB_SLOTS 4  // images whose tables can be alive at once
 
 // NCB = 32-output-channel blocks of the convolution (2: Cout = 64, the U-Net; 1: Cout = 32, the reward/end model and
 // the first actor-critic blocks).  The workgroup's consumer group is always 4 waves = NCB cout blocks x NPH pixel
 // halves of 128 pixels, so a Cout = 32 tile is 512 pixels (two 16x16 patches / eight 8x8 patches).
 // TAPS = 9 (3x3, pad 1) or 1 (1x1: the same halo'd patch geometry, only the centre window is loaded and read).
-template <bool B8_, int NCB_, int TAPS_ = 9>
+// JOINT: all 8 consumer waves work on ONE tile of twice the pixels (two 16x16 patches x 64 couts) instead of taking
+// alternate tiles: two MFMA waves per SIMD cover each other's LDS round trips, and a chunk's 36 KiB of weights (the
+// larger part of the LDS fill) is staged once per 512 pixels instead of once per 256.  The write-out of a finished tile
+// is then no longer hidden under the other group's MFMAs.
+template <bool B8_, int NCB_, int TAPS_ = 9, bool JOINT_ = false>
 struct WsGeom {
   static constexpr bool B8 = B8_;
   static constexpr int NCB = NCB_;
   static constexpr int TAPS = TAPS_;
+  static constexpr bool JOINT = JOINT_;
   static constexpr int COUT = 32 * NCB_;
-  static constexpr int NPH = 4 / NCB_;
+  static constexpr int NCW = JOINT_ ? 8 : 4;  // consumer waves per tile
+  static constexpr int NPH = NCW / NCB_;
   static constexpr int SUB = B8_ ? 2 * NPH : NPH / 2;
   static constexpr int TS = B8_ ? 8 : 16;
   static constexpr int PW = TS + 2;
@@ -61,9 +66,14 @@ struct WsGeom {
   static constexpr int WU = (W_UNITS + 255) / 256;          // units per producer thread
   static constexpr int BUF_UNITS = NPP * 4 + W_UNITS;       // one {patch, weights} buffer, 16-byte units
   static constexpr int CIN_MAX = NCB_ == 2 ? 128 : 64;
-  static constexpr int TAB_FLOATS = WS_TAB_SLOTS * SUB * CIN_MAX;
+  static constexpr int TAB_SLOTS = JOINT_ ? 3 : 4;  // tile generations whose tables can be alive at once (>= 3)
+  static constexpr int TAB_FLOATS = TAB_SLOTS * SUB * CIN_MAX;
   static constexpr int SMEM_BYTES = 2 * BUF_UNITS * 16 + 2 * TAB_FLOATS * 4;
-  static constexpr bool DOUBLE_STAGE = NCB_ == 2;           // two activation register sets only where they fit
+  static constexpr bool DOUBLE_STAGE = NCB_ == 2 && !JOINT_;          // two activation register sets only where they fit
+  // source pixel offsets of a tile cached in registers (one per item) or recomputed at every chunk: recomputing frees
+  // ITEMS registers (JOINT needs them) but costs ~18 VALU per item and chunk (measured r02e: 8x8 levels +25 %)
+  static constexpr bool CACHE_GOFF = !JOINT_;
+  static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
 };
 
 struct WsTile {
@@ -174,35 +184,41 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       const int py = rem / G::PW, px = rem - py * G::PW;
       ipos[it] = ok ? ((s << 16) | (py << 8) | px) : -1;
     }
-    int goff[G::ITEMS];   // source pixel index per item for tile `gk` (0 for items outside the image)
-    unsigned gzero = 0;   // bit it: item is conv zero padding / outside the tensor for tile `gk`
-    int gk = -1;
-    int tab_n[G::SUB];  // images whose tables are current, and their slot
+    int gk = -1;          // tile whose descriptors / tables are current
+    int tab_n[G::SUB];    // images whose tables are current, and their slot
 #pragma unroll
     for (int s2 = 0; s2 < G::SUB; ++s2) tab_n[s2] = -1;
     int tab_slot = -1;
+    WsTile ti[G::SUB];    // sub-tiles of tile gk (wave-uniform)
+    int goff[G::CACHE_GOFF ? G::ITEMS : 1];  // CACHE_GOFF: source pixel index per item for tile gk (0 outside the image)
+    unsigned gzero = 0;                      // CACHE_GOFF: bit it = item is conv zero padding / outside the tensor
     const u32x4* wglob = (const u32x4*)p.w_f16;
+    auto item_source = [&](int it, bool& inb) -> int {
+      const int s = ipos[it] >> 16, py = (ipos[it] >> 8) & 0xff, px = ipos[it] & 0xff;
+      WsTile t = ti[0];
+#pragma unroll
+      for (int kk = 1; kk < G::SUB; ++kk)
+        if (s == kk) t = ti[kk];
+      const int iy = t.y0 - 1 + py, ix = t.x0 - 1 + px;
+      const bool window = G::TAPS == 9 || (py >= 1 && py <= G::TS && px >= 1 && px <= G::TS);  // 1x1: no halo needed
+      inb = ipos[it] >= 0 && window && t.valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      return inb ? ((t.n * Hs + (iy >> up)) * Ws + (ix >> up)) : 0;
+    };
 
-    auto setup_tile = [&](int k) {  // goff + normalisation tables of tile k (slot k & 3)
+    auto setup_tile = [&](int k) {  // descriptors + normalisation tables of tile k
       const int tile = WS_TILE(k);
-      WsTile ti[G::SUB];
 #pragma unroll
       for (int s = 0; s < G::SUB; ++s) ti[s] = ws_subtile<G>(p, tile, s);
-      unsigned gz = 0;
+      if (G::CACHE_GOFF) {
+        unsigned gz = 0;
 #pragma unroll
-      for (int it = 0; it < G::ITEMS; ++it) {
-        const int s = ipos[it] >> 16, py = (ipos[it] >> 8) & 0xff, px = ipos[it] & 0xff;
-        WsTile t = ti[0];
-#pragma unroll
-        for (int kk = 1; kk < G::SUB; ++kk)
-          if (s == kk) t = ti[kk];
-        const int iy = t.y0 - 1 + py, ix = t.x0 - 1 + px;
-        const bool window = G::TAPS == 9 || (py >= 1 && py <= G::TS && px >= 1 && px <= G::TS);  // 1x1: no halo needed
-        const bool inb = ipos[it] >= 0 && window && t.valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        goff[it] = inb ? ((t.n * Hs + (iy >> up)) * Ws + (ix >> up)) : 0;
-        gz |= (inb ? 0u : 1u) << it;
+        for (int it = 0; it < G::ITEMS; ++it) {
+          bool inb;
+          goff[G::CACHE_GOFF ? it : 0] = item_source(it, inb);
+          gz |= (inb ? 0u : 1u) << it;
+        }
+        gzero = gz;
       }
-      gzero = gz;
       // tables: all tiles of one image share them -- rebuild only when an image of the tile changes
       bool rebuild = false;
 #pragma unroll
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         rebuild |= nn != tab_n[s2];
         tab_n[s2] = nn;
       }
-      if (rebuild) tab_slot = (tab_slot + 1) & (WS_TAB_SLOTS - 1);
+      if (rebuild) tab_slot = tab_slot + 1 >= G::TAB_SLOTS ? 0 : tab_slot + 1;
       if (rebuild && tid < C0 + C1) {  // one channel per thread; visible to the other producers after the next barrier
         const int c = tid;
         const int si = c < C0 ? 0 : 1;
@@ -240,19 +256,24 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       const int c0 = (si ? ck - nch0 : ck) * 16 + 4 * q;
       const f32x4* base4 = (const f32x4*)sc.x + (c0 >> 2);  // 16-byte units: index = pixel * (C / 4)
       const unsigned cq = (unsigned)sc.C >> 2;
+      unsigned gz = gzero;
 #pragma unroll
       for (int it = 0; it < G::ITEMS; ++it) {
-        const int go = goff[it];
+        int go;
+        if (G::CACHE_GOFF) {
+          go = goff[G::CACHE_GOFF ? it : 0];
+        } else {
+          bool inb;
+          go = item_source(it, inb);
+          gz |= (inb ? 0u : 1u) << it;
+        }
 #if WS_ABL & 2
         st[it] = (f32x4){(float)go, 1.f, 2.f, (float)c0};
-#elif WS_ABL & 8
-        // timing proxy (wrong data): same number of 16-byte loads, but 8 consecutive lanes cover one FULL 128-byte line
-        st[it] = *(const f32x4*)(sc.x + (size_t)(go & ~1) * sc.C + ((go & 1) * 16 + 4 * q + (c0 & 32)));
 #else
         st[it] = base4[(unsigned)go * cq];
 #endif
       }
-      zmask = gzero;
+      zmask = gz;
     };
     // normalise / activate / split element e from its register set into patch buffer e & 1
     // mode (wave-uniform, hoisted out of the item loop as a compile-time tag): 0 = no prologue, 1 = norm, 2 = norm + SiLU
@@ -318,22 +339,59 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     f32x4 stage0[G::ITEMS], stage1[G::DOUBLE_STAGE ? G::ITEMS : 1];
     unsigned zm0 = 0, zm1 = 0;
     int sl0 = 0, sl1 = 0;
-    u32x4 wst[G::WU];
-    auto load_W = [&](int e) {
+#ifndef WS_WPF
+#define WS_WPF 0  // 1: weights fetched TWO steps ahead through two register sets (double-stage geometries only)
+#endif
+    constexpr bool WPF2 = WS_WPF && G::DOUBLE_STAGE;
+    u32x4 wst[G::WU], wst2[WPF2 ? G::WU : 1];
+    auto load_Wr = [&](int e, auto& ws) {
       const int ck = e % nchunks;
       const u32x4* w = wglob + (size_t)ck * G::W_UNITS + tid;
 #pragma unroll
       for (int i = 0; i < G::WU; ++i)
-        if (G::W_UNITS % 256 == 0 || tid + 256 * i < G::W_UNITS) wst[i] = w[256 * i];
+        if (G::W_UNITS % 256 == 0 || tid + 256 * i < G::W_UNITS) ws[i] = w[256 * i];
     };
-    auto store_W = [&](int e) {
+    auto store_Wr = [&](int e, const auto& ws) {
       u32x4* wl = bufs + (e & 1) * G::BUF_UNITS + G::NPP * 4;
 #pragma unroll
       for (int i = 0; i < G::WU; ++i)
-        if (G::W_UNITS % 256 == 0 || tid + 256 * i < G::W_UNITS) wl[tid + 256 * i] = wst[i];
+        if (G::W_UNITS % 256 == 0 || tid + 256 * i < G::W_UNITS) wl[tid + 256 * i] = ws[i];
     };
+    auto load_W = [&](int e) { load_Wr(e, wst); };
+    auto store_W = [&](int e) { store_Wr(e, wst); };
 
-    if (G::DOUBLE_STAGE) {
+    if (G::DOUBLE_STAGE && WPF2) {
+      // as below, with the weights of element e fetched two steps before they are copied into LDS (even elements
+      // through wst, odd ones through wst2): an L2 round trip under load is longer than one step's staging work
+      issue_S(0, stage0, zm0, sl0);
+      load_Wr(0, wst);
+      if (S > 1) issue_S(1, stage1, zm1, sl1);
+      if (S > 1) load_Wr(1, wst2);
+      __syncthreads();  // B(-1)
+      store_S(0, stage0, zm0, sl0);
+      if (S > 2) issue_S(2, stage0, zm0, sl0);
+      store_Wr(0, wst);
+      if (S > 2) load_Wr(2, wst);
+      __syncthreads();  // B0
+      for (int j = 0; j < S; j += 2) {
+        if (j + 1 < S) {
+          store_S(j + 1, stage1, zm1, sl1);
+          if (j + 3 < S) issue_S(j + 3, stage1, zm1, sl1);
+          store_Wr(j + 1, wst2);
+          if (j + 3 < S) load_Wr(j + 3, wst2);
+        }
+        __syncthreads();
+        if (j + 1 < S) {
+          if (j + 2 < S) {
+            store_S(j + 2, stage0, zm0, sl0);
+            if (j + 4 < S) issue_S(j + 4, stage0, zm0, sl0);
+            store_Wr(j + 2, wst);
+            if (j + 4 < S) load_Wr(j + 4, wst);
+          }
+          __syncthreads();
+        }
+      }
+    } else if (G::DOUBLE_STAGE) {
       // fill element 0; elements 1 and 2 in flight
       issue_S(0, stage0, zm0, sl0);
       load_W(0);
@@ -393,8 +451,9 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
 #endif
     // static priority: the MFMA waves win issue arbitration against the co-resident staging wave of their SIMD
     __builtin_amdgcn_s_setprio(WS_CONSUMER_PRIO);
-    const int cb = wave % G::NCB;  // 32-cout block == GroupNorm group
-    const int ph = wave / G::NCB;  // 128-pixel part of the tile
+    const int cwave = G::JOINT ? (int)(threadIdx.x >> 6) : wave;  // JOINT: both consumer groups share the tile
+    const int cb = cwave % G::NCB;  // 32-cout block == GroupNorm group
+    const int ph = cwave / G::NCB;  // 128-pixel part of the tile
     const int n31 = lane & 31, g = lane >> 5;
     int pixbase[4];
 #pragma unroll
@@ -548,7 +607,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     __syncthreads();  // B0
     int j = 0;
     for (int k = 0; k < nmy; ++k) {
-      if ((k & 1) == role) {
+      if (G::JOINT || (k & 1) == role) {
         // ---- this group's tile: MFMA only ----
         if (pending < 4) epi_blocks(4);  // (only if the other group's tile had too few steps to finish the write-out)
 #pragma unroll
@@ -610,6 +669,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           __syncthreads();  // B(j + 1)
         }
         epi_begin(k);  // written out while the other group computes the next tile
+        if (G::JOINT) epi_blocks(4);  // ... or right away: every consumer wave is needed for the next tile
       } else {
         // ---- the other group's tile: write our finished tile out, a slice per chunk step ----
         for (int ck = 0; ck < nchunks; ++ck, ++j) {
@@ -643,6 +703,8 @@ static int launch_f16ws(const dmd_conv_params& p, int ntiles, hipStream_t st) {
 int dmd_launch_conv_f16ws(const dmd_conv_params& p, hipStream_t st) {
   const bool b8 = p.W % 16 != 0;
   const int sub8 = p.N * (p.H / 8) * (p.W / 8), t16 = p.N * (p.H / 16) * (p.W / 16);
+  static const int joint = getenv("DIAMOND_WS_JOINT") ? atoi(getenv("DIAMOND_WS_JOINT")) : 0;
+  if (joint && p.taps == 9 && p.CoutPad == 64 && !b8 && t16 >= 512) return launch_f16ws<WsGeom<false, 2, 9, true>>(p, (t16 + 1) / 2, st);
   if (p.taps == 9) {
     if (p.CoutPad == 64) return b8 ? launch_f16ws<WsGeom<true, 2, 9>>(p, (sub8 + 3) / 4, st) : launch_f16ws<WsGeom<false, 2, 9>>(p, t16, st);
     return b8 ? launch_f16ws<WsGeom<true, 1, 9>>(p, (sub8 + 7) / 8, st) : launch_f16ws<WsGeom<false, 1, 9>>(p, (t16 + 1) / 2, st);
