@@ -7,7 +7,7 @@ tensors inside the loop, forcing a sync per step, diffusion_sampler.py:39,47); t
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Callable, List, Optional, Tuple
+from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 from torch import Tensor
@@ -48,6 +48,8 @@ class DiffusionSampler:
         self._host_sigmas = self.sigmas.detach().cpu()  # fp32 values, compared on the host
         # test hook: replaces torch.randn for the initial noise / churn draws (host-injected RNG)
         self.noise_fn: Optional[Callable[[Tuple[int, ...], torch.device], Tensor]] = None
+        self._graphs: Dict[tuple, "_CapturedSample"] = {}  # latency mode: one hipGraph per (buffers, ring heads)
+        self._graph_pool = None                             # ... all drawing their temporaries from one memory pool
 
     def _randn(self, shape, device) -> Tensor:
         if self.noise_fn is not None:
@@ -58,6 +60,25 @@ class DiffusionSampler:
     def sample(self, prev_obs: Tensor, prev_act: Tensor) -> Tuple[Tensor, List[Tensor]]:
         """Reference entry point (diffusion_sampler.py:30-58): prev_obs (B, T, C, H, W), prev_act (B, T)."""
         return self.sample_ring(prev_obs, prev_act, 0, 0)
+
+    @torch.no_grad()
+    def sample_ring_graphed(self, ctx_obs: Tensor, ctx_act: Tensor, obs_head: int, act_head: int) -> Tuple[Tensor, List[Tensor]]:
+        """Latency mode (play.py's B=1 world-model env, play.py:105-109 / game/play_env.py:113-124): the ~280 kernel
+        launches of one `sample` are captured once into a hipGraph per (context buffers, ring heads) and replayed -- at
+        B=1 every launch is latency-bound and the host cannot even issue them as fast as the GPU retires them.
+        The sigma schedule, conditioners and ring heads are launch constants of the captured graph; the context is read
+        from the SAME buffers at replay time (WorldModelEnv keeps its rings in place).  Returns fresh copies (the
+        graph's output buffers are overwritten by the next replay)."""
+        key = (ctx_obs.data_ptr(), ctx_act.data_ptr(), tuple(ctx_obs.shape), obs_head, act_head,
+               self.denoiser.inner_model.conv_in.weight._version)
+        cap = self._graphs.get(key)
+        if cap is None:
+            if len(self._graphs) > 64:
+                self._graphs.clear()
+            cap = _CapturedSample(self, ctx_obs, ctx_act, obs_head, act_head)
+            self._graphs[key] = cap
+        x, traj = cap.replay()
+        return x.clone(), [t.clone() for t in traj]
 
     @torch.no_grad()
     def sample_ring(self, ctx_obs: Tensor, ctx_act: Tensor, obs_head: int, act_head: int) -> Tuple[Tensor, List[Tensor]]:
@@ -107,3 +128,30 @@ class DiffusionSampler:
         nv.check(nv.lib().dmd_heun_step(nv.fptr(x), nv.fptr(denoised), nv.fptr(x_2), nv.fptr(denoised_2), sigma_hat,
                                         sigma_next, dt, nv.fptr(out), x.numel(), nv.stream()), "dmd_heun_step")
         return out
+
+
+class _CapturedSample:
+    """One `DiffusionSampler.sample_ring` call captured into a hipGraph (torch.cuda.CUDAGraph).  Every dmd_* entry
+    point is asynchronous on torch's current stream, allocates nothing and synchronises nothing (include/diamond_hip.h),
+    so the whole launch sequence -- including torch's own randn for the initial noise -- records into the capture
+    stream; two eager warm-up calls first populate the packed-weight / conditioner caches and set the kernels' LDS
+    attributes (none of which may happen during capture)."""
+
+    def __init__(self, sampler: DiffusionSampler, ctx_obs: Tensor, ctx_act: Tensor, obs_head: int, act_head: int) -> None:
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                sampler.sample_ring(ctx_obs, ctx_act, obs_head, act_head)
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        if sampler._graph_pool is None:
+            sampler._graph_pool = torch.cuda.graph_pool_handle()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, pool=sampler._graph_pool):  # replays are sequential and outputs are copied out
+            self.x, self.trajectory = sampler.sample_ring(ctx_obs, ctx_act, obs_head, act_head)
+
+    def replay(self) -> Tuple[Tensor, List[Tensor]]:
+        self.graph.replay()
+        return self.x, self.trajectory

@@ -19,6 +19,7 @@ structures behind it are designed for the GPU instead of transcribed:
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Any, Callable, Dict, Iterator, List, Optional, Tuple
 
@@ -28,6 +29,9 @@ from torch import Tensor
 from . import native as nv
 from .diffusion_sampler import DiffusionSampler, DiffusionSamplerConfig
 from .env_loop import sample_categorical
+
+
+GRAPH_SAMPLER_MAX_ENVS = 8  # below this the sampler is launch-latency-bound and runs as a replayed hipGraph
 
 
 @dataclass
@@ -116,12 +120,18 @@ class InitialConditionPool:
 
 class WorldModelEnv:
     def __init__(self, denoiser, rew_end_model, data_loader, cfg: WorldModelEnvConfig,
-                 return_denoising_trajectory: bool = False) -> None:
+                 return_denoising_trajectory: bool = False, graph_sampler: Optional[bool] = None) -> None:
+        """graph_sampler: replay the diffusion sampler as a captured hipGraph (latency mode).  None = automatic: on for
+        at most GRAPH_SAMPLER_MAX_ENVS envs (play.py's interactive env runs ONE), overridable with DIAMOND_GRAPH_SAMPLER=0/1."""
         self.sampler = DiffusionSampler(denoiser, cfg.diffusion_sampler)
         self.rew_end_model = rew_end_model
         self.horizon = cfg.horizon
         self.return_denoising_trajectory = return_denoising_trajectory
         self.num_envs = data_loader.batch_sampler.batch_size
+        if graph_sampler is None:
+            env = os.environ.get("DIAMOND_GRAPH_SAMPLER")
+            graph_sampler = (self.num_envs <= GRAPH_SAMPLER_MAX_ENVS) if env is None else env == "1"
+        self.graph_sampler = bool(graph_sampler)
         self.pool = InitialConditionPool(rew_end_model, data_loader, cfg.num_batches_to_preload, lambda: self.device)
         self._ctx: Optional[Tensor] = None  # (B, T, C, H, W) fp32 context ring
         self._act: Optional[Tensor] = None  # (B, T) int64 action ring
@@ -158,10 +168,14 @@ class WorldModelEnv:
         idx = self.pool.take(self.num_envs)
         dev = idx.device
         frames = self.pool.frames_u8 if self.pool.frames_u8 is not None else self.pool.frames_f32
-        self._ctx = torch.empty((self.num_envs,) + tuple(frames.shape[1:]), dtype=torch.float32, device=dev)
+        shape = (self.num_envs,) + tuple(frames.shape[1:])
+        if self._ctx is None or tuple(self._ctx.shape) != shape or self._ctx.device != dev:
+            # the rings are allocated once and reused by later resets: captured sampler graphs stay valid
+            self._ctx = torch.empty(shape, dtype=torch.float32, device=dev)
+            self._act = torch.empty(shape[:2], dtype=torch.long, device=dev)
         self._head = 0
         self.pool.scatter_frames(idx, None, self._ctx, 0)
-        self._act = self.pool.act[idx].clone()
+        self._act.copy_(self.pool.act[idx])
         self.hx_rew_end = self.pool.hx[idx].unsqueeze(0).clone()
         self.cx_rew_end = self.pool.cx[idx].unsqueeze(0).clone()
         self.ep_len = torch.zeros(self.num_envs, dtype=torch.long, device=dev)
@@ -210,6 +224,8 @@ class WorldModelEnv:
 
     @torch.no_grad()
     def predict_next_obs(self) -> Tuple[Tensor, List[Tensor]]:
+        if self.graph_sampler and self.sampler.noise_fn is None:
+            return self.sampler.sample_ring_graphed(self._ctx, self._act, self._head, self._head)
         return self.sampler.sample_ring(self._ctx, self._act, self._head, self._head)
 
     @torch.no_grad()

@@ -123,3 +123,38 @@ def test_ring_context_matches_roll_based_shadow(on_grid):
         # the newest action slot is written by the NEXT step (like the reference's act_buffer[:, -1])
         assert torch.equal(env.act_buffer[:, :-1], sh_act[:, :-1]), f"step {step}: action ring"
     assert pools_seen >= 1
+
+
+def test_graph_captured_sampler_equals_eager_bitwise():
+    """Latency mode (play.py's B=1 env): the sampler replayed as a hipGraph gives bit-identical frames to the eager
+    launch sequence, reads the CURRENT contents of the context rings at replay time, and one graph exists per ring
+    head."""
+    import diamond_amd as D
+    from diamond_amd.testing import fill_module_, synthetic_actions, synthetic_frames
+
+    agent = D.Agent(D.default_agent_config())
+    fill_module_(agent, WEIGHT_SEED)
+    agent = agent.to(DEV).eval()
+    g = torch.Generator().manual_seed(9)
+    sampler = D.DiffusionSampler(agent.denoiser, D.DiffusionSamplerConfig(num_steps_denoising=3))
+    ctx = synthetic_frames(g, 1, 4, 3, 64, 64).to(DEV)
+    act = synthetic_actions(g, 4, 1, 4).to(DEV)
+    noise = torch.randn(1, 3, 64, 64, generator=g).to(DEV)
+    sampler.noise_fn = lambda shape, dev: noise  # a device tensor: nothing is copied during capture
+    for head in (0, 3):
+        xe, te = sampler.sample_ring(ctx, act, head, head)
+        xg, tg = sampler.sample_ring_graphed(ctx, act, head, head)
+        assert torch.equal(xe, xg) and all(torch.equal(a, b) for a, b in zip(te, tg))
+        # new context in the same buffers: the replay must see it
+        ctx.copy_(synthetic_frames(g, 1, 4, 3, 64, 64).to(DEV))
+        act.copy_(synthetic_actions(g, 4, 1, 4).to(DEV))
+        noise.copy_(torch.randn(1, 3, 64, 64, generator=g).to(DEV))
+        xe2, _ = sampler.sample_ring(ctx, act, head, head)
+        xg2, _ = sampler.sample_ring_graphed(ctx, act, head, head)
+        assert torch.equal(xe2, xg2) and not torch.equal(xe2, xe)
+    assert len(sampler._graphs) == 2
+    # without the hook the noise comes from torch's generator inside the graph: a fresh draw per replay
+    sampler.noise_fn = None
+    a, _ = sampler.sample_ring_graphed(ctx, act, 1, 1)
+    b, _ = sampler.sample_ring_graphed(ctx, act, 1, 1)
+    assert torch.isfinite(a).all() and not torch.equal(a, b)
