@@ -62,7 +62,7 @@ class RunCtx:
         c = norm.in_channels
         stride = self.table.stride(0)
         return NormSpec(mul=self.table[:, off + c_start:], add=self.table[:, off + c + c_start:], mul_stride=stride,
-                        add_stride=stride, plus_one=True)
+                        add_stride=stride, plus_one=True, film_cols=(off + c_start, off + c + c_start))
 
 
 class FilmTable:
@@ -99,7 +99,7 @@ class GroupNorm(nn.Module):
         self.norm = nn.GroupNorm(_groups(in_channels), in_channels, eps=GN_EPS)
 
     def spec(self, ctx: RunCtx) -> NormSpec:
-        return NormSpec(mul=ctx.cache.f32(self.norm.weight), add=ctx.cache.f32(self.norm.bias))
+        return NormSpec(mul=ctx.cache.f32(self.norm.weight), add=ctx.cache.f32(self.norm.bias), gn_module=self.norm)
 
 
 class AdaGroupNorm(nn.Module):
@@ -131,10 +131,11 @@ class SelfAttention2d(nn.Module):
         # GN affine fused into the qkv 1x1 conv's load; out_proj adds the NORMALISED input
         # back (reference blocks.py:64,72), recomputed from x + its statistics in the epilogue.
         qkv = E.conv2d([(x, nv.PROLOGUE_NORM, spec)], ctx.cache.conv_weight(self.qkv_proj), ctx.cache.conv_bias(self.qkv_proj),
-                       3 * c, taps=1, want_stats=False, naive=ctx.naive)
+                       3 * c, taps=1, want_stats=False, naive=ctx.naive, module=self.qkv_proj)
         y = E.attention(qkv, c, c // self.n_head)
         return E.conv2d([(Act(y), nv.PROLOGUE_NONE, None)], ctx.cache.conv_weight(self.out_proj),
-                        ctx.cache.conv_bias(self.out_proj), c, taps=1, residual=x, residual_norm=spec, naive=ctx.naive)
+                        ctx.cache.conv_bias(self.out_proj), c, taps=1, residual=x, residual_norm=spec, naive=ctx.naive,
+                        module=self.out_proj)
 
 
 class FourierFeatures(nn.Module):
@@ -152,7 +153,7 @@ class Downsample(nn.Module):
 
     def run(self, ctx: RunCtx, x: Act) -> Act:
         return E.conv2d([(x, nv.PROLOGUE_NONE, None)], ctx.cache.conv_weight(self.conv), ctx.cache.conv_bias(self.conv),
-                        self.conv.out_channels, stride=2, naive=ctx.naive)
+                        self.conv.out_channels, stride=2, naive=ctx.naive, module=self.conv)
 
 
 class Upsample(nn.Module):
@@ -163,7 +164,7 @@ class Upsample(nn.Module):
     def run(self, ctx: RunCtx, x: Act) -> Act:
         # nearest x2 is folded into the conv's gather: in[y >> 1][x >> 1]
         return E.conv2d([(x, nv.PROLOGUE_NONE, None)], ctx.cache.conv_weight(self.conv), ctx.cache.conv_bias(self.conv),
-                        self.conv.out_channels, upsample=True, naive=ctx.naive, w_f16=ctx.w16(self.conv))
+                        self.conv.out_channels, upsample=True, naive=ctx.naive, w_f16=ctx.w16(self.conv), module=self.conv)
 
 
 class SmallResBlock(nn.Module):
@@ -195,16 +196,16 @@ class ResBlock(nn.Module):
         else:
             r = E.conv2d([(a, nv.PROLOGUE_NONE, None) for a in xs], ctx.cache.conv_weight(self.proj),
                          ctx.cache.conv_bias(self.proj), cout, taps=1, want_stats=False, naive=ctx.naive,
-                         w_f16=ctx.w16(self.proj))
+                         w_f16=ctx.w16(self.proj), module=self.proj)
         srcs, c0 = [], 0
         for a in xs:
             srcs.append((a, nv.PROLOGUE_NORM_SILU, ctx.film_spec(self.norm1, c0)))
             c0 += a.C
         h = E.conv2d(srcs, ctx.cache.conv_weight(self.conv1), ctx.cache.conv_bias(self.conv1), cout, naive=ctx.naive,
-                     w_f16=ctx.w16(self.conv1), fast_math=ctx.fast_math)
+                     w_f16=ctx.w16(self.conv1), fast_math=ctx.fast_math, module=self.conv1)
         h = E.conv2d([(h, nv.PROLOGUE_NORM_SILU, ctx.film_spec(self.norm2))], ctx.cache.conv_weight(self.conv2),
                      ctx.cache.conv_bias(self.conv2), cout, residual=r, naive=ctx.naive, w_f16=ctx.w16(self.conv2),
-                     fast_math=ctx.fast_math)
+                     fast_math=ctx.fast_math, module=self.conv2)
         if not isinstance(self.attn, nn.Identity):
             h = self.attn.run(ctx, h)
         return h

@@ -61,12 +61,12 @@ struct GnBwdElem {
   float xh, du, dxh;
 };
 
-__device__ __forceinline__ GnBwdElem gn_bwd_elem(float x, float da, float mean, float rstd, float mul, float add) {
+__device__ __forceinline__ GnBwdElem gn_bwd_elem(float x, float da, float mean, float rstd, float mul, float add, bool silu) {
   GnBwdElem r;
   r.xh = (x - mean) * rstd;
   const float u = r.xh * mul + add;
   const float sg = dmd_sigmoid(u);
-  r.du = da * (sg * (1.0f + u * (1.0f - sg)));
+  r.du = silu ? da * (sg * (1.0f + u * (1.0f - sg))) : da;  // identity activation: attention pre-norm (blocks.py:64)
   r.dxh = r.du * mul;
   return r;
 }
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const dmd_gn_bwd_par
     const f32x4 dv = *(const f32x4*)(p.da + off);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const GnBwdElem r = gn_bwd_elem(xv[e], dv[e], mean, rstd, mul[e], add[e]);
+      const GnBwdElem r = gn_bwd_elem(xv[e], dv[e], mean, rstd, mul[e], add[e], p.identity_activation == 0);
       s1 += (double)r.dxh;
       s2 += (double)r.dxh * (double)r.xh;
       dm[e] += r.du * r.xh;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const dmd_gn_bwd_para
     if (p.dskip) o = *(const f32x4*)(p.dskip + off);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const GnBwdElem r = gn_bwd_elem(xv[e], dv[e], mean, rstd, mul[e], add[e]);
+      const GnBwdElem r = gn_bwd_elem(xv[e], dv[e], mean, rstd, mul[e], add[e], p.identity_activation == 0);
       o[e] += rstd * (r.dxh - m1 - r.xh * m2);
     }
     *(f32x4*)(p.dx + off) = o;
@@ -515,6 +515,8 @@ extern "C" int dmd_conv2d_wgrad(const dmd_wgrad_params* p, dmd_stream_t stream) 
   int rc = -1;
   if (p->taps == 9) {
     if (nco == 2 && nci == 1) rc = launch_wgrad<2, 1, 9>(*p, st);
+    else if (nco == 4 && nci == 1) rc = launch_wgrad<4, 1, 9>(*p, st);  // denoiser conv_in (15 -> 64)
+    else if (nco == 1 && nci == 4) rc = launch_wgrad<1, 4, 9>(*p, st);  // denoiser conv_out (64 -> 3, dy padded to 16)
     else if (nco == 2 && nci == 2) rc = launch_wgrad<2, 2, 9>(*p, st);
     else if (nco == 4 && nci == 2) rc = launch_wgrad<4, 2, 9>(*p, st);
     else if (nco == 4 && nci == 4) rc = launch_wgrad<4, 4, 9>(*p, st);

@@ -38,6 +38,9 @@ class Denoiser(nn.Module):
         self.inner_model = InnerModel(cfg.inner_model)
         self.sample_sigma_training = None
         self._cond_cache = {}  # float sigma -> (1, 4) device conditioners
+        # test hook: replaces torch.randn in the training step (host-injected draws, reference RNG order)
+        self.randn_fn = None
+        self._train_params = None
 
     @property
     def device(self) -> torch.device:
@@ -47,7 +50,7 @@ class Denoiser(nn.Module):
         assert self.sample_sigma_training is None
 
         def sample_sigma(n: int, device: torch.device):
-            s = torch.randn(n, device=device) * cfg.scale + cfg.loc
+            s = self._randn((n,), device) * cfg.scale + cfg.loc
             return s.exp().clip(cfg.sigma_min, cfg.sigma_max)
 
         self.sample_sigma_training = sample_sigma
@@ -130,7 +133,81 @@ class Denoiser(nn.Module):
         f = self.compute_model_output(noisy_next_obs, obs, act, sigma, ring=ring)
         return self.wrap_model_output(noisy_next_obs, f, sigma)
 
+    # -- training step (reference denoiser.py:60-63,93-122) -------------------------------------------------------
+    def _randn(self, shape, device) -> Tensor:
+        if self.randn_fn is not None:
+            return self.randn_fn(tuple(shape)).to(device)
+        return torch.randn(*shape, device=device)
+
+    def apply_noise(self, x: Tensor, sigma: Tensor, sigma_offset_noise: float) -> Tensor:
+        b, c, _, _ = x.shape
+        offset_noise = sigma_offset_noise * self._randn((b, c, 1, 1), x.device)
+        return x + offset_noise + self._randn(tuple(x.shape), x.device) * sigma.reshape(-1, 1, 1, 1)
+
+    def _training_conditioners(self, sigma: Tensor):
+        """compute_conditioners (:66-72) for a (B,) device sigma, as fp32 torch ops in the reference's order."""
+        s = (sigma ** 2 + self.cfg.sigma_offset_noise ** 2).sqrt()
+        c_in = 1 / (s ** 2 + self.cfg.sigma_data ** 2).sqrt()
+        c_skip = self.cfg.sigma_data ** 2 / (s ** 2 + self.cfg.sigma_data ** 2)
+        c_out = s * c_skip.sqrt()
+        c_noise = s.log() / 4
+        return c_in, c_out, c_skip, c_noise
+
+    def model_output_with_grad(self, noisy_next_obs: Tensor, obs: Tensor, act: Tensor, conditioners,
+                               precision: Optional[str] = None) -> Tensor:
+        """F = inner_model(x * c_in, c_noise, obs / sigma_data, act) (:74-77) differentiable w.r.t. every parameter:
+        the U-Net forward runs on the HIP kernels while its launches are recorded, its backward is
+        unet_train.UNetTrainFn; the cond vector / FiLM table (tiny GEMMs) are torch ops under autograd."""
+        import math
+        import torch.nn.functional as F
+        from . import unet_train as UT
+        from .blocks import FilmTable
+
+        im = self.inner_model
+        c_in, c_out, c_skip, c_noise = conditioners
+        n, cx, h, w = noisy_next_obs.shape
+        cobs = obs.shape[1]
+        cond4 = torch.stack((c_in, c_out, c_skip, c_noise), dim=1).detach().float().contiguous()
+        cpad = (cx + cobs + 15) // 16 * 16
+        packed = torch.empty(n, h, w, cpad, device=self.device, dtype=torch.float32)
+        xc, oc = noisy_next_obs.detach().contiguous(), obs.detach().contiguous()
+        nv.check(nv.lib().dmd_edm_pack_input(nv.fptr(xc), nv.fptr(oc), nv.fptr(cond4), 4, float(self.cfg.sigma_data), nv.fptr(packed),
+                                             n, cx, cobs, h, w, cpad, 1, 0, nv.stream()), "dmd_edm_pack_input")
+        # cond = cond_proj(noise_emb(c_noise) + act_emb(act))  (inner_model.py:45, blocks.py:84-87)
+        f = 2 * math.pi * c_noise.detach().unsqueeze(1) @ im.noise_emb.weight
+        cond = im.cond_proj(torch.cat([f.cos(), f.sin()], dim=-1) + im.act_emb(act))
+        if im._film is None:
+            im._film = FilmTable(im.unet)
+        w_cat = torch.cat([m.linear.weight for m in im._film.norms], dim=0)
+        b_cat = torch.cat([m.linear.bias for m in im._film.norms], dim=0)
+        table = F.linear(cond, w_cat, b_cat)
+        if self._train_params is None:
+            self._train_params = UT.trainable_unet_params(im)
+        return UT.UNetTrainFn.apply(im, packed, table, precision or UT.TRAIN_PRECISION, *self._train_params)
+
     def forward(self, batch):
-        raise NotImplementedError(
-            "Denoiser.forward (the denoiser TRAINING loss, reference denoiser.py:93-122) needs the U-Net backward "
-            "kernels: SURVEY.md §8(f) row 2, not built yet")
+        """Denoising loss over a segment with autoregressive refresh of the context (reference :93-122)."""
+        import torch.nn.functional as F
+
+        n = self.cfg.inner_model.num_steps_conditioning
+        seq_length = batch.obs.size(1) - n
+        all_obs = batch.obs.clone()
+        loss = 0
+        for i in range(seq_length):
+            obs = all_obs[:, i:n + i]
+            next_obs = all_obs[:, n + i]
+            act = batch.act[:, i:n + i]
+            mask = batch.mask_padding[:, n + i]
+            b, t, c, h, w = obs.shape
+            obs = obs.reshape(b, t * c, h, w)
+            sigma = self.sample_sigma_training(b, self.device)
+            noisy_next_obs = self.apply_noise(next_obs, sigma, self.cfg.sigma_offset_noise)
+            cs = self._training_conditioners(sigma)
+            model_output = self.model_output_with_grad(noisy_next_obs, obs, act, cs)
+            c_in, c_out, c_skip, c_noise = (v.reshape(-1, 1, 1, 1) for v in cs)
+            target = (next_obs - c_skip * noisy_next_obs) / c_out
+            loss = loss + F.mse_loss(model_output[mask], target[mask])
+            denoised = self.wrap_model_output(noisy_next_obs, model_output.detach(), sigma)
+            all_obs[:, n + i] = denoised
+        loss = loss / seq_length
+        return loss, {"loss_denoising": loss.detach()}

@@ -47,6 +47,32 @@ class LaunchProfiler:
 PROFILER: Optional[LaunchProfiler] = None
 
 
+@dataclass
+class ConvRecord:
+    """One dmd_conv2d launch of a recorded forward (training): everything its backward needs."""
+    srcs: list  # [(Act, prologue, NormSpec | None)]
+    module: nn.Module  # the nn.Conv2d whose weight / bias this launch used
+    taps: int
+    stride: int
+    upsample: bool
+    residual: Optional["Act"]
+    residual_norm: Optional["NormSpec"]
+    out: "Act"
+    out_nchw: bool
+
+
+@dataclass
+class AttnRecord:
+    qkv: "Act"
+    out: Tensor
+    c: int
+    head_dim: int
+
+
+# recording tape of the current forward (None: inference, nothing is recorded)
+TAPE: Optional[list] = None
+
+
 def kernel_key(p) -> str:
     """Name of the kernel instantiation dmd_conv2d launches for these parameters, spelled like rocprofv3's kernel
     trace (so bench.py's records, profiles/*_kernel_stats.csv and profiles/*pmc*.json share one key)."""
@@ -61,6 +87,7 @@ class Act:
     t: Tensor
     stats: Optional[Tensor] = None
     tiles: int = 0
+    needs_grad: bool = True  # False: network input (the training backward stops here)
 
     @property
     def shape(self):
@@ -80,6 +107,10 @@ class NormSpec:
     mul_stride: int = 0
     add_stride: int = 0
     plus_one: bool = False
+    # where the gradients of mul / add go in the training backward (unet_train.py): columns of the batched FiLM
+    # table (mul_col, add_col), or the nn.GroupNorm module whose affine parameters these are
+    film_cols: Optional[Tuple[int, int]] = None
+    gn_module: Optional[nn.Module] = None
 
     def to_native(self, a: Act) -> nv.Norm:
         assert a.stats is not None, "normalising an activation that has no statistics"
@@ -163,6 +194,7 @@ def conv2d(
     naive: Optional[bool] = None,
     w_f16: Optional[Tensor] = None,
     fast_math: bool = False,
+    module: Optional[nn.Module] = None,
 ) -> Act:
     a0 = srcs[0][0]
     n, hs, ws, _ = a0.shape
@@ -218,7 +250,11 @@ def conv2d(
         PROFILER.records.append((kernel_key(p), flops, nbytes, e0, e1))
     else:
         nv.check(fn(C.byref(p), nv.stream()), "dmd_conv2d")
-    return Act(out, stats, tiles)
+    result = Act(out, stats, tiles)
+    if TAPE is not None:
+        assert module is not None, "recording a conv launch that does not name its nn.Conv2d"
+        TAPE.append(ConvRecord(list(srcs), module, taps, stride, upsample, residual, residual_norm, result, out_nchw))
+    return result
 
 
 def gn_stats(t: Tensor) -> Act:
@@ -251,6 +287,8 @@ def attention(qkv: Act, c: int, head_dim: int = 8) -> Tensor:
     assert c3 == 3 * c
     out = torch.empty(n, h, w, c, device=qkv.t.device, dtype=torch.float32)
     nv.check(nv.lib().dmd_attention(nv.fptr(qkv.t), nv.fptr(out), n, h * w, c, head_dim, nv.stream()), "dmd_attention")
+    if TAPE is not None:
+        TAPE.append(AttnRecord(qkv, out, c, head_dim))
     return out
 
 

@@ -66,18 +66,22 @@ class InnerModel(nn.Module):
         y = E.linear(x, self._cache.f32(l0.weight), self._cache.f32(l0.bias), silu=True)
         return E.linear(y, self._cache.f32(l2.weight), self._cache.f32(l2.bias))
 
-    def run(self, packed_in: Tensor, cond: Tensor, naive: Optional[bool] = None, precision: Optional[str] = None) -> Tensor:
-        """packed_in: NHWC16 [obs/sigma_data | noisy*c_in | 0]; returns F as NCHW (N,3,H,W)."""
+    def run(self, packed_in: Tensor, cond: Optional[Tensor], naive: Optional[bool] = None, precision: Optional[str] = None,
+            table: Optional[Tensor] = None) -> Tensor:
+        """packed_in: NHWC16 [obs/sigma_data | noisy*c_in | 0]; returns F as NCHW (N,3,H,W).
+        table: the batched FiLM table if the caller already has it (the training path computes it under autograd)."""
         if self._film is None:
             self._film = FilmTable(self.unet)
-        table = self._film.compute(cond)
+        if table is None:
+            table = self._film.compute(cond)
         ctx = RunCtx(self._cache, self._film, table, naive, precision)
-        x = E.conv2d([(E.Act(packed_in), nv.PROLOGUE_NONE, None)], self._cache.conv_weight(self.conv_in),
-                     self._cache.conv_bias(self.conv_in), self.conv_in.out_channels, naive=naive, w_f16=ctx.w16(self.conv_in))
+        x = E.conv2d([(E.Act(packed_in, needs_grad=False), nv.PROLOGUE_NONE, None)], self._cache.conv_weight(self.conv_in),
+                     self._cache.conv_bias(self.conv_in), self.conv_in.out_channels, naive=naive, w_f16=ctx.w16(self.conv_in),
+                     module=self.conv_in)
         x = self.unet.run(ctx, x)
         co = self.conv_out
         w16 = self._cache.conv_weight_f16x2_head(co) if (ctx.precision == "f16x2" and not naive) else None
         cpad = 32 if w16 is not None else None  # the split kernel's 32-cout instance, real channels stored as NCHW
         return E.conv2d([(x, nv.PROLOGUE_NORM_SILU, self.norm_out.spec(ctx))], self._cache.conv_weight(co, cpad),
                         self._cache.conv_bias(co, cpad), co.out_channels, want_stats=False, out_nchw=True, naive=naive,
-                        fast_math=ctx.fast_math, w_f16=w16, cout_padded=cpad).t
+                        fast_math=ctx.fast_math, w_f16=w16, cout_padded=cpad, module=co).t

@@ -50,7 +50,7 @@ class LinearParams(C.Structure):
 
 
 class GnBwdParams(C.Structure):
-    _fields_ = [("N", C.c_int32), ("HW", C.c_int32), ("C", C.c_int32), ("reserved", C.c_int32), ("x", C.c_void_p),
+    _fields_ = [("N", C.c_int32), ("HW", C.c_int32), ("C", C.c_int32), ("identity_activation", C.c_int32), ("x", C.c_void_p),
                 ("norm", Norm), ("da", C.c_void_p), ("dskip", C.c_void_p), ("dx", C.c_void_p), ("workspace", C.c_void_p),
                 ("dmul", C.c_void_p), ("dadd", C.c_void_p)]
 
@@ -64,7 +64,7 @@ class WgradParams(C.Structure):
 EXPORTS = (
     "dmd_conv2d", "dmd_conv2d_kernel_name", "dmd_conv2d_naive", "dmd_conv_stat_tiles", "dmd_pack_conv_weight", "dmd_conv2d_f16x2_eligible",
     "dmd_conv1x1_stream_eligible",
-    "dmd_pack_conv_weight_f16x2", "dmd_linear", "dmd_attention",
+    "dmd_pack_conv_weight_f16x2", "dmd_linear", "dmd_attention", "dmd_attention_bwd", "dmd_attention_bwd_workspace_floats",
     "dmd_edm_pack_input", "dmd_cond_embed", "dmd_edm_denoised", "dmd_euler_step", "dmd_heun_step", "dmd_quantize_u8",
     "dmd_dequant_gather", "dmd_nchw_to_nhwc",
     "dmd_nhwc_to_nchw", "dmd_gn_stats", "dmd_maxpool2", "dmd_lstm_pointwise", "dmd_categorical_sample",
@@ -95,6 +95,10 @@ def lib() -> C.CDLL:
         L.dmd_conv2d_f16x2_eligible.argtypes = [C.POINTER(ConvParams)]
         L.dmd_conv1x1_stream_eligible.argtypes = [C.POINTER(ConvParams)]
         L.dmd_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.dmd_attention_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_void_p]
+        L.dmd_attention_bwd_workspace_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.dmd_attention_bwd_workspace_floats.restype = C.c_int64
         L.dmd_edm_pack_input.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.dmd_cond_embed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

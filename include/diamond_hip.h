@@ -123,6 +123,11 @@ int dmd_linear(const dmd_linear_params* p, dmd_stream_t stream);
  * K/V tiles through LDS with an online softmax.  qkv is NHWC (N, T, 3C): q | k | v channel
  * thirds, head h = channels [h*d, (h+1)*d) of each third (blocks.py:66-71).  d == 8. */
 int dmd_attention(const float* qkv, float* out, int N, int T, int C, int head_dim, dmd_stream_t stream);
+/* Backward of dmd_attention (autograd of blocks.py:66-71 under the denoiser training loss, denoiser.py:93-122):
+ * y = the forward's output, dy its gradient -> dqkv (N, T, 3C) in the qkv layout.  workspace: dmd_attention_bwd_workspace_floats. */
+int64_t dmd_attention_bwd_workspace_floats(int N, int T, int C);
+int dmd_attention_bwd(const float* qkv, const float* y, const float* dy, float* dqkv, float* workspace, int N, int T, int C,
+                      int head_dim, dmd_stream_t stream);
 
 /* ---- EDM preconditioning / sampler pointwise (denoiser.py:74-84, diffusion_sampler.py:45-56) ---- */
 /* The four EDM conditioners (c_in, c_out, c_skip, c_noise; compute_conditioners denoiser.py:66-72)
@@ -192,13 +197,13 @@ int dmd_categorical_sample(const float* logits, const float* expo, int64_t* out,
 int dmd_maxpool2_bwd(const float* dpooled, const uint8_t* argmax, float* dx, int N, int H, int W, int C,
                      dmd_stream_t stream);
 
-/* Backward of a = SiLU(GroupNorm(x) * mul' + add) (mul' = mul or 1 + mul, as in dmd_norm):
+/* Backward of a = act(GroupNorm(x) * mul' + add), act = SiLU or identity (mul' = mul or 1 + mul, as in dmd_norm):
  *   dx = d a / d x applied to da (+ dskip, the gradient of the residual branch around the block)
  *   dmul[n][c] = sum_hw du * xhat,  dadd[n][c] = sum_hw du   (the caller sums over n for affine
  *   parameters shared by the batch). */
 typedef struct dmd_gn_bwd_params {
   int32_t N, HW, C;
-  int32_t reserved;
+  int32_t identity_activation; /* 0: a = SiLU(u) (AdaGroupNorm / SmallResBlock); 1: a = u (attention pre-norm, blocks.py:64) */
   const float* x;      /* NHWC input of the GroupNorm                          */
   dmd_norm norm;       /* its statistics + multiplicative/additive parameters  */
   const float* da;     /* gradient w.r.t. the activated tensor                 */

@@ -255,7 +255,40 @@ def gen_window_teacher_forced():
     save("window_tf.pt", out)
 
 
+def gen_denoiser_train():
+    """Denoiser.forward (the denoising TRAINING loss with autoregressive context refresh, denoiser.py:93-122) +
+    loss.backward() of the reference: loss and every parameter gradient."""
+    from data import Batch
+    from models.diffusion import SigmaDistributionConfig
+
+    agent = ref_agent()
+    den = agent.denoiser
+    den.setup_training(SigmaDistributionConfig(loc=-0.4, scale=1.2, sigma_min=2e-3, sigma_max=20))
+    g = torch.Generator().manual_seed(31)
+    b, t = 2, 6  # 4 conditioning frames + 2 predicted ones
+    obs = synthetic_frames(g, b, t, 3, 64, 64)
+    act = synthetic_actions(g, 4, b, t)
+    mask = torch.ones(b, t, dtype=torch.bool)
+    mask[1, 5] = False  # a padded step: excluded from the loss of the second prediction
+    batch = Batch(obs=obs, act=act, rew=None, end=None, trunc=None, mask_padding=mask, info=None, segment_ids=None)
+    den.zero_grad()
+    torch.manual_seed(77)  # consumed by sample_sigma / apply_noise (denoiser.py:55,62-63)
+    loss, logs = den(batch)
+    loss.backward()
+    grads = {k: p.grad.clone() for k, p in den.named_parameters()}
+    assert all(v is not None for v in grads.values())
+    save("denoiser_train.pt", {
+        "seed": 31, "rng_seed": 77, "b": b, "t": t, "loss": loss.detach(),
+        "grad_norms": {k: v.double().norm() for k, v in grads.items()},
+        "grads": {k: (v if v.numel() <= 4096 else v.flatten()[::13].clone()) for k, v in grads.items()},  # every 13th element of the larger tensors
+    })
+    print("denoiser training step: loss", float(loss))
+
+
 def main():
+    if "--denoiser-train" in sys.argv:
+        gen_denoiser_train()
+        return
     if "--window-tf" in sys.argv or "--actor-critic" in sys.argv:  # (re)generate single fixtures
         if "--window-tf" in sys.argv:
             gen_window_teacher_forced()
@@ -270,6 +303,7 @@ def main():
     gen_actor_critic(agent)
     gen_window()
     gen_window_teacher_forced()
+    gen_denoiser_train()
     # attention at 16x16 and 8x8 inside the U-Net (BASELINE config 5 uses attn_depths=[0,0,1,1])
     gen_denoiser(ref_agent(denoiser_attn_depths=(0, 0, 1, 1)), "attn0011", b=1)
 
