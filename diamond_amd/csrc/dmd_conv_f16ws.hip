@@ -100,6 +100,36 @@ __device__ __forceinline__ float ws_silu(float t) {
   return t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * t));
 }
 
+#ifndef WS_TRACE
+#define WS_TRACE 0  // development: per-step s_memtime stamps of workgroup WS_TRACE_WG into a device buffer (tools/debug/ws_trace.py)
+#endif
+#if WS_TRACE
+#define WS_TRACE_WG 37
+#define WS_TRACE_N 4096
+__device__ unsigned long long ws_trace_buf[3][WS_TRACE_N];
+__device__ int ws_trace_cnt[3];
+#define WS_STAMP(role_, tag_, step_)                                                                                  \
+  do {                                                                                                                 \
+    if (blockIdx.x == WS_TRACE_WG && (threadIdx.x & 255) == 0) {                                                        \
+      const int i_ = ws_trace_cnt[role_];                                                                              \
+      if (i_ < WS_TRACE_N) {                                                                                           \
+        ws_trace_buf[role_][i_] = (__builtin_readcyclecounter() << 16) | ((unsigned long long)(tag_) << 12) | ((step_) & 0xfff); \
+        ws_trace_cnt[role_] = i_ + 1;                                                                                  \
+      }                                                                                                                \
+    }                                                                                                                  \
+  } while (0)
+extern "C" int dmd_ws_trace_dump(unsigned long long* host, int* counts) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(host, HIP_SYMBOL(ws_trace_buf), sizeof(unsigned long long) * 3 * WS_TRACE_N);
+  hipMemcpyFromSymbol(counts, HIP_SYMBOL(ws_trace_cnt), sizeof(int) * 3);
+  int zero[3] = {0, 0, 0};
+  hipMemcpyToSymbol(HIP_SYMBOL(ws_trace_cnt), zero, sizeof(zero));
+  return WS_TRACE_N;
+}
+#else
+#define WS_STAMP(role_, tag_, step_) do {} while (0)
+#endif
+
 #ifndef WS_PIPE
 #define WS_PIPE 0  // 1: tap-level software pipeline of the fragment reads. Measured r02b: 5 % SLOWER than the compiler's tap-by-tap order (367 vs 350 us on the 64x64 residual conv)
 #endif
@@ -408,21 +438,32 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         if (j + 1 < S) __syncthreads();
         continue;
 #endif
+        WS_STAMP(2, 0, j);
         if (j + 1 < S) {
           load_W(j + 1);
+          WS_STAMP(2, 1, j);
           store_S(j + 1, stage1, zm1, sl1);
+          WS_STAMP(2, 2, j);
           if (j + 3 < S) issue_S(j + 3, stage1, zm1, sl1);
+          WS_STAMP(2, 3, j);
           store_W(j + 1);
+          WS_STAMP(2, 4, j);
         }
         __syncthreads();
+        WS_STAMP(2, 5, j);
         if (j + 1 < S) {
           if (j + 2 < S) {
             load_W(j + 2);
+            WS_STAMP(2, 1, j + 1);
             store_S(j + 2, stage0, zm0, sl0);
+            WS_STAMP(2, 2, j + 1);
             if (j + 4 < S) issue_S(j + 4, stage0, zm0, sl0);
+            WS_STAMP(2, 3, j + 1);
             store_W(j + 2);
+            WS_STAMP(2, 4, j + 1);
           }
           __syncthreads();
+          WS_STAMP(2, 5, j + 1);
         }
       }
     } else {
@@ -616,6 +657,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           for (int r = 0; r < 16; ++r) acc[blk][r] = 0.f;
         for (int ck = 0; ck < nchunks; ++ck, ++j) {
           const u32x4* buf = bufs + (j & 1) * G::BUF_UNITS;
+          WS_STAMP(role, 0, j);
 #if WS_PIPE
           // Software pipeline over the taps: the 10 fragment reads of tap t + 1 are issued between the 12 MFMAs of tap t
           // (two fragment sets), so an LDS round trip (100+ cycles under the producers' write bursts) is covered by a
@@ -666,15 +708,20 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
             }
           }
 #endif
+          WS_STAMP(role, 1, j);
           __syncthreads();  // B(j + 1)
+          WS_STAMP(role, 2, j);
         }
         epi_begin(k);  // written out while the other group computes the next tile
         if (G::JOINT) epi_blocks(4);  // ... or right away: every consumer wave is needed for the next tile
       } else {
         // ---- the other group's tile: write our finished tile out, a slice per chunk step ----
         for (int ck = 0; ck < nchunks; ++ck, ++j) {
+          WS_STAMP(role, 8, j);
           if (pending < 4) epi_blocks(blocks_per_step);
+          WS_STAMP(role, 9, j);
           __syncthreads();  // B(j + 1)
+          WS_STAMP(role, 10, j);
         }
       }
     }
