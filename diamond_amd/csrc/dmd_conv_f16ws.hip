@@ -73,6 +73,14 @@ struct WsGeom {
   // source pixel offsets of a tile cached in registers (one per item) or recomputed at every chunk: recomputing frees
   // ITEMS registers (JOINT needs them) but costs ~18 VALU per item and chunk (measured r02e: 8x8 levels +25 %)
   static constexpr bool CACHE_GOFF = !JOINT_;
+  // The chunk weights (36 KiB per step, L2 -> registers -> LDS) are copied by the consumer group that is NOT computing
+  // the current tile (it only writes its finished tile out and otherwise waits at the barriers) instead of by the
+  // producers: measured r02i, the weight loads cost the producers -- the critical path of every step, they stall at
+  // ISSUE while the vector-memory queue is backed up -- 15 % of the kernel.  JOINT has no idle group.
+#ifndef WS_W_BY_IDLE
+#define WS_W_BY_IDLE 0  // measured r02j: 346 vs 296 us on the 64x64 conv, 8.5k vs 9.75k frames/s -- the "idle" group is not idle enough
+#endif
+  static constexpr bool W_BY_IDLE = WS_W_BY_IDLE && !JOINT_;
   static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
 };
 
@@ -176,7 +184,8 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
   float* tab_b = tab_a + G::TAB_FLOATS;
 
 #ifndef WS_ABL
-#define WS_ABL 0  // development only: 1 = producers idle in steady state, 2 = no activation loads, 4 = no store_S, 16 = no MFMA loop
+#define WS_ABL 0  // development only (WRONG results): 1 = producers idle in steady state, 2 = no activation loads, 4 = no store_S, 16 = no MFMA loop,
+                  // 32 = no weight global loads, 64 = no weight LDS writes either, 128 = no epilogue global stores / residual loads
 #endif
   const int role = threadIdx.x >> 8;  // 0, 1: consumer groups (even / odd tiles), 2: producer (staging)
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
@@ -379,16 +388,29 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       const u32x4* w = wglob + (size_t)ck * G::W_UNITS + tid;
 #pragma unroll
       for (int i = 0; i < G::WU; ++i)
-        if (G::W_UNITS % 256 == 0 || tid + 256 * i < G::W_UNITS) ws[i] = w[256 * i];
+        if (G::W_UNITS % 256 == 0 || tid + 256 * i < G::W_UNITS) {
+#if WS_ABL & 32
+          ws[i] = (u32x4){(unsigned)(size_t)w, 0x3c003c00u, 0u, (unsigned)i};
+#else
+          ws[i] = w[256 * i];
+#endif
+        }
     };
     auto store_Wr = [&](int e, const auto& ws) {
+#if WS_ABL & 64
+      if (e > 1) return;
+#endif
       u32x4* wl = bufs + (e & 1) * G::BUF_UNITS + G::NPP * 4;
 #pragma unroll
       for (int i = 0; i < G::WU; ++i)
         if (G::W_UNITS % 256 == 0 || tid + 256 * i < G::W_UNITS) wl[tid + 256 * i] = ws[i];
     };
-    auto load_W = [&](int e) { load_Wr(e, wst); };
-    auto store_W = [&](int e) { store_Wr(e, wst); };
+    auto load_W = [&](int e) {
+      if (!G::W_BY_IDLE) load_Wr(e, wst);
+    };
+    auto store_W = [&](int e) {
+      if (!G::W_BY_IDLE) store_Wr(e, wst);
+    };
 
     if (G::DOUBLE_STAGE && WPF2) {
       // as below, with the weights of element e fetched two steps before they are copied into LDS (even elements
@@ -604,14 +626,14 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           f32x4 rv[4];
 #pragma unroll
           for (int qd = 0; qd < 4; ++qd)
-            rv[qd] = p.residual ? *(const f32x4*)(p.residual + (size_t)pixoff[blk] * 4 + 8 * qd) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            rv[qd] = (p.residual && !(WS_ABL & 128)) ? *(const f32x4*)(p.residual + (size_t)pixoff[blk] * 4 + 8 * qd) : (f32x4){0.f, 0.f, 0.f, 0.f};
           float fs = 0.f, fq = 0.f;  // fp32 over the lane's 16 values of this block, fp64 across
 #pragma unroll
           for (int qd = 0; qd < 4; ++qd) {
             f32x4 v = (f32x4){acc[blk][4 * qd], acc[blk][4 * qd + 1], acc[blk][4 * qd + 2], acc[blk][4 * qd + 3]};
             v += bias[qd];
             v += rv[qd];
-            *(f32x4*)(op + 8 * qd) = v;
+            if (!(WS_ABL & 128) || v[0] == 1.2345e30f) *(f32x4*)(op + 8 * qd) = v;
             fs += (v[0] + v[1]) + (v[2] + v[3]);
             // Sum of squares as an fma chain into its own register, NOT as in-place squares of v: with the squares
             // written over v's registers (`v_mul_f32 v48, v48, v48` right behind the `global_store_dwordx4 v[48:51]`),
@@ -644,7 +666,28 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     };
     const int blocks_per_step = nchunks >= 4 ? 1 : (nchunks >= 2 ? 2 : 4);
 
+    // ---- weight copy of the idle group (W_BY_IDLE): element e's 36 KiB into buffer e & 1 ----
+    u32x4 cw[G::W_BY_IDLE ? G::WU : 1];
+    const u32x4* cwglob = (const u32x4*)p.w_f16;
+    auto cons_load_W = [&](int e) {
+      const int ck = e % nchunks;
+      const u32x4* w = cwglob + (size_t)ck * G::W_UNITS + tid;
+#pragma unroll
+      for (int i = 0; i < G::WU; ++i)
+        if (G::W_UNITS % 256 == 0 || tid + 256 * i < G::W_UNITS) cw[G::W_BY_IDLE ? i : 0] = w[256 * i];
+    };
+    auto cons_store_W = [&](int e) {
+      u32x4* wl = (u32x4*)bufs + (e & 1) * G::BUF_UNITS + G::NPP * 4;
+#pragma unroll
+      for (int i = 0; i < G::WU; ++i)
+        if (G::W_UNITS % 256 == 0 || tid + 256 * i < G::W_UNITS) wl[tid + 256 * i] = cw[G::W_BY_IDLE ? i : 0];
+    };
+
     __syncthreads();  // B(-1)
+    if (G::W_BY_IDLE && role == 1) {  // group 1 is idle during tile 0: it provides the first chunk's weights
+      cons_load_W(0);
+      cons_store_W(0);
+    }
     __syncthreads();  // B0
     int j = 0;
     for (int k = 0; k < nmy; ++k) {
@@ -718,7 +761,10 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         // ---- the other group's tile: write our finished tile out, a slice per chunk step ----
         for (int ck = 0; ck < nchunks; ++ck, ++j) {
           WS_STAMP(role, 8, j);
+          const bool wnext = G::W_BY_IDLE && j + 1 < S;  // this (idle) group copies the next step's weights
+          if (wnext) cons_load_W(j + 1);
           if (pending < 4) epi_blocks(blocks_per_step);
+          if (wnext) cons_store_W(j + 1);
           WS_STAMP(role, 9, j);
           __syncthreads();  // B(j + 1)
           WS_STAMP(role, 10, j);

@@ -1,0 +1,9 @@
+#!/bin/bash
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r02j; mkdir -p $O; cd $R
+echo "=== tests (idle-group weight copy)"; timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_tpw.py -m gpu -q -p no:cacheprovider > $O/tests.log 2>&1; tail -3 $O/tests.log; grep FAILED $O/tests.log | head
+echo "=== conv_bench W_BY_IDLE=1"; timeout 200 python tools/conv_bench.py 2>&1 | grep -v amdgpu.ids | tee $O/conv_bench_idle.log
+echo "=== conv_bench W_BY_IDLE=0"; DIAMOND_LIB=$R/diamond_amd/ablate/libdiamond_hip_noidle.so timeout 200 python tools/conv_bench.py 2>&1 | grep -v amdgpu.ids | tee $O/conv_bench_noidle.log
+for v in idle noidle idle noidle; do lib=$R/diamond_amd/libdiamond_hip.so; [ $v = noidle ] && lib=$R/diamond_amd/ablate/libdiamond_hip_noidle.so
+ DIAMOND_LIB=$lib timeout 300 python bench.py --no-cpu-baseline --no-exact-fp32 > $O/bench_$v.json 2> $O/bench_$v.err; python -c "
+import json; d=json.load(open('$O/bench_$v.json')); print('$v bench', d['value'], d['roofline']['avg_launch_ms'])"; done
