@@ -118,12 +118,9 @@ __device__ unsigned long long ws_trace_buf[3][WS_TRACE_N];
 __device__ int ws_trace_cnt[3];
 #define WS_STAMP(role_, tag_, step_)                                                                                  \
   do {                                                                                                                 \
-    if (blockIdx.x == WS_TRACE_WG && (threadIdx.x & 255) == 0) {                                                        \
-      const int i_ = ws_trace_cnt[role_];                                                                              \
-      if (i_ < WS_TRACE_N) {                                                                                           \
-        ws_trace_buf[role_][i_] = (__builtin_readcyclecounter() << 16) | ((unsigned long long)(tag_) << 12) | ((step_) & 0xfff); \
-        ws_trace_cnt[role_] = i_ + 1;                                                                                  \
-      }                                                                                                                \
+    if (blockIdx.x == WS_TRACE_WG && (threadIdx.x & 255) == 0 && ws_ti < WS_TRACE_N) {                                  \
+      ws_trace_buf[role_][ws_ti] = (__builtin_readcyclecounter() << 16) | ((unsigned long long)(tag_) << 12) | ((step_) & 0xfff); \
+      ws_trace_cnt[role_] = ++ws_ti;                                                                                   \
     }                                                                                                                  \
   } while (0)
 extern "C" int dmd_ws_trace_dump(unsigned long long* host, int* counts) {
@@ -188,6 +185,9 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
                   // 32 = no weight global loads, 64 = no weight LDS writes either, 128 = no epilogue global stores / residual loads
 #endif
   const int role = threadIdx.x >> 8;  // 0, 1: consumer groups (even / odd tiles), 2: producer (staging)
+#if WS_TRACE
+  int ws_ti = 0;  // next trace slot of this role's stamping thread (stores only: no load on the stamping path)
+#endif
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int up = p.upsample;
   const int Hs = p.H >> up, Ws = p.W >> up;
