@@ -3,9 +3,9 @@ REINFORCE-with-baseline loss over a 15-step imagined rollout, and lambda-returns
 
 Execution: the conv encoder (all of the model's convolution/GroupNorm/SiLU/pooling work)
 runs on hand-written HIP kernels, forward AND backward, behind one torch.autograd.Function
-(diamond_amd/ac_native.py).  The LSTM cell and the two linear heads are plain GEMMs + gate
-pointwise ops issued as torch ops (rocBLAS) under ordinary autograd.  There is no CPU path:
-a CPU tensor raises.
+(diamond_amd/ac_native.py); the LSTM cell and the two linear heads likewise (MFMA GEMMs `dmd_linear`,
+`dmd_lstm_pointwise(_bwd)`, diamond_amd/lstm_native.py), one Function per policy step chained by torch for BPTT.
+There is no CPU path: a CPU tensor raises.
 """
 from __future__ import annotations
 
@@ -100,13 +100,10 @@ class ActorCritic(nn.Module):
             hx_cx = (z, z)
         hx, cx = hx_cx
         x = self.encode(obs)
-        # nn.LSTMCell (reference :72): gate order i, f, g, o
-        gates = F.linear(x, self.lstm.weight_ih, self.lstm.bias_ih) + F.linear(hx, self.lstm.weight_hh, self.lstm.bias_hh)
-        i, f, g, o = gates.chunk(4, dim=1)
-        cx = torch.sigmoid(f) * cx + torch.sigmoid(i) * torch.tanh(g)
-        hx = torch.sigmoid(o) * torch.tanh(cx)
-        logits = F.linear(hx, self.actor_linear.weight, self.actor_linear.bias)
-        val = F.linear(hx, self.critic_linear.weight, self.critic_linear.bias).squeeze(dim=1)
+        # nn.LSTMCell (gate order i, f, g, o) + the two heads (reference :72-73): dmd_linear / dmd_lstm_pointwise
+        # forward and backward (lstm_native.LstmHeadsFn)
+        from .lstm_native import lstm_heads
+        logits, val, hx, cx = lstm_heads(self._native_encoder.cache, x, hx, cx, self.lstm, self.actor_linear, self.critic_linear)
         return ActorCriticOutput(logits, val, (hx, cx))
 
     def forward(self):

@@ -261,6 +261,32 @@ __global__ void lstm_pointwise_kernel(const float* __restrict__ gates, const flo
   h[idx] = og * tanhf(cn);
 }
 
+// LSTM cell backward (autograd of nn.LSTMCell under the actor-critic loss, actor_critic.py:46,72 / trainer.py:366):
+// gates = pre-activations (i, f, g, o) saved by the forward, dh / dc = gradients w.r.t. the new h / c (either may be NULL)
+// -> dgates (N, 4 Hd), dc_prev (N, Hd)
+__global__ void lstm_pointwise_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev,
+                                          const float* __restrict__ c_new, const float* __restrict__ dh,
+                                          const float* __restrict__ dc, float* __restrict__ dgates, float* __restrict__ dc_prev,
+                                          int N, int Hd) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * Hd) return;
+  const int n = idx / Hd, k = idx - n * Hd;
+  const float* gr = gates + (size_t)n * 4 * Hd;
+  const float ig = dmd_sigmoid(gr[k]);
+  const float fg = dmd_sigmoid(gr[Hd + k]);
+  const float gg = tanhf(gr[2 * Hd + k]);
+  const float og = dmd_sigmoid(gr[3 * Hd + k]);
+  const float tc = tanhf(c_new[idx]);
+  const float dhv = dh ? dh[idx] : 0.f;
+  const float dcv = (dc ? dc[idx] : 0.f) + dhv * og * (1.0f - tc * tc);
+  float* dg = dgates + (size_t)n * 4 * Hd;
+  dg[k] = dcv * gg * ig * (1.0f - ig);
+  dg[Hd + k] = dcv * c_prev[idx] * fg * (1.0f - fg);
+  dg[2 * Hd + k] = dcv * ig * (1.0f - gg * gg);
+  dg[3 * Hd + k] = dhv * tc * og * (1.0f - og);
+  dc_prev[idx] = dcv * fg;
+}
+
 // ---- Categorical(logits).sample() with injected E ~ Exp(1): argmax(softmax(logits) / E) -------
 __global__ void categorical_sample_kernel(const float* __restrict__ logits, const float* __restrict__ expo,
                                           int64_t* __restrict__ out, int N, int A) {
@@ -401,6 +427,15 @@ extern "C" int dmd_lstm_pointwise(const float* gates, const float* c_prev, float
   DMD_CHECK_ARG(gates && c_prev && h && c, "lstm_pointwise: null");
   hipLaunchKernelGGL(lstm_pointwise_kernel, dim3(nblk((size_t)N * Hd, 256)), dim3(256), 0, (hipStream_t)stream, gates, c_prev,
                      h, c, N, Hd);
+  DMD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dmd_lstm_pointwise_bwd(const float* gates, const float* c_prev, const float* c_new, const float* dh,
+                                      const float* dc, float* dgates, float* dc_prev, int N, int Hd, dmd_stream_t stream) {
+  DMD_CHECK_ARG(gates && c_prev && c_new && dgates && dc_prev, "lstm_pointwise_bwd: null");
+  hipLaunchKernelGGL(lstm_pointwise_bwd_kernel, dim3(nblk((size_t)N * Hd, 256)), dim3(256), 0, (hipStream_t)stream, gates,
+                     c_prev, c_new, dh, dc, dgates, dc_prev, N, Hd);
   DMD_LAUNCH_CHECK();
   return 0;
 }

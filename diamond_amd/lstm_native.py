@@ -1,0 +1,96 @@
+"""LSTMCell + actor / critic heads of the actor-critic on the hand-written kernels, forward AND backward
+(reference models/actor_critic.py:46-48,72-73: `nn.LSTMCell(1024, 512)`, `actor_linear`, `critic_linear`, under
+`loss.backward()`, trainer.py:366).
+
+One `torch.autograd.Function` per policy step: gate GEMMs and head GEMM on `dmd_linear` (v_mfma_f32_16x16x4_f32, exact
+fp32 fma chains), gate nonlinearity in `dmd_lstm_pointwise`; the backward is `dmd_lstm_pointwise_bwd` plus the
+transposed GEMMs, again on `dmd_linear` -- its operands are K-contiguous ("NT"), so the data/weight gradients use
+transposed copies of the (small) activation matrices and version-cached transposed weights.  BPTT over the 15-step
+window is torch's ordinary chaining of these Functions through (hx, cx).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+from . import engine as E
+from . import native as nv
+
+
+def _pad_k(t: Tensor) -> Tensor:
+    """(M, K) -> contiguous (M, K rounded up to 16) (dmd_linear contracts over multiples of 16)."""
+    k = t.shape[1]
+    kp = (k + 15) // 16 * 16
+    t = t.contiguous()
+    return t if kp == k else F.pad(t, (0, kp - k))
+
+
+def _mm_nt(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """a (M, K) @ w (N, K)^T on dmd_linear, K zero-padded to a multiple of 16."""
+    a, w = _pad_k(a), _pad_k(w)
+    return E.linear(a, w, bias, out=out, accumulate=accumulate)
+
+
+class LstmHeadsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cache: E.PackCache, x: Tensor, hx: Tensor, cx: Tensor, w_ih: Tensor, w_hh: Tensor, b_ih: Tensor,
+                b_hh: Tensor, w_heads: Tensor, b_heads: Tensor):
+        x, hx, cx = x.detach().float().contiguous(), hx.detach().float().contiguous(), cx.detach().float().contiguous()
+        n, hd = hx.shape
+        gates = E.linear(x, w_ih.detach(), b_ih.detach())
+        E.linear(hx, w_hh.detach(), b_hh.detach(), out=gates, accumulate=True)
+        h = torch.empty_like(hx)
+        c = torch.empty_like(cx)
+        nv.check(nv.lib().dmd_lstm_pointwise(nv.fptr(gates), nv.fptr(cx), nv.fptr(h), nv.fptr(c), n, hd, nv.stream()),
+                 "dmd_lstm_pointwise")
+        heads = E.linear(h, w_heads.detach().contiguous(), b_heads.detach().contiguous())
+        ctx.save_for_backward(x, hx, cx, gates, h, c, w_heads)
+        # transposed weights for the data gradients: cached per parameter version (forward sees the Parameter objects)
+        ctx.w_ih_t = cache.get(w_ih, "T", lambda w: w.detach().t().contiguous()) if ctx.needs_input_grad[1] else None
+        ctx.w_hh_t = cache.get(w_hh, "T", lambda w: w.detach().t().contiguous()) if ctx.needs_input_grad[2] else None
+        return heads, h, c
+
+    @staticmethod
+    def backward(ctx, dheads: Optional[Tensor], dh: Optional[Tensor], dc: Optional[Tensor]):
+        x, hx, cx, gates, h, c, w_heads = ctx.saved_tensors
+        n, hd = hx.shape
+        need = ctx.needs_input_grad  # (cache, x, hx, cx, w_ih, w_hh, b_ih, b_hh, w_heads, b_heads)
+        dw_heads = db_heads = None
+        dh_total = None if dh is None else dh.detach().float().contiguous()
+        if dheads is not None:
+            dheads = dheads.detach().float().contiguous()
+            # dh += dheads @ W_heads ; dW_heads = dheads^T @ h ; db_heads = sum dheads
+            wt = w_heads.detach().t().contiguous()  # (hd, A + 1)
+            dh_total = _mm_nt(dheads, wt, out=dh_total.clone() if dh_total is not None else None, accumulate=dh_total is not None)
+            dw_heads = _mm_nt(dheads.t(), h.t())
+            db_heads = dheads.sum(0)
+        dgates = torch.empty_like(gates)
+        dc_prev = torch.empty_like(cx)
+        dcc = None if dc is None else dc.detach().float().contiguous()
+        nv.check(nv.lib().dmd_lstm_pointwise_bwd(nv.fptr(gates), nv.fptr(cx), nv.fptr(c), nv.fptr(dh_total), nv.fptr(dcc),
+                                                 nv.fptr(dgates), nv.fptr(dc_prev), n, hd, nv.stream()), "dmd_lstm_pointwise_bwd")
+        dx = dhx = None
+        if need[1]:
+            dx = _mm_nt(dgates, ctx.w_ih_t)
+        if need[2]:
+            dhx = _mm_nt(dgates, ctx.w_hh_t)
+        dgt = dgates.t().contiguous()
+        dw_ih = _mm_nt(dgt, x.t())
+        dw_hh = _mm_nt(dgt, hx.t())
+        db = dgates.sum(0)
+        return (None, dx, dhx, dc_prev if need[3] else None, dw_ih, dw_hh, db, db, dw_heads, db_heads)
+
+
+def lstm_heads(cache: E.PackCache, x: Tensor, hx: Tensor, cx: Tensor, lstm, actor_linear, critic_linear
+               ) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """(logits_act, val, hx', cx') of reference actor_critic.py:72-73."""
+    if not x.is_cuda:
+        raise RuntimeError("diamond_amd kernels need GPU tensors (there is no CPU path)")
+    w_heads = torch.cat((actor_linear.weight, critic_linear.weight), dim=0)
+    b_heads = torch.cat((actor_linear.bias, critic_linear.bias), dim=0)
+    heads, h, c = LstmHeadsFn.apply(cache, x, hx, cx, lstm.weight_ih, lstm.weight_hh, lstm.bias_ih, lstm.bias_hh, w_heads, b_heads)
+    a = actor_linear.out_features
+    return heads[:, :a], heads[:, a], h, c

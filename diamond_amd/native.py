@@ -67,7 +67,7 @@ EXPORTS = (
     "dmd_pack_conv_weight_f16x2", "dmd_linear", "dmd_attention", "dmd_attention_bwd", "dmd_attention_bwd_workspace_floats",
     "dmd_edm_pack_input", "dmd_cond_embed", "dmd_edm_denoised", "dmd_euler_step", "dmd_heun_step", "dmd_quantize_u8",
     "dmd_dequant_gather", "dmd_nchw_to_nhwc",
-    "dmd_nhwc_to_nchw", "dmd_gn_stats", "dmd_maxpool2", "dmd_lstm_pointwise", "dmd_categorical_sample",
+    "dmd_nhwc_to_nchw", "dmd_gn_stats", "dmd_maxpool2", "dmd_lstm_pointwise", "dmd_lstm_pointwise_bwd", "dmd_categorical_sample",
     "dmd_maxpool2_bwd", "dmd_gn_bwd_workspace_bytes", "dmd_gn_silu_bwd", "dmd_wgrad_workspace_floats", "dmd_conv2d_wgrad",
     "dmd_last_error", "dmd_abi_version",
 )
@@ -117,6 +117,8 @@ def lib() -> C.CDLL:
         L.dmd_maxpool2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p]
         L.dmd_lstm_pointwise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.dmd_lstm_pointwise_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_int, C.c_int, C.c_void_p]
         L.dmd_categorical_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.dmd_conv_stat_tiles.argtypes = [C.c_int, C.c_int]
         L.dmd_maxpool2_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]

@@ -186,6 +186,11 @@ int dmd_maxpool2(const float* x, float* out, uint8_t* argmax, double* out_stats,
 int dmd_lstm_pointwise(const float* gates, const float* c_prev, float* h, float* c, int N, int Hd,
                        dmd_stream_t stream);
 
+/* backward of dmd_lstm_pointwise: gates = the forward's pre-activations, dh / dc = gradients w.r.t. the new h / c
+ * (NULL = zero) -> dgates (N, 4*Hd), dc_prev (N, Hd)   (autograd of nn.LSTMCell, actor_critic.py:46,72) */
+int dmd_lstm_pointwise_bwd(const float* gates, const float* c_prev, const float* c_new, const float* dh, const float* dc,
+                           float* dgates, float* dc_prev, int N, int Hd, dmd_stream_t stream);
+
 /* argmax(softmax(logits) / E) with injected exponential draws E == Categorical(logits).sample()
  * (env_loop.py:32, world_model_env.py:103-104). */
 int dmd_categorical_sample(const float* logits, const float* expo, int64_t* out, int N, int A, dmd_stream_t stream);
