@@ -338,7 +338,7 @@ def main():
         key = max(summ, key=lambda k: summ[k]["ms"])
         d = summ[key]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        split = key.startswith("conv_f16ws") or (key.startswith("conv1x1_stream") and key.endswith("true>"))
+        split = key.startswith("conv_f16ws") or (key.startswith("conv1x1_stream") and key.endswith("true>"))  # split-fp16 kernels
         peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
         pmc, pmc_set = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")

@@ -36,12 +36,20 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const dmd_linear_param
     n = n < p.N ? n : p.N - 1;
     wrow[b] = p.W + (size_t)n * p.ldw + 4 * kg;
   }
+  // K loop, software-pipelined: the fragments of step k0 + 16 are in flight while the 16 MFMAs of step k0 issue
+  // (these GEMMs are L2-resident and latency-bound: without the prefetch every step waits a full L2 round trip)
+  f32x4 af[2], wf[2], an[2], wn[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    af[b] = *(const f32x4*)(arow[b]);
+    wf[b] = *(const f32x4*)(wrow[b]);
+  }
   for (int k0 = 0; k0 < p.K; k0 += 16) {
-    f32x4 af[2], wf[2];
+    const int kn = k0 + 16 < p.K ? k0 + 16 : k0;  // last step: harmless reload
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      af[b] = *(const f32x4*)(arow[b] + k0);
-      wf[b] = *(const f32x4*)(wrow[b] + k0);
+      an[b] = *(const f32x4*)(arow[b] + kn);
+      wn[b] = *(const f32x4*)(wrow[b] + kn);
     }
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
@@ -50,6 +58,11 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const dmd_linear_param
 #pragma unroll
         for (int t = 0; t < 4; ++t)
           acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nb][t], af[mb][t], acc[nb][mb], 0, 0, 0);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      af[b] = an[b];
+      wf[b] = wn[b];
+    }
   }
   // D rows = n (4*kg + r), cols = m (i)
 #pragma unroll
