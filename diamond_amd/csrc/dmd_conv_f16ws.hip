@@ -623,17 +623,30 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         }
         if (pixoff[blk] >= 0) {
           float* op = p.out + (size_t)pixoff[blk] * 4;
+#if WS_ABL & 256
+          // timing proxy (WRONG results): the same bytes as fully coalesced 1 KiB-per-instruction accesses
+          const size_t cbase = (size_t)__shfl(pixoff[blk], 0, 64) * 4 + (size_t)lane * 4;
+#endif
           f32x4 rv[4];
 #pragma unroll
-          for (int qd = 0; qd < 4; ++qd)
+          for (int qd = 0; qd < 4; ++qd) {
+#if WS_ABL & 256
+            rv[qd] = p.residual ? *(const f32x4*)(p.residual + cbase + 256 * qd) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#else
             rv[qd] = (p.residual && !(WS_ABL & 128)) ? *(const f32x4*)(p.residual + (size_t)pixoff[blk] * 4 + 8 * qd) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#endif
+          }
           float fs = 0.f, fq = 0.f;  // fp32 over the lane's 16 values of this block, fp64 across
 #pragma unroll
           for (int qd = 0; qd < 4; ++qd) {
             f32x4 v = (f32x4){acc[blk][4 * qd], acc[blk][4 * qd + 1], acc[blk][4 * qd + 2], acc[blk][4 * qd + 3]};
             v += bias[qd];
             v += rv[qd];
+#if WS_ABL & 256
+            *(f32x4*)(p.out + cbase + 256 * qd) = v;
+#else
             if (!(WS_ABL & 128) || v[0] == 1.2345e30f) *(f32x4*)(op + 8 * qd) = v;
+#endif
             fs += (v[0] + v[1]) + (v[2] + v[3]);
             // Sum of squares as an fma chain into its own register, NOT as in-place squares of v: with the squares
             // written over v's registers (`v_mul_f32 v48, v48, v48` right behind the `global_store_dwordx4 v[48:51]`),
