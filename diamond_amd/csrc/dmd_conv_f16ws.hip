@@ -47,8 +47,14 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // alternate tiles: two MFMA waves per SIMD cover each other's LDS round trips, and a chunk's 36 KiB of weights (the
 // larger part of the LDS fill) is staged once per 512 pixels instead of once per 256.  The write-out of a finished tile
 // is then no longer hidden under the other group's MFMAs.
-template <bool B8_, int NCB_, int TAPS_ = 9, bool JOINT_ = false>
+// P8: ONE consumer group (waves 0-3, every tile, write-out right after the tile) and EIGHT producer waves (4-11): the
+// measured critical path of a step is the producers' staging + their stalls at vector-memory issue, so the
+// four waves that otherwise only write tiles out and wait become producers.  Measured r02o (DIAMOND_WS_P8=1): the K loop
+// gets ~12 % faster, the now exposed write-out costs ~14 %: 287 vs 280 us on the 64x64 conv, 9.5k vs 9.9k frames/s.
+template <bool B8_, int NCB_, int TAPS_ = 9, bool JOINT_ = false, bool P8_ = false>
 struct WsGeom {
+  static constexpr bool P8 = P8_;
+  static constexpr int NPT = P8_ ? 512 : 256;  // producer threads
   static constexpr bool B8 = B8_;
   static constexpr int NCB = NCB_;
   static constexpr int TAPS = TAPS_;
@@ -61,9 +67,9 @@ struct WsGeom {
   static constexpr int PW = TS + 2;
   static constexpr int PPS = PW * PW;
   static constexpr int NPP = SUB * PPS;
-  static constexpr int ITEMS = (NPP * 4 + 255) / 256;
+  static constexpr int ITEMS = (NPP * 4 + NPT - 1) / NPT;
   static constexpr int W_UNITS = TAPS_ * 2 * 2 * COUT;      // 16-byte units of one chunk's weights
-  static constexpr int WU = (W_UNITS + 255) / 256;          // units per producer thread
+  static constexpr int WU = (W_UNITS + NPT - 1) / NPT;      // units per producer thread
   static constexpr int BUF_UNITS = NPP * 4 + W_UNITS;       // one {patch, weights} buffer, 16-byte units
   static constexpr int CIN_MAX = NCB_ == 2 ? 128 : 64;
   static constexpr int TAB_SLOTS = JOINT_ ? 3 : 4;  // tile generations whose tables can be alive at once (>= 3)
@@ -80,7 +86,7 @@ struct WsGeom {
 #ifndef WS_W_BY_IDLE
 #define WS_W_BY_IDLE 0  // measured r02j: 346 vs 296 us on the 64x64 conv, 8.5k vs 9.75k frames/s -- the "idle" group is not idle enough
 #endif
-  static constexpr bool W_BY_IDLE = WS_W_BY_IDLE && !JOINT_;
+  static constexpr bool W_BY_IDLE = WS_W_BY_IDLE && !JOINT_ && !P8_;
   static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
 };
 
@@ -184,11 +190,13 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
 #define WS_ABL 0  // development only (WRONG results): 1 = producers idle in steady state, 2 = no activation loads, 4 = no store_S, 16 = no MFMA loop,
                   // 32 = no weight global loads, 64 = no weight LDS writes either, 128 = no epilogue global stores / residual loads
 #endif
-  const int role = threadIdx.x >> 8;  // 0, 1: consumer groups (even / odd tiles), 2: producer (staging)
+  // 0, 1: consumer groups (even / odd tiles), 2: producer (staging); P8: 0 = the consumer group, 2 = producers (threads 256..767)
+  const int role = G::P8 ? (threadIdx.x >> 8 ? 2 : 0) : (int)(threadIdx.x >> 8);
 #if WS_TRACE
   int ws_ti = 0;  // next trace slot of this role's stamping thread (stores only: no load on the stamping path)
 #endif
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int tid = (G::P8 && threadIdx.x >= 256) ? (int)threadIdx.x - 256 : (int)(threadIdx.x & 255);  // index inside the role
+  const int lane = tid & 63, wave = tid >> 6;
   const int up = p.upsample;
   const int Hs = p.H >> up, Ws = p.W >> up;
   const int C0 = p.src[0].C;
@@ -212,10 +220,10 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     const int q = tid & 3;
     int ipos[G::ITEMS];  // (sub << 16) | (py << 8) | px; -1: no item (beyond the patch)
     // 8-byte unit index of the h half-quad of item `it` in a patch (recomputed where needed: registers are scarce)
-    auto loff_of = [&](int it) { return ((it * 64 + (tid >> 2)) * 4 + (((q >> 1) + ((ipos[it] & 0xff) >> 1)) & 3)) * 2 + (q & 1); };
+    auto loff_of = [&](int it) { return ((it * (G::NPT / 4) + (tid >> 2)) * 4 + (((q >> 1) + ((ipos[it] & 0xff) >> 1)) & 3)) * 2 + (q & 1); };
 #pragma unroll
     for (int it = 0; it < G::ITEMS; ++it) {
-      const int id = it * 256 + tid;
+      const int id = it * G::NPT + tid;
       const int pp = id >> 2;
       const bool ok = pp < G::NPP;
       const int s = G::SUB == 1 ? 0 : (ok ? pp / G::PPS : 0);
@@ -354,7 +362,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           hv[el] = h;
           lv[el] = (_Float16)(x - (float)h);
         }
-        if ((it + 1) * 256 <= G::NPP * 4 || ipos[it] >= 0) {  // only the last item row can fall beyond the patch
+        if ((it + 1) * G::NPT <= G::NPP * 4 || ipos[it] >= 0) {  // only the last item row can fall beyond the patch
           const int lo = loff_of(it);
           pb[lo] = __builtin_bit_cast(uint2, hv);
           pb[lo ^ 4] = __builtin_bit_cast(uint2, lv);
@@ -388,11 +396,11 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       const u32x4* w = wglob + (size_t)ck * G::W_UNITS + tid;
 #pragma unroll
       for (int i = 0; i < G::WU; ++i)
-        if (G::W_UNITS % 256 == 0 || tid + 256 * i < G::W_UNITS) {
+        if (G::W_UNITS % G::NPT == 0 || tid + G::NPT * i < G::W_UNITS) {
 #if WS_ABL & 32
           ws[i] = (u32x4){(unsigned)(size_t)w, 0x3c003c00u, 0u, (unsigned)i};
 #else
-          ws[i] = w[256 * i];
+          ws[i] = w[G::NPT * i];
 #endif
         }
     };
@@ -403,7 +411,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       u32x4* wl = bufs + (e & 1) * G::BUF_UNITS + G::NPP * 4;
 #pragma unroll
       for (int i = 0; i < G::WU; ++i)
-        if (G::W_UNITS % 256 == 0 || tid + 256 * i < G::W_UNITS) wl[tid + 256 * i] = ws[i];
+        if (G::W_UNITS % G::NPT == 0 || tid + G::NPT * i < G::W_UNITS) wl[tid + G::NPT * i] = ws[i];
     };
     auto load_W = [&](int e) {
       if (!G::W_BY_IDLE) load_Wr(e, wst);
@@ -704,7 +712,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     __syncthreads();  // B0
     int j = 0;
     for (int k = 0; k < nmy; ++k) {
-      if (G::JOINT || (k & 1) == role) {
+      if (G::JOINT || G::P8 || (k & 1) == role) {
         // ---- this group's tile: MFMA only ----
         if (pending < 4) epi_blocks(4);  // (only if the other group's tile had too few steps to finish the write-out)
 #pragma unroll
@@ -769,7 +777,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           WS_STAMP(role, 2, j);
         }
         epi_begin(k);  // written out while the other group computes the next tile
-        if (G::JOINT) epi_blocks(4);  // ... or right away: every consumer wave is needed for the next tile
+        if (G::JOINT || G::P8) epi_blocks(4);  // ... or right away: every consumer wave is needed for the next tile
       } else {
         // ---- the other group's tile: write our finished tile out, a slice per chunk step ----
         for (int ck = 0; ck < nchunks; ++ck, ++j) {
@@ -799,7 +807,12 @@ static int launch_f16ws(const dmd_conv_params& p, int ntiles, hipStream_t st) {
   }
   // persistent: one 768-thread workgroup per CU (LDS-limited), contiguous tile ranges (neighbouring tiles share
   // halo rows and, inside one image, the normalisation statistics)
-  const int ncu = 256;
+  static int ncu = 0;  // compute units of the current device (MI355X: 256), queried once
+  if (ncu == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    ncu = n;
+  }
   const int tpw = (ntiles + ncu - 1) / ncu;
   const int nwg = (ntiles + tpw - 1) / tpw;
   hipLaunchKernelGGL((conv_f16ws_kernel<G>), dim3(nwg), dim3(768), G::SMEM_BYTES, st, p, ntiles, tpw);
@@ -810,6 +823,8 @@ int dmd_launch_conv_f16ws(const dmd_conv_params& p, hipStream_t st) {
   const bool b8 = p.W % 16 != 0;
   const int sub8 = p.N * (p.H / 8) * (p.W / 8), t16 = p.N * (p.H / 16) * (p.W / 16);
   static const int joint = getenv("DIAMOND_WS_JOINT") ? atoi(getenv("DIAMOND_WS_JOINT")) : 0;
+  static const int p8 = getenv("DIAMOND_WS_P8") ? atoi(getenv("DIAMOND_WS_P8")) : 0;
+  if (p8 && p.taps == 9 && p.CoutPad == 64 && !b8) return launch_f16ws<WsGeom<false, 2, 9, false, true>>(p, t16, st);
   if (joint && p.taps == 9 && p.CoutPad == 64 && !b8 && t16 >= 512) return launch_f16ws<WsGeom<false, 2, 9, true>>(p, (t16 + 1) / 2, st);
   if (p.taps == 9) {
     if (p.CoutPad == 64) return b8 ? launch_f16ws<WsGeom<true, 2, 9>>(p, (sub8 + 3) / 4, st) : launch_f16ws<WsGeom<false, 2, 9>>(p, t16, st);
