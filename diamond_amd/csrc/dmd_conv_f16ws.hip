@@ -83,8 +83,11 @@ struct WsGeom {
   // the current tile (it only writes its finished tile out and otherwise waits at the barriers) instead of by the
   // producers: measured r02i, the weight loads cost the producers -- the critical path of every step, they stall at
   // ISSUE while the vector-memory queue is backed up -- 15 % of the kernel.  JOINT has no idle group.
+#ifndef WS_W_DMA
+#define WS_W_DMA 1  // with WS_W_BY_IDLE: the idle group moves the weights with LDS-DMA (global_load_lds, no registers)
+#endif
 #ifndef WS_W_BY_IDLE
-#define WS_W_BY_IDLE 0  // measured r02j: 346 vs 296 us on the 64x64 conv, 8.5k vs 9.75k frames/s -- the "idle" group is not idle enough
+#define WS_W_BY_IDLE 1  // r02j: through registers 346 vs 296 us (spills, the group arrives late at the barrier); r02p: with LDS-DMA (WS_W_DMA) +1.4 % end to end
 #endif
   static constexpr bool W_BY_IDLE = WS_W_BY_IDLE && !JOINT_ && !P8_;
   static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
@@ -688,20 +691,35 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     const int blocks_per_step = nchunks >= 4 ? 1 : (nchunks >= 2 ? 2 : 4);
 
     // ---- weight copy of the idle group (W_BY_IDLE): element e's 36 KiB into buffer e & 1 ----
-    u32x4 cw[G::W_BY_IDLE ? G::WU : 1];
+    u32x4 cw[(G::W_BY_IDLE && !WS_W_DMA) ? G::WU : 1];
     const u32x4* cwglob = (const u32x4*)p.w_f16;
     auto cons_load_W = [&](int e) {
       const int ck = e % nchunks;
       const u32x4* w = cwglob + (size_t)ck * G::W_UNITS + tid;
+#if WS_W_DMA
+      // LDS-DMA: lane l of a wave lands at (wave-uniform base) + 16 l; round i moves units [256 i, 256 i + 256)
+      u32x4* wl = (u32x4*)bufs + (e & 1) * G::BUF_UNITS + G::NPP * 4 + wave * 64;
 #pragma unroll
       for (int i = 0; i < G::WU; ++i)
-        if (G::W_UNITS % 256 == 0 || tid + 256 * i < G::W_UNITS) cw[G::W_BY_IDLE ? i : 0] = w[256 * i];
+        if (G::W_UNITS % 256 == 0 || 256 * i + wave * 64 < G::W_UNITS)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w + 256 * i),
+                                           (__attribute__((address_space(3))) void*)(wl + 256 * i), 16, 0, 0);
+#else
+#pragma unroll
+      for (int i = 0; i < G::WU; ++i)
+        if (G::W_UNITS % 256 == 0 || tid + 256 * i < G::W_UNITS) cw[(G::W_BY_IDLE && !WS_W_DMA) ? i : 0] = w[256 * i];
+#endif
     };
     auto cons_store_W = [&](int e) {
+#if WS_W_DMA
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA writes have landed before the step's barrier
+      (void)e;
+#else
       u32x4* wl = (u32x4*)bufs + (e & 1) * G::BUF_UNITS + G::NPP * 4;
 #pragma unroll
       for (int i = 0; i < G::WU; ++i)
-        if (G::W_UNITS % 256 == 0 || tid + 256 * i < G::W_UNITS) wl[tid + 256 * i] = cw[G::W_BY_IDLE ? i : 0];
+        if (G::W_UNITS % 256 == 0 || tid + 256 * i < G::W_UNITS) wl[tid + 256 * i] = cw[(G::W_BY_IDLE && !WS_W_DMA) ? i : 0];
+#endif
     };
 
     __syncthreads();  // B(-1)
