@@ -90,6 +90,16 @@ struct WsGeom {
 #define WS_W_BY_IDLE 1  // r02j: through registers 346 vs 296 us (spills, the group arrives late at the barrier); r02p: with LDS-DMA (WS_W_DMA) +1.4 % end to end
 #endif
   static constexpr bool W_BY_IDLE = WS_W_BY_IDLE && !JOINT_ && !P8_;
+  // REV: tiles with an odd index inside their image walk the K chunks in DESCENDING order, so that at every tile
+  // boundary of the persistent walk the last chunk of one tile is the first chunk of the next and its 36 KiB of weights
+  // are already in LDS: one weight fetch in `nchunks` saved (a quarter of the weight bytes at Cin = 64, ALL but the
+  // first at Cin = 16).  The kernel runs at the CU's memory-path ceiling (~17 GB/s per CU whatever the mix of
+  // activations / weights / outputs), half of the bytes are weights.  The order depends only on the tile's
+  // position inside its image, never on the batch: results stay bitwise independent of the launch configuration.
+#ifndef WS_REV
+#define WS_REV 0  // measured r02r: correct (bitwise tpw tests pass) but no gain (10.0k vs 10.2k frames/s, conv 269 vs 266 us)
+#endif
+  static constexpr bool REV = WS_REV && W_BY_IDLE && SUB == 1;
   static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
 };
 
@@ -214,6 +224,13 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
   // bits -> the same HBM channels).
   const int rot = (blockIdx.x * 7) % nmy;
 #define WS_TILE(k) (tile0 + (((k) + rot) >= nmy ? (k) + rot - nmy : (k) + rot))
+  const int tiles_per_img = (p.H / G::TS) * (p.W / G::TS);
+  // K chunk (16 input channels) processed by stream element e
+  auto chunk_of = [&](int e) -> int {
+    const int k = e / nchunks, ck = e - k * nchunks;
+    if (!G::REV) return ck;
+    return ((WS_TILE(k) % tiles_per_img) & 1) ? nchunks - 1 - ck : ck;
+  };
 
   if (role == 2) {
     // =================================== PRODUCER ===================================
@@ -298,7 +315,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
 
     // activation loads of stream element e into a register set (+ which items are conv zero padding)
     auto issue_S = [&](int e, auto& st, unsigned& zmask, int& slot_out) {
-      const int k = e / nchunks, ck = e - k * nchunks;
+      const int k = e / nchunks, ck = chunk_of(e);
       if (k != gk) setup_tile(k);
       slot_out = tab_slot;
       const int si = ck < nch0 ? 0 : 1;
@@ -329,7 +346,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     // mode (wave-uniform, hoisted out of the item loop as a compile-time tag): 0 = no prologue, 1 = norm, 2 = norm + SiLU
     auto store_S_mode = [&](auto mode_tag, int e, const auto& st, unsigned zmask, int slot) {
       constexpr int MODE = decltype(mode_tag)::value;
-      const int ck = e % nchunks;
+      const int ck = chunk_of(e);
       const int cc = ck * 16 + 4 * q;
       uint2* pb = (uint2*)(bufs + (e & 1) * G::BUF_UNITS);
       // single-image tiles: the (a, b) rows of this thread's channel quad are the same for every item -> ONE pair of
@@ -376,7 +393,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
 #if WS_ABL & 4
       if (e > 1) return;
 #endif
-      const int ck = e % nchunks;
+      const int ck = chunk_of(e);
       const int prologue = p.src[ck < nch0 ? 0 : 1].prologue;
       if (prologue == DMD_PROLOGUE_NORM_SILU)
         store_S_mode(std::integral_constant<int, 2>{}, e, st, zmask, slot);
@@ -395,7 +412,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     constexpr bool WPF2 = WS_WPF && G::DOUBLE_STAGE;
     u32x4 wst[G::WU], wst2[WPF2 ? G::WU : 1];
     auto load_Wr = [&](int e, auto& ws) {
-      const int ck = e % nchunks;
+      const int ck = chunk_of(e);
       const u32x4* w = wglob + (size_t)ck * G::W_UNITS + tid;
 #pragma unroll
       for (int i = 0; i < G::WU; ++i)
@@ -693,12 +710,11 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     // ---- weight copy of the idle group (W_BY_IDLE): element e's 36 KiB into buffer e & 1 ----
     u32x4 cw[(G::W_BY_IDLE && !WS_W_DMA) ? G::WU : 1];
     const u32x4* cwglob = (const u32x4*)p.w_f16;
-    auto cons_load_W = [&](int e) {
-      const int ck = e % nchunks;
+    auto cons_load_W = [&](int ck, int wbuf) {
       const u32x4* w = cwglob + (size_t)ck * G::W_UNITS + tid;
 #if WS_W_DMA
       // LDS-DMA: lane l of a wave lands at (wave-uniform base) + 16 l; round i moves units [256 i, 256 i + 256)
-      u32x4* wl = (u32x4*)bufs + (e & 1) * G::BUF_UNITS + G::NPP * 4 + wave * 64;
+      u32x4* wl = (u32x4*)bufs + wbuf * G::BUF_UNITS + G::NPP * 4 + wave * 64;
 #pragma unroll
       for (int i = 0; i < G::WU; ++i)
         if (G::W_UNITS % 256 == 0 || 256 * i + wave * 64 < G::W_UNITS)
@@ -710,12 +726,12 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         if (G::W_UNITS % 256 == 0 || tid + 256 * i < G::W_UNITS) cw[(G::W_BY_IDLE && !WS_W_DMA) ? i : 0] = w[256 * i];
 #endif
     };
-    auto cons_store_W = [&](int e) {
+    auto cons_store_W = [&](int wbuf) {
 #if WS_W_DMA
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA writes have landed before the step's barrier
-      (void)e;
+      (void)wbuf;
 #else
-      u32x4* wl = (u32x4*)bufs + (e & 1) * G::BUF_UNITS + G::NPP * 4;
+      u32x4* wl = (u32x4*)bufs + wbuf * G::BUF_UNITS + G::NPP * 4;
 #pragma unroll
       for (int i = 0; i < G::WU; ++i)
         if (G::W_UNITS % 256 == 0 || tid + 256 * i < G::W_UNITS) wl[tid + 256 * i] = cw[(G::W_BY_IDLE && !WS_W_DMA) ? i : 0];
@@ -724,10 +740,18 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
 
     __syncthreads();  // B(-1)
     if (G::W_BY_IDLE && role == 1) {  // group 1 is idle during tile 0: it provides the first chunk's weights
-      cons_load_W(0);
+      cons_load_W(chunk_of(0), 0);
       cons_store_W(0);
     }
     __syncthreads();  // B0
+    // weight buffer of the current step (== j & 1 unless a tile boundary re-used the previous step's weights, REV)
+    int wb = 0, cur_ck = chunk_of(0);
+    // step j -> j + 1: which chunk comes next, can its weights stay where they are, and where do they live
+    auto next_weights = [&](int jn, int& ck_n, bool& reuse, int& wb_n) {
+      ck_n = chunk_of(jn);
+      reuse = G::REV && ck_n == cur_ck;
+      wb_n = reuse ? wb : (wb ^ 1);
+    };
     int j = 0;
     for (int k = 0; k < nmy; ++k) {
       if (G::JOINT || G::P8 || (k & 1) == role) {
@@ -738,7 +762,8 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[blk][r] = 0.f;
         for (int ck = 0; ck < nchunks; ++ck, ++j) {
-          const u32x4* buf = bufs + (j & 1) * G::BUF_UNITS;
+          const u32x4* buf = bufs + (j & 1) * G::BUF_UNITS;   // patch of this step
+          const u32x4* bufw = bufs + wb * G::BUF_UNITS;        // weights of this step
           WS_STAMP(role, 0, j);
 #if WS_PIPE
           // Software pipeline over the taps: the 10 fragment reads of tap t + 1 are issued between the 12 MFMAs of tap t
@@ -748,6 +773,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           // bit-identical to the unpipelined loop.
           constexpr int NT = (WS_ABL & 16) ? 0 : G::TAPS;
           WsFrag fa, fb;
+          static_assert(!G::REV, "WS_PIPE reads weights and patch from one buffer: build with -DWS_REV=0");
           if (NT > 0) ws_load_frag<G>(buf, 0, wunit, pixbase, posh, fa);
 #pragma unroll
           for (int tt = 0; tt < NT; tt += 2) {
@@ -768,12 +794,12 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
             const int dy = win / 3, dx = win % 3;
             h8 bh[4], bl[4];
             const int toff = dy * G::PW + dx;
-            const h8 ah = __builtin_bit_cast(h8, buf[(tap * 2 + 0) * 2 * G::COUT + wunit]);
+            const h8 ah = __builtin_bit_cast(h8, bufw[(tap * 2 + 0) * 2 * G::COUT + wunit]);
             bh[0] = __builtin_bit_cast(h8, buf[(pixbase[0] + toff) * 4 + posh[dx]]);
             bh[1] = __builtin_bit_cast(h8, buf[(pixbase[1] + toff) * 4 + posh[dx]]);
             bl[0] = __builtin_bit_cast(h8, buf[(pixbase[0] + toff) * 4 + (posh[dx] ^ 2)]);
             bl[1] = __builtin_bit_cast(h8, buf[(pixbase[1] + toff) * 4 + (posh[dx] ^ 2)]);
-            const h8 al = __builtin_bit_cast(h8, buf[(tap * 2 + 1) * 2 * G::COUT + wunit]);
+            const h8 al = __builtin_bit_cast(h8, bufw[(tap * 2 + 1) * 2 * G::COUT + wunit]);
             bh[2] = __builtin_bit_cast(h8, buf[(pixbase[2] + toff) * 4 + posh[dx]]);
             bh[3] = __builtin_bit_cast(h8, buf[(pixbase[3] + toff) * 4 + posh[dx]]);
             bl[2] = __builtin_bit_cast(h8, buf[(pixbase[2] + toff) * 4 + (posh[dx] ^ 2)]);
@@ -793,6 +819,13 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           WS_STAMP(role, 1, j);
           __syncthreads();  // B(j + 1)
           WS_STAMP(role, 2, j);
+          if (j + 1 < S) {
+            int ck_n, wb_n;
+            bool reuse;
+            next_weights(j + 1, ck_n, reuse, wb_n);
+            cur_ck = ck_n;
+            wb = wb_n;
+          }
         }
         epi_begin(k);  // written out while the other group computes the next tile
         if (G::JOINT || G::P8) epi_blocks(4);  // ... or right away: every consumer wave is needed for the next tile
@@ -800,13 +833,20 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         // ---- the other group's tile: write our finished tile out, a slice per chunk step ----
         for (int ck = 0; ck < nchunks; ++ck, ++j) {
           WS_STAMP(role, 8, j);
-          const bool wnext = G::W_BY_IDLE && j + 1 < S;  // this (idle) group copies the next step's weights
-          if (wnext) cons_load_W(j + 1);
+          int ck_n = 0, wb_n = wb ^ 1;
+          bool reuse = false;
+          if (j + 1 < S) next_weights(j + 1, ck_n, reuse, wb_n);
+          const bool wnext = G::W_BY_IDLE && j + 1 < S && !reuse;  // this (idle) group copies the next step's weights
+          if (wnext) cons_load_W(ck_n, wb_n);
           if (pending < 4) epi_blocks(blocks_per_step);
-          if (wnext) cons_store_W(j + 1);
+          if (wnext) cons_store_W(wb_n);
           WS_STAMP(role, 9, j);
           __syncthreads();  // B(j + 1)
           WS_STAMP(role, 10, j);
+          if (j + 1 < S) {
+            cur_ck = ck_n;
+            wb = wb_n;
+          }
         }
       }
     }
