@@ -170,3 +170,67 @@ print('ok')
     out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-3000:]
+
+
+def test_ring_env_bookkeeping_matches_roll_based_shadow_cpu():
+    """Host logic of the new WorldModelEnv on CPU tensors (no kernel is launched: the two re-assignable callables are
+    stubbed, the pool is pre-filled as fp32): ring advance, resets from the pool (serving order + the reference's
+    'drop the remainder and reload' rule, world_model_env.py:133-139), returned observations, final_observation and
+    burnin_obs against a shadow that rolls its buffers like the reference (world_model_env.py:64-89)."""
+    from types import SimpleNamespace
+
+    b, t, c, h, w = 3, 4, 1, 2, 2
+    g = torch.Generator().manual_seed(0)
+    rounds = [(torch.randn(2 * b, t, c, h, w, generator=g), torch.randint(0, 4, (2 * b, t), generator=g)) for _ in range(6)]
+    loader = SimpleNamespace(batch_sampler=SimpleNamespace(batch_size=b))
+    fake_den = SimpleNamespace(device=torch.device("cpu"))
+    env = D.WorldModelEnv.__new__(D.WorldModelEnv)
+    env.sampler = SimpleNamespace(denoiser=fake_den, noise_fn=None)
+    env.rew_end_model, env.horizon, env.return_denoising_trajectory, env.num_envs = None, 3, False, b
+    env.graph_sampler, env.expo_fn = False, None
+    env._ctx = env._act = None
+    env._head = 0
+    from diamond_amd.world_model_env import InitialConditionPool
+
+    pool = InitialConditionPool(None, loader, 2, lambda: torch.device("cpu"))
+    served = {"n": 0}
+
+    def preload():  # stands in for the kernel-backed preload: one round = 2 batches of b rows, kept as an fp32 pool
+        obs, act = rounds[served["n"]]
+        served["n"] += 1
+        pool.frames_u8, pool.frames_f32, pool.act = None, obs, act
+        pool.hx, pool.cx = torch.zeros(2 * b, 8), torch.zeros(2 * b, 8)
+        pool._cursor = 0
+
+    pool._preload = preload
+    env.pool = pool
+    obs0, _ = env.reset()
+    sh_obs, sh_act = rounds[0][0][:b].clone(), rounds[0][1][:b].clone()
+    cursor, rnd = b, 0
+    assert torch.equal(obs0, sh_obs[:, -1]) and torch.equal(env.obs_buffer, sh_obs)
+    state = {}
+    env.predict_next_obs = lambda: (state["nxt"], [])
+    env.predict_rew_end = lambda next_obs: (torch.zeros(b), state["end"])
+    for step in range(14):
+        act = torch.randint(0, 4, (b,), generator=g)
+        state["nxt"] = torch.randn(b, c, h, w, generator=g)
+        state["end"] = (torch.rand(b, generator=g) < 0.3).long()
+        obs, rew, end, trunc, info = env.step(act)
+        sh_act[:, -1] = act
+        sh_obs, sh_act = sh_obs.roll(-1, dims=1), sh_act.roll(-1, dims=1)
+        sh_obs[:, -1] = state["nxt"]
+        dead = torch.logical_or(end, trunc)
+        if dead.any():
+            nd = int(dead.sum())
+            if cursor + nd > 2 * b:
+                rnd, cursor = rnd + 1, 0
+            sh_obs[dead] = rounds[rnd][0][cursor:cursor + nd]
+            sh_act[dead] = rounds[rnd][1][cursor:cursor + nd]
+            cursor += nd
+            assert torch.equal(info["final_observation"], state["nxt"][dead])
+            assert torch.equal(info["burnin_obs"], sh_obs[dead, :-1])
+        assert torch.equal(obs, sh_obs[:, -1]), step
+        assert torch.equal(env.obs_buffer, sh_obs), step
+        assert torch.equal(env.act_buffer[:, :-1], sh_act[:, :-1]), step
+        assert obs.data_ptr() != env._ctx.data_ptr()  # returned observations never alias the ring
+    assert served["n"] == rnd + 1 and rnd >= 1
