@@ -336,6 +336,10 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         }
 #if WS_ABL & 2
         st[it] = (f32x4){(float)go, 1.f, 2.f, (float)c0};
+#elif WS_ABL & 512
+        st[it] = base4[((unsigned)go & 0x3fffu) * cq];  // timing proxy: same loads folded into a 4 MB (L2-resident) window
+#elif WS_ABL & 1024
+        st[it] = base4[((unsigned)go & 0xfffffu) * cq];  // ... into a 256 MB window (Infinity-Cache-sized)
 #else
         st[it] = base4[(unsigned)go * cq];
 #endif
@@ -440,7 +444,44 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       if (!G::W_BY_IDLE) store_Wr(e, wst);
     };
 
-    if (G::DOUBLE_STAGE && WPF2) {
+#ifndef WS_TRIPLE
+#define WS_TRIPLE 0  // 1: THREE activation register sets (loads three steps ahead) where the weights are moved by the idle group
+#endif
+    constexpr bool TRIPLE = WS_TRIPLE && G::DOUBLE_STAGE && G::W_BY_IDLE;
+    f32x4 stage2[TRIPLE ? G::ITEMS : 1];
+    unsigned zm2 = 0;
+    int sl2 = 0;
+    if (TRIPLE) {
+      // element e lives in register set e % 3; step j stores element j + 1 and re-issues its set for element j + 4
+      issue_S(0, stage0, zm0, sl0);
+      if (S > 1) issue_S(1, stage1, zm1, sl1);
+      if (S > 2) issue_S(2, stage2, zm2, sl2);
+      __syncthreads();  // B(-1)
+      store_S(0, stage0, zm0, sl0);
+      if (S > 3) issue_S(3, stage0, zm0, sl0);
+      __syncthreads();  // B0
+      for (int j = 0; j < S; j += 3) {
+        if (j + 1 < S) {
+          store_S(j + 1, stage1, zm1, sl1);
+          if (j + 4 < S) issue_S(j + 4, stage1, zm1, sl1);
+        }
+        __syncthreads();
+        if (j + 1 < S) {
+          if (j + 2 < S) {
+            store_S(j + 2, stage2, zm2, sl2);
+            if (j + 5 < S) issue_S(j + 5, stage2, zm2, sl2);
+          }
+          __syncthreads();
+          if (j + 2 < S) {
+            if (j + 3 < S) {
+              store_S(j + 3, stage0, zm0, sl0);
+              if (j + 6 < S) issue_S(j + 6, stage0, zm0, sl0);
+            }
+            __syncthreads();
+          }
+        }
+      }
+    } else if (G::DOUBLE_STAGE && WPF2) {
       // as below, with the weights of element e fetched two steps before they are copied into LDS (even elements
       // through wst, odd ones through wst2): an L2 round trip under load is longer than one step's staging work
       issue_S(0, stage0, zm0, sl0);
@@ -711,6 +752,9 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     u32x4 cw[(G::W_BY_IDLE && !WS_W_DMA) ? G::WU : 1];
     const u32x4* cwglob = (const u32x4*)p.w_f16;
     auto cons_load_W = [&](int ck, int wbuf) {
+#if WS_ABL & 32
+      if (wbuf >= 0) return;  // ablation: the weights are never moved (LDS keeps whatever it held)
+#endif
       const u32x4* w = cwglob + (size_t)ck * G::W_UNITS + tid;
 #if WS_W_DMA
       // LDS-DMA: lane l of a wave lands at (wave-uniform base) + 16 l; round i moves units [256 i, 256 i + 256)
