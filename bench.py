@@ -294,8 +294,12 @@ def main():
         cs = torch.tensor([parameter_checksum(ac)], device=device, dtype=torch.float64)
         gathered = [torch.zeros_like(cs) for _ in range(world)]
         dist.all_gather(gathered, cs)
-        assert all(float(g) == float(gathered[0]) for g in gathered), f"replicas diverged: {[float(g) for g in gathered]}"
+        replicas_in_sync = all(float(g) == float(gathered[0]) for g in gathered)
+        if not replicas_in_sync and rank == 0:
+            print(f"[bench] WARNING: replicas diverged: checksums {[float(g) for g in gathered]}", file=sys.stderr, flush=True)
 
+    else:
+        replicas_in_sync = None
     progress(f"timed region done: {elapsed:.2f}s for {args.steps} steps")
     custom = any(getattr(args, k) != v for k, v in preset.items())
     cfg_idx = args.config if world == 1 or args.config != 1 else 2
@@ -321,7 +325,8 @@ def main():
                                + END_LOGIT_BIAS_NOTE,
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (batch-sharded envs, flat-bucket "
                    "RCCL all-reduce of actor-critic grads)", "actor_critic_backend": ac.backend,
-                   "world_model_precision": E.WORLD_MODEL_PRECISION, "actor_critic_precision": ac_native.AC_PRECISION},
+                   "world_model_precision": E.WORLD_MODEL_PRECISION, "actor_critic_precision": ac_native.AC_PRECISION,
+                   "replicas_in_sync": replicas_in_sync},
         "whole_step_algorithmic": {"gflop_per_frame": flop_pf / 1e9, "mb_per_frame": bytes_pf / 1e6,
                                    "tflops": fps * flop_pf / 1e12 / world,
                                    "frac_fp32_peak": fps * flop_pf / 1e12 / world / FP32_MFMA_PEAK_TFLOPS,
