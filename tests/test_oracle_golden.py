@@ -102,7 +102,7 @@ def test_actor_critic_forward_backward():
         assert rel_err(mine.detach(), gold[key]) < 2e-5, key
     assert rel_err(loss.detach(), gold["loss"]) < 2e-5
     for k, n in gold["grad_norms"].items():
-        assert abs(float(sd[k].grad.norm()) - float(n)) <= 5e-5 * float(n) + 1e-7, k
+        assert abs(float(sd[k].grad.double().norm()) - float(n)) <= 5e-5 * float(n) + 1e-7, k
     for k, gr in gold["grads_small"].items():
         assert rel_err(sd[k].grad, gr) < 5e-5, k
 
