@@ -74,7 +74,9 @@ struct WsGeom {
   static constexpr int CIN_MAX = NCB_ == 2 ? 128 : 64;
   static constexpr int TAB_SLOTS = JOINT_ ? 3 : 4;  // tile generations whose tables can be alive at once (>= 3)
   static constexpr int TAB_FLOATS = TAB_SLOTS * SUB * CIN_MAX;
-  static constexpr int SMEM_BYTES = 2 * BUF_UNITS * 16 + 2 * TAB_FLOATS * 4;
+  // raw fp32 patch of one chunk as the LDS-DMA writes it: unit (it * 256 + tid), the last item only where it has pixels
+  static constexpr int RAW_UNITS = (ITEMS - 1) * 256 + ((NPP * 4 - (ITEMS - 1) * 256 + 63) / 64) * 64;
+  static constexpr int SMEM_BASE = 2 * BUF_UNITS * 16 + 2 * TAB_FLOATS * 4;
   static constexpr bool DOUBLE_STAGE = NCB_ == 2 && !JOINT_;          // two activation register sets only where they fit
   // source pixel offsets of a tile cached in registers (one per item) or recomputed at every chunk: recomputing frees
   // ITEMS registers (JOINT needs them) but costs ~18 VALU per item and chunk (measured r02e: 8x8 levels +25 %)
@@ -100,7 +102,15 @@ struct WsGeom {
 #define WS_REV 0  // measured r02r: correct (bitwise tpw tests pass) but no gain (10.0k vs 10.2k frames/s, conv 269 vs 266 us)
 #endif
   static constexpr bool REV = WS_REV && W_BY_IDLE && SUB == 1;
-  static_assert(SMEM_BYTES <= 160 * 1024, "LDS budget");
+  // A_DMA: the ACTIVATIONS, too, are moved by the idle consumer group with LDS-DMA (raw fp32 patch of element e + 2 into a
+  // two-slot LDS ring while element e is computed); the producers then never touch global memory: they read the raw patch
+  // from LDS, normalise / activate / split it and write the h/l patch.  Needs 2 x RAW_UNITS x 16 more bytes of LDS.
+#ifndef WS_A_DMA
+#define WS_A_DMA 0  // measured r02x: correct (108 conv tests) but the idle group becomes the critical path: 294 vs 264 us, 9.1k vs 9.8k frames/s
+#endif
+  static constexpr bool A_DMA = WS_A_DMA && WS_W_DMA && W_BY_IDLE && DOUBLE_STAGE && SUB == 1 && !P8_ &&
+                                (SMEM_BASE + 2 * RAW_UNITS * 16 <= 160 * 1024);
+  static constexpr int SMEM_BYTES = SMEM_BASE + (A_DMA ? 2 * RAW_UNITS * 16 : 0);
 };
 
 struct WsTile {
@@ -198,6 +208,8 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
   u32x4* bufs = (u32x4*)smem_raw;  // [2][BUF_UNITS]: patch [NPP][4] then weights [9][2][2][64]
   float* tab_a = (float*)(bufs + 2 * G::BUF_UNITS);  // [slot][SUB][CIN_MAX]
   float* tab_b = tab_a + G::TAB_FLOATS;
+  u32x4* rawring = (u32x4*)(tab_b + G::TAB_FLOATS);  // [2][RAW_UNITS] (A_DMA only)
+  static_assert(G::SMEM_BYTES <= 160 * 1024, "LDS budget");
 
 #ifndef WS_ABL
 #define WS_ABL 0  // development only (WRONG results): 1 = producers idle in steady state, 2 = no activation loads, 4 = no store_S, 16 = no MFMA loop,
@@ -451,7 +463,29 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     f32x4 stage2[TRIPLE ? G::ITEMS : 1];
     unsigned zm2 = 0;
     int sl2 = 0;
-    if (TRIPLE) {
+    if (G::A_DMA) {
+      // the raw patch of element e was DMA'd into rawring slot e & 1 by the idle consumer group (two steps before it is
+      // consumed); here: LDS -> registers -> prologue math -> h/l patch of buffer e & 1
+      auto stage_from_lds = [&](int e) {  // requires: descriptors / tables of element e's tile are current AND visible
+        const u32x4* rs = rawring + (e & 1) * G::RAW_UNITS;
+        f32x4 st[G::ITEMS];
+#pragma unroll
+        for (int it = 0; it < G::ITEMS; ++it)
+          st[it] = (it * 256 + tid < G::RAW_UNITS) ? __builtin_bit_cast(f32x4, rs[it * 256 + tid]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        store_S(e, st, gzero, tab_slot);
+        // the next element's tile: its tables go to a fresh slot and become visible at the barrier that ends this step
+        if (e + 1 < S && (e + 1) / nchunks != gk) setup_tile((e + 1) / nchunks);
+      };
+      __syncthreads();  // B(-1): the raw patches of elements 0 and 1 have landed; the tables of tile 0 need one more barrier
+      setup_tile(0);
+      __syncthreads();  // B(-1'): tables visible
+      stage_from_lds(0);
+      __syncthreads();  // B0
+      for (int j = 0; j < S; ++j) {
+        if (j + 1 < S) stage_from_lds(j + 1);
+        __syncthreads();
+      }
+    } else if (TRIPLE) {
       // element e lives in register set e % 3; step j stores element j + 1 and re-issues its set for element j + 4
       issue_S(0, stage0, zm0, sl0);
       if (S > 1) issue_S(1, stage1, zm1, sl1);
@@ -782,10 +816,44 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
 #endif
     };
 
-    __syncthreads();  // B(-1)
-    if (G::W_BY_IDLE && role == 1) {  // group 1 is idle during tile 0: it provides the first chunk's weights
-      cons_load_W(chunk_of(0), 0);
-      cons_store_W(0);
+    // ---- A_DMA: raw activation patch of stream element E into rawring slot E & 1 (same (item, lane) -> patch position
+    //      mapping as the producers' `ipos`; conv zero padding is applied by the producers) ----
+    auto cons_dma_acts = [&](int E) {
+      const int k = E / nchunks, ck = chunk_of(E);
+      const WsTile t = ws_subtile<G>(p, WS_TILE(k), 0);
+      const int si = ck < nch0 ? 0 : 1;
+      const dmd_conv_src& sc = p.src[si];
+      const int c0 = (si ? ck - nch0 : ck) * 16 + 4 * (tid & 3);
+      u32x4* rs = rawring + (E & 1) * G::RAW_UNITS + wave * 64;
+#pragma unroll
+      for (int it = 0; it < G::ITEMS; ++it) {
+        if (it * 256 + wave * 64 >= G::RAW_UNITS) continue;  // wave-uniform: the last item has pixels in wave 0 only
+        const int pp = it * 64 + (tid >> 2);
+        const int py = pp / G::PW, px = pp - py * G::PW;
+        const int iy = t.y0 - 1 + py, ix = t.x0 - 1 + px;
+        const bool window = G::TAPS == 9 || (py >= 1 && py <= G::TS && px >= 1 && px <= G::TS);
+        const bool inb = pp < G::NPP && window && t.valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const int go = inb ? ((t.n * Hs + (iy >> up)) * Ws + (ix >> up)) : 0;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sc.x + (size_t)(unsigned)go * sc.C + c0),
+                                         (__attribute__((address_space(3))) void*)(rs + it * 256), 16, 0, 0);
+      }
+    };
+
+    if (G::A_DMA) {
+      if (role == 1) {  // group 1 is idle during tile 0: raw patches of elements 0 and 1 + the first chunk's weights
+        cons_dma_acts(0);
+        if (S > 1) cons_dma_acts(1);
+        cons_load_W(chunk_of(0), 0);
+        cons_store_W(0);
+      }
+      __syncthreads();  // B(-1)
+      __syncthreads();  // B(-1')
+    } else {
+      __syncthreads();  // B(-1)
+      if (G::W_BY_IDLE && role == 1) {  // group 1 is idle during tile 0: it provides the first chunk's weights
+        cons_load_W(chunk_of(0), 0);
+        cons_store_W(0);
+      }
     }
     __syncthreads();  // B0
     // weight buffer of the current step (== j & 1 unless a tile boundary re-used the previous step's weights, REV)
@@ -881,9 +949,10 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           bool reuse = false;
           if (j + 1 < S) next_weights(j + 1, ck_n, reuse, wb_n);
           const bool wnext = G::W_BY_IDLE && j + 1 < S && !reuse;  // this (idle) group copies the next step's weights
+          if (G::A_DMA && j + 2 < S) cons_dma_acts(j + 2);          // ... and the raw activations two steps ahead
           if (wnext) cons_load_W(ck_n, wb_n);
           if (pending < 4) epi_blocks(blocks_per_step);
-          if (wnext) cons_store_W(wb_n);
+          if (wnext || (G::A_DMA && j + 2 < S)) cons_store_W(wb_n);  // vmcnt(0): the DMA writes have landed
           WS_STAMP(role, 9, j);
           __syncthreads();  // B(j + 1)
           WS_STAMP(role, 10, j);
