@@ -396,3 +396,44 @@ def test_denoiser_training_step_vs_reference_golden():
         bad = {k: v for k, v in errs.items() if v >= 1e-4}
         assert not bad, (precision, bad)
     UT.TRAIN_PRECISION = "f16x2"
+
+
+@pytest.mark.parametrize("name,steps,order,churn,b", [("euler4_churn", 4, 1, 1.0, 2), ("heun6_churn", 6, 2, 2.0, 1),
+                                                      ("heun50_configs3", 50, 2, 0.0, 1)])
+def test_sampler_branches_bit_exact_vs_oracle_control_flow(agent, name, steps, order, churn, b):
+    """DiffusionSampler.sample's remaining branches (reference diffusion_sampler.py:39-43 churn, :52-56 Heun, the 50-step
+    2nd-order schedule of BASELINE configs[3] = 99 denoiser calls): the oracle's restatement of the loop is run with THIS
+    denoiser plugged in (`denoise_fn`), so every difference left is the sampler's own control flow / pointwise arithmetic
+    (host-side sigma schedule, churn injection, fused Euler and Heun kernels) -- which must be bit-exact."""
+    import diamond_amd as D
+    from diamond_amd.testing import synthetic_actions, synthetic_frames
+    from oracle import diamond_oracle as O
+
+    g = torch.Generator().manual_seed(steps * 10 + order)
+    prev_obs = synthetic_frames(g, b, 4, 3, 64, 64)
+    prev_act = synthetic_actions(g, 4, b, 4)
+    cfg = D.DiffusionSamplerConfig(num_steps_denoising=steps, order=order, s_churn=churn)
+    sspec = O.SamplerSpec(num_steps_denoising=steps, order=order, s_churn=churn)
+    draws = [torch.randn(b, 3, 64, 64, generator=g) for _ in range(steps + 1)]  # x0, then one churn draw per step
+
+    calls = {"n": 0}
+
+    def hip_denoise(x, sigma, obs, act):
+        calls["n"] += 1
+        return agent.denoiser.denoise(x.to(DEV), sigma, obs.to(DEV), act.to(DEV)).cpu()
+
+    it_ref = iter(draws[1:])
+    x_ref, traj_ref = O.sample(None, None, sspec, prev_obs, prev_act, draws[0], churn_noise=lambda x: next(it_ref),
+                               denoise_fn=hip_denoise)
+    n_ref = calls["n"]
+    sampler = D.DiffusionSampler(agent.denoiser, cfg)
+    it_mine = iter(draws)
+    sampler.noise_fn = lambda shape, dev: next(it_mine).to(dev)
+    calls["n"] = 0
+    x, traj = sampler.sample(prev_obs.to(DEV), prev_act.to(DEV))
+    assert len(traj) == len(traj_ref) == steps + 1
+    if order == 2:
+        assert n_ref == 2 * steps - 1  # Heun skips the second evaluation of the last step (next_sigma == 0)
+    for i, (a, r) in enumerate(zip(traj, traj_ref)):
+        assert torch.equal(a.cpu(), r), f"{name}: trajectory point {i} differs"
+    assert torch.equal(x.cpu(), x_ref)
