@@ -41,8 +41,8 @@ def save(name, obj):
     print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
 
 
-def gen_denoiser(agent, tag, h=64, w=64, b=2):
-    """Denoiser.denoise at the three sampler sigmas + a per-sample (B,) sigma."""
+def gen_denoiser(agent, tag, h=64, w=64, b=2, only=None):
+    """Denoiser.denoise at the three sampler sigmas + a per-sample (B,) sigma (`only`: indices to keep)."""
     from models.diffusion import DiffusionSampler, DiffusionSamplerConfig
 
     g = torch.Generator().manual_seed(11)
@@ -54,6 +54,8 @@ def gen_denoiser(agent, tag, h=64, w=64, b=2):
     out = {"sigmas": sampler.sigmas.clone(), "seed": 11}
     with torch.no_grad():
         for i, sigma in enumerate(list(sampler.sigmas[:-1]) + [torch.tensor([0.7, 1.9][:b])]):
+            if only is not None and i not in only:
+                continue
             x = noise * sigma.reshape(-1, 1, 1, 1) + obs[:, -3:] * 0.5
             cs = den.compute_conditioners(sigma)
             f = den.compute_model_output(x, obs, act, cs)
@@ -289,6 +291,9 @@ def main():
     if "--denoiser-train" in sys.argv:
         gen_denoiser_train()
         return
+    if "--denoiser-256" in sys.argv:  # BASELINE configs[4] shape: one 256x256 frame, attention at the two deepest levels
+        gen_denoiser(ref_agent(denoiser_attn_depths=(0, 0, 1, 1)), "attn0011_256", h=256, w=256, b=1, only=(1, 3))
+        return
     if "--window-tf" in sys.argv or "--actor-critic" in sys.argv:  # (re)generate single fixtures
         if "--window-tf" in sys.argv:
             gen_window_teacher_forced()
@@ -306,6 +311,7 @@ def main():
     gen_denoiser_train()
     # attention at 16x16 and 8x8 inside the U-Net (BASELINE config 5 uses attn_depths=[0,0,1,1])
     gen_denoiser(ref_agent(denoiser_attn_depths=(0, 0, 1, 1)), "attn0011", b=1)
+    gen_denoiser(ref_agent(denoiser_attn_depths=(0, 0, 1, 1)), "attn0011_256", h=256, w=256, b=1, only=(1, 3))
 
 
 if __name__ == "__main__":

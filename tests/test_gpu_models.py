@@ -42,13 +42,13 @@ def agent():
     return make_agent()
 
 
-def _denoiser_inputs(gold, b):
+def _denoiser_inputs(gold, b, h=64, w=64):
     from diamond_amd.testing import synthetic_actions, synthetic_frames
 
     g = torch.Generator().manual_seed(gold["seed"])
-    obs = synthetic_frames(g, b, 12, 64, 64)
+    obs = synthetic_frames(g, b, 12, h, w)
     act = synthetic_actions(g, 4, b, 4)
-    noise = torch.randn(b, 3, 64, 64, generator=g)
+    noise = torch.randn(b, 3, h, w, generator=g)
     return obs, act, noise
 
 
@@ -328,6 +328,24 @@ def test_window_teacher_forced_vs_reference_golden_1e4():
         print(f"window {wi}:", {k: f"{v:.2e}" for k, v in errs.items()})
         bad = {k: v for k, v in errs.items() if v >= 1e-4}
         assert not bad, (wi, bad)
+
+
+def test_denoiser_256x256_attention_vs_reference_golden():
+    """BASELINE configs[4] shape pinned to the REFERENCE itself (tests/golden/denoiser_attn0011_256.pt: one 256x256 frame,
+    attention at the two deepest levels = 1024- and 4096-token attention, a scalar and a per-sample sigma)."""
+    gold = load_golden("denoiser_attn0011_256.pt")
+    ag = make_agent((0, 0, 1, 1))
+    obs, act, noise = _denoiser_inputs(gold, 1, 256, 256)
+    sig = gold["sigmas"]
+    for i, sigma in ((1, sig[1]), (3, torch.tensor([0.7]))):
+        x = noise * sigma.reshape(-1, 1, 1, 1) + obs[:, -3:] * 0.5
+        for prec in ("f16x2", "f32"):
+            f = ag.denoiser.compute_model_output(x.to(DEV), obs.to(DEV), act.to(DEV), sigma, precision=prec)
+            err = rel_err(f, gold[f"model_output_{i}"])
+            print(f"256x256 vs reference golden, sigma#{i} {prec}: {err:.3e}")
+            assert err < 1e-4, (i, prec, err)
+        d = ag.denoiser.denoise(x.to(DEV), sigma, obs.to(DEV), act.to(DEV))
+        check_quantised(u8(d), gold[f"denoised_u8_{i}"], max_frac=3e-4)
 
 
 def test_denoiser_256x256_attention_vs_oracle():
