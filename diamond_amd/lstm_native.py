@@ -84,6 +84,62 @@ class LstmHeadsFn(torch.autograd.Function):
         return (None, dx, dhx, dc_prev if need[3] else None, dw_ih, dw_hh, db, db, dw_heads, db_heads)
 
 
+class LinearFn(torch.autograd.Function):
+    """y = x W^T (+ b) on dmd_linear, forward and backward (the LSTM input projection over a whole segment and the
+    two head linears of RewEndModel's training step, reference rew_end_model.py:35-40,53-54)."""
+
+    @staticmethod
+    def forward(ctx, cache: E.PackCache, x: Tensor, w: Tensor, b: Optional[Tensor]):
+        x = x.detach().float().contiguous()
+        y = _mm_nt(x, w.detach(), None if b is None else b.detach().contiguous())
+        ctx.save_for_backward(x)
+        # a Parameter is transposed once per version; a derived weight (the permuted weight_ih) on every call
+        ctx.w_t = (cache.get(w, "T", lambda t: t.detach().t().contiguous()) if isinstance(w, torch.nn.Parameter)
+                   else w.detach().t().contiguous()) if ctx.needs_input_grad[1] else None
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        (x,) = ctx.saved_tensors
+        dy = dy.detach().float().contiguous()
+        dx = _mm_nt(dy, ctx.w_t) if ctx.needs_input_grad[1] else None
+        dw = _mm_nt(dy.t(), x.t())
+        return None, dx, dw, dy.sum(0) if ctx.has_bias else None
+
+
+class LstmStepFn(torch.autograd.Function):
+    """One step of nn.LSTM given the precomputed input projection gx = x W_ih^T + b_ih:
+    (h', c') = cell(gx + hx W_hh^T + b_hh, cx).  BPTT over the segment is torch chaining these through (hx, cx)."""
+
+    @staticmethod
+    def forward(ctx, cache: E.PackCache, gx: Tensor, hx: Tensor, cx: Tensor, w_hh: Tensor, b_hh: Tensor):
+        hx, cx = hx.detach().float().contiguous(), cx.detach().float().contiguous()
+        n, hd = hx.shape
+        gates = gx.detach().float().clone(memory_format=torch.contiguous_format)
+        E.linear(hx, w_hh.detach(), b_hh.detach(), out=gates, accumulate=True)
+        h, c = torch.empty_like(hx), torch.empty_like(cx)
+        nv.check(nv.lib().dmd_lstm_pointwise(nv.fptr(gates), nv.fptr(cx), nv.fptr(h), nv.fptr(c), n, hd, nv.stream()),
+                 "dmd_lstm_pointwise")
+        ctx.save_for_backward(hx, cx, gates, c)
+        ctx.w_hh_t = cache.get(w_hh, "T", lambda w: w.detach().t().contiguous())
+        return h, c
+
+    @staticmethod
+    def backward(ctx, dh: Optional[Tensor], dc: Optional[Tensor]):
+        hx, cx, gates, c = ctx.saved_tensors
+        n, hd = hx.shape
+        dhc = None if dh is None else dh.detach().float().contiguous()
+        dcc = None if dc is None else dc.detach().float().contiguous()
+        dgates, dc_prev = torch.empty_like(gates), torch.empty_like(cx)
+        nv.check(nv.lib().dmd_lstm_pointwise_bwd(nv.fptr(gates), nv.fptr(cx), nv.fptr(c), nv.fptr(dhc), nv.fptr(dcc),
+                                                 nv.fptr(dgates), nv.fptr(dc_prev), n, hd, nv.stream()), "dmd_lstm_pointwise_bwd")
+        need = ctx.needs_input_grad  # (cache, gx, hx, cx, w_hh, b_hh)
+        dhx = _mm_nt(dgates, ctx.w_hh_t) if need[2] else None
+        dw_hh = _mm_nt(dgates.t(), hx.t())
+        return None, dgates, dhx, dc_prev if need[3] else None, dw_hh, dgates.sum(0)
+
+
 def lstm_heads(cache: E.PackCache, x: Tensor, hx: Tensor, cx: Tensor, lstm, actor_linear, critic_linear
                ) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """(logits_act, val, hx', cx') of reference actor_critic.py:72-73."""

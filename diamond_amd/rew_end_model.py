@@ -1,8 +1,9 @@
-"""Reward / termination model (reference models/rew_end_model.py), inference path native.
+"""Reward / termination model (reference models/rew_end_model.py): inference and training step on the HIP kernels.
 
 `predict_rew_end` is on every WorldModelEnv.step (world_model_env.py:95-105) and in the
 initial-condition burn-in (:123-124).  Encoder = the same fused conv / FiLM / attention
 kernels as the denoiser at C = 32; the LSTM step is two MFMA GEMMs + one pointwise kernel.
+`forward(batch)` is the training loss of trainer.py:365 (recorded forward + hand-written backward, see unet_train.py).
 """
 from __future__ import annotations
 
@@ -59,8 +60,9 @@ class RewEndEncoder(nn.Module):
         self.downsamples = nn.ModuleList([nn.Identity()] + [Downsample(c) for c in channels[:-1]] + [nn.Identity()])
 
     def run(self, ctx: RunCtx, x_nhwc16: Tensor) -> E.Act:
-        x = E.conv2d([(E.Act(x_nhwc16), nv.PROLOGUE_NONE, None)], ctx.cache.conv_weight(self.conv_in),
-                     ctx.cache.conv_bias(self.conv_in), self.conv_in.out_channels, naive=ctx.naive, w_f16=ctx.w16(self.conv_in))
+        x = E.conv2d([(E.Act(x_nhwc16, needs_grad=False), nv.PROLOGUE_NONE, None)], ctx.cache.conv_weight(self.conv_in),
+                     ctx.cache.conv_bias(self.conv_in), self.conv_in.out_channels, naive=ctx.naive, w_f16=ctx.w16(self.conv_in),
+                     module=self.conv_in)
         for blocks, down in zip(self.blocks, self.downsamples):
             if not isinstance(down, nn.Identity):
                 x = down.run(ctx, x)
@@ -80,6 +82,7 @@ class RewEndModel(nn.Module):
         init_lstm(self.lstm)
         self._cache = E.PackCache()
         self._film: Optional[FilmTable] = None
+        self._train_params: Optional[List[nn.Parameter]] = None
 
     @property
     def device(self) -> torch.device:
@@ -130,6 +133,88 @@ class RewEndModel(nn.Module):
         logits = E.linear(y, self._cache.f32(self.head[2].weight), None).reshape(b, t, -1)
         return logits[:, :, :-2], logits[:, :, -2:], (hx.unsqueeze(0), cx.unsqueeze(0))
 
+    # -- training step (reference rew_end_model.py:57-90) ----------------------------------------------------------
+    def logits_with_grad(self, obs: Tensor, act: Tensor, next_obs: Tensor, precision: Optional[str] = None) -> Tensor:
+        """predict_rew_end's logits (B, T, 5), from a zero LSTM state, differentiable w.r.t. every parameter.  Encoder:
+        the inference kernels under a recorded tape with the hand-written backward (unet_train.EncoderTrainFn);
+        LSTM over the segment and the head: lstm_native.LinearFn / LstmStepFn; action embedding and the FiLM table
+        (tiny gathers / GEMMs) are torch ops under autograd."""
+        import torch.nn.functional as F
+        from . import unet_train as UT
+        from .blocks import AdaGroupNorm
+        from .lstm_native import LinearFn, LstmStepFn
+
+        b, t, c, h, w = obs.shape
+        x = torch.cat((obs.reshape(b * t, c, h, w), next_obs.reshape(b * t, c, h, w)), dim=1).detach()
+        x16 = E.nchw_to_nhwc(x, 16)
+        cond = self.act_emb(act.reshape(b * t))
+        if self._film is None:
+            self._film = FilmTable(self.encoder)
+        film = self._film
+        table = F.linear(cond, torch.cat([m.linear.weight for m in film.norms], dim=0),
+                         torch.cat([m.linear.bias for m in film.norms], dim=0))
+        if self._train_params is None:
+            skip = {id(p) for m in self.encoder.modules() if isinstance(m, AdaGroupNorm) for p in m.parameters()}
+            self._train_params = [p for p in self.encoder.parameters() if id(p) not in skip]
+        precision = precision or UT.TRAIN_PRECISION
+
+        def run(tab: Tensor) -> Tensor:
+            return self.encoder.run(RunCtx(self._cache, film, tab, precision=precision), x16).t
+
+        feat = UT.EncoderTrainFn.apply(run, self._cache, table, precision, *self._train_params)  # (b t, s, s, e) NHWC
+        hd, e = self.cfg.lstm_dim, self.cfg.channels[-1]
+        w_ih = self.lstm.weight_ih_l0
+        s_ = feat.shape[1]
+        w_ih_nhwc = w_ih.reshape(4 * hd, e, s_, s_).permute(0, 2, 3, 1).reshape(4 * hd, -1)  # (e h w) -> (h w e) columns
+        gx = LinearFn.apply(self._cache, feat.reshape(b * t, -1), w_ih_nhwc, self.lstm.bias_ih_l0).reshape(b, t, 4 * hd)
+        hx = torch.zeros(b, hd, device=obs.device)
+        cx = torch.zeros(b, hd, device=obs.device)
+        ys = []
+        for i in range(t):
+            hx, cx = LstmStepFn.apply(self._cache, gx[:, i], hx, cx, self.lstm.weight_hh_l0, self.lstm.bias_hh_l0)
+            ys.append(hx)
+        y = torch.stack(ys, dim=1).reshape(b * t, hd)
+        y = F.silu(LinearFn.apply(self._cache, y, self.head[0].weight, self.head[0].bias))
+        return LinearFn.apply(self._cache, y, self.head[2].weight, None).reshape(b, t, -1)
+
     def forward(self, batch):
-        raise NotImplementedError("RewEndModel.forward (training loss, reference rew_end_model.py:57-90) needs the encoder "
-                                  "backward kernels: out of the imagined-rollout path (SURVEY.md §8f)")
+        """Cross-entropy losses of the reward (sign-clipped, 3 classes) and termination (2 classes) heads over the
+        unpadded steps of a segment, with the true final observation put back where the episode ended (reference
+        rew_end_model.py:57-90).  Returns (loss, metrics) with the reference's metric names."""
+        import torch.nn.functional as F
+
+        obs = batch.obs[:, :-1]
+        act = batch.act[:, :-1]
+        next_obs = batch.obs[:, 1:]
+        rew = batch.rew[:, :-1]
+        end = batch.end[:, :-1]
+        mask = batch.mask_padding[:, :-1]
+        dead = end.bool().any(dim=1)
+        if dead.any():
+            final_obs = torch.stack([i["final_observation"] for i, d in zip(batch.info, dead) if d]).to(obs.device)
+            next_obs[dead, end[dead].argmax(dim=1)] = final_obs  # writes through to batch.obs, like the reference
+        logits = self.logits_with_grad(obs, act, next_obs)
+        logits_rew, logits_end = logits[:, :, :-2][mask], logits[:, :, -2:][mask]
+        target_rew = rew[mask].sign().long().add(1)
+        target_end = end[mask]
+        loss_rew = F.cross_entropy(logits_rew, target_rew)
+        loss_end = F.cross_entropy(logits_end, target_end)
+        loss = loss_rew + loss_end
+        metrics = {
+            "loss_rew": loss_rew.detach(),
+            "loss_end": loss_end.detach(),
+            "loss_total": loss.detach(),
+            "confusion_matrix": {
+                "rew": confusion_matrix(logits_rew, target_rew, 3),
+                "end": confusion_matrix(logits_end, target_end, 2),
+            },
+        }
+        return loss, metrics
+
+
+def confusion_matrix(logits: Tensor, target: Tensor, num_classes: int) -> Tensor:
+    """torcheval.metrics.functional.multiclass_confusion_matrix(logits, target, num_classes) (a pinned dependency of
+    the reference, rew_end_model.py:8,84-85; not vendored): entry [i, j] counts samples of true class i predicted
+    (argmax) as class j, int64."""
+    pred = logits.detach().argmax(dim=1)
+    return torch.bincount(target.detach().long() * num_classes + pred, minlength=num_classes ** 2).reshape(num_classes, num_classes)

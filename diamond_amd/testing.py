@@ -64,3 +64,20 @@ def initial_condition_batches(seed: int, batch: int, num_actions: int, t: int = 
     g = torch.Generator().manual_seed(seed)
     while True:
         yield synthetic_frames(g, batch, t, c, h, w), synthetic_actions(g, num_actions, batch, t)
+
+
+def rew_end_train_batch(g, b=3, t=6):
+    """Synthetic (B, T) segment for RewEndModel.forward: rewards in {-2..2}, one episode end (sample 1, step 3) with its
+    `final_observation`, and a padded tail (sample 2).  Shared by tests/golden/make_golden.py and the parity test (tensors on CPU)."""
+    obs = synthetic_frames(g, b, t, 3, 64, 64)
+    act = synthetic_actions(g, 4, b, t)
+    rew = torch.randint(-2, 3, (b, t), generator=g).float()
+    end = torch.zeros(b, t, dtype=torch.long)
+    end[1, 3] = 1
+    mask = torch.ones(b, t, dtype=torch.bool)
+    mask[1, 4:] = False  # steps after the end of the episode are padding
+    mask[2, 4:] = False
+    info = [{} for _ in range(b)]
+    info[1]["final_observation"] = synthetic_frames(g, 1, 3, 64, 64)[0]
+    return dict(obs=obs, act=act, rew=rew, end=end, trunc=torch.zeros(b, t, dtype=torch.long), mask_padding=mask, info=info,
+                segment_ids=None)

@@ -138,15 +138,21 @@ class _ParamGrads:
             self.add_param(spec.gn_module.bias, dadd.sum(0))
 
 
-def backward_tape(tape: List, cache: E.PackCache, d_out_nchw: Tensor, table: Tensor, use_f16: bool) -> _ParamGrads:
-    """Walk the recorded launches in reverse; returns the parameter / FiLM-table gradients."""
+def backward_tape(tape: List, cache: E.PackCache, d_out: Tensor, table: Tensor, use_f16: bool,
+                  out_nhwc: Optional[Tensor] = None) -> _ParamGrads:
+    """Walk the recorded launches in reverse; returns the parameter / FiLM-table gradients.
+    `out_nhwc` None: the tape ends with the NCHW head convolution (U-Net) and `d_out` is (N, 3, H, W); otherwise
+    `out_nhwc` is the recorded NHWC activation the network returned (an encoder) and `d_out` its gradient."""
     grads = _Grads()
     pg = _ParamGrads(table)
     pending_norm: Dict[int, Tensor] = {}  # gradient w.r.t. GN_affine(x) handed over by a residual_norm consumer
-    last = tape[-1]
-    assert isinstance(last, ConvRecord) and last.out_nchw, "the tape must end with the NCHW head convolution"
-    # dF (N, 3, H, W) -> NHWC with the channels zero-padded to 16 (wgrad / dgrad work on 16-channel groups)
-    grads.add(last.out.t, E.nchw_to_nhwc(d_out_nchw.contiguous().float(), 16))
+    if out_nhwc is None:
+        last = tape[-1]
+        assert isinstance(last, ConvRecord) and last.out_nchw, "the tape must end with the NCHW head convolution"
+        # dF (N, 3, H, W) -> NHWC with the channels zero-padded to 16 (wgrad / dgrad work on 16-channel groups)
+        grads.add(last.out.t, E.nchw_to_nhwc(d_out.contiguous().float(), 16))
+    else:
+        grads.add(out_nhwc, d_out.contiguous().float())
     for rec in reversed(tape):
         if isinstance(rec, AttnRecord):
             dy = grads.pop(rec.out)
@@ -239,15 +245,44 @@ class UNetTrainFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out: Tensor):
-        # The backward is linear in d_out: run it on d_out * 2^k with the largest entry O(1) and scale the results back
-        # (exact in fp32).  Loss gradients are ~1e-5 and smaller; the split-fp16 dgrad operands have an absolute
-        # resolution floor of 2^-25 (dmd_conv_f16ws.hip) that unscaled gradients would sit on.
-        d_out = d_out.detach().float()
-        amax = d_out.abs().amax()
-        k = torch.where(amax > 0, torch.floor(-torch.log2(amax.clamp_min(1e-37))), torch.zeros_like(amax)).clamp(-120, 120)
-        inv = torch.exp2(-k)
-        pg = backward_tape(ctx.tape, ctx.inner._cache, d_out * torch.exp2(k), ctx.table, use_f16=ctx.precision == "f16x2")
+        pg, inv = scaled_backward(ctx.tape, ctx.inner._cache, d_out, ctx.table, use_f16=ctx.precision == "f16x2")
         ctx.tape = None  # free the saved activations
+        grads = tuple(None if pg.by_param.get(id(p)) is None else pg.by_param[id(p)] * inv for p in ctx.params)
+        return (None, None, pg.dtable * inv, None, *grads)
+
+
+def scaled_backward(tape: List, cache: E.PackCache, d_out: Tensor, table: Tensor, use_f16: bool,
+                    out_nhwc: Optional[Tensor] = None) -> Tuple[_ParamGrads, Tensor]:
+    """backward_tape on d_out * 2^k with the largest entry O(1); returns (gradients of the scaled problem, 2^-k).
+    The backward is linear in d_out, so scaling back is exact in fp32.  Loss gradients are ~1e-5 and smaller; the
+    split-fp16 dgrad operands have an absolute resolution floor of 2^-25 (dmd_conv_f16ws.hip) that unscaled gradients
+    would sit on."""
+    d_out = d_out.detach().float()
+    amax = d_out.abs().amax()
+    k = torch.where(amax > 0, torch.floor(-torch.log2(amax.clamp_min(1e-37))), torch.zeros_like(amax)).clamp(-120, 120)
+    return backward_tape(tape, cache, d_out * torch.exp2(k), table, use_f16, out_nhwc), torch.exp2(-k)
+
+
+class EncoderTrainFn(torch.autograd.Function):
+    """feat = encoder.run(x, table) (an AdaGN-ResBlock encoder returning an NHWC activation: RewEndEncoder) with the
+    same recorded-tape backward as the U-Net.  `run(table) -> Tensor` executes the forward."""
+
+    @staticmethod
+    def forward(ctx, run, cache: E.PackCache, table: Tensor, precision: str, *params: Tensor) -> Tensor:
+        assert E.TAPE is None, "nested recording"
+        E.TAPE = []
+        try:
+            out = run(table.detach())
+            tape = E.TAPE
+        finally:
+            E.TAPE = None
+        ctx.cache, ctx.tape, ctx.table, ctx.precision, ctx.out, ctx.params = cache, tape, table.detach(), precision, out, params
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out: Tensor):
+        pg, inv = scaled_backward(ctx.tape, ctx.cache, d_out, ctx.table, ctx.precision == "f16x2", out_nhwc=ctx.out)
+        ctx.tape = ctx.out = None
         grads = tuple(None if pg.by_param.get(id(p)) is None else pg.by_param[id(p)] * inv for p in ctx.params)
         return (None, None, pg.dtable * inv, None, *grads)
 

@@ -63,9 +63,15 @@ def install():
     g.utils = _mod("gymnasium.utils", RecordConstructorArgs=_RCA)
     te = _mod("torcheval")
     te.metrics = _mod("torcheval.metrics")
-    te.metrics.functional = _mod(
-        "torcheval.metrics.functional", multiclass_confusion_matrix=lambda *a, **k: None
-    )
+
+    def multiclass_confusion_matrix(input, target, num_classes):
+        """torcheval (absent here) semantics as published: [i, j] = #samples of true class i predicted argmax j."""
+        import torch
+
+        pred = input.argmax(dim=1) if input.ndim == 2 else input
+        return torch.bincount(target.long() * num_classes + pred, minlength=num_classes ** 2).reshape(num_classes, num_classes)
+
+    te.metrics.functional = _mod("torcheval.metrics.functional", multiclass_confusion_matrix=multiclass_confusion_matrix)
     if REF_SRC not in sys.path:
         sys.path.insert(0, REF_SRC)
 

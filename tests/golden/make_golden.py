@@ -21,7 +21,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import _refimport as R  # noqa: E402
 
 R.install()
-from diamond_amd.testing import fill_module_, initial_condition_batches, synthetic_actions, synthetic_frames  # noqa: E402
+from diamond_amd.testing import (fill_module_, initial_condition_batches, rew_end_train_batch, synthetic_actions,  # noqa: E402
+                                 synthetic_frames)
 
 torch.set_num_threads(8)
 WEIGHT_SEED = 7
@@ -287,7 +288,33 @@ def gen_denoiser_train():
     print("denoiser training step: loss", float(loss))
 
 
+def gen_rew_end_train():
+    """RewEndModel.forward (reward / termination cross-entropies over a segment, rew_end_model.py:57-90) +
+    loss.backward() of the reference: losses, confusion matrices and every parameter gradient."""
+    from data import Batch
+
+    agent = ref_agent()
+    m = agent.rew_end_model
+    g = torch.Generator().manual_seed(41)
+    batch = Batch(**rew_end_train_batch(g))
+    m.zero_grad()
+    loss, logs = m(batch)
+    loss.backward()
+    grads = {k: p.grad.clone() for k, p in m.named_parameters()}
+    assert all(v is not None for v in grads.values())
+    save("rew_end_train.pt", {
+        "seed": 41, "loss": loss.detach(), "loss_rew": logs["loss_rew"], "loss_end": logs["loss_end"],
+        "cm_rew": logs["confusion_matrix"]["rew"], "cm_end": logs["confusion_matrix"]["end"],
+        "grad_norms": {k: v.double().norm() for k, v in grads.items()},
+        "grads": {k: (v if v.numel() <= 4096 else v.flatten()[::13].clone()) for k, v in grads.items()},
+    })
+    print("rew/end training step: loss", float(loss), "cm_rew", logs["confusion_matrix"]["rew"].tolist())
+
+
 def main():
+    if "--rew-end-train" in sys.argv:
+        gen_rew_end_train()
+        return
     if "--denoiser-train" in sys.argv:
         gen_denoiser_train()
         return
@@ -309,6 +336,7 @@ def main():
     gen_window()
     gen_window_teacher_forced()
     gen_denoiser_train()
+    gen_rew_end_train()
     # attention at 16x16 and 8x8 inside the U-Net (BASELINE config 5 uses attn_depths=[0,0,1,1])
     gen_denoiser(ref_agent(denoiser_attn_depths=(0, 0, 1, 1)), "attn0011", b=1)
     gen_denoiser(ref_agent(denoiser_attn_depths=(0, 0, 1, 1)), "attn0011_256", h=256, w=256, b=1, only=(1, 3))

@@ -234,3 +234,18 @@ def test_ring_env_bookkeeping_matches_roll_based_shadow_cpu():
         assert torch.equal(env.act_buffer[:, :-1], sh_act[:, :-1]), step
         assert obs.data_ptr() != env._ctx.data_ptr()  # returned observations never alias the ring
     assert served["n"] == rnd + 1 and rnd >= 1
+
+
+def test_confusion_matrix_matches_sklearn():
+    """RewEndModel.forward's metrics (reference rew_end_model.py:84-85 via torcheval, absent here): rows = true class,
+    columns = argmax prediction, checked against scikit-learn's definition."""
+    import numpy as np
+    from sklearn.metrics import confusion_matrix as sk_cm
+    from diamond_amd.rew_end_model import confusion_matrix
+
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(40, 3, generator=g)
+    target = torch.randint(0, 3, (40,), generator=g)
+    cm = confusion_matrix(logits, target, 3)
+    assert cm.dtype == torch.int64 and cm.shape == (3, 3)
+    np.testing.assert_array_equal(cm.numpy(), sk_cm(target.numpy(), logits.argmax(1).numpy(), labels=[0, 1, 2]))

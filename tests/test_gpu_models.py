@@ -416,6 +416,48 @@ def test_denoiser_training_step_vs_reference_golden():
     UT.TRAIN_PRECISION = "f16x2"
 
 
+def test_rew_end_training_step_vs_reference_golden():
+    """§8b `RewEndModel.forward(batch)` (trainer.py:365): reward / termination cross-entropies over a (3, 6) segment with
+    an episode end (final_observation written back), padded steps, + loss.backward() -- encoder on the recorded HIP
+    forward with the hand-written backward, LSTM over the segment and the head on dmd_linear / dmd_lstm_pointwise(_bwd)
+    -- against the reference's losses, confusion matrices and gradients: 1e-4 on every loss, gradient tensor
+    (max-abs relative) and gradient norm."""
+    from types import SimpleNamespace
+    from diamond_amd import unet_train as UT
+    from diamond_amd.testing import rew_end_train_batch
+
+    gold = load_golden("rew_end_train.pt")
+    ag = make_agent()
+    m = ag.rew_end_model
+    m.train()
+    try:
+        for precision in ("f16x2", "f32"):
+            UT.TRAIN_PRECISION = precision
+            d = rew_end_train_batch(torch.Generator().manual_seed(gold["seed"]))
+            batch = SimpleNamespace(**{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in d.items()})
+            m.zero_grad()
+            loss, logs = m(batch)
+            loss.backward()
+            assert torch.equal(logs["confusion_matrix"]["rew"].cpu(), gold["cm_rew"])
+            assert torch.equal(logs["confusion_matrix"]["end"].cpu(), gold["cm_end"])
+            errs = {"loss": rel_err(loss.detach(), gold["loss"]), "loss_rew": rel_err(logs["loss_rew"], gold["loss_rew"]),
+                    "loss_end": rel_err(logs["loss_end"], gold["loss_end"])}
+            for k, p in m.named_parameters():
+                assert p.grad is not None, f"no gradient for {k}"
+                gref = gold["grads"][k]
+                mine = p.grad if gref.shape == p.grad.shape else p.grad.flatten()[::13]
+                errs["grad " + k] = rel_err(mine, gref)
+                n = float(gold["grad_norms"][k])
+                errs["|grad| " + k] = abs(float(p.grad.double().norm()) - n) / (n + 1e-30)
+            worst = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+            print(f"rew/end training step [{precision}]: loss {float(loss):.6f} (ref {float(gold['loss']):.6f}); worst:",
+                  [(k, f"{v:.2e}") for k, v in worst])
+            bad = {k: v for k, v in errs.items() if v >= 1e-4}
+            assert not bad, (precision, bad)
+    finally:
+        UT.TRAIN_PRECISION = "f16x2"
+
+
 @pytest.mark.parametrize("name,steps,order,churn,b", [("euler4_churn", 4, 1, 1.0, 2), ("heun6_churn", 6, 2, 2.0, 1),
                                                       ("heun50_configs3", 50, 2, 0.0, 1)])
 def test_sampler_branches_bit_exact_vs_oracle_control_flow(agent, name, steps, order, churn, b):
