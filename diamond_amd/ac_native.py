@@ -11,8 +11,7 @@ activations inside the wgrad kernel's staging pass.  Kernel map:
   backward  dmd_maxpool2_bwd -> dmd_conv2d_wgrad (dW, db) -> dmd_conv2d on the flipped/transposed
             weight (dgrad) -> dmd_gn_silu_bwd (dx, dgamma, dbeta; adds the skip-branch gradient)
 
-The LSTM cell and the two heads downstream are plain GEMMs + gate pointwise ops and run as
-torch ops (rocBLAS/hipBLASLt) under ordinary autograd.
+The LSTM cell and the two heads downstream run on dmd_linear / dmd_lstm_pointwise(_bwd): lstm_native.LstmHeadsFn.
 """
 from __future__ import annotations
 

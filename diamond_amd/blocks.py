@@ -131,11 +131,11 @@ class SelfAttention2d(nn.Module):
         # GN affine fused into the qkv 1x1 conv's load; out_proj adds the NORMALISED input
         # back (reference blocks.py:64,72), recomputed from x + its statistics in the epilogue.
         qkv = E.conv2d([(x, nv.PROLOGUE_NORM, spec)], ctx.cache.conv_weight(self.qkv_proj), ctx.cache.conv_bias(self.qkv_proj),
-                       3 * c, taps=1, want_stats=False, naive=ctx.naive, module=self.qkv_proj)
+                       3 * c, taps=1, want_stats=False, naive=ctx.naive, fast_math=ctx.fast_math, module=self.qkv_proj)
         y = E.attention(qkv, c, c // self.n_head)
         return E.conv2d([(Act(y), nv.PROLOGUE_NONE, None)], ctx.cache.conv_weight(self.out_proj),
                         ctx.cache.conv_bias(self.out_proj), c, taps=1, residual=x, residual_norm=spec, naive=ctx.naive,
-                        module=self.out_proj)
+                        fast_math=ctx.fast_math, module=self.out_proj)
 
 
 class FourierFeatures(nn.Module):
@@ -153,7 +153,7 @@ class Downsample(nn.Module):
 
     def run(self, ctx: RunCtx, x: Act) -> Act:
         return E.conv2d([(x, nv.PROLOGUE_NONE, None)], ctx.cache.conv_weight(self.conv), ctx.cache.conv_bias(self.conv),
-                        self.conv.out_channels, stride=2, naive=ctx.naive, module=self.conv)
+                        self.conv.out_channels, stride=2, naive=ctx.naive, fast_math=ctx.fast_math, module=self.conv)
 
 
 class Upsample(nn.Module):

@@ -29,8 +29,14 @@
 
 #define DMD_CIN_MAX 256
 
-template <int WN_, bool CFGB_, int TAPS_, int STRIDE_>
+// SPLIT_ (DMD_PRECISION_F16X2 launches the wave-specialised kernel does not cover: stride 2, 192-channel qkv, odd
+// shapes): same staging and tiling, but the operands are kept as split-fp16 pieces -- a patch unit holds {h4, l4} of its
+// four channels instead of four floats (same 16 bytes; the fragment layout of v_mfma_f32_16x16x16_f16 is the fp32 one,
+// 4 consecutive k per lane), the weight fragment is split in registers once per tap, and a product is three f16 MFMAs
+// (w_h x_l + w_l x_h + w_h x_h) into the fp32 accumulator: 24 matrix-pipe cycles per 16 channels instead of 128.
+template <int WN_, bool CFGB_, int TAPS_, int STRIDE_, bool SPLIT_ = false>
 struct ConvGeom {
+  static constexpr bool SPLIT = SPLIT_;
   static constexpr int WN = WN_;
   static constexpr int WM = 4 / WN_;
   static constexpr int MB = 8 / WM;
@@ -48,6 +54,21 @@ struct ConvGeom {
   // stride-2 patches are ~4x larger: single-buffer them to stay under 64 KiB of static LDS
   static constexpr int NBUF = STRIDE_ == 2 ? 1 : 2;
 };
+
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+// four fp32 values -> {h4 h, h4 l} in the same 16 bytes: h = fp16(x), l = fp16(x - h).  No clamp: see the range contract
+// in dmd_conv_f16ws.hip (an operand beyond the fp16 range turns into NaNs, never into a silently saturated value).
+__device__ __forceinline__ f32x4 split_h4l4(f32x4 v) {
+  h4 hh, ll;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hh[e] = (_Float16)v[e];
+    ll[e] = (_Float16)(v[e] - (float)hh[e]);
+  }
+  const uint2 a = __builtin_bit_cast(uint2, hh), b = __builtin_bit_cast(uint2, ll);
+  return __builtin_bit_cast(f32x4, (uint4){a.x, a.y, b.x, b.y});
+}
 
 struct TileInfo {
   int n, y0, x0;
@@ -217,14 +238,26 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const dmd_conv_params
           v[e] = t;
         }
       }
+      if (G::SPLIT) v = split_h4l4(v);
       if (loff[it] >= 0) patch[buf][loff[it]] = v;
     }
   };
 
+  // A chunk's weight fragments (TAPS x 16 bytes per lane, L2-resident) are fetched all at once, right after the last MFMA
+  // that reads the previous chunk's, so that ONE L2 round trip per chunk overlaps with the staging of the next patch:
+  // fetched tap by tap, one step ahead, the latency (~1 us) was exposed at every tap once the MFMAs of a tap take
+  // 0.1 us (SPLIT) -- a stride-2 launch with few workgroups was a chain of 36 such round trips.  (A second register set,
+  // loaded a whole chunk ahead, spills in the stride-2 instances.)
+  f32x4 wreg[G::TAPS];
+  auto load_weights = [&](int ck, f32x4 (&dst)[G::TAPS]) {
+#pragma unroll
+    for (int tap = 0; tap < G::TAPS; ++tap) dst[tap] = *(const f32x4*)(wlane + (size_t)(ck * G::TAPS + tap) * wstep);
+  };
+
   __syncthreads();  // tables visible
   load_chunk(0);
+  load_weights(0, wreg);
   store_chunk(0, 0);
-  f32x4 wcur = *(const f32x4*)wlane;
   __syncthreads();
 
   for (int ck = 0; ck < nchunks; ++ck) {
@@ -235,10 +268,23 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const dmd_conv_params
     for (int tap = 0; tap < G::TAPS; ++tap) {
       const int dy = G::TAPS == 9 ? tap / 3 : 0;
       const int dx = G::TAPS == 9 ? tap % 3 : 0;
-      const f32x4 wf = wcur;
-      {
-        const int step = ck * G::TAPS + tap + 1;
-        if (step < nchunks * G::TAPS) wcur = *(const f32x4*)(wlane + (size_t)step * wstep);
+      const f32x4 wf = wreg[tap];
+      if (G::SPLIT) {
+        const uint4 wb = __builtin_bit_cast(uint4, split_h4l4(wf));
+        const h4 wh = __builtin_bit_cast(h4, (uint2){wb.x, wb.y}), wl = __builtin_bit_cast(h4, (uint2){wb.z, wb.w});
+#pragma unroll
+        for (int mb = 0; mb < G::MB; ++mb) {
+          const int pix = pixbase[mb] + dy * G::PW + dx;
+          const uint4 xb = __builtin_bit_cast(uint4, patch[buf][pix * 4 + ((kg + 2 * (pix >> 2)) & 3)]);
+          const h4 xh = __builtin_bit_cast(h4, (uint2){xb.x, xb.y}), xl = __builtin_bit_cast(h4, (uint2){xb.z, xb.w});
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh, xl, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x16f16(wl, xh, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh, xh, acc[mb], 0, 0, 0);
+        }
+        // keep the fragment reads of a tap next to its MFMAs: left alone, the scheduler hoists the reads of all nine taps
+        // (72 x 16 bytes per lane) above the first MFMA and the stride-2 instances spill
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
       }
 #pragma unroll
       for (int mb = 0; mb < G::MB; ++mb) {
@@ -250,6 +296,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const dmd_conv_params
         acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[3], xf[3], acc[mb], 0, 0, 0);
       }
     }
+    if (more) load_weights(ck + 1, wreg);
     if (G::NBUF == 1) __syncthreads();  // everyone done reading the only buffer
     if (more) store_chunk(ck + 1, G::NBUF == 2 ? (buf ^ 1) : 0);
     __syncthreads();
@@ -482,12 +529,20 @@ static int validate_conv(const dmd_conv_params* p) {
   return 0;
 }
 
+static int conv_mfma_split(const dmd_conv_params& p) {
+  static const int on = getenv("DIAMOND_CONV_MFMA_SPLIT") ? atoi(getenv("DIAMOND_CONV_MFMA_SPLIT")) : 1;
+  return on && (p.precision & 0xff) == DMD_PRECISION_F16X2;
+}
+
 template <int WN, bool CFGB, int TAPS, int STRIDE>
 static void launch_conv(const dmd_conv_params& p, int groups, hipStream_t st) {
   using G = ConvGeom<WN, CFGB, TAPS, STRIDE>;
   const int tiles = (p.H / G::TH) * (p.W / G::TW) * p.N;
   dim3 grid((tiles + G::SUB - 1) / G::SUB, groups);
-  hipLaunchKernelGGL((conv_mfma_kernel<G>), grid, dim3(256), 0, st, p);
+  if (conv_mfma_split(p))
+    hipLaunchKernelGGL((conv_mfma_kernel<ConvGeom<WN, CFGB, TAPS, STRIDE, true>>), grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((conv_mfma_kernel<G>), grid, dim3(256), 0, st, p);
 }
 
 template <int TAPS, int STRIDE>
@@ -548,7 +603,8 @@ extern "C" int dmd_conv2d_kernel_name(const dmd_conv_params* p, char* buf, int b
              (j && !p8) ? "true" : "false", p8 ? "true" : "false");
   } else {
     const int wn = p->CoutPad % 64 == 0 ? 4 : (p->CoutPad % 32 == 0 ? 2 : 1);
-    snprintf(buf, buf_len, "conv_mfma_kernel<ConvGeom<%d, %s, %d, %d>>", wn, b8 ? "true" : "false", p->taps, p->stride);
+    snprintf(buf, buf_len, "conv_mfma_kernel<ConvGeom<%d, %s, %d, %d, %s>>", wn, b8 ? "true" : "false", p->taps, p->stride,
+             conv_mfma_split(*p) ? "true" : "false");
   }
   return 0;
 }

@@ -205,7 +205,8 @@ def backward_tape(tape: List, cache: E.PackCache, d_out: Tensor, table: Tensor, 
                 db = db_i[:cout]
             if a.needs_grad:
                 wp, w16 = _dgrad_weights(cache, conv, c0, c0 + ci_real, cpad, use_f16)
-                da = E.conv2d([(Act(dy_k), nv.PROLOGUE_NONE, None)], wp, None, ci_real, taps=rec.taps, want_stats=False, w_f16=w16).t
+                da = E.conv2d([(Act(dy_k), nv.PROLOGUE_NONE, None)], wp, None, ci_real, taps=rec.taps, want_stats=False, w_f16=w16,
+                              fast_math=use_f16).t
                 if rec.upsample:
                     da = _sum_pool2(da)
                 if prologue == nv.PROLOGUE_NONE:

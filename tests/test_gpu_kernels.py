@@ -124,12 +124,13 @@ def test_conv2d(case, impl):
     want_stats = (cout % 32 == 0) and not nchw
     w16 = None
     if impl == "f16x2":
-        if not (stride == 1 and not nchw and not (taps == 1 and up) and
+        # shapes conv_f16ws_kernel covers take its packed split weights; the others (stride 2, other channel counts, NCHW
+        # heads) run conv_mfma_kernel's SPLIT instance, selected by the precision flag alone
+        if (stride == 1 and not nchw and not (taps == 1 and up) and
                 ((cout == 64 and cin <= 128) or (cout == 32 and cin <= 64))):
-            pytest.skip("shape not covered by the split-fp16 kernel (runs exact fp32)")
-        w16 = nv.pack_conv_weight_f16x2(wgt.float().to(DEV))
+            w16 = nv.pack_conv_weight_f16x2(wgt.float().to(DEV))
     out = E.conv2d(srcs, wp, bp, cout, taps=taps, stride=stride, upsample=up, residual=r_act, want_stats=want_stats,
-                   out_nchw=nchw, naive=(impl == "naive"), w_f16=w16)
+                   out_nchw=nchw, naive=(impl == "naive"), w_f16=w16, fast_math=(impl == "f16x2"))
     torch.cuda.synchronize()
     got = out.t if nchw else out.t.permute(0, 3, 1, 2)
     err = rel_err(got, ref)
