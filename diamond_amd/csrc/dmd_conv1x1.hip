@@ -13,6 +13,26 @@
 #include "dmd_common.h"
 
 #define C1X1_CIN_MAX 128
+// Development switches, all measured on the 64x64 level (805 MB per launch, default 189 us = 4.3 TB/s) and left off:
+// nontemporal loads 203 us, nontemporal stores 186 us, PB = 4 at Cin = 128 196 us, 512 / 2048 persistent workgroups
+// 187 / 189 us; timing proxies with fully coalesced 1 KiB-per-instruction loads 189 us, loads and stores 177 us.  The
+// practical ceiling of this 2 : 1 read : write mix on the chip is 5.0 TB/s = 160 us (tools/probe/read_bw_probe.hip:
+// 6.0 TB/s read-only, the same through registers and through LDS-DMA), so the kernel sits at 85 % of it.
+#ifndef C1X1_NT_LOAD
+#define C1X1_NT_LOAD 0
+#endif
+#ifndef C1X1_ABL_LINEAR
+#define C1X1_ABL_LINEAR 0
+#endif
+#ifndef C1X1_NT_STORE
+#define C1X1_NT_STORE 0
+#endif
+#ifndef C1X1_PB128
+#define C1X1_PB128 2
+#endif
+#ifndef C1X1_NWG
+#define C1X1_NWG 1024
+#endif
 
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
@@ -67,7 +87,13 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const dmd_conv_para
       for (int pb = 0; pb < PB; ++pb) {
         size_t pix = pix0 + pb * 16 + j;
         pix = pix < npix ? pix : npix - 1;  // clamp: duplicates are never stored
+#if C1X1_ABL_LINEAR  // timing proxy (WRONG results): the same bytes as fully coalesced 1 KiB-per-instruction reads
+        xf[ks][pb] = *((const f32x4*)(sc.x + pix0 * sc.C) + (size_t)((ks < nk0 ? ks : ks - nk0) * PB + pb) * 64 + lane);
+#elif C1X1_NT_LOAD
+        xf[ks][pb] = __builtin_nontemporal_load((const f32x4*)(sc.x + pix * sc.C + c0));
+#else
         xf[ks][pb] = *(const f32x4*)(sc.x + pix * sc.C + c0);
+#endif
       }
     }
     h4 xh[SPLIT ? NK : 1][PB], xl[SPLIT ? NK : 1][PB];
@@ -118,7 +144,15 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const dmd_conv_para
       const size_t pix = pix0 + pb * 16 + j;
       if (pix < npix) {
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) *(f32x4*)(p.out + pix * 64 + cb * 16 + 4 * kg) = acc[cb][pb];
+        for (int cb = 0; cb < 4; ++cb) {
+#if C1X1_ABL_LINEAR & 2  // timing proxy: fully coalesced stores
+          *((f32x4*)(p.out + pix0 * 64) + (size_t)(pb * 4 + cb) * 64 + lane) = acc[cb][pb];
+#elif C1X1_NT_STORE
+          __builtin_nontemporal_store(acc[cb][pb], (f32x4*)(p.out + pix * 64 + cb * 16 + 4 * kg));
+#else
+          *(f32x4*)(p.out + pix * 64 + cb * 16 + 4 * kg) = acc[cb][pb];
+#endif
+        }
       }
     }
   }
@@ -141,7 +175,7 @@ static void launch1x1s(const dmd_conv_params& p, hipStream_t st) {
   const size_t npix = (size_t)p.N * p.H * p.W;
   const int tpix = 64 * PB;
   const int tiles = (int)((npix + tpix - 1) / tpix);
-  const int nwg = tiles < 1024 ? tiles : 1024;  // persistent: the weights are staged into LDS once per workgroup
+  const int nwg = tiles < C1X1_NWG ? tiles : C1X1_NWG;  // persistent: the weights are staged into LDS once per workgroup
   const int tpw = (tiles + nwg - 1) / nwg;
   hipLaunchKernelGGL((conv1x1_stream_kernel<NK, PB, SPLIT>), dim3((tiles + tpw - 1) / tpw), dim3(256), 0, st, p, tiles, tpw);
 }
@@ -157,7 +191,7 @@ static void launch1x1(const dmd_conv_params& p, hipStream_t st) {
 int dmd_launch_conv1x1_stream(const dmd_conv_params& p, hipStream_t st) {
   int cin = 0;
   for (int i = 0; i < p.nsrc; ++i) cin += p.src[i].C;
-  if (cin == 128) launch1x1<8, 2>(p, st);
+  if (cin == 128) launch1x1<8, C1X1_PB128>(p, st);
   else if (cin == 64) launch1x1<4, 4>(p, st);
   else launch1x1<2, 4>(p, st);
   return 0;
