@@ -598,7 +598,7 @@ extern "C" int dmd_conv2d_kernel_name(const dmd_conv_params* p, char* buf, int b
     static const int joint = getenv("DIAMOND_WS_JOINT") ? atoi(getenv("DIAMOND_WS_JOINT")) : 0;
     const bool j = joint && p->taps == 9 && p->CoutPad == 64 && !b8 && p->N * (p->H / 16) * (p->W / 16) >= 512;
     static const int p8env = getenv("DIAMOND_WS_P8") ? atoi(getenv("DIAMOND_WS_P8")) : 0;
-    const bool p8 = p8env && p->taps == 9 && p->CoutPad == 64 && !b8;
+    const bool p8 = p->taps == 9 && !b8 && (((p8env & 1) && p->CoutPad == 64) || ((p8env & 2) && p->CoutPad == 32));
     snprintf(buf, buf_len, "conv_f16ws_kernel<WsGeom<%s, %d, %d, %s, %s>>", b8 ? "true" : "false", p->CoutPad == 64 ? 2 : 1, p->taps,
              (j && !p8) ? "true" : "false", p8 ? "true" : "false");
   } else {

@@ -51,6 +51,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // measured critical path of a step is the producers' staging + their stalls at vector-memory issue, so the
 // four waves that otherwise only write tiles out and wait become producers.  Measured r02o (DIAMOND_WS_P8=1): the K loop
 // gets ~12 % faster, the now exposed write-out costs ~14 %: 287 vs 280 us on the 64x64 conv, 9.5k vs 9.9k frames/s.
+// On the 32-cout instance (DIAMOND_WS_P8=2; twice the staging per MFMA) it is a wash: 64x64 Cin 32 152 vs 147 us,
+// Cin 16 71 vs 80 us, 32x32 37 vs 39.5 us, 16x16 19 vs 22 us.
 template <bool B8_, int NCB_, int TAPS_ = 9, bool JOINT_ = false, bool P8_ = false>
 struct WsGeom {
   static constexpr bool P8 = P8_;
@@ -995,7 +997,8 @@ int dmd_launch_conv_f16ws(const dmd_conv_params& p, hipStream_t st) {
   const int sub8 = p.N * (p.H / 8) * (p.W / 8), t16 = p.N * (p.H / 16) * (p.W / 16);
   static const int joint = getenv("DIAMOND_WS_JOINT") ? atoi(getenv("DIAMOND_WS_JOINT")) : 0;
   static const int p8 = getenv("DIAMOND_WS_P8") ? atoi(getenv("DIAMOND_WS_P8")) : 0;
-  if (p8 && p.taps == 9 && p.CoutPad == 64 && !b8) return launch_f16ws<WsGeom<false, 2, 9, false, true>>(p, t16, st);
+  if ((p8 & 1) && p.taps == 9 && p.CoutPad == 64 && !b8) return launch_f16ws<WsGeom<false, 2, 9, false, true>>(p, t16, st);
+  if ((p8 & 2) && p.taps == 9 && p.CoutPad == 32 && !b8) return launch_f16ws<WsGeom<false, 1, 9, false, true>>(p, (t16 + 1) / 2, st);
   if (joint && p.taps == 9 && p.CoutPad == 64 && !b8 && t16 >= 512) return launch_f16ws<WsGeom<false, 2, 9, true>>(p, (t16 + 1) / 2, st);
   if (p.taps == 9) {
     if (p.CoutPad == 64) return b8 ? launch_f16ws<WsGeom<true, 2, 9>>(p, (sub8 + 3) / 4, st) : launch_f16ws<WsGeom<false, 2, 9>>(p, t16, st);

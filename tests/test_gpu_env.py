@@ -158,3 +158,70 @@ def test_graph_captured_sampler_equals_eager_bitwise():
     a, _ = sampler.sample_ring_graphed(ctx, act, 1, 1)
     b, _ = sampler.sample_ring_graphed(ctx, act, 1, 1)
     assert torch.isfinite(a).all() and not torch.equal(a, b)
+
+
+def test_batch_shard_invariance_at_full_batch():
+    """§8e: imagined envs shard along the batch axis with no data-path exchange, so an env's trajectory must not depend
+    on which other envs share its launch.  The 256 envs of configs[1] stepped as ONE batch vs as two shards of 128 with
+    the same per-env initial conditions, sampler noise, exponential draws and policy: frames, rewards, ends, policy
+    logits, values and sampled actions are BITWISE identical (convolutions: launch-configuration independent tiles;
+    linears: the summation order depends on K only; pointwise kernels: per element)."""
+    import diamond_amd as D
+    from diamond_amd.env_loop import sample_categorical
+    from diamond_amd.testing import fill_module_, synthetic_actions, synthetic_frames
+
+    agent = D.Agent(D.default_agent_config())
+    fill_module_(agent, WEIGHT_SEED)
+    agent = agent.to(DEV).eval()
+    n, steps = 256, 3
+    g = torch.Generator().manual_seed(21)
+    obs0 = synthetic_frames(g, n, 4, 3, 64, 64)
+    act0 = synthetic_actions(g, 4, n, 4)
+
+    def bank(tag, k, shape_tail, lo, hi, exponential=False):
+        gg = torch.Generator().manual_seed(1000 * tag + k)
+        t = torch.empty(n, *shape_tail)
+        t = t.exponential_(1, generator=gg) if exponential else t.normal_(generator=gg)
+        return t[lo:hi].to(DEV)
+
+    def run(lo, hi):
+        b = hi - lo
+        env = D.WorldModelEnv(agent.denoiser, agent.rew_end_model, _Loader(b, [(obs0[lo:hi], act0[lo:hi])]),
+                              D.WorldModelEnvConfig(horizon=50, num_batches_to_preload=1,
+                                                    diffusion_sampler=D.DiffusionSamplerConfig(num_steps_denoising=3)))
+        calls = {"noise": 0, "expo": 0, "pi": 0}
+
+        def noise_fn(shape, device):
+            calls["noise"] += 1
+            return bank(1, calls["noise"], shape[1:], lo, hi)
+
+        def expo_fn(logits):
+            calls["expo"] += 1
+            e = bank(2, calls["expo"], logits.shape[1:], lo, hi, exponential=True)
+            if logits.shape[-1] == 2:  # termination head: class 0 always wins -> no mid-window resets (pool order)
+                e[..., 0] = 1e-30
+            return e
+
+        env.sampler.noise_fn = noise_fn
+        env.expo_fn = expo_fn
+        obs, _ = env.reset()
+        hx = torch.zeros(b, agent.actor_critic.lstm_dim, device=DEV)
+        cx = torch.zeros(b, agent.actor_critic.lstm_dim, device=DEV)
+        out = []
+        for _ in range(steps):
+            with torch.no_grad():
+                o = agent.actor_critic.predict_act_value(obs, (hx, cx))
+            hx, cx = o.hx_cx
+            calls["pi"] += 1
+            act = sample_categorical(o.logits_act, bank(3, calls["pi"], o.logits_act.shape[1:], lo, hi, exponential=True))
+            obs, rew, end, trunc, _ = env.step(act)
+            assert not bool(end.any()) and not bool(trunc.any())
+            out.append((o.logits_act.clone(), o.val.clone(), act.clone(), obs.clone(), rew.clone(), end.clone()))
+        return out
+
+    full = run(0, n)
+    for lo, hi in ((0, 128), (128, 256)):
+        part = run(lo, hi)
+        for s, (f, p) in enumerate(zip(full, part)):
+            for name, a, c in zip(("logits", "value", "action", "frame", "reward", "end"), f, p):
+                assert torch.equal(a[lo:hi], c), f"step {s}: {name} of envs [{lo}, {hi}) depends on the batch it ran in"

@@ -19,21 +19,25 @@ SHAPES = [  # N, H, [Cins], prologue, residual, upsample
     (256, 8, [64], 1, True, False),
     (256, 8, [64, 64], 1, False, False),
 ]
+COUT = int(os.environ.get("CONV_BENCH_COUT", "64"))
+if COUT == 32:
+    SHAPES = [(256, 64, [32], 1, True, False), (256, 64, [16], 0, False, False), (256, 32, [32], 1, True, False),
+              (256, 16, [32], 1, True, False)]
 for n, h, cins, prologue, res, up in SHAPES:
     hs = h // 2 if up else h
     srcs = []
     for c in cins:
-        a = E.gn_stats(torch.randn(n, hs, hs, c, device=dev))
+        a = E.gn_stats(torch.randn(n, hs, hs, c, device=dev)) if prologue else E.Act(torch.randn(n, hs, hs, c, device=dev))
         spec = E.NormSpec(mul=torch.randn(n, c, device=dev) * 0.1, add=torch.randn(n, c, device=dev) * 0.1, mul_stride=c,
                           add_stride=c, plus_one=True) if prologue else None
         srcs.append((a, prologue, spec))
     cin = sum(cins)
-    w = torch.randn(64, cin, 3, 3, device=dev) / (cin * 9) ** 0.5
+    w = torch.randn(COUT, cin, 3, 3, device=dev) / (cin * 9) ** 0.5
     wp = nv.pack_conv_weight(w)
     w16 = nv.pack_conv_weight_f16x2(w) if prec == "f16x2" else None
-    b = torch.zeros(64, device=dev)
-    r = E.Act(torch.randn(n, h, h, 64, device=dev)) if res else None
-    run = lambda: E.conv2d(srcs, wp, b, 64, upsample=up, residual=r, w_f16=w16)
+    b = torch.zeros(COUT, device=dev)
+    r = E.Act(torch.randn(n, h, h, COUT, device=dev)) if res else None
+    run = lambda: E.conv2d(srcs, wp, b, COUT, upsample=up, residual=r, w_f16=w16)
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -45,6 +49,6 @@ for n, h, cins, prologue, res, up in SHAPES:
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    flops = 2.0 * n * h * h * 64 * cin * 9
-    nbytes = 4.0 * (n * hs * hs * cin + n * h * h * 64 * (2 if res else 1))
+    flops = 2.0 * n * h * h * COUT * cin * 9
+    nbytes = 4.0 * (n * hs * hs * cin + n * h * h * COUT * (2 if res else 1))
     print(f"N{n} {h}x{h} cin{cin} pro{prologue} res{int(res)} up{int(up)}: {ms*1e3:8.1f} us  {flops/ms/1e9:7.1f} TF/s  {nbytes/ms/1e6:7.0f} GB/s", flush=True)
