@@ -10,6 +10,7 @@ calls `run()`; on a CPU tensor it raises -- there is no fallback path.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -22,6 +23,8 @@ from .engine import Act, NormSpec
 GN_GROUP_SIZE = 32
 GN_EPS = 1e-5
 ATTN_HEAD_DIM = 8
+# DIAMOND_LOWRES_CHAIN=0: run the 8x8 level of the U-Net launch by launch instead of as one dmd_lowres_chain call
+LOWRES_CHAIN = os.environ.get("DIAMOND_LOWRES_CHAIN", "1") != "0"
 
 
 def conv3x3(cin: int, cout: int, stride: int = 1) -> nn.Conv2d:
@@ -250,15 +253,105 @@ class UNet(nn.Module):
              f"{x.shape[1]}x{x.shape[2]}.  The reference pads to a multiple of 2**num_down and crops (blocks.py:227-229,247): "
              "sizes that are not multiples of 8 at every level are not supported by this implementation")
         skips: List[List[Act]] = []
-        for blocks, down in zip(self.d_blocks, self.downsamples):
+        last = len(self.d_blocks) - 1
+        chained = False
+        for li, (blocks, down) in enumerate(zip(self.d_blocks, self.downsamples)):
             if not isinstance(down, nn.Identity):
                 x = down.run(ctx, x)
+            if li == last and self._chain_eligible(ctx, x):
+                # deepest level at 8x8: its down blocks, the mid blocks and its up blocks as ONE launch (dmd_lowres.hip)
+                x = self._run_lowres_chain(ctx, x)
+                chained = True
+                break
             x_down = x
             x, outs = blocks.run(ctx, x)
             skips.append([x_down] + outs)
-        x, _ = self.mid_blocks.run(ctx, x)
-        for blocks, up, skip in zip(self.u_blocks, self.upsamples, reversed(skips)):
+        if not chained:
+            x, _ = self.mid_blocks.run(ctx, x)
+        for ui, (blocks, up) in enumerate(zip(self.u_blocks, self.upsamples)):
+            if chained and ui == 0:
+                continue
+            skip = skips[len(self.u_blocks) - 1 - ui]
             if not isinstance(up, nn.Identity):
                 x = up.run(ctx, x)
             x, _ = blocks.run(ctx, x, skip[::-1])
         return x
+
+    # -- the 8x8 level as one launch ------------------------------------------------------------------------------
+    def _chain_blocks(self) -> List["ResBlock"]:
+        return list(self.d_blocks[-1].resblocks) + list(self.mid_blocks.resblocks) + list(self.u_blocks[0].resblocks)
+
+    def _chain_eligible(self, ctx: RunCtx, x: Act) -> bool:
+        """dmd_lowres_chain covers: split-fp16 inference (no recording for a backward), 8x8 x 64 channels at the deepest
+        level with 64-channel neighbours, at most two down blocks (three skip slots) and eight blocks in all."""
+        if not LOWRES_CHAIN or ctx.precision != "f16x2" or ctx.naive or E.TAPE is not None or E._USE_NAIVE:
+            return False
+        if len(self.d_blocks) < 2 or tuple(x.shape[1:]) != (8, 8, 64):
+            return False
+        blks = self._chain_blocks()
+        nd = len(self.d_blocks[-1].resblocks)
+        if nd > 2 or len(blks) > nv.CHAIN_MAX_BLOCKS or len(self.u_blocks[0].resblocks) != nd + 1:
+            return False
+        for i, b in enumerate(blks):
+            cat = i >= len(blks) - (nd + 1)
+            if b.conv1.out_channels != 64 or b.conv1.in_channels != (128 if cat else 64) or isinstance(b.proj, nn.Identity) == cat:
+                return False
+        return True
+
+    def _run_lowres_chain(self, ctx: RunCtx, x: Act) -> Act:
+        import ctypes as C
+
+        cache = ctx.cache
+        blks = self._chain_blocks()
+        nd = len(self.d_blocks[-1].resblocks)
+        n_up = nd + 1
+        p = nv.LowresChainParams()
+        n = x.shape[0]
+        out = torch.empty_like(x.t)
+        p.N, p.nblocks, p.input_save_slot = n, len(blks), 0  # slot 0 = the level's input, slot j + 1 = output of down block j
+        p.x, p.out = nv.ptr(x.t), nv.ptr(out)
+        p.table, p.table_stride = nv.ptr(ctx.table), ctx.table.stride(0)
+        keep = []  # tensors whose pointers are in `p` (the caches own them; this list only documents the lifetime)
+        for i, b in enumerate(blks):
+            cb = p.blocks[i]
+            up_i = i - (len(blks) - n_up)
+            cb.skip_slot = nd - up_i if up_i >= 0 else -1  # up block i concatenates skips[::-1][i]
+            cb.save_slot = i + 1 if i < nd else -1
+            o1, c1 = ctx.film.offset[id(b.norm1)], b.norm1.in_channels
+            cb.film1_mul[0], cb.film1_add[0] = o1, o1 + c1
+            cb.film1_mul[1], cb.film1_add[1] = o1 + 64, o1 + c1 + 64
+            o2, c2 = ctx.film.offset[id(b.norm2)], b.norm2.in_channels
+            cb.film2_mul, cb.film2_add = o2, o2 + c2
+            ts = [cache.conv_weight_f16x2(b.conv1), cache.conv_weight_f16x2(b.conv2), cache.conv_bias(b.conv1), cache.conv_bias(b.conv2)]
+            cb.w1, cb.w2, cb.b1, cb.b2 = (nv.ptr(t) for t in ts)
+            if not isinstance(b.proj, nn.Identity):
+                tp = [cache.conv_weight_f16x2(b.proj), cache.conv_bias(b.proj)]
+                cb.wproj, cb.bproj = nv.ptr(tp[0]), nv.ptr(tp[1])
+                ts += tp
+            if not isinstance(b.attn, nn.Identity):
+                a = b.attn
+                cb.has_attn = 1
+                qkv = [cache.get(a.qkv_proj.weight, f"qkv16[{k}]", lambda w, k=k: nv.pack_conv_weight_f16x2(w.detach().float()[64 * k:64 * k + 64].contiguous()))
+                       for k in range(3)]
+                ta = qkv + [cache.conv_weight_f16x2(a.out_proj), cache.f32(a.norm.norm.weight), cache.f32(a.norm.norm.bias),
+                            cache.f32(a.qkv_proj.bias), cache.conv_bias(a.out_proj)]
+                cb.wq, cb.wk, cb.wv, cb.wo, cb.gn_gamma, cb.gn_beta, cb.bqkv, cb.bo = (nv.ptr(t) for t in ta)
+                ts += ta
+            keep.append(ts)
+        if E.PROFILER is not None:
+            flops = 0.0
+            for b in blks:
+                flops += 2.0 * n * 64 * 64 * 9 * (b.conv1.in_channels + 64)
+                if not isinstance(b.proj, nn.Identity):
+                    flops += 2.0 * n * 64 * 64 * 128
+                if not isinstance(b.attn, nn.Identity):
+                    flops += 2.0 * n * 64 * 64 * 64 * 4 + 4.0 * n * 64 * 64 * 64
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            nv.check(nv.lib().dmd_lowres_chain(C.byref(p), nv.stream()), "dmd_lowres_chain")
+            e1.record()
+            E.PROFILER.records.append(("lowres_chain_kernel", flops, 8.0 * x.t.numel(), e0, e1))
+        else:
+            nv.check(nv.lib().dmd_lowres_chain(C.byref(p), nv.stream()), "dmd_lowres_chain")
+        del keep
+        return Act(out)

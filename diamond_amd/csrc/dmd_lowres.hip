@@ -1,0 +1,461 @@
+// lowres_chain_kernel -- the whole 8x8 level of the denoiser's U-Net (reference blocks.py:232-246: the deepest
+// d_blocks, the two mid blocks with attention, the deepest u_blocks = 7 ResBlocks, 14 3x3 convolutions, 3 skip
+// projections, 2 attention blocks at the default configuration) in ONE launch, one workgroup per image.
+//
+// Why: at 8x8 a convolution of the whole batch is 1.2 GFLOP; launched on its own it is a ~25 us latency chain (launch,
+// GroupNorm tables, pipeline fill, 4-8 chunk steps, write-out) on 64 of the 256 CUs, and the level is 14 such launches
+// plus 1x1s and attention per denoiser call: 520 us for 1.5 % of the FLOPs.  Here every activation of the
+// chain (64 pixels x 64 channels fp32 = 16 KiB) stays in LDS, GroupNorm statistics are two-group reductions inside the
+// workgroup, and the only global traffic is the chain input / output and the (L2-resident) weights.
+//
+// Arithmetic: the split-fp16 form of dmd_conv_f16ws.hip (x = h + l, three v_mfma_f32_32x32x16_f16 per product, fp32
+// accumulate, same packed weights, same v_exp/v_rcp SiLU); statistics accumulated in fp64 across lanes like the conv
+// epilogues.  A wave owns 32 pixels x 32 output channels (one f32x16 accumulator).
+// LDS: 5 activation slots (3 saved skips, X, H) + the halo'd split patch of one conv input (2 sources x 100 px x 64 ch,
+// the slot-rotated layout of dmd_conv_f16ws.hip: conflict-free ds_read_b128 for every tap) -- overlaid by q | k | v
+// during attention -- = 139 KiB.
+#include "dmd_common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define LR_SS 68                    // floats per pixel row of a slot (64 + 4: staggers the banks of consecutive pixels)
+#define LR_SLOT (64 * LR_SS)
+#define LR_NSLOT 5                  // 0..2: saved skips, 3: X (current), 4: H (intermediate)
+#define LR_X 3
+#define LR_H 4
+#define LR_P_UNITS (2 * 100 * 4 * 4)  // 16-byte units: [source][patch pixel][16-channel chunk][rotated position]
+#define LR_QS 196                   // floats per pixel row of the q | k | v overlay
+#ifndef LR_ABL
+#define LR_ABL 0  // development only (WRONG results): 1 = no weight loads, 2 = no attention core, 4 = no statistics pass, 8 = no FiLM table loads
+#endif
+#ifndef LR_TRACE
+#define LR_TRACE 0  // development: s_memtime stamps of workgroup 0 at the phase boundaries (tools/chain_bench.py --trace)
+#endif
+#if LR_TRACE
+__device__ unsigned long long lr_trace_buf[512];
+__device__ int lr_trace_n;
+#define LR_STAMP(tag_)                                                                              \
+  do {                                                                                              \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && lr_ti < 512)                                         \
+      lr_trace_buf[lr_ti++] = (__builtin_readcyclecounter() << 8) | (unsigned long long)(tag_);   \
+  } while (0)
+extern "C" int dmd_lowres_trace_dump(unsigned long long* host) {
+  hipDeviceSynchronize();
+  int n = 0;
+  hipMemcpyFromSymbol(&n, HIP_SYMBOL(lr_trace_n), sizeof(int));
+  hipMemcpyFromSymbol(host, HIP_SYMBOL(lr_trace_buf), sizeof(unsigned long long) * 512);
+  return n;
+}
+#else
+#define LR_STAMP(tag_) do {} while (0)
+#endif
+#define LR_SMEM_BYTES ((LR_NSLOT * LR_SLOT + LR_P_UNITS * 4 + 256 + 32) * 4 + 64)
+
+__device__ __forceinline__ float lr_silu(float t) {
+  return t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * t));
+}
+
+// 8 fp32 values -> split-fp16 pieces (no clamp: the range contract of dmd_conv_f16ws.hip)
+__device__ __forceinline__ void lr_split8(const f32x4 a, const f32x4 b, h8& h, h8& l) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const _Float16 ha = (_Float16)a[e], hb = (_Float16)b[e];
+    h[e] = ha;
+    h[4 + e] = hb;
+    l[e] = (_Float16)(a[e] - (float)ha);
+    l[4 + e] = (_Float16)(b[e] - (float)hb);
+  }
+}
+
+__global__ __launch_bounds__(256) void lowres_chain_kernel(const dmd_lowres_chain_params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lr_smem[];
+  float* slots = (float*)lr_smem;
+  u32x4* P = (u32x4*)(slots + LR_NSLOT * LR_SLOT);
+  float* QKV = (float*)P;
+  float* tabA = (float*)(P + LR_P_UNITS);
+  float* tabB = tabA + 128;
+  float* stat = tabB + 128;             // [slot][group][mean, rstd]
+  double* red = (double*)(stat + 32);   // [wave][sum, sum of squares]
+
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n31 = lane & 31, g = lane >> 5;
+  const int pb = wave & 1, cb = wave >> 1;  // 32-pixel block, 32-cout block of this wave
+  const int pxl = 32 * pb + n31;            // this lane's output pixel
+  const int row0 = pxl >> 3, col = pxl & 7;
+  const float* trow = p.table + (size_t)n * p.table_stride;
+  const int wlane = g * 64 + cb * 32 + n31;  // this lane's 16-byte unit inside a (tap, h|l) weight row
+
+  auto slot = [&](int s) -> float* { return slots + s * LR_SLOT; };
+#if LR_TRACE
+  int lr_ti = 0;
+#endif
+
+  // ---- GroupNorm statistics of a slot (2 groups of 32 channels over 64 pixels), optionally copied to a second slot ----
+  auto compute_stats = [&](int s, int also) {
+    __syncthreads();  // the slot is complete
+#if LR_ABL & 4
+    if (tid < 2) { stat[(s * 2 + tid) * 2] = 0.f; stat[(s * 2 + tid) * 2 + 1] = 1.f; if (also >= 0) { stat[(also * 2 + tid) * 2] = 0.f; stat[(also * 2 + tid) * 2 + 1] = 1.f; } }
+    __syncthreads();
+    return;
+#endif
+    const float* r = slot(s) + (tid & 63) * LR_SS + 16 * wave;  // wave w: channels [16 w, 16 w + 16) -> group w >> 1
+    float fs = 0.f, fq = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *(const f32x4*)(r + 4 * q);
+      fs += (v[0] + v[1]) + (v[2] + v[3]);
+      fq = __builtin_fmaf(v[0], v[0], fq);
+      fq = __builtin_fmaf(v[1], v[1], fq);
+      fq = __builtin_fmaf(v[2], v[2], fq);
+      fq = __builtin_fmaf(v[3], v[3], fq);
+    }
+    const double a = dmd_wave_sum((double)fs), b = dmd_wave_sum((double)fq);
+    if (lane == 0) {
+      red[2 * wave] = a;
+      red[2 * wave + 1] = b;
+    }
+    __syncthreads();
+    if (tid < 2) {
+      const double sum = red[4 * tid] + red[4 * tid + 2], ssq = red[4 * tid + 1] + red[4 * tid + 3];
+      const double m = sum / 2048.0;
+      double var = ssq / 2048.0 - m * m;
+      var = var < 0.0 ? 0.0 : var;
+      const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)DMD_GN_EPS));
+      stat[(s * 2 + tid) * 2] = mean;
+      stat[(s * 2 + tid) * 2 + 1] = rstd;
+      if (also >= 0) {
+        stat[(also * 2 + tid) * 2] = mean;
+        stat[(also * 2 + tid) * 2 + 1] = rstd;
+      }
+    }
+    __syncthreads();
+  };
+
+  // ---- per-channel (a, b) of y = x * a + b for the sources of a convolution ----
+  auto tab_film = [&](int nsrc, int s0, int s1, int mul0, int add0, int mul1, int add1) {
+    if (tid < 64 * nsrc) {
+      const int src = tid >> 6, ch = tid & 63, sl = src ? s1 : s0;
+      const float mean = stat[(sl * 2 + (ch >> 5)) * 2], rstd = stat[(sl * 2 + (ch >> 5)) * 2 + 1];
+#if LR_ABL & 8
+      const float mul = 1.0f + 1e-3f * ch, add = 1e-3f * (src ? mul1 : mul0);
+#else
+      const float mul = 1.0f + trow[(src ? mul1 : mul0) + ch];  // AdaGroupNorm: xn * (1 + scale) + shift (blocks.py:41-45)
+      const float add = trow[(src ? add1 : add0) + ch];
+#endif
+      const float a = rstd * mul;
+      tabA[tid] = a;
+      tabB[tid] = add - mean * a;
+    }
+    __syncthreads();
+  };
+  auto tab_affine = [&](int s, const float* gamma, const float* beta) {
+    if (tid < 64) {
+      const float mean = stat[(s * 2 + (tid >> 5)) * 2], rstd = stat[(s * 2 + (tid >> 5)) * 2 + 1];
+      const float a = rstd * gamma[tid];
+      tabA[tid] = a;
+      tabB[tid] = beta[tid] - mean * a;
+    }
+    __syncthreads();
+  };
+
+  // ---- SiLU(norm(x)) of the sources, split and zero-padded, into the halo'd patch ----
+  // item it * 256 + tid = (patch pixel pp = it * 16 + (tid >> 4), channel quad tid & 15): the same for every convolution
+  int soff[7];  // float offset of the item's source pixel inside a slot, -1: zero padding (halo) / no item
+  int poff[7];  // 8-byte unit of the item's h piece inside a source's patch; the l piece sits 4 units (one rotation of 2) away
+  {
+    const int q16 = tid & 15, chunk = q16 >> 2, q = q16 & 3;
+#pragma unroll
+    for (int it = 0; it < 7; ++it) {
+      const int pp = it * 16 + (tid >> 4);
+      const int py = pp / 10, px = pp - 10 * py;
+      const bool inside = pp < 100 && py >= 1 && py <= 8 && px >= 1 && px <= 8;
+      soff[it] = inside ? ((py - 1) * 8 + (px - 1)) * LR_SS + 4 * q16 : (pp < 100 ? -1 : -2);
+      const int pos = ((q >> 1) + (px >> 1)) & 3;
+      poff[it] = ((pp * 4 + chunk) * 4 + pos) * 2 + (q & 1);
+    }
+  }
+  auto stage_patch = [&](int nsrc, int s0, int s1) {
+    uint2* P8 = (uint2*)P;
+    for (int src = 0; src < nsrc; ++src) {
+      const float* sp = slot(src ? s1 : s0);
+      const f32x4 ta = *(const f32x4*)(tabA + src * 64 + 4 * (tid & 15)), tb = *(const f32x4*)(tabB + src * 64 + 4 * (tid & 15));
+#pragma unroll
+      for (int it = 0; it < 7; ++it) {
+        if (soff[it] == -2) continue;  // beyond the patch (last item row)
+        h4 hv = {0, 0, 0, 0}, lv = {0, 0, 0, 0};
+        if (soff[it] >= 0) {
+          const f32x4 v = *(const f32x4*)(sp + soff[it]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x = lr_silu(__builtin_fmaf(v[e], ta[e], tb[e]));
+            const _Float16 h = (_Float16)x;
+            hv[e] = h;
+            lv[e] = (_Float16)(x - (float)h);
+          }
+        }
+        const int u = src * 3200 + poff[it];
+        P8[u] = __builtin_bit_cast(uint2, hv);
+        P8[u ^ 4] = __builtin_bit_cast(uint2, lv);
+      }
+    }
+    __syncthreads();
+  };
+
+  // ---- 3x3 convolution of the staged patch: acc += W * patch.  Weights: 18 fragments (9 taps x h | l) per 16-channel
+  // chunk straight from L2 into registers, one chunk ahead; chunk 0 is prefetched into `wpre` by the caller BEFORE the
+  // statistics / table / staging phases that precede the MFMA loop (one wave per SIMD: nothing else hides an L2 round trip)
+  u32x4 wpre[18];
+  auto load_w = [&](const void* w16, int ck, u32x4 (&w)[18]) {
+    const u32x4* wg = (const u32x4*)w16 + wlane;
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+#if LR_ABL & 1
+      w[i] = (u32x4){0x3c003c00u, (unsigned)(ck + i), 0x3c003c00u, (unsigned)lane};
+#else
+      w[i] = wg[(size_t)(ck * 18 + i) * 128];
+#endif
+    }
+  };
+  auto prefetch_w = [&](const void* w16) { load_w(w16, 0, wpre); };
+  auto conv3x3 = [&](f32x16& acc, int nck, const void* w16) {
+    u32x4 wb[18];
+    // one accumulator per product type (w_h x_h | w_h x_l | w_l x_h): three independent MFMA chains instead of one
+    // dependent chain of 27 per chunk (a wave is alone on its SIMD: a dependent v_mfma_32x32x16 waits out its predecessor)
+    f32x16 acc1, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[r] = acc2[r] = 0.f;
+    auto compute = [&](int ck, const u32x4 (&w)[18]) {
+      const int src = ck >> 2, chunk = ck & 3;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap % 3;
+        const int pp = (row0 + dy) * 10 + col + dx;
+        const int base = ((src * 100 + pp) * 4 + chunk) * 4;
+        const int pos = (g + ((col + dx) >> 1)) & 3;
+        const h8 bh = __builtin_bit_cast(h8, P[base + pos]);
+        const h8 bl = __builtin_bit_cast(h8, P[base + (pos ^ 2)]);
+        const h8 ah = __builtin_bit_cast(h8, w[2 * tap]), al = __builtin_bit_cast(h8, w[2 * tap + 1]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
+      }
+    };
+    for (int ck = 0; ck < nck; ck += 2) {  // nck = 4 | 8; wpre holds chunk ck on entry
+      load_w(w16, ck + 1, wb);
+      compute(ck, wpre);
+      if (ck + 2 < nck) load_w(w16, ck + 2, wpre);
+      compute(ck + 1, wb);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acc1[r] + acc2[r];  // the two small correction sums first
+  };
+
+  // ---- 1x1 convolution of a raw fp32 slot (64 channels, row stride `ss`): acc += W[ck0 .. ck0 + 4) * x, operands split on the fly ----
+  auto conv1x1 = [&](f32x16& acc, const float* x, int ss, const void* w16, int ck0) {
+    const u32x4* wg = (const u32x4*)w16 + wlane;
+    u32x4 w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#if LR_ABL & 1
+      w[i] = (u32x4){0x3c003c00u, (unsigned)(ck0 + i), 0x3c003c00u, (unsigned)lane};
+#else
+      w[i] = wg[(size_t)(ck0 * 2 + i) * 128];
+#endif
+    }
+    const float* xr = x + pxl * ss + 8 * g;
+#pragma unroll
+    for (int chunk = 0; chunk < 4; ++chunk) {
+      h8 bh, bl;
+      lr_split8(*(const f32x4*)(xr + 16 * chunk), *(const f32x4*)(xr + 16 * chunk + 4), bh, bl);
+      const h8 ah = __builtin_bit_cast(h8, w[2 * chunk]), al = __builtin_bit_cast(h8, w[2 * chunk + 1]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+    }
+  };
+
+  // ---- accumulator -> dst[pixel][c0 + channel] (+ biases, + residual): lane owns couts cb*32 + 8 qd + 4 g + (0..3) of pixel pxl ----
+  auto epilogue = [&](const f32x16& acc, float* dst, int ds, int c0, const float* bias_a, const float* bias_b, const float* resid) {
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int c = cb * 32 + 8 * qd + 4 * g;
+      f32x4 v = (f32x4){acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]};
+      if (bias_a) v += *(const f32x4*)(bias_a + c);
+      if (bias_b) v += *(const f32x4*)(bias_b + c);
+      if (resid) v += *(const f32x4*)(resid + pxl * LR_SS + c);
+      *(f32x4*)(dst + pxl * ds + c0 + c) = v;
+    }
+  };
+  auto zero = [&](f32x16& acc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  };
+
+  // =============================== the chain ===============================
+  float* X = slot(LR_X);
+  float* H = slot(LR_H);
+  for (int id = tid; id < 64 * 16; id += 256) {
+    const int px = id >> 4, q = id & 15;
+    const f32x4 v = *(const f32x4*)(p.x + ((size_t)n * 64 + px) * 64 + 4 * q);
+    *(f32x4*)(X + px * LR_SS + 4 * q) = v;
+    if (p.input_save_slot >= 0) *(f32x4*)(slot(p.input_save_slot) + px * LR_SS + 4 * q) = v;
+  }
+  compute_stats(LR_X, p.input_save_slot);
+  LR_STAMP(0);
+
+  for (int b = 0; b < p.nblocks; ++b) {
+    const dmd_chain_block& B = p.blocks[b];
+    const int nsrc = B.skip_slot >= 0 ? 2 : 1;
+    const int sk = B.skip_slot >= 0 ? B.skip_slot : 0;
+    f32x16 acc;
+    // ---- conv1(SiLU(AdaGN1(cat(x, skip)))) -> H ----
+    LR_STAMP(1);
+    prefetch_w(B.w1);
+    tab_film(nsrc, LR_X, sk, B.film1_mul[0], B.film1_add[0], B.film1_mul[1], B.film1_add[1]);
+    LR_STAMP(2);
+    stage_patch(nsrc, LR_X, sk);
+    LR_STAMP(3);
+    zero(acc);
+    conv3x3(acc, 4 * nsrc, B.w1);
+    LR_STAMP(4);
+    prefetch_w(B.w2);
+    epilogue(acc, H, LR_SS, 0, B.b1, nullptr, nullptr);
+    LR_STAMP(5);
+    compute_stats(LR_H, -1);
+    LR_STAMP(6);
+    // ---- conv2(SiLU(AdaGN2(h))) + r -> X,  r = proj(cat(x, skip)) (accumulated first) or x ----
+    zero(acc);
+    if (B.wproj) {
+      conv1x1(acc, X, LR_SS, B.wproj, 0);
+      conv1x1(acc, slot(sk), LR_SS, B.wproj, 4);
+    }
+    LR_STAMP(7);
+    tab_film(1, LR_H, 0, B.film2_mul, B.film2_add, 0, 0);
+    stage_patch(1, LR_H, 0);  // (its barrier also orders the projection's reads of X before the epilogue's writes)
+    LR_STAMP(8);
+    conv3x3(acc, 4, B.w2);
+    LR_STAMP(9);
+    epilogue(acc, X, LR_SS, 0, B.b2, B.wproj ? B.bproj : nullptr, B.wproj ? nullptr : X);
+    compute_stats(LR_X, -1);
+    LR_STAMP(10);
+    // ---- SelfAttention2d: x_n = GN(x); y = softmax(q k^T / sqrt 8) v per head; x = x_n + out_proj(y) ----
+    if (B.has_attn) {
+      tab_affine(LR_X, B.gn_gamma, B.gn_beta);
+      for (int id = tid; id < 64 * 16; id += 256) {
+        const int px = id >> 4, q = id & 15;
+        const f32x4 v = *(const f32x4*)(X + px * LR_SS + 4 * q);
+        const f32x4 ta = *(const f32x4*)(tabA + 4 * q), tb = *(const f32x4*)(tabB + 4 * q);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(v[e], ta[e], tb[e]);
+        *(f32x4*)(H + px * LR_SS + 4 * q) = o;
+      }
+      __syncthreads();  // x_n complete; the patch region is free (conv2's reads ended before its epilogue)
+      LR_STAMP(11);
+      const void* wqkv[3] = {B.wq, B.wk, B.wv};
+#pragma unroll
+      for (int part = 0; part < 3; ++part) {
+        zero(acc);
+        conv1x1(acc, H, LR_SS, wqkv[part], 0);
+        epilogue(acc, QKV, LR_QS, 64 * part, B.bqkv + 64 * part, nullptr, nullptr);
+      }
+      __syncthreads();
+      LR_STAMP(12);
+      // one (head, query) per thread and pass: 8 heads x 64 queries; a wave = the 64 queries of one head (K / V rows broadcast)
+      for (int it = 0; it < ((LR_ABL & 2) ? 0 : 2); ++it) {
+        const int head = 4 * it + wave, qi = lane;
+        const float* qp = QKV + qi * LR_QS + head * 8;
+        const f32x4 q0 = *(const f32x4*)qp, q1 = *(const f32x4*)(qp + 4);
+        const float inv = 1.0f / sqrtf(8.0f);  // (q k^T) / sqrt(d), blocks.py:68
+        float sc[64];  // the row of scores stays in registers (fully unrolled loops)
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+          const float* kp = QKV + j * LR_QS + 64 + head * 8;
+          const f32x4 k0 = *(const f32x4*)kp, k1 = *(const f32x4*)(kp + 4);
+          float sv = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sv = __builtin_fmaf(q0[e], k0[e], sv);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sv = __builtin_fmaf(q1[e], k1[e], sv);
+          sv *= inv;
+          sc[j] = sv;
+          m = fmaxf(m, sv);
+        }
+        float l = 0.f;
+        f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+          const float pr = __builtin_amdgcn_exp2f((sc[j] - m) * 1.4426950408889634f);
+          l += pr;
+          const float* vp = QKV + j * LR_QS + 128 + head * 8;
+          const f32x4 v0 = *(const f32x4*)vp, v1 = *(const f32x4*)(vp + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o0[e] = __builtin_fmaf(pr, v0[e], o0[e]);
+            o1[e] = __builtin_fmaf(pr, v1[e], o1[e]);
+          }
+        }
+        const float rl = 1.0f / l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o0[e] *= rl;
+          o1[e] *= rl;
+        }
+        *(f32x4*)(X + qi * LR_SS + head * 8) = o0;  // y overwrites x (dead: its normalised copy is in H)
+        *(f32x4*)(X + qi * LR_SS + head * 8 + 4) = o1;
+      }
+      __syncthreads();
+      LR_STAMP(13);
+      zero(acc);
+      conv1x1(acc, X, LR_SS, B.wo, 0);
+      __syncthreads();  // every wave has read y
+      epilogue(acc, X, LR_SS, 0, B.bo, nullptr, H);
+      compute_stats(LR_X, -1);
+      LR_STAMP(14);
+    }
+    if (B.save_slot >= 0) {
+      for (int id = tid; id < 64 * 16; id += 256) {
+        const int px = id >> 4, q = id & 15;
+        *(f32x4*)(slot(B.save_slot) + px * LR_SS + 4 * q) = *(const f32x4*)(X + px * LR_SS + 4 * q);
+      }
+      if (tid < 4) stat[B.save_slot * 4 + tid] = stat[LR_X * 4 + tid];
+      __syncthreads();
+    }
+  }
+  for (int id = tid; id < 64 * 16; id += 256) {
+    const int px = id >> 4, q = id & 15;
+    *(f32x4*)(p.out + ((size_t)n * 64 + px) * 64 + 4 * q) = *(const f32x4*)(X + px * LR_SS + 4 * q);
+  }
+  LR_STAMP(15);
+#if LR_TRACE
+  if (blockIdx.x == 0 && threadIdx.x == 0) lr_trace_n = lr_ti;
+#endif
+}
+
+extern "C" int dmd_lowres_chain(const dmd_lowres_chain_params* p, dmd_stream_t stream) {
+  DMD_CHECK_ARG(p && p->x && p->out && p->table, "lowres_chain: null");
+  DMD_CHECK_ARG(p->N > 0 && p->nblocks > 0 && p->nblocks <= DMD_CHAIN_MAX_BLOCKS, "lowres_chain: N %d, nblocks %d", p->N, p->nblocks);
+  DMD_CHECK_ARG(p->input_save_slot >= -1 && p->input_save_slot <= 2, "lowres_chain: input_save_slot");
+  for (int b = 0; b < p->nblocks; ++b) {
+    const dmd_chain_block& B = p->blocks[b];
+    DMD_CHECK_ARG(B.w1 && B.w2 && B.b1 && B.b2, "lowres_chain: block %d: null conv weights", b);
+    DMD_CHECK_ARG(B.skip_slot >= -1 && B.skip_slot <= 2 && B.save_slot >= -1 && B.save_slot <= 2, "lowres_chain: block %d: slots", b);
+    DMD_CHECK_ARG((B.skip_slot >= 0) == (B.wproj != nullptr), "lowres_chain: block %d: a concatenated input needs its 1x1 projection (and only it)", b);
+    DMD_CHECK_ARG(!B.wproj || B.bproj, "lowres_chain: block %d: projection bias", b);
+    DMD_CHECK_ARG(!B.has_attn || (B.gn_gamma && B.gn_beta && B.wq && B.wk && B.wv && B.wo && B.bqkv && B.bo), "lowres_chain: block %d: attention parameters", b);
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lowres_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LR_SMEM_BYTES);
+    DMD_CHECK_ARG(e == hipSuccess, "lowres_chain: hipFuncSetAttribute(%d bytes): %s", (int)LR_SMEM_BYTES, hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(lowres_chain_kernel, dim3(p->N), dim3(256), LR_SMEM_BYTES, (hipStream_t)stream, *p);
+  DMD_LAUNCH_CHECK();
+  return 0;
+}

@@ -61,6 +61,23 @@ class WgradParams(C.Structure):
                 ("dbias", C.c_void_p)]
 
 
+CHAIN_MAX_BLOCKS = 8
+
+
+class ChainBlock(C.Structure):
+    _fields_ = [("skip_slot", C.c_int32), ("save_slot", C.c_int32), ("film1_mul", C.c_int32 * 2), ("film1_add", C.c_int32 * 2),
+                ("film2_mul", C.c_int32), ("film2_add", C.c_int32), ("has_attn", C.c_int32), ("reserved", C.c_int32),
+                ("w1", C.c_void_p), ("w2", C.c_void_p), ("wproj", C.c_void_p), ("b1", C.c_void_p), ("b2", C.c_void_p),
+                ("bproj", C.c_void_p), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p), ("wq", C.c_void_p), ("wk", C.c_void_p),
+                ("wv", C.c_void_p), ("wo", C.c_void_p), ("bqkv", C.c_void_p), ("bo", C.c_void_p)]
+
+
+class LowresChainParams(C.Structure):
+    _fields_ = [("N", C.c_int32), ("nblocks", C.c_int32), ("input_save_slot", C.c_int32), ("reserved", C.c_int32),
+                ("x", C.c_void_p), ("out", C.c_void_p), ("table", C.c_void_p), ("table_stride", C.c_int64),
+                ("blocks", ChainBlock * CHAIN_MAX_BLOCKS)]
+
+
 EXPORTS = (
     "dmd_conv2d", "dmd_conv2d_kernel_name", "dmd_conv2d_naive", "dmd_conv_stat_tiles", "dmd_pack_conv_weight", "dmd_conv2d_f16x2_eligible",
     "dmd_conv1x1_stream_eligible",
@@ -69,7 +86,7 @@ EXPORTS = (
     "dmd_dequant_gather", "dmd_nchw_to_nhwc",
     "dmd_nhwc_to_nchw", "dmd_gn_stats", "dmd_maxpool2", "dmd_lstm_pointwise", "dmd_lstm_pointwise_bwd", "dmd_categorical_sample",
     "dmd_maxpool2_bwd", "dmd_gn_bwd_workspace_bytes", "dmd_gn_silu_bwd", "dmd_wgrad_workspace_floats", "dmd_conv2d_wgrad",
-    "dmd_last_error", "dmd_abi_version",
+    "dmd_lowres_chain", "dmd_last_error", "dmd_abi_version",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -128,6 +145,7 @@ def lib() -> C.CDLL:
         L.dmd_wgrad_workspace_floats.argtypes = [C.POINTER(WgradParams)]
         L.dmd_wgrad_workspace_floats.restype = C.c_int64
         L.dmd_conv2d_wgrad.argtypes = [C.POINTER(WgradParams), C.c_void_p]
+        L.dmd_lowres_chain.argtypes = [C.POINTER(LowresChainParams), C.c_void_p]
         _lib = L
     return _lib
 

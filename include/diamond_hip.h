@@ -129,6 +129,50 @@ int64_t dmd_attention_bwd_workspace_floats(int N, int T, int C);
 int dmd_attention_bwd(const float* qkv, const float* y, const float* dy, float* dqkv, float* workspace, int N, int T, int C,
                       int head_dim, dmd_stream_t stream);
 
+/* ---- dmd_lowres_chain: a whole chain of ResBlocks at the 8x8 level of the denoiser's U-Net in ONE launch ----
+ * Replaces, for H = W = 8 and 64 channels, the launches of the deepest level of UNet.forward (reference blocks.py:232-246:
+ * d_blocks[-1], mid_blocks, u_blocks[0]) -- per ResBlock (blocks.py:141-147): optional 1x1 `proj` of the raw (concatenated)
+ * input, conv1(SiLU(AdaGN1(cat(x, skip)))), conv2(SiLU(AdaGN2(h))) + r, optional SelfAttention2d (blocks.py:62-72).
+ * One workgroup per image keeps every activation of the chain in LDS (64 pixels x 64 channels = 16 KiB per tensor); the
+ * convolutions use the split-fp16 MFMA arithmetic of dmd_conv2d's DMD_PRECISION_F16X2 path and the same packed weights
+ * (dmd_pack_conv_weight_f16x2).  At batch 256 these launches are latency chains of ~25 us each for 1.2 GFLOP. */
+#define DMD_CHAIN_MAX_BLOCKS 8
+typedef struct dmd_chain_block {
+  int32_t skip_slot;    /* -1: the block's input is x;  0..2: cat(x, saved[skip_slot]) (128 input channels)            */
+  int32_t save_slot;    /* -1, or 0..2: keep the block's OUTPUT in this slot for a later concatenation                  */
+  int32_t film1_mul[2]; /* FiLM-table column of AdaGN1's `scale` for the x part / the skip part                          */
+  int32_t film1_add[2]; /* ... of `shift`                                                                                */
+  int32_t film2_mul, film2_add;
+  int32_t has_attn, reserved;
+  const void* w1;       /* conv1 3x3, Cin 64 | 128 -> 64, dmd_pack_conv_weight_f16x2 layout                              */
+  const void* w2;       /* conv2 3x3, 64 -> 64                                                                           */
+  const void* wproj;    /* 1x1 128 -> 64 (f16x2 pack) or NULL (identity skip)                                            */
+  const float* b1;      /* (64)                                                                                          */
+  const float* b2;      /* (64)                                                                                          */
+  const float* bproj;   /* (64) or NULL                                                                                  */
+  const float* gn_gamma; /* attention: nn.GroupNorm affine (64), (64)                                                    */
+  const float* gn_beta;
+  const void* wq;       /* attention: 1x1 64 -> 64 packs of the q | k | v thirds of qkv_proj and of out_proj             */
+  const void* wk;
+  const void* wv;
+  const void* wo;
+  const float* bqkv;    /* (192) */
+  const float* bo;      /* (64)  */
+} dmd_chain_block;
+
+typedef struct dmd_lowres_chain_params {
+  int32_t N;                 /* images                                                            */
+  int32_t nblocks;           /* <= DMD_CHAIN_MAX_BLOCKS                                           */
+  int32_t input_save_slot;   /* -1, or the slot that keeps the chain INPUT for a later concatenation */
+  int32_t reserved;
+  const float* x;            /* NHWC (N, 8, 8, 64)                                                */
+  float* out;                /* NHWC (N, 8, 8, 64)                                                */
+  const float* table;        /* FiLM table (N, table_stride): every AdaGroupNorm.linear(cond) of the network, concatenated */
+  int64_t table_stride;
+  dmd_chain_block blocks[DMD_CHAIN_MAX_BLOCKS];
+} dmd_lowres_chain_params;
+int dmd_lowres_chain(const dmd_lowres_chain_params* p, dmd_stream_t stream);
+
 /* ---- EDM preconditioning / sampler pointwise (denoiser.py:74-84, diffusion_sampler.py:45-56) ---- */
 /* The four EDM conditioners (c_in, c_out, c_skip, c_noise; compute_conditioners denoiser.py:66-72)
  * are four scalars per sample: the host evaluates them with the reference's own fp32 op order

@@ -416,6 +416,38 @@ def test_denoiser_training_step_vs_reference_golden():
     UT.TRAIN_PRECISION = "f16x2"
 
 
+@pytest.mark.parametrize("attn_depths,b", [((0, 0, 0, 0), 5), ((0, 0, 0, 1), 2)])
+def test_lowres_chain_matches_launch_by_launch(attn_depths, b):
+    """dmd_lowres_chain (the 8x8 level of the U-Net -- down blocks, attention mid blocks, up blocks with concatenated skips
+    -- in ONE launch with LDS-resident activations) against the launch-by-launch path on the same weights: 1e-5 on the
+    model output (same split-fp16 arithmetic, different summation grouping), and the fused launch is really taken.  The
+    second case adds attention inside the level's own down / up blocks (attn_depths[3] = 1)."""
+    from diamond_amd import blocks as BL
+    from diamond_amd import engine as E
+    from diamond_amd.testing import synthetic_actions, synthetic_frames
+
+    ag = make_agent(attn_depths)
+    g = torch.Generator().manual_seed(17 + b)
+    obs = synthetic_frames(g, b, 12, 64, 64).to(DEV)
+    act = synthetic_actions(g, 4, b, 4).to(DEV)
+    x = torch.randn(b, 3, 64, 64, generator=g).to(DEV)
+    sigma = torch.tensor([5.0, 0.3, 0.002, 1.0, 20.0][:b], device=DEV)
+    outs = {}
+    try:
+        for mode in (True, False):
+            BL.LOWRES_CHAIN = mode
+            E.PROFILER = E.LaunchProfiler()
+            outs[mode] = ag.denoiser.compute_model_output(x, obs, act, sigma).clone()
+            keys = E.PROFILER.summary()
+            assert ("lowres_chain_kernel" in keys) == mode, keys.keys()
+    finally:
+        BL.LOWRES_CHAIN = True
+        E.PROFILER = None
+    err = rel_err(outs[True], outs[False])
+    print(f"lowres chain vs launch-by-launch (attn_depths {attn_depths}): rel err {err:.3e}")
+    assert err < 1e-5, err
+
+
 def test_rew_end_training_step_vs_reference_golden():
     """§8b `RewEndModel.forward(batch)` (trainer.py:365): reward / termination cross-entropies over a (3, 6) segment with
     an episode end (final_observation written back), padded steps, + loss.backward() -- encoder on the recorded HIP
