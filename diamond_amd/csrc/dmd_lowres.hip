@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void lowres_chain_kernel(const dmd_lowres_chai
   extern __shared__ __attribute__((aligned(16))) unsigned char lr_smem[];
   float* slots = (float*)lr_smem;
   u32x4* P = (u32x4*)(slots + LR_NSLOT * LR_SLOT);
-  float* QKV = (float*)P;
+  float* QKV = (float*)P;               // overlay during attention
+  float* SCR = (float*)P;               // overlay after a convolution's MFMAs: [wave][16][64] K-split partial tiles
   float* tabA = (float*)(P + LR_P_UNITS);
   float* tabB = tabA + 128;
   float* stat = tabB + 128;             // [slot][group][mean, rstd]
@@ -83,9 +84,11 @@ __global__ __launch_bounds__(256) void lowres_chain_kernel(const dmd_lowres_chai
   const int n = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n31 = lane & 31, g = lane >> 5;
-  const int pb = wave & 1, cb = wave >> 1;  // 32-pixel block, 32-cout block of this wave
-  const int pxl = 32 * pb + n31;            // this lane's output pixel
-  const int row0 = pxl >> 3, col = pxl & 7;
+  // A wave accumulates ALL 64 pixels (two 32-pixel blocks) x the 32 couts of block cb over the K chunks of parity kh
+  // (each weight fragment feeds two pixel blocks, half the L2 weight traffic of a pixel split, and twice the MFMA work
+  // behind every fragment fetch); the two K halves are added through LDS and wave (cb, kh) finishes pixel block kh.
+  const int cb = wave & 1, kh = wave >> 1;
+  const int pxl = 32 * kh + n31;  // the pixel this lane finishes (epilogue)
   const float* trow = p.table + (size_t)n * p.table_stride;
   const int wlane = g * 64 + cb * 32 + n31;  // this lane's 16-byte unit inside a (tap, h|l) weight row
 
@@ -94,15 +97,28 @@ __global__ __launch_bounds__(256) void lowres_chain_kernel(const dmd_lowres_chai
   int lr_ti = 0;
 #endif
 
-  // ---- GroupNorm statistics of a slot (2 groups of 32 channels over 64 pixels), optionally copied to a second slot ----
-  auto compute_stats = [&](int s, int also) {
-    __syncthreads();  // the slot is complete
-#if LR_ABL & 4
-    if (tid < 2) { stat[(s * 2 + tid) * 2] = 0.f; stat[(s * 2 + tid) * 2 + 1] = 1.f; if (also >= 0) { stat[(also * 2 + tid) * 2] = 0.f; stat[(also * 2 + tid) * 2 + 1] = 1.f; } }
+  // ---- mean / rstd of the two GroupNorm groups from the per-wave partial sums in `red` (wave = (cb, kh): group cb) ----
+  auto finish_stats = [&](int s, int also) {
     __syncthreads();
-    return;
-#endif
-    const float* r = slot(s) + (tid & 63) * LR_SS + 16 * wave;  // wave w: channels [16 w, 16 w + 16) -> group w >> 1
+    if (tid < 2) {
+      const double sum = red[2 * tid] + red[2 * (tid + 2)], ssq = red[2 * tid + 1] + red[2 * (tid + 2) + 1];
+      const double m = sum / 2048.0;
+      double var = ssq / 2048.0 - m * m;
+      var = var < 0.0 ? 0.0 : var;
+      const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)DMD_GN_EPS));
+      stat[(s * 2 + tid) * 2] = mean;
+      stat[(s * 2 + tid) * 2 + 1] = rstd;
+      if (also >= 0) {
+        stat[(also * 2 + tid) * 2] = mean;
+        stat[(also * 2 + tid) * 2 + 1] = rstd;
+      }
+    }
+    __syncthreads();
+  };
+  // statistics of a slot that no epilogue produced (the chain input): wave (cb, kh) sums channels [32 cb + 16 kh, +16)
+  auto slot_stats = [&](int s, int also) {
+    __syncthreads();
+    const float* r = slot(s) + lane * LR_SS + 32 * cb + 16 * kh;
     float fs = 0.f, fq = 0.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -118,35 +134,15 @@ __global__ __launch_bounds__(256) void lowres_chain_kernel(const dmd_lowres_chai
       red[2 * wave] = a;
       red[2 * wave + 1] = b;
     }
-    __syncthreads();
-    if (tid < 2) {
-      const double sum = red[4 * tid] + red[4 * tid + 2], ssq = red[4 * tid + 1] + red[4 * tid + 3];
-      const double m = sum / 2048.0;
-      double var = ssq / 2048.0 - m * m;
-      var = var < 0.0 ? 0.0 : var;
-      const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)DMD_GN_EPS));
-      stat[(s * 2 + tid) * 2] = mean;
-      stat[(s * 2 + tid) * 2 + 1] = rstd;
-      if (also >= 0) {
-        stat[(also * 2 + tid) * 2] = mean;
-        stat[(also * 2 + tid) * 2 + 1] = rstd;
-      }
-    }
-    __syncthreads();
+    finish_stats(s, also);
   };
 
-  // ---- per-channel (a, b) of y = x * a + b for the sources of a convolution ----
-  auto tab_film = [&](int nsrc, int s0, int s1, int mul0, int add0, int mul1, int add1) {
+  // ---- per-channel (a, b) of y = x * a + b for the sources of a convolution; (mul, add) = this thread's FiLM entries ----
+  auto tab_film = [&](int nsrc, int s0, int s1, float mul, float add) {
     if (tid < 64 * nsrc) {
       const int src = tid >> 6, ch = tid & 63, sl = src ? s1 : s0;
       const float mean = stat[(sl * 2 + (ch >> 5)) * 2], rstd = stat[(sl * 2 + (ch >> 5)) * 2 + 1];
-#if LR_ABL & 8
-      const float mul = 1.0f + 1e-3f * ch, add = 1e-3f * (src ? mul1 : mul0);
-#else
-      const float mul = 1.0f + trow[(src ? mul1 : mul0) + ch];  // AdaGroupNorm: xn * (1 + scale) + shift (blocks.py:41-45)
-      const float add = trow[(src ? add1 : add0) + ch];
-#endif
-      const float a = rstd * mul;
+      const float a = rstd * (1.0f + mul);  // AdaGroupNorm: xn * (1 + scale) + shift (blocks.py:41-45)
       tabA[tid] = a;
       tabB[tid] = add - mean * a;
     }
@@ -164,7 +160,7 @@ __global__ __launch_bounds__(256) void lowres_chain_kernel(const dmd_lowres_chai
 
   // ---- SiLU(norm(x)) of the sources, split and zero-padded, into the halo'd patch ----
   // item it * 256 + tid = (patch pixel pp = it * 16 + (tid >> 4), channel quad tid & 15): the same for every convolution
-  int soff[7];  // float offset of the item's source pixel inside a slot, -1: zero padding (halo) / no item
+  int soff[7];  // float offset of the item's source pixel inside a slot, -1: zero padding (halo), -2: no item
   int poff[7];  // 8-byte unit of the item's h piece inside a source's patch; the l piece sits 4 units (one rotation of 2) away
   {
     const int q16 = tid & 15, chunk = q16 >> 2, q = q16 & 3;
@@ -205,9 +201,10 @@ __global__ __launch_bounds__(256) void lowres_chain_kernel(const dmd_lowres_chai
     __syncthreads();
   };
 
-  // ---- 3x3 convolution of the staged patch: acc += W * patch.  Weights: 18 fragments (9 taps x h | l) per 16-channel
-  // chunk straight from L2 into registers, one chunk ahead; chunk 0 is prefetched into `wpre` by the caller BEFORE the
-  // statistics / table / staging phases that precede the MFMA loop (one wave per SIMD: nothing else hides an L2 round trip)
+  // ---- 3x3 convolution of the staged patch: acc[blk] += W * patch over this wave's K chunks (kh, kh + 2, ...).
+  // Weights: 18 fragments (9 taps x h | l) per chunk straight from L2 into registers, one of the wave's chunks ahead;
+  // its first chunk is prefetched into `wpre` by the caller BEFORE the statistics / table / staging phases that precede
+  // the MFMA loop (one wave per SIMD: nothing else hides an L2 round trip) ----
   u32x4 wpre[18];
   auto load_w = [&](const void* w16, int ck, u32x4 (&w)[18]) {
     const u32x4* wg = (const u32x4*)w16 + wlane;
@@ -220,102 +217,168 @@ __global__ __launch_bounds__(256) void lowres_chain_kernel(const dmd_lowres_chai
 #endif
     }
   };
-  auto prefetch_w = [&](const void* w16) { load_w(w16, 0, wpre); };
-  auto conv3x3 = [&](f32x16& acc, int nck, const void* w16) {
+  auto prefetch_w = [&](const void* w16) { load_w(w16, kh, wpre); };
+  const int prow = n31 >> 3, pcol = n31 & 7;  // this lane's pixel inside a 32-pixel block (4 rows of 8)
+  auto conv3x3 = [&](f32x16 (&acc)[2], int nck, const void* w16) {
     u32x4 wb[18];
-    // one accumulator per product type (w_h x_h | w_h x_l | w_l x_h): three independent MFMA chains instead of one
-    // dependent chain of 27 per chunk (a wave is alone on its SIMD: a dependent v_mfma_32x32x16 waits out its predecessor)
-    f32x16 acc1, acc2;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc1[r] = acc2[r] = 0.f;
     auto compute = [&](int ck, const u32x4 (&w)[18]) {
       const int src = ck >> 2, chunk = ck & 3;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3, dx = tap % 3;
-        const int pp = (row0 + dy) * 10 + col + dx;
-        const int base = ((src * 100 + pp) * 4 + chunk) * 4;
-        const int pos = (g + ((col + dx) >> 1)) & 3;
-        const h8 bh = __builtin_bit_cast(h8, P[base + pos]);
-        const h8 bl = __builtin_bit_cast(h8, P[base + (pos ^ 2)]);
+        const int pos = (g + ((pcol + dx) >> 1)) & 3;
+        const int pp0 = (prow + dy) * 10 + pcol + dx;  // block 0: rows 0..3; block 1: 4 rows (40 patch pixels) further
+        const int base0 = ((src * 100 + pp0) * 4 + chunk) * 4, base1 = base0 + 40 * 16;
+        const h8 bh0 = __builtin_bit_cast(h8, P[base0 + pos]), bh1 = __builtin_bit_cast(h8, P[base1 + pos]);
+        const h8 bl0 = __builtin_bit_cast(h8, P[base0 + (pos ^ 2)]), bl1 = __builtin_bit_cast(h8, P[base1 + (pos ^ 2)]);
         const h8 ah = __builtin_bit_cast(h8, w[2 * tap]), al = __builtin_bit_cast(h8, w[2 * tap + 1]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh1, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl1, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh1, acc[1], 0, 0, 0);
       }
     };
-    for (int ck = 0; ck < nck; ck += 2) {  // nck = 4 | 8; wpre holds chunk ck on entry
-      load_w(w16, ck + 1, wb);
+    for (int ck = kh; ck < nck; ck += 4) {  // nck = 4 | 8; wpre holds chunk ck on entry
+      load_w(w16, ck + 2, wb);              // (ck + 2 < nck always: nck is a multiple of 4)
       compute(ck, wpre);
-      if (ck + 2 < nck) load_w(w16, ck + 2, wpre);
-      compute(ck + 1, wb);
+      if (ck + 4 < nck) load_w(w16, ck + 4, wpre);
+      compute(ck + 2, wb);
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] += acc1[r] + acc2[r];  // the two small correction sums first
   };
 
-  // ---- 1x1 convolution of a raw fp32 slot (64 channels, row stride `ss`): acc += W[ck0 .. ck0 + 4) * x, operands split on the fly ----
-  auto conv1x1 = [&](f32x16& acc, const float* x, int ss, const void* w16, int ck0) {
+  // ---- 1x1 convolution of a raw fp32 slot (64 channels = 4 chunks, row stride `ss`): acc[blk] += W[ck0 + c] * x over the
+  // chunks c of parity kh, operands split on the fly ----
+  auto conv1x1 = [&](f32x16 (&acc)[2], const float* x, int ss, const void* w16, int ck0) {
     const u32x4* wg = (const u32x4*)w16 + wlane;
-    u32x4 w[8];
+    u32x4 w[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int hl = 0; hl < 2; ++hl) {
 #if LR_ABL & 1
-      w[i] = (u32x4){0x3c003c00u, (unsigned)(ck0 + i), 0x3c003c00u, (unsigned)lane};
+        w[2 * i + hl] = (u32x4){0x3c003c00u, (unsigned)(ck0 + i), 0x3c003c00u, (unsigned)lane};
 #else
-      w[i] = wg[(size_t)(ck0 * 2 + i) * 128];
+        w[2 * i + hl] = wg[(size_t)((ck0 + kh + 2 * i) * 2 + hl) * 128];
 #endif
+      }
     }
-    const float* xr = x + pxl * ss + 8 * g;
+    const float* xr = x + n31 * ss + 8 * g;
 #pragma unroll
-    for (int chunk = 0; chunk < 4; ++chunk) {
-      h8 bh, bl;
-      lr_split8(*(const f32x4*)(xr + 16 * chunk), *(const f32x4*)(xr + 16 * chunk + 4), bh, bl);
-      const h8 ah = __builtin_bit_cast(h8, w[2 * chunk]), al = __builtin_bit_cast(h8, w[2 * chunk + 1]);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+    for (int i = 0; i < 2; ++i) {
+      const int chunk = kh + 2 * i;
+      const h8 ah = __builtin_bit_cast(h8, w[2 * i]), al = __builtin_bit_cast(h8, w[2 * i + 1]);
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        h8 bh, bl;
+        const float* xp = xr + blk * 32 * ss + 16 * chunk;
+        lr_split8(*(const f32x4*)xp, *(const f32x4*)(xp + 4), bh, bl);
+        acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[blk], 0, 0, 0);
+        acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[blk], 0, 0, 0);
+        acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[blk], 0, 0, 0);
+      }
     }
   };
 
-  // ---- accumulator -> dst[pixel][c0 + channel] (+ biases, + residual): lane owns couts cb*32 + 8 qd + 4 g + (0..3) of pixel pxl ----
-  auto epilogue = [&](const f32x16& acc, float* dst, int ds, int c0, const float* bias_a, const float* bias_b, const float* resid) {
+  // ---- K-split reduction + epilogue.  Every wave has finished its MFMAs (and with them its reads of the patch, which the
+  // scratch overlays): wave (cb, kh) hands the tile of pixel block 1 - kh to its partner through LDS, adds the partner's
+  // tile of block kh (always as partial(kh = 0) + partial(kh = 1)), then bias / residual / store; `scr`: 16 KiB of LDS nobody
+// reads at that point (the patch region, or the X slot while q | k | v are being built); lane owns couts
+  // cb*32 + 8 qd + 4 g + (0..3) of pixel pxl.  want_stats: GroupNorm sums of the written tensor (the wave's 32 couts are
+  // exactly group cb) -> stat[stat_slot]. ----
+  auto finish = [&](f32x16 (&acc)[2], float* dst, int ds, int c0, const float* bias_a, const float* bias_b, const float* resid,
+                    float* scr, int stat_slot) {
+    __syncthreads();  // every wave is past its MFMAs / the previous user of the scratch
+    float* mine = scr + (size_t)wave * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[r * 64 + lane] = kh ? acc[0][r] : acc[1][r];
+    __syncthreads();
+    const float* theirs = scr + (size_t)(wave ^ 2) * 1024;
+    f32x16 v16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float own = kh ? acc[1][r] : acc[0][r], other = theirs[r * 64 + lane];
+      v16[r] = kh ? other + own : own + other;
+    }
+    float fs = 0.f, fq = 0.f;
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
       const int c = cb * 32 + 8 * qd + 4 * g;
-      f32x4 v = (f32x4){acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]};
+      f32x4 v = (f32x4){v16[4 * qd], v16[4 * qd + 1], v16[4 * qd + 2], v16[4 * qd + 3]};
       if (bias_a) v += *(const f32x4*)(bias_a + c);
       if (bias_b) v += *(const f32x4*)(bias_b + c);
       if (resid) v += *(const f32x4*)(resid + pxl * LR_SS + c);
       *(f32x4*)(dst + pxl * ds + c0 + c) = v;
+      fs += (v[0] + v[1]) + (v[2] + v[3]);
+      fq = __builtin_fmaf(v[0], v[0], fq);
+      fq = __builtin_fmaf(v[1], v[1], fq);
+      fq = __builtin_fmaf(v[2], v[2], fq);
+      fq = __builtin_fmaf(v[3], v[3], fq);
+    }
+    if (stat_slot >= 0) {
+#if !(LR_ABL & 4)
+      const double a = dmd_wave_sum((double)fs), b = dmd_wave_sum((double)fq);
+      if (lane == 0) {
+        red[2 * wave] = a;
+        red[2 * wave + 1] = b;
+      }
+#endif
+      finish_stats(stat_slot, -1);
     }
   };
-  auto zero = [&](f32x16& acc) {
+  auto zero = [&](f32x16 (&acc)[2]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+  };
+
+  // FiLM entries of this thread for a block: (scale, shift) of norm1 (tid < 128: source tid >> 6, channel tid & 63) and of
+  // norm2 (tid < 64), fetched one block ahead (a table row is touched for the first time here: HBM latency)
+  auto film_fetch = [&](int b, float (&f)[4]) {
+    f[0] = f[1] = f[2] = f[3] = 0.f;
+    if (b >= p.nblocks) return;
+    const dmd_chain_block& B = p.blocks[b];
+#if !(LR_ABL & 8)
+    if (tid < 128) {
+      const int src = tid >> 6, ch = tid & 63;
+      if (src == 0 || B.skip_slot >= 0) {
+        f[0] = trow[B.film1_mul[src] + ch];
+        f[1] = trow[B.film1_add[src] + ch];
+      }
+      if (src == 0) {
+        f[2] = trow[B.film2_mul + ch];
+        f[3] = trow[B.film2_add + ch];
+      }
+    }
+#endif
   };
 
   // =============================== the chain ===============================
   float* X = slot(LR_X);
   float* H = slot(LR_H);
+  float film_cur[4], film_nxt[4];
+  film_fetch(0, film_nxt);
+  prefetch_w(p.blocks[0].w1);
   for (int id = tid; id < 64 * 16; id += 256) {
     const int px = id >> 4, q = id & 15;
     const f32x4 v = *(const f32x4*)(p.x + ((size_t)n * 64 + px) * 64 + 4 * q);
     *(f32x4*)(X + px * LR_SS + 4 * q) = v;
     if (p.input_save_slot >= 0) *(f32x4*)(slot(p.input_save_slot) + px * LR_SS + 4 * q) = v;
   }
-  compute_stats(LR_X, p.input_save_slot);
+  slot_stats(LR_X, p.input_save_slot);
   LR_STAMP(0);
 
   for (int b = 0; b < p.nblocks; ++b) {
     const dmd_chain_block& B = p.blocks[b];
     const int nsrc = B.skip_slot >= 0 ? 2 : 1;
     const int sk = B.skip_slot >= 0 ? B.skip_slot : 0;
-    f32x16 acc;
-    // ---- conv1(SiLU(AdaGN1(cat(x, skip)))) -> H ----
+#pragma unroll
+    for (int e = 0; e < 4; ++e) film_cur[e] = film_nxt[e];
+    film_fetch(b + 1, film_nxt);
+    f32x16 acc[2];
+    // ---- conv1(SiLU(AdaGN1(cat(x, skip)))) -> H  (its first weights were prefetched during the previous block) ----
     LR_STAMP(1);
-    prefetch_w(B.w1);
-    tab_film(nsrc, LR_X, sk, B.film1_mul[0], B.film1_add[0], B.film1_mul[1], B.film1_add[1]);
+    tab_film(nsrc, LR_X, sk, film_cur[0], film_cur[1]);
     LR_STAMP(2);
     stage_patch(nsrc, LR_X, sk);
     LR_STAMP(3);
@@ -323,9 +386,7 @@ __global__ __launch_bounds__(256) void lowres_chain_kernel(const dmd_lowres_chai
     conv3x3(acc, 4 * nsrc, B.w1);
     LR_STAMP(4);
     prefetch_w(B.w2);
-    epilogue(acc, H, LR_SS, 0, B.b1, nullptr, nullptr);
-    LR_STAMP(5);
-    compute_stats(LR_H, -1);
+    finish(acc, H, LR_SS, 0, B.b1, nullptr, nullptr, SCR, LR_H);
     LR_STAMP(6);
     // ---- conv2(SiLU(AdaGN2(h))) + r -> X,  r = proj(cat(x, skip)) (accumulated first) or x ----
     zero(acc);
@@ -334,13 +395,13 @@ __global__ __launch_bounds__(256) void lowres_chain_kernel(const dmd_lowres_chai
       conv1x1(acc, slot(sk), LR_SS, B.wproj, 4);
     }
     LR_STAMP(7);
-    tab_film(1, LR_H, 0, B.film2_mul, B.film2_add, 0, 0);
-    stage_patch(1, LR_H, 0);  // (its barrier also orders the projection's reads of X before the epilogue's writes)
+    tab_film(1, LR_H, 0, film_cur[2], film_cur[3]);
+    stage_patch(1, LR_H, 0);  // (its barriers also order the projection's reads of X before the epilogue's writes)
     LR_STAMP(8);
     conv3x3(acc, 4, B.w2);
     LR_STAMP(9);
-    epilogue(acc, X, LR_SS, 0, B.b2, B.wproj ? B.bproj : nullptr, B.wproj ? nullptr : X);
-    compute_stats(LR_X, -1);
+    if (!B.has_attn && b + 1 < p.nblocks) prefetch_w(p.blocks[b + 1].w1);
+    finish(acc, X, LR_SS, 0, B.b2, B.wproj ? B.bproj : nullptr, B.wproj ? nullptr : X, SCR, LR_X);
     LR_STAMP(10);
     // ---- SelfAttention2d: x_n = GN(x); y = softmax(q k^T / sqrt 8) v per head; x = x_n + out_proj(y) ----
     if (B.has_attn) {
@@ -354,14 +415,16 @@ __global__ __launch_bounds__(256) void lowres_chain_kernel(const dmd_lowres_chai
         for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(v[e], ta[e], tb[e]);
         *(f32x4*)(H + px * LR_SS + 4 * q) = o;
       }
-      __syncthreads();  // x_n complete; the patch region is free (conv2's reads ended before its epilogue)
+      __syncthreads();  // x_n complete
       LR_STAMP(11);
+      // q, k, v -> the q | k | v overlay of the patch region; their K-split reductions go through the X slot (x is dead:
+      // its normalised copy is in H, and y is written only after the attention core)
       const void* wqkv[3] = {B.wq, B.wk, B.wv};
 #pragma unroll
       for (int part = 0; part < 3; ++part) {
         zero(acc);
         conv1x1(acc, H, LR_SS, wqkv[part], 0);
-        epilogue(acc, QKV, LR_QS, 64 * part, B.bqkv + 64 * part, nullptr, nullptr);
+        finish(acc, QKV, LR_QS, 64 * part, B.bqkv + 64 * part, nullptr, nullptr, X, -1);
       }
       __syncthreads();
       LR_STAMP(12);
@@ -409,13 +472,12 @@ __global__ __launch_bounds__(256) void lowres_chain_kernel(const dmd_lowres_chai
         *(f32x4*)(X + qi * LR_SS + head * 8) = o0;  // y overwrites x (dead: its normalised copy is in H)
         *(f32x4*)(X + qi * LR_SS + head * 8 + 4) = o1;
       }
-      __syncthreads();
+      __syncthreads();  // y complete; q | k | v are dead (the scratch may overwrite them)
       LR_STAMP(13);
       zero(acc);
       conv1x1(acc, X, LR_SS, B.wo, 0);
-      __syncthreads();  // every wave has read y
-      epilogue(acc, X, LR_SS, 0, B.bo, nullptr, H);
-      compute_stats(LR_X, -1);
+      if (b + 1 < p.nblocks) prefetch_w(p.blocks[b + 1].w1);
+      finish(acc, X, LR_SS, 0, B.bo, nullptr, H, SCR, LR_X);  // (its first barrier: every wave has read y)
       LR_STAMP(14);
     }
     if (B.save_slot >= 0) {

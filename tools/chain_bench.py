@@ -42,7 +42,7 @@ if "--trace" in sys.argv:  # needs a -DLR_TRACE=1 build (DIAMOND_LIB=...)
         t, tag = buf[i] >> 8, buf[i] & 0xff
         tot.setdefault(tag, []).append(t - prev)
         prev = t
-    clk = 100e6  # s_memtime / readcyclecounter: 100 MHz constant clock on gfx9
+    clk = 1.97e9  # shader clock (s_memtime ticks are shader cycles; ~1.97 GHz measured from the whole-call time)
     for tag in sorted(tot):
         v = tot[tag]
         print(f"{names.get(tag, tag):16s} n={len(v):2d} total {sum(v) / clk * 1e6:7.1f} us  each {sum(v) / len(v) / clk * 1e6:6.2f} us")
