@@ -70,6 +70,24 @@ __device__ __forceinline__ void lr_split8(const f32x4 a, const f32x4 b, h8& h, h
   }
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// wave64 sum on the DPP network (no LDS round trips): quad swaps and row mirrors leave the 16-lane row total in every
+// lane of a row, row_bcast:15 / row_bcast:31 chain the four rows; the total is read from lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float lr_dpp_add(float x) {
+  return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float lr_wave_sum(float x) {
+  x = lr_dpp_add<0xB1, 0xf>(x);   // quad_perm [1, 0, 3, 2]
+  x = lr_dpp_add<0x4E, 0xf>(x);   // quad_perm [2, 3, 0, 1]
+  x = lr_dpp_add<0x141, 0xf>(x);  // row_half_mirror
+  x = lr_dpp_add<0x140, 0xf>(x);  // row_mirror
+  x = lr_dpp_add<0x142, 0xa>(x);  // row_bcast:15 -> rows 1, 3
+  x = lr_dpp_add<0x143, 0xc>(x);  // row_bcast:31 -> rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+
 __global__ __launch_bounds__(256) void lowres_chain_kernel(const dmd_lowres_chain_params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lr_smem[];
   float* slots = (float*)lr_smem;
@@ -129,10 +147,10 @@ __global__ __launch_bounds__(256) void lowres_chain_kernel(const dmd_lowres_chai
       fq = __builtin_fmaf(v[2], v[2], fq);
       fq = __builtin_fmaf(v[3], v[3], fq);
     }
-    const double a = dmd_wave_sum((double)fs), b = dmd_wave_sum((double)fq);
+    const float a = lr_wave_sum(fs), b = lr_wave_sum(fq);
     if (lane == 0) {
-      red[2 * wave] = a;
-      red[2 * wave + 1] = b;
+      red[2 * wave] = (double)a;
+      red[2 * wave + 1] = (double)b;
     }
     finish_stats(s, also);
   };
@@ -290,16 +308,22 @@ __global__ __launch_bounds__(256) void lowres_chain_kernel(const dmd_lowres_chai
   auto finish = [&](f32x16 (&acc)[2], float* dst, int ds, int c0, const float* bias_a, const float* bias_b, const float* resid,
                     float* scr, int stat_slot) {
     __syncthreads();  // every wave is past its MFMAs / the previous user of the scratch
-    float* mine = scr + (size_t)wave * 1024;
+    f32x4* mine = (f32x4*)(scr + (size_t)wave * 1024);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mine[r * 64 + lane] = kh ? acc[0][r] : acc[1][r];
+    for (int qd = 0; qd < 4; ++qd)
+      mine[qd * 64 + lane] = kh ? (f32x4){acc[0][4 * qd], acc[0][4 * qd + 1], acc[0][4 * qd + 2], acc[0][4 * qd + 3]}
+                                : (f32x4){acc[1][4 * qd], acc[1][4 * qd + 1], acc[1][4 * qd + 2], acc[1][4 * qd + 3]};
     __syncthreads();
-    const float* theirs = scr + (size_t)(wave ^ 2) * 1024;
+    const f32x4* theirs = (const f32x4*)(scr + (size_t)(wave ^ 2) * 1024);
     f32x16 v16;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float own = kh ? acc[1][r] : acc[0][r], other = theirs[r * 64 + lane];
-      v16[r] = kh ? other + own : own + other;
+    for (int qd = 0; qd < 4; ++qd) {
+      const f32x4 other = theirs[qd * 64 + lane];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float own = kh ? acc[1][4 * qd + e] : acc[0][4 * qd + e];
+        v16[4 * qd + e] = kh ? other[e] + own : own + other[e];
+      }
     }
     float fs = 0.f, fq = 0.f;
 #pragma unroll
@@ -318,10 +342,10 @@ __global__ __launch_bounds__(256) void lowres_chain_kernel(const dmd_lowres_chai
     }
     if (stat_slot >= 0) {
 #if !(LR_ABL & 4)
-      const double a = dmd_wave_sum((double)fs), b = dmd_wave_sum((double)fq);
+      const float a = lr_wave_sum(fs), b = lr_wave_sum(fq);
       if (lane == 0) {
-        red[2 * wave] = a;
-        red[2 * wave + 1] = b;
+        red[2 * wave] = (double)a;
+        red[2 * wave + 1] = (double)b;
       }
 #endif
       finish_stats(stat_slot, -1);
@@ -434,6 +458,9 @@ __global__ __launch_bounds__(256) void lowres_chain_kernel(const dmd_lowres_chai
         const float* qp = QKV + qi * LR_QS + head * 8;
         const f32x4 q0 = *(const f32x4*)qp, q1 = *(const f32x4*)(qp + 4);
         const float inv = 1.0f / sqrtf(8.0f);  // (q k^T) / sqrt(d), blocks.py:68
+        // Variants measured (per attention block, one wave per SIMD: the K / V rows are wave-uniform LDS reads whose latency is
+        // the cost): this row-at-a-time loop 11.5 us; v_pk_fma_f32 dot products 14 us; rows fetched 16 at a time 9 us, but
+        // the extra live registers spill into the convolution loops of the same kernel (+11 us there).
         float sc[64];  // the row of scores stays in registers (fully unrolled loops)
         float m = -INFINITY;
 #pragma unroll
