@@ -23,8 +23,9 @@ from .engine import Act, NormSpec
 GN_GROUP_SIZE = 32
 GN_EPS = 1e-5
 ATTN_HEAD_DIM = 8
-# DIAMOND_LOWRES_CHAIN=0: run the 8x8 level of the U-Net launch by launch instead of as one dmd_lowres_chain call
-LOWRES_CHAIN = os.environ.get("DIAMOND_LOWRES_CHAIN", "1") != "0"
+# DIAMOND_LOWRES_CHAIN: bit 0 = the 8x8 level of the denoiser's U-Net as one dmd_lowres_chain launch, bit 1 = the 8x8 tail of
+# the reward / end encoder as one dmd_lowres_chain32 launch (default 3 = both; 0 = launch by launch).
+LOWRES_CHAIN = int(os.environ.get("DIAMOND_LOWRES_CHAIN", "3"))
 
 
 def conv3x3(cin: int, cout: int, stride: int = 1) -> nn.Conv2d:
@@ -284,7 +285,7 @@ class UNet(nn.Module):
     def _chain_eligible(self, ctx: RunCtx, x: Act) -> bool:
         """dmd_lowres_chain covers: split-fp16 inference (no recording for a backward), 8x8 x 64 channels at the deepest
         level with 64-channel neighbours, at most two down blocks (three skip slots) and eight blocks in all."""
-        if not LOWRES_CHAIN or ctx.precision != "f16x2" or ctx.naive or E.TAPE is not None or E._USE_NAIVE:
+        if not (int(LOWRES_CHAIN) & 1) or ctx.precision != "f16x2" or ctx.naive or E.TAPE is not None or E._USE_NAIVE:
             return False
         if len(self.d_blocks) < 2 or tuple(x.shape[1:]) != (8, 8, 64):
             return False

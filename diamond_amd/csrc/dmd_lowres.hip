@@ -526,6 +526,302 @@ __global__ __launch_bounds__(256) void lowres_chain_kernel(const dmd_lowres_chai
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// lowres_chain32_kernel -- the same idea for the reward / end model's encoder (reference rew_end_model.py:93-133): its last
+// two ResBlocks groups run at 8x8 with 32 channels (one GroupNorm group), no concatenated skips, attention (4 heads) in
+// the final group.  Wave (pb, kh) = 32-pixel block pb x all 32 couts over the K chunk kh (a 32-channel input is two
+// 16-channel chunks); the two K halves are exchanged through LDS and wave kh finishes cout quads {2 kh, 2 kh + 1}.
+// ------------------------------------------------------------------------------------------------------------------
+#define L3_SS 36                     // floats per pixel row of a slot (32 + 4)
+#define L3_SLOT (64 * L3_SS)
+#define L3_REGION_FLOATS (64 * 100)  // patch (100 px x 2 chunks x 4 units x 4 floats = 3200) | q k v overlay [64][100] | scratch
+#define L3_SMEM_BYTES ((2 * L3_SLOT + L3_REGION_FLOATS + 64 + 32) * 4 + 64)
+
+__global__ __launch_bounds__(256) void lowres_chain32_kernel(const dmd_lowres_chain_params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lr_smem[];
+  float* X = (float*)lr_smem;
+  float* H = X + L3_SLOT;
+  u32x4* P = (u32x4*)(H + L3_SLOT);
+  float* QKV = (float*)P;  // [64][100]: q | k | v (96) + 4 pad
+  float* SCR = (float*)P;  // [wave][8][64] K-split partial half tiles
+  float* tabA = (float*)P + L3_REGION_FLOATS;
+  float* tabB = tabA + 32;
+  float* stat = tabB + 32;            // [0]: X (mean, rstd), [1]: H
+  double* red = (double*)(stat + 32);
+
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n31 = lane & 31, g = lane >> 5;
+  const int pb = wave & 1, kh = wave >> 1;
+  const int pxl = 32 * pb + n31;
+  const int prow = 4 * pb + (n31 >> 3), pcol = n31 & 7;
+  const float* trow = p.table + (size_t)n * p.table_stride;
+  const int wlane = g * 32 + n31;  // 16-byte unit inside a (tap, h|l) weight row of a 32-cout pack
+
+  auto finish_stats = [&](int s) {
+    __syncthreads();
+    if (tid == 0) {
+      const double sum = (red[0] + red[2]) + (red[4] + red[6]), ssq = (red[1] + red[3]) + (red[5] + red[7]);
+      const double m = sum / 2048.0;
+      double var = ssq / 2048.0 - m * m;
+      var = var < 0.0 ? 0.0 : var;
+      stat[2 * s] = (float)m;
+      stat[2 * s + 1] = (float)(1.0 / sqrt(var + (double)DMD_GN_EPS));
+    }
+    __syncthreads();
+  };
+  auto publish_sums = [&](float fs, float fq) {
+    const float a = lr_wave_sum(fs), b = lr_wave_sum(fq);
+    if (lane == 0) {
+      red[2 * wave] = (double)a;
+      red[2 * wave + 1] = (double)b;
+    }
+  };
+  auto tab_film = [&](int s, float mul, float add) {
+    if (tid < 32) {
+      const float a = stat[2 * s + 1] * (1.0f + mul);
+      tabA[tid] = a;
+      tabB[tid] = add - stat[2 * s] * a;
+    }
+    __syncthreads();
+  };
+  auto tab_affine = [&](int s, const float* gamma, const float* beta) {
+    if (tid < 32) {
+      const float a = stat[2 * s + 1] * gamma[tid];
+      tabA[tid] = a;
+      tabB[tid] = beta[tid] - stat[2 * s] * a;
+    }
+    __syncthreads();
+  };
+
+  // staging items: it * 256 + tid = (patch pixel pp = it * 32 + (tid >> 3), channel quad q8 = tid & 7)
+  int soff[4], poff[4];
+  {
+    const int q8 = tid & 7, chunk = q8 >> 2, q = q8 & 3;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int pp = it * 32 + (tid >> 3);
+      const int py = pp / 10, px = pp - 10 * py;
+      const bool inside = pp < 100 && py >= 1 && py <= 8 && px >= 1 && px <= 8;
+      soff[it] = inside ? ((py - 1) * 8 + (px - 1)) * L3_SS + 4 * q8 : (pp < 100 ? -1 : -2);
+      const int pos = ((q >> 1) + (px >> 1)) & 3;
+      poff[it] = ((pp * 2 + chunk) * 4 + pos) * 2 + (q & 1);
+    }
+  }
+  auto stage_patch = [&](const float* sp) {
+    uint2* P8 = (uint2*)P;
+    const f32x4 ta = *(const f32x4*)(tabA + 4 * (tid & 7)), tb = *(const f32x4*)(tabB + 4 * (tid & 7));
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      if (soff[it] == -2) continue;
+      h4 hv = {0, 0, 0, 0}, lv = {0, 0, 0, 0};
+      if (soff[it] >= 0) {
+        const f32x4 v = *(const f32x4*)(sp + soff[it]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = lr_silu(__builtin_fmaf(v[e], ta[e], tb[e]));
+          const _Float16 h = (_Float16)x;
+          hv[e] = h;
+          lv[e] = (_Float16)(x - (float)h);
+        }
+      }
+      P8[poff[it]] = __builtin_bit_cast(uint2, hv);
+      P8[poff[it] ^ 4] = __builtin_bit_cast(uint2, lv);
+    }
+    __syncthreads();
+  };
+
+  u32x4 wpre[18];  // this wave's chunk (kh) of the next 3x3 convolution, fetched ahead of the phases that precede its use
+  auto prefetch_w = [&](const void* w16) {
+    const u32x4* wg = (const u32x4*)w16 + wlane;
+#pragma unroll
+    for (int i = 0; i < 18; ++i) wpre[i] = wg[(size_t)(kh * 18 + i) * 64];
+  };
+  auto conv3x3 = [&](f32x16& acc) {  // acc += W[chunk kh] * patch, weights in wpre
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap % 3;
+      const int pp = (prow + dy) * 10 + pcol + dx;
+      const int base = (pp * 2 + kh) * 4;
+      const int pos = (g + ((pcol + dx) >> 1)) & 3;
+      const h8 bh = __builtin_bit_cast(h8, P[base + pos]), bl = __builtin_bit_cast(h8, P[base + (pos ^ 2)]);
+      const h8 ah = __builtin_bit_cast(h8, wpre[2 * tap]), al = __builtin_bit_cast(h8, wpre[2 * tap + 1]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+    }
+  };
+  auto conv1x1 = [&](f32x16& acc, const float* x, const void* w16) {  // acc += W[chunk kh] * x, raw fp32 slot, split on the fly
+    const u32x4* wg = (const u32x4*)w16 + wlane;
+    const h8 ah = __builtin_bit_cast(h8, wg[(size_t)(kh * 2) * 64]), al = __builtin_bit_cast(h8, wg[(size_t)(kh * 2 + 1) * 64]);
+    const float* xp = x + pxl * L3_SS + 16 * kh + 8 * g;
+    h8 bh, bl;
+    lr_split8(*(const f32x4*)xp, *(const f32x4*)(xp + 4), bh, bl);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+  };
+  // K-split exchange + epilogue: wave (pb, kh) finishes cout quads qd = 2 kh, 2 kh + 1 (couts 8 qd + 4 g + (0..3)) of pixel pxl
+  auto finish = [&](const f32x16& acc, float* dst, int ds, int c0, const float* bias, const float* resid, float* scr, int stat_slot) {
+    __syncthreads();
+    f32x4* mine = (f32x4*)(scr + (size_t)wave * 512);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int qd = 2 * (1 - kh) + i;  // the quads the partner finishes
+      mine[i * 64 + lane] = (f32x4){acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]};
+    }
+    __syncthreads();
+    const f32x4* theirs = (const f32x4*)(scr + (size_t)(wave ^ 2) * 512);
+    float fs = 0.f, fq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int qd = 2 * kh + i;
+      const int c = 8 * qd + 4 * g;
+      const f32x4 other = theirs[i * 64 + lane];
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = kh ? other[e] + acc[4 * qd + e] : acc[4 * qd + e] + other[e];  // partial(kh = 0) + partial(kh = 1)
+      if (bias) v += *(const f32x4*)(bias + c);
+      if (resid) v += *(const f32x4*)(resid + pxl * L3_SS + c);
+      *(f32x4*)(dst + pxl * ds + c0 + c) = v;
+      fs += (v[0] + v[1]) + (v[2] + v[3]);
+      fq = __builtin_fmaf(v[0], v[0], fq);
+      fq = __builtin_fmaf(v[1], v[1], fq);
+      fq = __builtin_fmaf(v[2], v[2], fq);
+      fq = __builtin_fmaf(v[3], v[3], fq);
+    }
+    if (stat_slot >= 0) {
+      publish_sums(fs, fq);
+      finish_stats(stat_slot);
+    }
+  };
+  auto zero = [&](f32x16& acc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  };
+  auto film_fetch = [&](int b, float (&f)[4]) {
+    f[0] = f[1] = f[2] = f[3] = 0.f;
+    if (b >= p.nblocks || tid >= 32) return;
+    const dmd_chain_block& B = p.blocks[b];
+    f[0] = trow[B.film1_mul[0] + tid];
+    f[1] = trow[B.film1_add[0] + tid];
+    f[2] = trow[B.film2_mul + tid];
+    f[3] = trow[B.film2_add + tid];
+  };
+
+  float film_cur[4], film_nxt[4];
+  film_fetch(0, film_nxt);
+  prefetch_w(p.blocks[0].w1);
+  {
+    float fs = 0.f, fq = 0.f;
+    for (int id = tid; id < 64 * 8; id += 256) {
+      const int px = id >> 3, q = id & 7;
+      const f32x4 v = *(const f32x4*)(p.x + ((size_t)n * 64 + px) * 32 + 4 * q);
+      *(f32x4*)(X + px * L3_SS + 4 * q) = v;
+      fs += (v[0] + v[1]) + (v[2] + v[3]);
+      fq = __builtin_fmaf(v[0], v[0], fq);
+      fq = __builtin_fmaf(v[1], v[1], fq);
+      fq = __builtin_fmaf(v[2], v[2], fq);
+      fq = __builtin_fmaf(v[3], v[3], fq);
+    }
+    publish_sums(fs, fq);
+    finish_stats(0);
+  }
+  for (int b = 0; b < p.nblocks; ++b) {
+    const dmd_chain_block& B = p.blocks[b];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) film_cur[e] = film_nxt[e];
+    film_fetch(b + 1, film_nxt);
+    f32x16 acc;
+    // conv1(SiLU(AdaGN1(x))) -> H
+    tab_film(0, film_cur[0], film_cur[1]);
+    stage_patch(X);
+    zero(acc);
+    conv3x3(acc);
+    prefetch_w(B.w2);
+    finish(acc, H, L3_SS, 0, B.b1, nullptr, SCR, 1);
+    // conv2(SiLU(AdaGN2(h))) + x -> X
+    tab_film(1, film_cur[2], film_cur[3]);
+    stage_patch(H);
+    zero(acc);
+    conv3x3(acc);
+    if (b + 1 < p.nblocks) prefetch_w(p.blocks[b + 1].w1);
+    finish(acc, X, L3_SS, 0, B.b2, X, SCR, 0);
+    if (B.has_attn) {
+      tab_affine(0, B.gn_gamma, B.gn_beta);
+      for (int id = tid; id < 64 * 8; id += 256) {
+        const int px = id >> 3, q = id & 7;
+        const f32x4 v = *(const f32x4*)(X + px * L3_SS + 4 * q);
+        const f32x4 ta = *(const f32x4*)(tabA + 4 * q), tb = *(const f32x4*)(tabB + 4 * q);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(v[e], ta[e], tb[e]);
+        *(f32x4*)(H + px * L3_SS + 4 * q) = o;
+      }
+      __syncthreads();
+      const void* wqkv[3] = {B.wq, B.wk, B.wv};
+#pragma unroll
+      for (int part = 0; part < 3; ++part) {  // q | k | v -> the overlay; the K-split exchange goes through the (dead) X slot
+        zero(acc);
+        conv1x1(acc, H, wqkv[part]);
+        finish(acc, QKV, 100, 32 * part, B.bqkv + 32 * part, nullptr, X, -1);
+      }
+      __syncthreads();
+      {  // 4 heads x 64 queries: wave = head, lane = query
+        const int head = wave, qi = lane;
+        const float* qp = QKV + qi * 100 + head * 8;
+        const f32x4 q0 = *(const f32x4*)qp, q1 = *(const f32x4*)(qp + 4);
+        const float inv = 1.0f / sqrtf(8.0f);
+        float sc[64];
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+          const float* kp = QKV + j * 100 + 32 + head * 8;
+          const f32x4 k0 = *(const f32x4*)kp, k1 = *(const f32x4*)(kp + 4);
+          float sv = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sv = __builtin_fmaf(q0[e], k0[e], sv);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sv = __builtin_fmaf(q1[e], k1[e], sv);
+          sv *= inv;
+          sc[j] = sv;
+          m = fmaxf(m, sv);
+        }
+        float l = 0.f;
+        f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+          const float pr = __builtin_amdgcn_exp2f((sc[j] - m) * 1.4426950408889634f);
+          l += pr;
+          const float* vp = QKV + j * 100 + 64 + head * 8;
+          const f32x4 v0 = *(const f32x4*)vp, v1 = *(const f32x4*)(vp + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o0[e] = __builtin_fmaf(pr, v0[e], o0[e]);
+            o1[e] = __builtin_fmaf(pr, v1[e], o1[e]);
+          }
+        }
+        const float rl = 1.0f / l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o0[e] *= rl;
+          o1[e] *= rl;
+        }
+        *(f32x4*)(X + qi * L3_SS + head * 8) = o0;
+        *(f32x4*)(X + qi * L3_SS + head * 8 + 4) = o1;
+      }
+      __syncthreads();
+      zero(acc);
+      conv1x1(acc, X, B.wo);
+      finish(acc, X, L3_SS, 0, B.bo, H, SCR, 0);  // its first barrier: every wave has read y
+    }
+  }
+  for (int id = tid; id < 64 * 8; id += 256) {
+    const int px = id >> 3, q = id & 7;
+    *(f32x4*)(p.out + ((size_t)n * 64 + px) * 32 + 4 * q) = *(const f32x4*)(X + px * L3_SS + 4 * q);
+  }
+}
+
 extern "C" int dmd_lowres_chain(const dmd_lowres_chain_params* p, dmd_stream_t stream) {
   DMD_CHECK_ARG(p && p->x && p->out && p->table, "lowres_chain: null");
   DMD_CHECK_ARG(p->N > 0 && p->nblocks > 0 && p->nblocks <= DMD_CHAIN_MAX_BLOCKS, "lowres_chain: N %d, nblocks %d", p->N, p->nblocks);
@@ -545,6 +841,26 @@ extern "C" int dmd_lowres_chain(const dmd_lowres_chain_params* p, dmd_stream_t s
     attr_set = true;
   }
   hipLaunchKernelGGL(lowres_chain_kernel, dim3(p->N), dim3(256), LR_SMEM_BYTES, (hipStream_t)stream, *p);
+  DMD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dmd_lowres_chain32(const dmd_lowres_chain_params* p, dmd_stream_t stream) {
+  DMD_CHECK_ARG(p && p->x && p->out && p->table, "lowres_chain32: null");
+  DMD_CHECK_ARG(p->N > 0 && p->nblocks > 0 && p->nblocks <= DMD_CHAIN_MAX_BLOCKS, "lowres_chain32: N %d, nblocks %d", p->N, p->nblocks);
+  for (int b = 0; b < p->nblocks; ++b) {
+    const dmd_chain_block& B = p->blocks[b];
+    DMD_CHECK_ARG(B.w1 && B.w2 && B.b1 && B.b2, "lowres_chain32: block %d: null conv weights", b);
+    DMD_CHECK_ARG(B.skip_slot < 0 && B.save_slot < 0 && !B.wproj, "lowres_chain32: block %d: no concatenated inputs at 32 channels", b);
+    DMD_CHECK_ARG(!B.has_attn || (B.gn_gamma && B.gn_beta && B.wq && B.wk && B.wv && B.wo && B.bqkv && B.bo), "lowres_chain32: block %d: attention parameters", b);
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lowres_chain32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L3_SMEM_BYTES);
+    DMD_CHECK_ARG(e == hipSuccess, "lowres_chain32: hipFuncSetAttribute(%d bytes): %s", (int)L3_SMEM_BYTES, hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(lowres_chain32_kernel, dim3(p->N), dim3(256), L3_SMEM_BYTES, (hipStream_t)stream, *p);
   DMD_LAUNCH_CHECK();
   return 0;
 }

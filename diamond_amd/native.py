@@ -86,7 +86,7 @@ EXPORTS = (
     "dmd_dequant_gather", "dmd_nchw_to_nhwc",
     "dmd_nhwc_to_nchw", "dmd_gn_stats", "dmd_maxpool2", "dmd_lstm_pointwise", "dmd_lstm_pointwise_bwd", "dmd_categorical_sample",
     "dmd_maxpool2_bwd", "dmd_gn_bwd_workspace_bytes", "dmd_gn_silu_bwd", "dmd_wgrad_workspace_floats", "dmd_conv2d_wgrad",
-    "dmd_lowres_chain", "dmd_last_error", "dmd_abi_version",
+    "dmd_lowres_chain", "dmd_lowres_chain32", "dmd_last_error", "dmd_abi_version",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -146,6 +146,7 @@ def lib() -> C.CDLL:
         L.dmd_wgrad_workspace_floats.restype = C.c_int64
         L.dmd_conv2d_wgrad.argtypes = [C.POINTER(WgradParams), C.c_void_p]
         L.dmd_lowres_chain.argtypes = [C.POINTER(LowresChainParams), C.c_void_p]
+        L.dmd_lowres_chain32.argtypes = [C.POINTER(LowresChainParams), C.c_void_p]
         _lib = L
     return _lib
 

@@ -63,11 +63,62 @@ class RewEndEncoder(nn.Module):
         x = E.conv2d([(E.Act(x_nhwc16, needs_grad=False), nv.PROLOGUE_NONE, None)], ctx.cache.conv_weight(self.conv_in),
                      ctx.cache.conv_bias(self.conv_in), self.conv_in.out_channels, naive=ctx.naive, w_f16=ctx.w16(self.conv_in),
                      module=self.conv_in)
-        for blocks, down in zip(self.blocks, self.downsamples):
+        tail = len(self.blocks) - 2  # the last level and the final attention group both run at the deepest resolution
+        for i, (blocks, down) in enumerate(zip(self.blocks, self.downsamples)):
             if not isinstance(down, nn.Identity):
                 x = down.run(ctx, x)
+            if i == tail and self._chain_eligible(ctx, x):
+                return self._run_lowres_chain(ctx, x)  # both groups as ONE launch (dmd_lowres.hip, 32-channel kernel)
             x, _ = blocks.run(ctx, x)
         return x
+
+    def _chain_blocks(self):
+        return list(self.blocks[-2].resblocks) + list(self.blocks[-1].resblocks)
+
+    def _chain_eligible(self, ctx: RunCtx, x: E.Act) -> bool:
+        from . import blocks as BL
+
+        if not (int(BL.LOWRES_CHAIN) & 2) or ctx.precision != "f16x2" or ctx.naive or E.TAPE is not None or E._USE_NAIVE:
+            return False
+        if tuple(x.shape[1:]) != (8, 8, 32):
+            return False
+        blks = self._chain_blocks()
+        return len(blks) <= nv.CHAIN_MAX_BLOCKS and all(
+            b.conv1.in_channels == 32 and b.conv1.out_channels == 32 and isinstance(b.proj, nn.Identity) for b in blks)
+
+    def _run_lowres_chain(self, ctx: RunCtx, x: E.Act) -> E.Act:
+        import ctypes as C
+
+        cache = ctx.cache
+        blks = self._chain_blocks()
+        p = nv.LowresChainParams()
+        n = x.shape[0]
+        out = torch.empty_like(x.t)
+        p.N, p.nblocks, p.input_save_slot = n, len(blks), -1
+        p.x, p.out = nv.ptr(x.t), nv.ptr(out)
+        p.table, p.table_stride = nv.ptr(ctx.table), ctx.table.stride(0)
+        keep = []  # (the caches own these tensors; the list documents what the parameter block points at)
+        for i, b in enumerate(blks):
+            cb = p.blocks[i]
+            cb.skip_slot = cb.save_slot = -1
+            o1, o2 = ctx.film.offset[id(b.norm1)], ctx.film.offset[id(b.norm2)]
+            cb.film1_mul[0], cb.film1_add[0] = o1, o1 + 32
+            cb.film2_mul, cb.film2_add = o2, o2 + 32
+            ts = [cache.conv_weight_f16x2(b.conv1), cache.conv_weight_f16x2(b.conv2), cache.conv_bias(b.conv1), cache.conv_bias(b.conv2)]
+            cb.w1, cb.w2, cb.b1, cb.b2 = (nv.ptr(t) for t in ts)
+            if not isinstance(b.attn, nn.Identity):
+                a = b.attn
+                cb.has_attn = 1
+                qkv = [cache.get(a.qkv_proj.weight, f"qkv16[{k}]", lambda w, k=k: nv.pack_conv_weight_f16x2(w.detach().float()[32 * k:32 * k + 32].contiguous()))
+                       for k in range(3)]
+                ta = qkv + [cache.conv_weight_f16x2(a.out_proj), cache.f32(a.norm.norm.weight), cache.f32(a.norm.norm.bias),
+                            cache.f32(a.qkv_proj.bias), cache.conv_bias(a.out_proj)]
+                cb.wq, cb.wk, cb.wv, cb.wo, cb.gn_gamma, cb.gn_beta, cb.bqkv, cb.bo = (nv.ptr(t) for t in ta)
+                ts += ta
+            keep.append(ts)
+        nv.check(nv.lib().dmd_lowres_chain32(C.byref(p), nv.stream()), "dmd_lowres_chain32")
+        del keep
+        return E.Act(out)
 
 
 class RewEndModel(nn.Module):

@@ -172,6 +172,10 @@ typedef struct dmd_lowres_chain_params {
   dmd_chain_block blocks[DMD_CHAIN_MAX_BLOCKS];
 } dmd_lowres_chain_params;
 int dmd_lowres_chain(const dmd_lowres_chain_params* p, dmd_stream_t stream);
+/* The same for the 8x8 x 32-channel tail of the reward / end model's encoder (reference rew_end_model.py:93-133: the last
+ * level's ResBlocks and the final attention ResBlocks; no concatenated inputs): x / out are NHWC (N, 8, 8, 32), packs are the
+ * 32-cout form of dmd_pack_conv_weight_f16x2, q | k | v are 32-channel thirds (4 heads). */
+int dmd_lowres_chain32(const dmd_lowres_chain_params* p, dmd_stream_t stream);
 
 /* ---- EDM preconditioning / sampler pointwise (denoiser.py:74-84, diffusion_sampler.py:45-56) ---- */
 /* The four EDM conditioners (c_in, c_out, c_skip, c_noise; compute_conditioners denoiser.py:66-72)

@@ -435,17 +435,52 @@ def test_lowres_chain_matches_launch_by_launch(attn_depths, b):
     outs = {}
     try:
         for mode in (True, False):
-            BL.LOWRES_CHAIN = mode
+            BL.LOWRES_CHAIN = 3 if mode else 0
             E.PROFILER = E.LaunchProfiler()
             outs[mode] = ag.denoiser.compute_model_output(x, obs, act, sigma).clone()
             keys = E.PROFILER.summary()
             assert ("lowres_chain_kernel" in keys) == mode, keys.keys()
     finally:
-        BL.LOWRES_CHAIN = True
+        BL.LOWRES_CHAIN = 3
         E.PROFILER = None
     err = rel_err(outs[True], outs[False])
     print(f"lowres chain vs launch-by-launch (attn_depths {attn_depths}): rel err {err:.3e}")
     assert err < 1e-5, err
+
+
+def test_rew_end_lowres_chain_matches_launch_by_launch(agent):
+    """dmd_lowres_chain32 (the 8x8 x 32-channel tail of the reward / end encoder: last level + the final attention group in
+    one launch) against the launch-by-launch path: logits and LSTM state within 1e-5, burn-in (T = 3) and step form."""
+    from diamond_amd import blocks as BL
+    from diamond_amd.testing import synthetic_actions, synthetic_frames
+
+    g = torch.Generator().manual_seed(23)
+    obs = synthetic_frames(g, 5, 4, 3, 64, 64).to(DEV)
+    act = synthetic_actions(g, 4, 5, 4).to(DEV)
+    m = agent.rew_end_model
+    outs = {}
+    calls = {"n": 0}
+    real = m.encoder._run_lowres_chain
+
+    def spy(ctx, x):
+        calls["n"] += 1
+        return real(ctx, x)
+
+    m.encoder._run_lowres_chain = spy
+    try:
+        for mode in (True, False):
+            BL.LOWRES_CHAIN = 3 if mode else 0
+            calls["n"] = 0
+            lr, le, (hx, cx) = m.predict_rew_end(obs[:, :-1], act[:, :-1], obs[:, 1:])
+            lr2, le2, (hx2, cx2) = m.predict_rew_end(obs[:, -1:], act[:, -1:], obs[:, :1], (hx, cx))
+            outs[mode] = [t.clone() for t in (lr, le, hx, cx, lr2, le2, hx2, cx2)]
+            assert (calls["n"] == 2) == mode
+    finally:
+        BL.LOWRES_CHAIN = 3
+        del m.encoder._run_lowres_chain
+    errs = [rel_err(a, b) for a, b in zip(outs[True], outs[False])]
+    print("rew/end lowres chain vs launch-by-launch:", [f"{e:.2e}" for e in errs])
+    assert max(errs) < 1e-5, errs
 
 
 def test_rew_end_training_step_vs_reference_golden():
