@@ -190,7 +190,7 @@ def precision_label(E, ac_native):
     wm = ("world-model convs (3x3 stride 1 / 2, 1x1): fp32 operands split into 2 x fp16 pieces, 3 x v_mfma_f32_*_f16 per product, "
           "fp32 accumulate (fp32-class, 22-bit operands); attention core, linears: exact fp32 v_mfma_f32_16x16x4_f32"
           if E.WORLD_MODEL_PRECISION == "f16x2" else "world model: exact fp32 v_mfma_f32_16x16x4_f32")
-    ac = ("actor-critic encoder forward + dgrad convs: same split-fp16 form, weight gradients exact fp32 MFMA"
+    ac = ("actor-critic encoder forward, dgrad and weight-gradient convs: same split-fp16 form"
           if ac_native.AC_PRECISION == "f16x2" else "actor-critic encoder fwd/bwd: exact fp32 MFMA")
     short = "f32" if (E.WORLD_MODEL_PRECISION, ac_native.AC_PRECISION) == ("f32", "f32") else "f32 via split-f16 MFMA"
     return f"{short} ({wm}; {ac}; LSTM cells / heads: exact fp32 MFMA (dmd_linear))"

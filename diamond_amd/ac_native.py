@@ -44,7 +44,9 @@ def _maxpool_bwd(dp: Tensor, arg: Tensor) -> Tensor:
 
 
 def _wgrad(x: Act, prologue: int, spec: Optional[NormSpec], dy: Tensor, taps: int, cin_real: int,
-           want_bias: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
+           want_bias: bool = True, split: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+    """dW, db of a convolution.  split: operands as split-fp16 pairs (needs dy pre-scaled to O(1): the callers' 2^k scaling);
+    False: exact fp32 fma chain."""
     n, h, w, cout = dy.shape
     k = 3 if taps == 9 else 1
     p = nv.WgradParams()
@@ -56,6 +58,7 @@ def _wgrad(x: Act, prologue: int, spec: Optional[NormSpec], dy: Tensor, taps: in
     if prologue != nv.PROLOGUE_NONE:
         p.src.norm = spec.to_native(x)
     p.dy = nv.ptr(dy)
+    p.precision = nv.PRECISION_F16X2 if (split and not WGRAD_EXACT) else nv.PRECISION_F32
     ws = torch.empty(int(nv.lib().dmd_wgrad_workspace_floats(C.byref(p))), device=dy.device, dtype=torch.float32)
     dw = torch.empty(cout, cin_real, k, k, device=dy.device, dtype=torch.float32)
     db = torch.empty(cout, device=dy.device, dtype=torch.float32) if want_bias else None
@@ -85,6 +88,8 @@ def _gn_silu_bwd(x: Act, spec: NormSpec, da: Tensor, dskip: Optional[Tensor]) ->
 # shape is covered (fp32-class accuracy, see dmd_conv_f16ws.hip), "f32" = exact fp32 MFMA.  The weight gradient
 # (contraction over pixels) always runs on the exact fp32 MFMA kernel.
 AC_PRECISION = os.environ.get("DIAMOND_AC_PRECISION", "f16x2")
+# DIAMOND_WGRAD_EXACT=1: weight gradients on the exact-fp32 instance of the wgrad kernel even where forward / dgrad run split
+WGRAD_EXACT = os.environ.get("DIAMOND_WGRAD_EXACT", "0") == "1"
 
 
 def _transposed(w: Tensor) -> Tensor:
@@ -170,6 +175,7 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dfeat: Tensor):
         plan, cache = ctx.plan, ctx.cache
+        split = AC_PRECISION == "f16x2"  # weight gradients in the split-fp16 form too (exact fp32 with DIAMOND_AC_PRECISION=f32)
         last_x, _ = ctx.saved[-1]
         blk_last, pool_last = plan.blocks[-1]
         cl = blk_last.f[2].out_channels
@@ -189,7 +195,7 @@ class _EncoderFn(torch.autograd.Function):
             gn, conv = blk.f[0].norm, blk.f[2]
             spec = NormSpec(mul=cache.f32(gn.weight), add=cache.f32(gn.bias))
             dy = _maxpool_bwd(dcur, arg) if pool else dcur
-            dw, db = _wgrad(x, nv.PROLOGUE_NORM_SILU, spec, dy, 9, conv.in_channels)
+            dw, db = _wgrad(x, nv.PROLOGUE_NORM_SILU, spec, dy, 9, conv.in_channels, split=split)
             da = E.conv2d([(Act(dy), nv.PROLOGUE_NONE, None)], _dgrad_weight(cache, conv), None, conv.in_channels,
                           want_stats=False, w_f16=_dgrad_w16(cache, conv)).t
             sp = blk.skip_projection
@@ -197,7 +203,7 @@ class _EncoderFn(torch.autograd.Function):
             if isinstance(sp, nn.Identity):
                 dskip = dy
             else:
-                dws, dbs = _wgrad(x, nv.PROLOGUE_NONE, None, dy, 1, sp.in_channels)
+                dws, dbs = _wgrad(x, nv.PROLOGUE_NONE, None, dy, 1, sp.in_channels, split=split)
                 dskip = E.conv2d([(Act(dy), nv.PROLOGUE_NONE, None)], _dgrad_weight(cache, sp), None, sp.in_channels, taps=1,
                                  want_stats=False).t
                 g_skip = [dws, dbs]
@@ -206,7 +212,7 @@ class _EncoderFn(torch.autograd.Function):
             grads_rev += list(reversed([dmul.sum(0), dadd.sum(0), dw, db] + g_skip))
             dcur = dx
         ci = plan.conv_in
-        dw_in, db_in = _wgrad(Act(ctx.x16), nv.PROLOGUE_NONE, None, dcur, 9, ctx.cimg)
+        dw_in, db_in = _wgrad(Act(ctx.x16), nv.PROLOGUE_NONE, None, dcur, 9, ctx.cimg, split=split)
         grads = [g * inv_scale for g in [dw_in, db_in] + list(reversed(grads_rev))]
         return (None, None, None, *grads)
 

@@ -297,7 +297,31 @@ __device__ __forceinline__ SubTile wgrad_subtile(int N, int H, int W, int gs) {
   return t;
 }
 
-template <class G>
+typedef _Float16 wg_h4 __attribute__((ext_vector_type(4)));
+
+// fp32 -> its split-fp16 pieces packed into the same 4 bytes: h = fp16(x) in the low half, l = fp16(x - h) in the high half
+__device__ __forceinline__ float wg_pack_hl(float x) {
+  const _Float16 h = (_Float16)x;
+  const _Float16 l = (_Float16)(x - (float)h);
+  const unsigned u = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+  return __builtin_bit_cast(float, u);
+}
+// four packed values (k = 0..3) -> the h and the l operand of v_mfma_f32_16x16x16_f16
+__device__ __forceinline__ void wg_unpack4(const float (&r)[4], wg_h4& h, wg_h4& l) {
+  const unsigned r0 = __builtin_bit_cast(unsigned, r[0]), r1 = __builtin_bit_cast(unsigned, r[1]);
+  const unsigned r2 = __builtin_bit_cast(unsigned, r[2]), r3 = __builtin_bit_cast(unsigned, r[3]);
+  const uint2 hh = {__builtin_amdgcn_perm(r1, r0, 0x05040100u), __builtin_amdgcn_perm(r3, r2, 0x05040100u)};
+  const uint2 ll = {__builtin_amdgcn_perm(r1, r0, 0x07060302u), __builtin_amdgcn_perm(r3, r2, 0x07060302u)};
+  h = __builtin_bit_cast(wg_h4, hh);
+  l = __builtin_bit_cast(wg_h4, ll);
+}
+
+// SPLIT (dmd_wgrad_params.precision == DMD_PRECISION_F16X2): the staged activations and dy are kept as packed split-fp16
+// pairs (same 4 bytes per value, same LDS layout) and 16 pixels are contracted per MFMA -- three
+// v_mfma_f32_16x16x16_f16 per (cout block, column block) instead of four v_mfma_f32_16x16x4_f32 per 4 pixels: 24 instead
+// of 128 matrix-pipe cycles per 16 pixels.  Lane (i, kg) supplies pixels {kg, kg + 4, kg + 8, kg + 12} of a 2 x 8 pixel
+// group (the same two-lanes-per-bank ds_read_b32 pattern as the exact path).  The bias gradient sums the raw dy.
+template <class G, bool SPLIT>
 __global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, int tiles_total, int tiles_per_wg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* patch = smem;                        // [2][PP][SB]
@@ -370,6 +394,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, in
           }
         }
       }
+      if (SPLIT) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = wg_pack_hl(v[e]);
+      }
       *(f32x4*)(patch + (size_t)pp2 * G::SB + 4 * q) = v;
     }
     // ---- stage dy (zero for a missing second subtile) ----
@@ -382,9 +410,44 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, in
       f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (t.valid) v = *(const f32x4*)(p.dy + (((size_t)t.n * p.H + t.y0 + (r >> 3)) * p.W + t.x0 + (r & 7)) * G::COUT + 4 * q);
       bsum += v;
+      if (SPLIT) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = wg_pack_hl(v[e]);
+      }
       *(f32x4*)(dyt + (size_t)pix * G::SA + 4 * q) = v;
     }
     __syncthreads();
+    if (SPLIT) {
+      // ---- 8 k-groups of 16 pixels (2 rows x 8 columns of a subtile) ----
+      // boff[] carries + kg * SB and aoff + kg * SA (pixel kg of the group); the other three pixels of this lane are
+      // 4 columns / one row further
+#pragma unroll 1
+      for (int kq = 0; kq < 8; ++kq) {
+        const int s = kq >> 2, j = kq & 3;
+        const float* ap = dyt + (size_t)(s * 64 + j * 16) * G::SA + aoff;
+        const float* bp = patch + (size_t)(s * G::PP + 2 * j * G::PW) * G::SB;
+        wg_h4 ah[G::NCO], al[G::NCO];
+#pragma unroll
+        for (int a = 0; a < G::NCO; ++a) {
+          const float r[4] = {ap[a * 16], ap[a * 16 + 4 * G::SA], ap[a * 16 + 8 * G::SA], ap[a * 16 + 12 * G::SA]};
+          wg_unpack4(r, ah[a], al[a]);
+        }
+#pragma unroll
+        for (int b = 0; b < G::CB; ++b) {
+          const float* q0 = bp + boff[b];
+          const float r[4] = {q0[0], q0[4 * G::SB], q0[G::PW * G::SB], q0[(G::PW + 4) * G::SB]};
+          wg_h4 bh, bl;
+          wg_unpack4(r, bh, bl);
+#pragma unroll
+          for (int a = 0; a < G::NCO; ++a) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[a], bl, acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x16f16(al[a], bh, acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[a], bh, acc[a][b], 0, 0, 0);
+          }
+        }
+      }
+      continue;
+    }
     // ---- 32 k-groups of 4 pixels ----
 #pragma unroll 2
     for (int kq = 0; kq < 32; ++kq) {
@@ -487,12 +550,17 @@ static int launch_wgrad(const dmd_wgrad_params& p, hipStream_t st) {
   wgrad_plan(&p, &tiles, &num_wg, &tpw);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<G, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        G::SMEM_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM_BYTES);
     DMD_CHECK_ARG(e == hipSuccess, "wgrad: hipFuncSetAttribute(%d bytes): %s", G::SMEM_BYTES, hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad_kernel<G>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
+  if ((p.precision & 0xff) == DMD_PRECISION_F16X2)
+    hipLaunchKernelGGL((wgrad_kernel<G, true>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
+  else
+    hipLaunchKernelGGL((wgrad_kernel<G, false>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
   const int per_total = G::NB * NCO * 256 + NCO * 16;
   float* ws2 = p.workspace + (size_t)num_wg * per_total;
   hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((per_total + 255) / 256, WGRAD_SLICES), dim3(256), 0, st, p.workspace, num_wg,

@@ -58,7 +58,7 @@ class GnBwdParams(C.Structure):
 class WgradParams(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cout", C.c_int32), ("taps", C.c_int32),
                 ("cin_real", C.c_int32), ("src", ConvSrc), ("dy", C.c_void_p), ("workspace", C.c_void_p), ("dw", C.c_void_p),
-                ("dbias", C.c_void_p)]
+                ("dbias", C.c_void_p), ("precision", C.c_int32), ("reserved", C.c_int32)]
 
 
 CHAIN_MAX_BLOCKS = 8

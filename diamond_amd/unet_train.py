@@ -31,7 +31,7 @@ from . import native as nv
 from .ac_native import _gn_silu_bwd, _transposed, _wgrad
 from .engine import Act, AttnRecord, ConvRecord, NormSpec
 
-TRAIN_PRECISION = "f16x2"  # arithmetic of the forward and dgrad convolutions (wgrad is always exact fp32); "f32" = exact
+TRAIN_PRECISION = "f16x2"  # arithmetic of the forward, dgrad and wgrad convolutions (split-fp16 operands, fp32 accumulate); "f32" = exact
 
 
 def _key(t: Tensor) -> int:
@@ -194,12 +194,12 @@ def backward_tape(tape: List, cache: E.PackCache, d_out: Tensor, table: Tensor, 
             if cout > 64 and not head:  # qkv (192 channels): the wgrad instances take at most 64 output channels
                 parts = []
                 for o in range(0, cout, 64):
-                    dwp, dbp = _wgrad(src, prologue, spec, dy_k[..., o:o + 64].contiguous(), rec.taps, ci_real)
+                    dwp, dbp = _wgrad(src, prologue, spec, dy_k[..., o:o + 64].contiguous(), rec.taps, ci_real, split=use_f16)
                     parts.append((dwp, dbp))
                 dw_i = torch.cat([p_[0] for p_ in parts], dim=0)
                 db_i = torch.cat([p_[1] for p_ in parts], dim=0)
             else:
-                dw_i, db_i = _wgrad(src, prologue, spec, dy_k, rec.taps, ci_real)
+                dw_i, db_i = _wgrad(src, prologue, spec, dy_k, rec.taps, ci_real, split=use_f16)
             dws.append(dw_i[:cout])
             if si == 0:
                 db = db_i[:cout]

@@ -282,6 +282,8 @@ typedef struct dmd_wgrad_params {
   float* workspace;    /* dmd_wgrad_workspace_floats(p) floats */
   float* dw;           /* OIHW (Cout, cin_real, k, k) */
   float* dbias;        /* (Cout) or NULL */
+  int32_t precision;   /* DMD_PRECISION_F32 (exact fp32 fma chain) | DMD_PRECISION_F16X2 (split-fp16 operands, fp32 accumulate) */
+  int32_t reserved;
 } dmd_wgrad_params;
 int64_t dmd_wgrad_workspace_floats(const dmd_wgrad_params* p);
 int dmd_conv2d_wgrad(const dmd_wgrad_params* p, dmd_stream_t stream);
