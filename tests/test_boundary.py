@@ -114,22 +114,31 @@ def test_c_abi_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_the_header():
-    """sizeof of the ctypes mirrors must equal the C structs (compiled with gcc)."""
+    """sizeof of the ctypes mirrors -- and the offsets of the fields most likely to drift -- must equal the C structs
+    (compiled with gcc from include/diamond_hip.h)."""
     import subprocess
     import tempfile
     from diamond_amd import native
 
-    src = '#include <stdio.h>\n#include "diamond_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu",sizeof(dmd_norm),' \
-          'sizeof(dmd_conv_src),sizeof(dmd_conv_params),sizeof(dmd_linear_params),sizeof(dmd_gn_bwd_params),' \
-          'sizeof(dmd_wgrad_params));return 0;}'
+    structs = [("dmd_norm", native.Norm), ("dmd_conv_src", native.ConvSrc), ("dmd_conv_params", native.ConvParams),
+               ("dmd_linear_params", native.LinearParams), ("dmd_gn_bwd_params", native.GnBwdParams),
+               ("dmd_wgrad_params", native.WgradParams), ("dmd_chain_block", native.ChainBlock),
+               ("dmd_lowres_chain_params", native.LowresChainParams)]
+    offsets = [("dmd_conv_params", native.ConvParams, "w_f16"), ("dmd_conv_params", native.ConvParams, "precision"),
+               ("dmd_wgrad_params", native.WgradParams, "precision"), ("dmd_chain_block", native.ChainBlock, "w1"),
+               ("dmd_chain_block", native.ChainBlock, "bo"), ("dmd_lowres_chain_params", native.LowresChainParams, "table_stride"),
+               ("dmd_lowres_chain_params", native.LowresChainParams, "blocks")]
+    body = "".join(f'printf("%zu ", sizeof({c}));' for c, _ in structs)
+    body += "".join(f'printf("%zu ", offsetof({c}, {f}));' for c, _, f in offsets)
+    src = f'#include <stdio.h>\n#include <stddef.h>\n#include "diamond_hip.h"\nint main(){{{body}return 0;}}'
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
         open(c, "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", os.path.join(d, "s")])
-        sizes = [int(v) for v in subprocess.check_output([os.path.join(d, "s")]).split()]
-    mine = [ctypes.sizeof(t) for t in (native.Norm, native.ConvSrc, native.ConvParams, native.LinearParams, native.GnBwdParams,
-                                     native.WgradParams)]
-    assert sizes == mine
+        got = [int(v) for v in subprocess.check_output([os.path.join(d, "s")]).split()]
+    mine = [ctypes.sizeof(t) for _, t in structs] + [getattr(t, f).offset for _, t, f in offsets]
+    assert got == mine, list(zip([c for c, _ in structs] + [f"{c}.{f}" for c, _, f in offsets], got, mine))
+    assert native.CHAIN_MAX_BLOCKS == 8
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="the reference tree only exists in the build container")
