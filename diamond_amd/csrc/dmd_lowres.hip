@@ -9,11 +9,13 @@
 // workgroup, and the only global traffic is the chain input / output and the (L2-resident) weights.
 //
 // Arithmetic: the split-fp16 form of dmd_conv_f16ws.hip (x = h + l, three v_mfma_f32_32x32x16_f16 per product, fp32
-// accumulate, same packed weights, same v_exp/v_rcp SiLU); statistics accumulated in fp64 across lanes like the conv
-// epilogues.  A wave owns 32 pixels x 32 output channels (one f32x16 accumulator).
+// accumulate, same packed weights, same v_exp/v_rcp SiLU); GroupNorm sums leave the epilogue registers through the DPP
+// network (fp32 inside a wave, fp64 across waves).  Work split of the 64-channel kernel: wave (cb, kh) accumulates all 64
+// pixels x the 32 couts of block cb over the K chunks of parity kh; the two K halves meet in LDS.
 // LDS: 5 activation slots (3 saved skips, X, H) + the halo'd split patch of one conv input (2 sources x 100 px x 64 ch,
 // the slot-rotated layout of dmd_conv_f16ws.hip: conflict-free ds_read_b128 for every tap) -- overlaid by q | k | v
-// during attention -- = 139 KiB.
+// during attention and by the K-split exchange after a convolution's MFMAs -- = 139 KiB.
+// lowres_chain32_kernel (further down) is the 32-channel variant for the reward / end encoder's tail.
 #include "dmd_common.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
