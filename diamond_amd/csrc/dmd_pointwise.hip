@@ -15,31 +15,38 @@
 __global__ void edm_pack_input_kernel(const float* __restrict__ x, const float* __restrict__ obs,
                                       const float* __restrict__ cond, int cond_stride, float sd,
                                       float* __restrict__ out, int N, int Cx, int Cobs, int HW, int CPad, int T, int head) {
-  const int Q = CPad >> 2;
+  // thread = (4 consecutive pixels, 4 consecutive output channels): four 16-byte plane reads (a wave reads 256 contiguous
+  // bytes of each of its 4 planes), a 4x4 transpose in registers, four 16-byte NHWC stores
+  const int Q = CPad >> 2, HW4 = HW >> 2;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (size_t)N * HW * Q) return;
+  if (idx >= (size_t)N * HW4 * Q) return;
   const int qd = idx % Q;
-  const size_t np = idx / Q;
-  const int n = np / HW;
-  const int pix = np - (size_t)n * HW;
+  const size_t npq = idx / Q;
+  const int n = npq / HW4;
+  const int pix0 = 4 * (int)(npq - (size_t)n * HW4);
   const float c_in = cond[(size_t)n * cond_stride + 0];
   const int cimg = Cobs / T;
-  f32x4 v;
+  f32x4 t[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int cc = qd * 4 + e;
-    float t = 0.f;
+    t[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (cc < Cobs) {
       const int fr = cc / cimg, ci = cc - fr * cimg;
       int slot = fr + head;
       slot = slot >= T ? slot - T : slot;
-      t = obs[((size_t)n * Cobs + slot * cimg + ci) * HW + pix] / sd;  // rescaled_obs = obs / sigma_data, denoiser.py:75
+      const f32x4 v = *(const f32x4*)(obs + ((size_t)n * Cobs + slot * cimg + ci) * HW + pix0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[e][j] = v[j] / sd;  // rescaled_obs = obs / sigma_data, denoiser.py:75
     } else if (cc < Cobs + Cx) {
-      t = x[((size_t)n * Cx + (cc - Cobs)) * HW + pix] * c_in;  // denoiser.py:76
+      const f32x4 v = *(const f32x4*)(x + ((size_t)n * Cx + (cc - Cobs)) * HW + pix0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[e][j] = v[j] * c_in;  // denoiser.py:76
     }
-    v[e] = t;
   }
-  *(f32x4*)(out + np * CPad + qd * 4) = v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    *(f32x4*)(out + ((size_t)n * HW + pix0 + j) * CPad + qd * 4) = (f32x4){t[0][j], t[1][j], t[2][j], t[3][j]};
 }
 
 // ---- cond input: [cos(f) | sin(f)] + flatten(Embedding(act)),  f = 2 pi c_noise w -----------
@@ -325,8 +332,9 @@ extern "C" int dmd_edm_pack_input(const float* x, const float* obs, const float*
                                   dmd_stream_t stream) {
   DMD_CHECK_ARG(x && obs && cond && out, "edm_pack_input: null");
   DMD_CHECK_ARG(CPad % 4 == 0 && CPad >= Cx + Cobs, "edm_pack_input: CPad");
+  DMD_CHECK_ARG((H * W) % 4 == 0, "edm_pack_input: H * W must be a multiple of 4 (16-byte plane reads)");
   DMD_CHECK_ARG(T >= 1 && Cobs % T == 0 && head >= 0 && head < T, "edm_pack_input: ring T %d head %d Cobs %d", T, head, Cobs);
-  hipLaunchKernelGGL(edm_pack_input_kernel, dim3(nblk((size_t)N * H * W * (CPad / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(edm_pack_input_kernel, dim3(nblk((size_t)N * (H * W / 4) * (CPad / 4), 256)), dim3(256), 0, (hipStream_t)stream,
                      x, obs, cond, cond_stride, sigma_data, out, N, Cx, Cobs, H * W, CPad, T, head);
   DMD_LAUNCH_CHECK();
   return 0;
