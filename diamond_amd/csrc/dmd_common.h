@@ -9,6 +9,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define DMD_GN_EPS 1e-5  // models/blocks.py:13
+#define DMD_MAX_DEVICES 16  // per-device launch state (function attributes, CU counts) is indexed by hipGetDevice()
 
 void dmd_set_error(const char* fmt, ...);
 

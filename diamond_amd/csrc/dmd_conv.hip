@@ -595,12 +595,7 @@ extern "C" int dmd_conv2d_kernel_name(const dmd_conv_params* p, char* buf, int b
     snprintf(buf, buf_len, "conv1x1_stream_kernel<%d, %d, %s>", cin / 16, cin == 128 ? 2 : 4,
              (p->precision & 0xff) == DMD_PRECISION_F16X2 ? "true" : "false");
   } else if (dmd_conv2d_f16x2_eligible(p)) {
-    static const int joint = getenv("DIAMOND_WS_JOINT") ? atoi(getenv("DIAMOND_WS_JOINT")) : 0;
-    const bool j = joint && p->taps == 9 && p->CoutPad == 64 && !b8 && p->N * (p->H / 16) * (p->W / 16) >= 512;
-    static const int p8env = getenv("DIAMOND_WS_P8") ? atoi(getenv("DIAMOND_WS_P8")) : 0;
-    const bool p8 = p->taps == 9 && !b8 && (((p8env & 1) && p->CoutPad == 64) || ((p8env & 2) && p->CoutPad == 32));
-    snprintf(buf, buf_len, "conv_f16ws_kernel<WsGeom<%s, %d, %d, %s, %s>>", b8 ? "true" : "false", p->CoutPad == 64 ? 2 : 1, p->taps,
-             (j && !p8) ? "true" : "false", p8 ? "true" : "false");
+    snprintf(buf, buf_len, "conv_f16ws_kernel<WsGeom<%s, %d, %d>>", b8 ? "true" : "false", p->CoutPad == 64 ? 2 : 1, p->taps);
   } else {
     const int wn = p->CoutPad % 64 == 0 ? 4 : (p->CoutPad % 32 == 0 ? 2 : 1);
     snprintf(buf, buf_len, "conv_mfma_kernel<ConvGeom<%d, %s, %d, %d, %s>>", wn, b8 ? "true" : "false", p->taps, p->stride,

@@ -1,18 +1,29 @@
 #!/bin/bash
 # SQ-level counters for the conv kernels (two passes of <= 8 SQ counters), denoiser forwards only.
+#   bash tools/pmc_sq.sh <tag> [lib.so]     -> gpurun_out/pmc_sq_<tag>/pass{1,2}.json
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+TAG=${1:-head}
+[ -n "${2:-}" ] && export DIAMOND_LIB=$2
 export TMPDIR=/tmp
 cd /tmp
-mkdir -p $R/gpurun_out/pmc_sq
-rocprofv3 -L > $R/gpurun_out/pmc_sq/counters.txt 2>&1
+O=$R/gpurun_out/pmc_sq_$TAG
+mkdir -p $O
 i=0
-for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES" \
-           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_LDS SQ_INSTS_LDS GRBM_GUI_ACTIVE"; do
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_INSTS_MFMA SQ_WAIT_INST_LDS SQ_INSTS_LDS GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rm -rf /tmp/sq_$i
-  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/sq_$i -o sq -- python $R/tools/pmc_target.py 256 > $R/gpurun_out/pmc_sq/pass$i.log 2>&1
-  echo "rc=$?" >> $R/gpurun_out/pmc_sq/pass$i.log
-  f=$(find /tmp/sq_$i -name "*counter_collection.csv" | head -1)
-  [ -n "$f" ] && python $R/tools/pmc_parse_multi.py $f > $R/gpurun_out/pmc_sq/pass$i.json
+  rm -rf /tmp/sq_${TAG}_$i
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/sq_${TAG}_$i -o sq -- python $R/tools/pmc_target.py 256 > $O/pass$i.log 2>&1
+  echo "rc=$?" >> $O/pass$i.log
+  f=$(find /tmp/sq_${TAG}_$i -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && python $R/tools/pmc_parse_multi.py $f > $O/pass$i.json
+  k=$(find /tmp/sq_${TAG}_$i -name "*kernel_trace.csv" | head -1)
+  [ -n "$k" ] && python - "$k" > $O/pass${i}_durations.json <<'PY'
+import csv, json, sys, collections
+d = collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    d[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+print(json.dumps({k: {"launches": len(v), "avg_us": sum(v) / len(v) / 1e3} for k, v in d.items() if "conv" in k}, indent=1))
+PY
 done
