@@ -100,7 +100,10 @@ struct WsGeom {
   static constexpr int CIN_MAX = NCB_ == 2 ? 128 : 64;
   static constexpr int TAB_SLOTS = 4;  // tile generations whose tables can be alive at once (>= 3)
   static constexpr int TAB_FLOATS = TAB_SLOTS * SUB * CIN_MAX;
-  static constexpr int SMEM_BYTES = 2 * BUF_BYTES + 2 * TAB_FLOATS * 4;
+  // tables a, b (y = a x + b), c, d (exponent argument of the sigmoid, c x + d) + the bias row of the convolution.
+  // The 8-patch geometry has no room for c, d (8 table rows per slot): it derives them from a, b per item.
+  static constexpr bool CD_TABLES = !(B8_ && NCB_ == 1);
+  static constexpr int SMEM_BYTES = 2 * BUF_BYTES + (CD_TABLES ? 4 : 2) * TAB_FLOATS * 4 + COUT * 4;
   static constexpr bool DOUBLE_STAGE = NCB_ == 2;  // two activation register sets only where they fit
   // hand-counted inline-asm activation loads (header: PRODUCERS) where there are two register sets to keep apart and the
   // producers have registers to spare; the single-set geometries (11-13 items per thread, at the register cap) keep
@@ -144,16 +147,109 @@ __device__ __forceinline__ void ws_for(F&& f) {
   }
 }
 
+// The chunk barrier.  Not __syncthreads(): its fence makes hipcc drain every vector-memory operation it knows of
+// (`s_waitcnt vmcnt(0)`) in front of s_barrier, i.e. the write-out group would wait for the acknowledgement of its
+// global STORES at every step.  LDS traffic of this wave is complete (lgkmcnt(0)); LDS-DMA writes are awaited by hand
+// where they are issued (cons_land_W); global stores simply stay in flight.
+#ifndef WS_SYNCTHREADS
+#define WS_SYNCTHREADS 0
+#endif
+__device__ __forceinline__ void ws_barrier() {
+#if WS_SYNCTHREADS
+  __syncthreads();
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+// WS_TRACE (DMD_LAB builds only): s_memtime stamps of workgroup WS_TRACE_WG, one stream per role, read back with
+// tools/ws_trace.py: which role waits for which in a chunk step.
+#if defined(DMD_LAB) && defined(WS_TRACE)
+#define WS_TRACE_WG 37
+#define WS_TRACE_N 4096
+__device__ unsigned long long ws_trace_buf[3][WS_TRACE_N];
+__device__ int ws_trace_cnt[3];
+#define WS_TRACE_DECL int ws_ti = 0
+#define WS_STAMP(role_, tag_, step_)                                                                                  \
+  do {                                                                                                                 \
+    if (blockIdx.x == WS_TRACE_WG && (threadIdx.x & 255) == 0 && ws_ti < WS_TRACE_N) {                                  \
+      ws_trace_buf[role_][ws_ti] = (__builtin_readcyclecounter() << 16) | ((unsigned long long)(tag_) << 12) | ((step_) & 0xfff); \
+      ws_trace_cnt[role_] = ++ws_ti;                                                                                   \
+    }                                                                                                                  \
+  } while (0)
+extern "C" int dmd_ws_trace_dump(unsigned long long* host, int* counts) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(host, HIP_SYMBOL(ws_trace_buf), sizeof(unsigned long long) * 3 * WS_TRACE_N);
+  hipMemcpyFromSymbol(counts, HIP_SYMBOL(ws_trace_cnt), sizeof(int) * 3);
+  int zero[3] = {0, 0, 0};
+  hipMemcpyToSymbol(HIP_SYMBOL(ws_trace_cnt), zero, sizeof(zero));
+  return WS_TRACE_N;
+}
+#else
+#define WS_TRACE_DECL
+#define WS_STAMP(role_, tag_, step_) do {} while (0)
+#endif
+
 // ---- activation loads hipcc does not count (header: PRODUCERS) ----
 // "=&v": the destination never overlaps the address pair.  Nothing may read or move `dst` before ws_await names it.
 __device__ __forceinline__ void ws_aload(f32x4& dst, const f32x4* src) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(src) : "memory");
+}
+// the same with a wave-uniform base (SGPR pair) + a 32-bit per-lane byte offset: no 64-bit address arithmetic per load
+__device__ __forceinline__ void ws_aload(f32x4& dst, const void* base, unsigned voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(base) : "memory");
 }
 // wait until at most N vector-memory operations of this wave are outstanding; `v` is usable afterwards
 template <int N>
 __device__ __forceinline__ void ws_await(f32x4& v) {
   static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
   asm volatile("s_waitcnt vmcnt(%1) ; await %0" : "+v"(v) : "n"(N) : "memory");
+}
+
+// l pieces of two operands: fp16(x - h) as ONE mixed-precision fma per element (v_fma_mix reads the fp16 h piece
+// directly and rounds the exact fp32 difference to fp16) instead of cvt_f32_f16 + sub + cvt_f16_f32
+__device__ __forceinline__ unsigned ws_low_pair(float x0, float x1, unsigned h01) {
+  unsigned l01;
+  asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(l01)
+      : "v"(x0), "v"(x1), "v"(h01));
+  return l01;
+}
+
+// wave64 sum of a double on the DPP network (no LDS round trips, unlike __shfl_xor): quad swaps and row mirrors leave
+// the 16-lane row total in every lane of a row, row_bcast:15 / row_bcast:31 chain the four rows; total in lane 63
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double ws_dpp_add(double x) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, ROW_MASK, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, ROW_MASK, 0xf, false);
+  return x + __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
+}
+__device__ __forceinline__ double ws_wave_sum_lane63(double x) {
+  x = ws_dpp_add<0xB1, 0xf>(x);   // quad_perm [1, 0, 3, 2]
+  x = ws_dpp_add<0x4E, 0xf>(x);   // quad_perm [2, 3, 0, 1]
+  x = ws_dpp_add<0x141, 0xf>(x);  // row_half_mirror
+  x = ws_dpp_add<0x140, 0xf>(x);  // row_mirror
+  x = ws_dpp_add<0x142, 0xa>(x);  // row_bcast:15 -> rows 1, 3
+  x = ws_dpp_add<0x143, 0xc>(x);  // row_bcast:31 -> rows 2, 3
+  return x;
+}
+
+// one wait for a whole register set: the loads were issued two chunk steps earlier and have landed long before; what
+// matters is that the compiler may then interleave the staging arithmetic of ALL items (a staging wave is bound by the
+// latency of its dependent fma -> exp -> add -> rcp -> mul -> cvt chains, tools/probe/simd_share_probe.hip: ~10 cycles
+// per instruction with the 4 chains of one item in flight, 4 with enough of them)
+template <int N, int M>
+__device__ __forceinline__ void ws_await_set(f32x4 (&st)[M]) {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+  static_assert(M == 6 || M == 7, "register sets of the double-staged geometries");
+  if constexpr (M == 6)
+    asm volatile("s_waitcnt vmcnt(%6) ; await %0 %1 %2 %3 %4 %5"
+                 : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]), "+v"(st[4]), "+v"(st[5]) : "n"(N) : "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(%7) ; await %0 %1 %2 %3 %4 %5 %6"
+                 : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]), "+v"(st[4]), "+v"(st[5]), "+v"(st[6]) : "n"(N) : "memory");
 }
 
 // marks every element of a register set as used at this point (no instruction)
@@ -271,12 +367,16 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
   // [patch 0][patch 1][weights 0][weights 1]: patch [NPP][4 x 16 B], weights [TAPS][h|l][2][COUT] x 16 B
   float* tab_a = (float*)(smem_raw + 2 * G::BUF_BYTES);  // [slot][SUB][CIN_MAX]
   float* tab_b = tab_a + G::TAB_FLOATS;
+  float* tab_c = tab_b + G::TAB_FLOATS;  // (CD_TABLES)
+  float* tab_d = tab_c + G::TAB_FLOATS;
+  float* bias_lds = tab_b + (G::CD_TABLES ? 3 : 1) * G::TAB_FLOATS;  // [COUT]
   static_assert(G::SMEM_BYTES <= 160 * 1024, "LDS budget");
 
   // 0, 1: consumer groups (even / odd tiles), 2: producer (staging).  readfirstlane: wave-uniform by construction, and
   // the compiler must know it (scalar branches and scalar loop counters instead of exec-masked ones)
   const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
   const int tid = (int)(threadIdx.x & 255);  // index inside the role
+  WS_TRACE_DECL;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int up = p.upsample;
   const int Hs = p.H >> up, Ws = p.W >> up;
@@ -362,8 +462,16 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           float m = 0.f, a = 1.f, ad = 0.f;
           if (sc.prologue != DMD_PROLOGUE_NONE && ti[s].valid)
             norm_entry(sc.norm, ti[s].n, cl, sc.C, (double)DMD_GN_GROUP * Hs * Ws, &m, &a, &ad);
-          tab_a[(slot * G::SUB + s) * G::CIN_MAX + c] = a;
-          tab_b[(slot * G::SUB + s) * G::CIN_MAX + c] = ad - m * a;
+          const float bb = ad - m * a;
+          const bool silu = sc.prologue == DMD_PROLOGUE_NORM_SILU;
+          const int ti_ = (slot * G::SUB + s) * G::CIN_MAX + c;
+          tab_a[ti_] = a;
+          tab_b[ti_] = bb;
+          // sigmoid(t) = 1 / (1 + 2^(c x + d)), (c, d) = -log2(e) (a, b); no SiLU: 2^-126 -> the factor is exactly 1
+          if (G::CD_TABLES) {
+            tab_c[ti_] = silu ? -1.4426950408889634f * a : 0.f;
+            tab_d[ti_] = silu ? -1.4426950408889634f * bb : -126.f;
+          }
         }
       }
       gk = k;
@@ -380,66 +488,124 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       slot_out = tab_slot;
       const int si = ck < nch0 ? 0 : 1;
       const dmd_conv_src& sc = p.src[si];
-      const int c0 = (si ? ck - nch0 : ck) * 16 + 4 * q;
-      const f32x4* base4 = (const f32x4*)sc.x + (c0 >> 2);  // 16-byte units: index = pixel * (C / 4)
-      const unsigned cq = (unsigned)sc.C >> 2;
+      // source bytes of item `it` = wave-uniform base (source + this chunk's 64 bytes) + pixel * C * 4 + this lane's quad;
+      // 24-bit multiply: pixel indices and C * 4 are far below 2^24, the product fits 32 bits (launch check)
+      const char* base = (const char*)sc.x + (si ? ck - nch0 : ck) * 64;
+      const unsigned cbytes = (unsigned)sc.C * 4u;
       ws_for<0, G::ITEMS>([&](auto ic) {
         constexpr int it = decltype(ic)::value;
 #if WS_ABL & 2
-        const f32x4* src = (const f32x4*)p.src[0].x;
+        const unsigned voff = 16u * q;
 #else
-        const f32x4* src = base4 + (size_t)((unsigned)goff[it] * cq);
+        const unsigned voff = __umul24((unsigned)goff[it], cbytes) + 16u * q;
 #endif
         if constexpr (G::ASM_LOADS)
-          ws_aload(st[it], src);
+          ws_aload(st[it], base, voff);
         else
-          st[it] = *src;
+          st[it] = *(const f32x4*)(base + voff);
       });
       zmask = gzero;
     };
     // normalise / activate / split element e from its register set into patch e & 1.  ONE instance of this code for every
-    // prologue (the tables hold a = 1, b = 0 where there is no normalisation; SiLU is a wave-uniform select): with
-    // several instances hipcc assigns the pending registers differently per instance and copies them -- before the
-    // wait -- where the paths meet.  NEWER (ASM_LOADS) = loads issued after this set's: they may stay in flight.
+    // prologue (the tables hold a = 1, b = 0 where there is no normalisation and an exponent of -126 where there is no
+    // SiLU): with several instances hipcc assigns the pending registers differently per instance and copies them --
+    // before the wait -- where the paths meet.  34 VALU instructions per item (54 in round 2): every VALU instruction
+    // of a staging wave delays the MFMA issue of the consumer wave on its SIMD by a few cycles.
+    // NEWER (ASM_LOADS) = loads issued after this set's: they may stay in flight.
     auto stage_S = [&](int e, auto& st, unsigned zmask, int slot) {
       constexpr int NEWER = G::DOUBLE_STAGE ? G::ITEMS : 0;
       const int ck = e % nchunks;
-      const bool silu = p.src[ck < nch0 ? 0 : 1].prologue == DMD_PROLOGUE_NORM_SILU;
       const int cc = ck * 16 + 4 * q;
       uint2* pb = (uint2*)(smem_raw + (e & 1) * G::PATCH_BYTES);
-      // single-image tiles: the (a, b) rows of this thread's channel quad are the same for every item -> ONE pair of
+      // single-image tiles: the table rows of this thread's channel quad are the same for every item -> ONE set of
       // LDS reads per chunk instead of one (with its lgkmcnt stall) per item
-      f32x4 ta0 = (f32x4){1.f, 1.f, 1.f, 1.f}, tb0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const bool silu_ck = p.src[ck < nch0 ? 0 : 1].prologue == DMD_PROLOGUE_NORM_SILU;  // (only without c, d tables)
+      f32x4 ta0, tb0, tc0, td0;
       if (G::SUB == 1) {
         ta0 = *(const f32x4*)(tab_a + slot * G::CIN_MAX + cc);
         tb0 = *(const f32x4*)(tab_b + slot * G::CIN_MAX + cc);
+        tc0 = *(const f32x4*)(tab_c + slot * G::CIN_MAX + cc);
+        td0 = *(const f32x4*)(tab_d + slot * G::CIN_MAX + cc);
       }
-      ws_for<0, G::ITEMS>([&](auto ic) {
-        constexpr int it = decltype(ic)::value;
-        if constexpr (G::ASM_LOADS) ws_await<NEWER + G::ITEMS - 1 - it>(st[it]);
-        f32x4 v = st[it];
-        f32x4 ta = ta0, tb = tb0;
-        if (G::SUB > 1) {
-          const int s = ipos[it] >> 16;
-          ta = *(const f32x4*)(tab_a + (slot * G::SUB + s) * G::CIN_MAX + cc);
-          tb = *(const f32x4*)(tab_b + (slot * G::SUB + s) * G::CIN_MAX + cc);
-        }
-        h4 hv, lv;
-        const bool zero = (zmask >> it) & 1;  // conv zero padding is applied AFTER the activation (blocks.py:143-144)
+      if constexpr (G::ASM_LOADS) ws_await_set<NEWER>(st);
+      WS_STAMP(2, 7, e - 1);
+      // PHASE-wise over batches of items (fma | exp | add | rcp | mul + select | split), pinned with sched_barrier: every
+      // phase is BATCH x 4 independent instructions.  Item by item (the compiler's choice: fewest live registers) the
+      // wave runs one dependent chain of quarter-rate ops after the other and takes ~10 cycles per instruction.
+      // by the registers the geometry has left (several sub-tiles: four table rows per ITEM are live as well)
+      constexpr int BATCH = G::SUB == 1 ? G::ITEMS : 1;
+      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+      ws_for<0, (G::ITEMS + BATCH - 1) / BATCH>([&](auto bc) {
+        constexpr int I0 = decltype(bc)::value * BATCH;
+        constexpr int NB = (I0 + BATCH <= G::ITEMS) ? BATCH : G::ITEMS - I0;
+        float t[NB][4], u[NB][4];
 #pragma unroll
-        for (int el = 0; el < 4; ++el) {
-          const float t = __builtin_fmaf(v[el], ta[el], tb[el]);
-          const float u = silu ? ws_silu(t) : t;
-          const float x = zero ? 0.f : u;  // no clamp: out-of-range operands turn into NaN outputs (header)
-          const _Float16 h = (_Float16)x;
-          hv[el] = h;
-          lv[el] = (_Float16)(x - (float)h);
+        for (int i = 0; i < NB; ++i) {
+          const int it = I0 + i;
+          f32x4 ta = ta0, tb = tb0, tc = tc0, td = td0;
+          if (G::SUB > 1) {
+            const int to = (slot * G::SUB + (ipos[it] >> 16)) * G::CIN_MAX + cc;
+            ta = *(const f32x4*)(tab_a + to);
+            tb = *(const f32x4*)(tab_b + to);
+            if (G::CD_TABLES) {
+              tc = *(const f32x4*)(tab_c + to);
+              td = *(const f32x4*)(tab_d + to);
+            } else {
+#pragma unroll
+              for (int el = 0; el < 4; ++el) {
+                tc[el] = silu_ck ? -1.4426950408889634f * ta[el] : 0.f;
+                td[el] = silu_ck ? -1.4426950408889634f * tb[el] : -126.f;
+              }
+            }
+          }
+#pragma unroll
+          for (int el = 0; el < 4; ++el) {
+            // y = a v + b (GroupNorm / FiLM; a = 1, b = 0 without a prologue); SiLU = y / (1 + 2^(c v + d))
+            t[i][el] = __builtin_fmaf(st[it][el], ta[el], tb[el]);
+            u[i][el] = __builtin_fmaf(st[it][el], tc[el], td[el]);
+          }
         }
-        if ((it + 1) * G::NPT <= G::NPP * 4 || ipos[it] >= 0) {  // only the last item row can fall beyond the patch
-          const int lo = loff_of(it);
-          pb[lo] = __builtin_bit_cast(uint2, hv);
-          pb[lo ^ 4] = __builtin_bit_cast(uint2, lv);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+          for (int el = 0; el < 4; ++el) u[i][el] = __builtin_amdgcn_exp2f(u[i][el]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+          for (int el = 0; el < 4; ++el) u[i][el] = 1.0f + u[i][el];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+          for (int el = 0; el < 4; ++el) u[i][el] = __builtin_amdgcn_rcpf(u[i][el]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const bool zero = (zmask >> (I0 + i)) & 1;  // conv zero padding is applied AFTER the activation (blocks.py:143-144)
+#pragma unroll
+          for (int el = 0; el < 4; ++el) {
+            const float y = t[i][el] * u[i][el];
+            u[i][el] = zero ? 0.f : y;  // no clamp: out-of-range operands turn into NaN outputs (header)
+          }
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const int it = I0 + i;
+          const float* x = u[i];
+          const unsigned h01 = __builtin_bit_cast(unsigned, (h2){(_Float16)x[0], (_Float16)x[1]});
+          const unsigned h23 = __builtin_bit_cast(unsigned, (h2){(_Float16)x[2], (_Float16)x[3]});
+          const unsigned l01 = ws_low_pair(x[0], x[1], h01);
+          const unsigned l23 = ws_low_pair(x[2], x[3], h23);
+          if ((it + 1) * G::NPT <= G::NPP * 4 || ipos[it] >= 0) {  // only the last item row can fall beyond the patch
+            const int lo = loff_of(it);
+            pb[lo] = (uint2){h01, h23};
+            pb[lo ^ 4] = (uint2){l01, l23};
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       });
     };
 
@@ -451,23 +617,31 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       // element e + 1, real or dummy], in this order: every stage_S(e) is followed by issue_S(e + 2) into the same set.
       issue_S(0, stage0, zm0, sl0);
       issue_S(1, stage1, zm1, sl1);
-      __syncthreads();  // B(-1): the tables written by setup_tile are visible to all producers
+      ws_barrier();  // B(-1): the tables written by setup_tile are visible to all producers
       stage_S(0, stage0, zm0, sl0);
       issue_S(2, stage0, zm0, sl0);
-      __syncthreads();  // B0: buffer 0 = element 0
+      ws_barrier();  // B0: buffer 0 = element 0
       // step j: consumers compute element j, producers fill element j + 1 (register set (j + 1) & 1)
       for (int j = 0; j < S; j += 2) {
+        WS_STAMP(2, 0, j);
         if (j + 1 < S) {
           stage_S(j + 1, stage1, zm1, sl1);
+          WS_STAMP(2, 1, j);
           issue_S(j + 3, stage1, zm1, sl1);
+          WS_STAMP(2, 2, j);
         }
-        __syncthreads();
+        ws_barrier();
+        WS_STAMP(2, 3, j);
         if (j + 1 < S) {
+          WS_STAMP(2, 0, j + 1);
           if (j + 2 < S) {
             stage_S(j + 2, stage0, zm0, sl0);
+            WS_STAMP(2, 1, j + 1);
             issue_S(j + 4, stage0, zm0, sl0);
+            WS_STAMP(2, 2, j + 1);
           }
-          __syncthreads();
+          ws_barrier();
+          WS_STAMP(2, 3, j + 1);
         }
       }
       // the two dummy sets of the tail (elements S and S + 1): land, and are "used" here
@@ -479,16 +653,16 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     } else {
       // one register set: activations are fetched one step ahead only
       issue_S(0, stage0, zm0, sl0);
-      __syncthreads();  // B(-1)
+      ws_barrier();  // B(-1)
       stage_S(0, stage0, zm0, sl0);
       if (S > 1) issue_S(1, stage0, zm0, sl0);
-      __syncthreads();  // B0
+      ws_barrier();  // B0
       for (int j = 0; j < S; ++j) {
         if (j + 1 < S) {
           stage_S(j + 1, stage0, zm0, sl0);
           if (j + 2 < S) issue_S(j + 2, stage0, zm0, sl0);
         }
-        __syncthreads();
+        ws_barrier();
       }
     }
   } else {
@@ -559,14 +733,10 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       pending = 0;
     };
     // blocks [pending, pending + count) of the finished tile: bias, residual, store, statistics
-    auto epi_blocks = [&](int count) {
+    // `land`: wait for this wave's LDS-DMA (issued before the call) after the residual loads and BEFORE the stores of the
+    // first block, so that no store is older than the wait (the stores then stay in flight across the barrier)
+    auto epi_blocks = [&](int count, bool land = false) {
       const int first = pending, last = min(4, pending + count);
-      f32x4 bias[4];  // re-read per call (L1/L2 resident): not worth 16 registers across the MFMA loop
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        bias[qd] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bias[qd] = *(const f32x4*)(p.bias + cb * 32 + 8 * qd + 4 * g);
-      }
 #pragma unroll
       for (int blk = 0; blk < 4; ++blk) {
         if (blk < first || blk >= last) continue;  // uniform; keeps acc[] statically indexed
@@ -579,7 +749,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
             const int n = pixel / HW, rem = pixel - n * HW;
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-              if (c < p.Cout) p.out[((size_t)n * p.Cout + c) * HW + rem] = acc[blk][c] + bias[0][c];
+              if (c < p.Cout) p.out[((size_t)n * p.Cout + c) * HW + rem] = acc[blk][c];
           }
           continue;
         }
@@ -589,11 +759,14 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
 #pragma unroll
           for (int qd = 0; qd < 4; ++qd)
             rv[qd] = (p.residual && !(WS_ABL & 128)) ? *(const f32x4*)(p.residual + (size_t)pixoff[blk] * 4 + 8 * qd) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (land) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]) : : "memory");
+            land = false;
+          }
           float fs = 0.f, fq = 0.f;  // fp32 over the lane's 16 values of this block, fp64 across
 #pragma unroll
           for (int qd = 0; qd < 4; ++qd) {
             f32x4 v = (f32x4){acc[blk][4 * qd], acc[blk][4 * qd + 1], acc[blk][4 * qd + 2], acc[blk][4 * qd + 3]};
-            v += bias[qd];
             v += rv[qd];
             if (!(WS_ABL & 128) || v[0] == 1.2345e30f) *(f32x4*)(op + 8 * qd) = v;
             fs += (v[0] + v[1]) + (v[2] + v[3]);
@@ -612,13 +785,14 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           ssq[slot] += (double)fq;
         }
       }
+      if (land) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no block with stores in this call)
       pending = last;
       if (last == 4 && first < 4 && p.out_stats) {
 #pragma unroll
         for (int kk = 0; kk < NSTAT; ++kk) {
-          const double a = dmd_wave_sum(ssum[kk]);
-          const double b = dmd_wave_sum(ssq[kk]);
-          if (lane == 0 && stat_slot[kk] >= 0) {
+          const double a = ws_wave_sum_lane63(ssum[kk]);
+          const double b = ws_wave_sum_lane63(ssq[kk]);
+          if (lane == 63 && stat_slot[kk] >= 0) {
             double* o = p.out_stats + (size_t)stat_slot[kk] * 2;
             o[0] = a;
             o[1] = b;
@@ -645,21 +819,29 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     };
     auto cons_land_W = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };  // the DMA writes have landed before the step's barrier
 
-    __syncthreads();  // B(-1)
+    // the bias row of the convolution: accumulators START from it (no bias loads / adds in the write-out)
+    if (role == 0 && tid < G::COUT) bias_lds[tid] = p.bias ? p.bias[tid] : 0.f;
+    ws_barrier();  // B(-1)
     if (role == 1) {  // group 1 is idle during tile 0: it provides the first chunk's weights
       cons_load_W(0, 0);
       cons_land_W();
     }
-    __syncthreads();  // B0
+    ws_barrier();  // B0
     int j = 0;
     for (int k = 0; k < nmy; ++k) {
       if ((k & 1) == role) {
         // ---- this group's tile: fragment reads + MFMAs only ----
         if (pending < 4) epi_blocks(4);  // (only if the other group's tile had too few steps to finish the write-out)
+        {
+          // lane owns couts cb*32 + 8 qd + 4 g + (0..3), qd = 0..3, of its pixel of each block
+          f32x4 bq[4];
 #pragma unroll
-        for (int blk = 0; blk < 4; ++blk)
+          for (int qd = 0; qd < 4; ++qd) bq[qd] = *(const f32x4*)(bias_lds + cb * 32 + 8 * qd + 4 * g);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[blk][r] = 0.f;
+          for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[blk][r] = bq[r >> 2][r & 3];
+        }
         // operands of the tile's first half-tap (the one exposed LDS round trip per tile)
         ws_addr_move<G>(ad, (j & 1) - apar);
         apar = j & 1;
@@ -675,8 +857,11 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         bn = b;
         constexpr int LH = (G::HALVES - 1) % 2;
         for (int ck = 0; ck < nchunks; ++ck, ++j) {
+          WS_STAMP(role, 4, j);
           ws_chunk_body<G>(acc, a, b, lds, ad);
-          __syncthreads();  // B(j + 1): every fragment of buffer j is in registers; buffer j + 1 is complete
+          WS_STAMP(role, 5, j);
+          ws_barrier();  // B(j + 1): every fragment of buffer j is in registers; buffer j + 1 is complete
+          WS_STAMP(role, 6, j);
           // the held-back last half-tap, under the first fragment reads of the next chunk (other buffer pair).  After
           // the tile's last chunk these reads fetch the other group's first fragments (or, at the end of the stream,
           // stale LDS) and are simply dropped: unconditional, so that the accumulators stay in one set of registers
@@ -691,10 +876,16 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         // ---- the other group's tile: write our finished tile out, a slice per chunk step, and move the weights ----
         for (int ck = 0; ck < nchunks; ++ck, ++j) {
           const bool wnext = j + 1 < S;  // this (idle) group copies the next step's weights
+          WS_STAMP(role, 8, j);
           if (wnext) cons_load_W((j + 1) % nchunks, (j + 1) & 1);
-          if (pending < 4) epi_blocks(blocks_per_step);
-          if (wnext) cons_land_W();
-          __syncthreads();  // B(j + 1)
+          WS_STAMP(role, 9, j);
+          if (pending < 4)
+            epi_blocks(blocks_per_step, wnext);
+          else if (wnext)
+            cons_land_W();
+          WS_STAMP(role, 10, j);
+          ws_barrier();  // B(j + 1)
+          WS_STAMP(role, 11, j);
         }
       }
     }
@@ -785,6 +976,11 @@ extern "C" int dmd_conv2d_f16x2_eligible(const dmd_conv_params* p) {
   int cin = 0;
   for (int i = 0; i < p->nsrc; ++i) cin += p->src[i].C;
   if (cin > (p->CoutPad == 64 ? 128 : 64)) return 0;
+  // the producers address a source as base + 32-bit byte offset formed by a 24-bit multiply (pixel index x C * 4)
+  const long long src_pixels = (long long)p->N * (p->H >> p->upsample) * (p->W >> p->upsample);
+  if (src_pixels >= (1ll << 24)) return 0;
+  for (int i = 0; i < p->nsrc; ++i)
+    if (src_pixels * p->src[i].C * 4 >= (1ll << 32)) return 0;
   const bool a16 = p->H % 16 == 0 && p->W % 16 == 0;
   const bool b8 = p->W % 16 != 0;
   return (a16 || b8) ? 1 : 0;

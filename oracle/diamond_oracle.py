@@ -331,10 +331,17 @@ def lstm_cell(x: Tensor, h: Tensor, c: Tensor, w_ih: Tensor, w_hh: Tensor, b_ih:
 # --------------------------------------------------------------------------------------
 # actor-critic (models/actor_critic.py)
 # --------------------------------------------------------------------------------------
-def ac_encoder(sd: SD, spec: ActorCriticSpec, x: Tensor) -> Tensor:
-    """ActorCriticEncoder actor_critic.py:101-113 + SmallResBlock blocks.py:116-123."""
+def ac_encoder(sd: SD, spec: ActorCriticSpec, x: Tensor, pool_choice=None, tie_gaps=None) -> Tensor:
+    """ActorCriticEncoder actor_critic.py:101-113 + SmallResBlock blocks.py:116-123.
+
+    pool_choice (test aid): one (N, C, Ho, Wo) tensor per MaxPool2d with the element (2 dy + dx) of each 2x2 window to
+    take INSTEAD of this function's own argmax -- teacher-forces the discrete pooling decisions of another run, so that
+    gradients can be compared where two window elements agree to within rounding (a tie broken the other way re-routes a
+    gradient entry: a finite difference that no tolerance on smooth arithmetic covers).  tie_gaps (list) receives, per
+    pooling layer, max over windows of (own max - chosen element) / max|x|: the caller asserts these are rounding-size."""
     x = conv(sd, "encoder.encoder.0", x)
     idx = 1
+    npool = 0
     for i, ch in enumerate(spec.channels):
         cin = spec.channels[max(0, i - 1)]
         p = f"encoder.encoder.{idx}"
@@ -344,7 +351,16 @@ def ac_encoder(sd: SD, spec: ActorCriticSpec, x: Tensor) -> Tensor:
         x = skip + y
         idx += 1
         if spec.down[i]:
-            x = F.max_pool2d(x, 2)
+            if pool_choice is None:
+                x = F.max_pool2d(x, 2)
+            else:
+                n, c, h, w = x.shape
+                win = x.reshape(n, c, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, c, h // 2, w // 2, 4)
+                chosen = win.gather(4, pool_choice[npool].long().unsqueeze(4)).squeeze(4)
+                if tie_gaps is not None:
+                    tie_gaps.append(float(((win.amax(4) - chosen).abs().max() / x.abs().max()).detach()))
+                x = chosen
+                npool += 1
             idx += 1
     return x
 

@@ -226,32 +226,56 @@ def test_rew_end_batch256_tpw_vs_oracle_sampled_envs():
 def test_actor_critic_encoder_batch256_tpw_fwd_bwd_vs_oracle():
     """ActorCritic.encode forward + every encoder parameter gradient at B=256 (the 64x64 convs walk 8 tiles per
     workgroup, wgrad contracts over 256 x 4096 pixels) with the upstream gradient at the scale the real loss produces
-    (mean over B*T: ~1e-6 .. 1e-4).  Truth = the oracle in FLOAT64 on all 256 images.  A contraction over 1M signed
-    fp32 terms is only good to ~4e-3 of its result in ANY fp32 evaluation order (the fp32 CPU oracle is that far from
-    fp64 itself: measured, tools/debug/r02b_debug.py), so the bar is: the HIP path is within 1e-4 of fp64 or, where fp32
-    arithmetic cannot be, not further from fp64 than 1.5x the fp32 CPU oracle's own distance -- and within 2e-4 of the
-    fp32 oracle everywhere."""
+    (mean over B*T: ~1e-6 .. 1e-4).  Truth = the oracle in FLOAT64 on all 256 images, with the MaxPool decisions of the
+    HIP run teacher-forced into it: of the 11.8M pooling windows a handful hold two elements that agree to within fp32
+    rounding, and a tie broken the other way re-routes one gradient entry (one flipped window of 1M moved a weight
+    gradient by 2e-4 in round 3, with forward activations equal to 3e-7; the "fp32 is only good to 4e-3 on 1M-term
+    contractions" of round 2 was the same effect between the fp32 and fp64 CPU oracles) -- the test asserts that every
+    forced choice IS such a tie (gap < 1e-5 of the tensor's scale), then compares smooth arithmetic only.
+    Bar: EVERY tensor within north_star's 1e-4 of fp64 (measured 1e-6); the fp32 CPU oracle's own distance is printed
+    next to ours."""
     import diamond_amd as D
+    from diamond_amd import ac_native
     from diamond_amd.testing import fill_module_, synthetic_frames
     from oracle import diamond_oracle as O
 
     agent = D.Agent(D.default_agent_config())
     fill_module_(agent, 5)
     ac = agent.actor_critic
+    sd0 = {k: v.detach().clone() for k, v in ac.state_dict().items()}
     g = torch.Generator().manual_seed(258)
     b = 256
     obs = synthetic_frames(g, b, 3, 64, 64)
     wfeat = torch.randn(b, 1024, generator=g) / (b * 15)
+
+    choices = []
+    orig_maxpool = ac_native._maxpool
+
+    def recording_maxpool(y):
+        out, arg = orig_maxpool(y)
+        choices.append(arg.permute(0, 3, 1, 2).cpu())  # (N, Ho, Wo, C) element index 2 dy + dx -> (N, C, Ho, Wo)
+        return out, arg
+
+    ac = ac.to(DEV)
+    ac_native._maxpool = recording_maxpool
+    try:
+        feat = ac.encode(obs.to(DEV))
+    finally:
+        ac_native._maxpool = orig_maxpool
+    (feat * wfeat.to(DEV)).sum().backward()
+
     ref, grads = {}, {}
     for dt in (torch.float32, torch.float64):
-        sd = {k: v.detach().clone().to(dt).requires_grad_(True) for k, v in ac.state_dict().items()}
-        ref[dt] = O.ac_encoder(sd, O.ActorCriticSpec(), obs.to(dt)).flatten(1)
+        sd = {k: v.clone().to(dt).requires_grad_(True) for k, v in sd0.items()}
+        gaps = []
+        ref[dt] = O.ac_encoder(sd, O.ActorCriticSpec(), obs.to(dt), pool_choice=choices, tie_gaps=gaps).flatten(1)
+        print(f"{dt}: forced pooling choices vs own maximum, gap / scale per pooling layer: {['%.1e' % v for v in gaps]}")
+        assert len(gaps) == len(choices) and max(gaps) < 1e-5, gaps
         (ref[dt] * wfeat.to(dt)).sum().backward()
         grads[dt] = {k: v.grad for k, v in sd.items() if v.grad is not None}
-    ac = ac.to(DEV)
-    feat = ac.encode(obs.to(DEV))
-    (feat * wfeat.to(DEV)).sum().backward()
-    assert rel_err(feat.detach(), ref[torch.float64].detach()) < 1e-4
+    e_feat = rel_err(feat.detach(), ref[torch.float64].detach())
+    print(f"B=256 features: hip vs fp64 {e_feat:.2e}")
+    assert e_feat < 1e-4
     bad = {}
     for k, p in ac.named_parameters():
         if not k.startswith("encoder."):
@@ -259,7 +283,8 @@ def test_actor_critic_encoder_batch256_tpw_fwd_bwd_vs_oracle():
         e_hip = rel_err(p.grad, grads[torch.float64][k])
         e_cpu = rel_err(grads[torch.float32][k], grads[torch.float64][k])
         e_pair = rel_err(p.grad, grads[torch.float32][k])
-        print(f"B=256 {k}: hip vs fp64 {e_hip:.2e}, cpu-fp32 vs fp64 {e_cpu:.2e}, hip vs cpu-fp32 {e_pair:.2e}")
-        if not (e_hip < max(1e-4, 1.5 * e_cpu) and e_pair < 2e-4):
+        print(f"B=256 {k}: hip vs fp64 {e_hip:.2e}, cpu-fp32 vs fp64 {e_cpu:.2e}, e_hip/e_cpu {e_hip / max(e_cpu, 1e-30):.2f}, "
+              f"hip vs cpu-fp32 {e_pair:.2e}")
+        if not e_hip < 1e-4:
             bad[k] = (e_hip, e_cpu, e_pair)
     assert not bad, bad
