@@ -11,6 +11,8 @@
 //   * O^T's D layout again has the query in the column (lane & 15): the running rescale
 //     exp(m_old - m_new) is a per-lane scalar.
 // One workgroup = 4 waves = 64 queries of one (image, head); keys stream in tiles of 256.
+#include <stdlib.h>
+
 #include "dmd_common.h"
 
 #define ATT_KB 256          // keys per LDS tile
@@ -95,10 +97,221 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// attention_f16x2_kernel -- the same attention for long sequences (T a multiple of 256: 1024 / 4096 tokens at the 32x32 /
+// 64x64 levels of the 256x256 configuration) on the f16 matrix cores with SPLIT fp32 operands (x = h + l, fp16 pieces,
+// as in dmd_conv_f16ws.hip).  With head_dim 8 a (query, key) pair costs 16 MACs and one exponential: the kernel is bound by
+// the vector unit (v_exp_f32 is quarter rate), so everything else is taken off it:
+//   * TWO passes over the keys instead of an online softmax.  Pass 1: S^T = K Q^T blocks and a running per-lane maximum
+//     (one cross-lane reduction per query at its end).  Pass 2: the score MFMA starts from the accumulator -m_q + 13, so
+//     its output is directly the exponent: p = 2^(s - m + 13) -- no subtraction, no per-block maximum, no rescaling of O,
+//     and exactly softmax's x - max(x) (blocks.py:69).  The 2^13 moves the split's absolute floor (2^-25) to 2^-38 of the
+//     largest weight and cancels in O / l.
+//   * log2(e) / sqrt(d) is folded into Q once per query (p = exp2: one v_exp_f32 per pair, no expf range code).
+//   * one v_mfma_f32_16x16x32_f16 per 16 keys x 16 queries does the whole split product q_h k_h + q_h k_l + q_l k_h:
+//     the K = 32 slots are {k_h | k_l | k_h | 0} against {q_h | q_h | q_l | 0} (8 dims each).
+//   * O^T[dim][query] += V^T P^T with A = [v_h ; v_l] stacked in the 16 rows and B = p_h, then p_l: two MFMAs per
+//     32 keys give (p_h + p_l)(v_h + v_l); rows dim and 8 + dim are added once at the end.  P never moves between lanes:
+//     the score MFMA leaves lane (j = lane & 15, kg = lane >> 4) with keys {4 kg + r} of a 16-key block for query j,
+//     and the P^T operand's k-slots are simply DEFINED as those keys (A reads V^T with the same map).
+// One workgroup = 4 waves x 64 queries (4 groups of 16) of one (image, head); K / V^T tiles of 256 keys are split once per
+// workgroup while staging and double-buffered in LDS.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 att_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 att_h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 att_h2 __attribute__((ext_vector_type(2)));
+
+#define AF_KT 256                   // keys per LDS tile
+#define AF_VS (AF_KT + 8)           // V^T row stride in halfs (+16 bytes: rows start on different banks)
+#define AF_QG 4                     // 16-query groups per wave
+#define AF_SHIFT 13.0f              // exponent offset of the weights (see above)
+
+struct AfTile {
+  att_h8 kh[AF_KT];       // [key] dims 0..7, h pieces
+  att_h8 kl[AF_KT];       // l pieces
+  _Float16 vt[16][AF_VS];  // rows 0..7: v_h[dim][key], rows 8..15: v_l[dim][key]
+};
+
+__device__ __forceinline__ void af_split8(const f32x4& a, const f32x4& b, att_h8& h, att_h8& l) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    h[e] = (_Float16)a[e];
+    l[e] = (_Float16)(a[e] - (float)h[e]);
+    h[4 + e] = (_Float16)b[e];
+    l[4 + e] = (_Float16)(b[e] - (float)h[4 + e]);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attention_f16x2_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T, int C,
+                                                              float qscale) {
+  __shared__ AfTile tiles[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kg = lane >> 4;
+  const int n = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * (64 * 4) + wave * 64;
+  const size_t row = (size_t)3 * C;
+  const float* base = qkv + (size_t)n * T * row;
+  const int ntiles = T / AF_KT;
+
+  // Q operand of S^T = K Q^T, per 16-query group: k-slots {q_h | q_h | q_l | 0}, scaled by log2(e) / sqrt(d)
+  att_h8 bq[AF_QG];
+#pragma unroll
+  for (int g = 0; g < AF_QG; ++g) {
+    const float* qp = base + (size_t)(q0 + g * 16 + j) * row + h * 8;
+    f32x4 a = *(const f32x4*)qp, b = *(const f32x4*)(qp + 4);
+    a *= qscale;
+    b *= qscale;
+    att_h8 qh, ql;
+    af_split8(a, b, qh, ql);
+    att_h8 z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.f;
+    bq[g] = kg < 2 ? qh : (kg == 2 ? ql : z);
+  }
+
+  // staging of one key tile: thread = key; K always, V^T in pass 2
+  f32x4 sk0, sk1, sv0, sv1;
+  auto stage_load = [&](int t, bool with_v) {
+    const float* kp = base + (size_t)(t * AF_KT + tid) * row + C + h * 8;
+    sk0 = *(const f32x4*)kp;
+    sk1 = *(const f32x4*)(kp + 4);
+    if (with_v) {
+      sv0 = *(const f32x4*)(kp + C);
+      sv1 = *(const f32x4*)(kp + C + 4);
+    }
+  };
+  auto stage_store = [&](AfTile& tl, bool with_v) {
+    att_h8 hh, ll;
+    af_split8(sk0, sk1, hh, ll);
+    tl.kh[tid] = hh;
+    tl.kl[tid] = ll;
+    if (with_v) {
+      af_split8(sv0, sv1, hh, ll);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        tl.vt[e][tid] = hh[e];
+        tl.vt[8 + e][tid] = ll[e];
+      }
+    }
+  };
+  // A operand of a score block: lane (key i = lane & 15, kg): slots {k_h | k_l | k_h | (k_h x 0)}
+  auto k_frag = [&](const AfTile& tl, int k0) -> att_h8 { return kg == 1 ? tl.kl[k0 + j] : tl.kh[k0 + j]; };
+
+  // ---------------- pass 1: row maxima ----------------
+  float mx[AF_QG];
+#pragma unroll
+  for (int g = 0; g < AF_QG; ++g) mx[g] = -INFINITY;
+  const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  stage_load(0, false);
+  stage_store(tiles[0], false);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const AfTile& tl = tiles[t & 1];
+    if (t + 1 < ntiles) stage_load(t + 1, false);
+#pragma unroll 2
+    for (int k0 = 0; k0 < AF_KT; k0 += 32) {
+      const att_h8 ka0 = k_frag(tl, k0), ka1 = k_frag(tl, k0 + 16);
+#pragma unroll
+      for (int g = 0; g < AF_QG; ++g) {
+        const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka0, bq[g], zero4, 0, 0, 0);
+        const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka1, bq[g], zero4, 0, 0, 0);
+        const float a = fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), b = fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3]));
+        mx[g] = fmaxf(mx[g], fmaxf(a, b));
+      }
+    }
+    if (t + 1 < ntiles) stage_store(tiles[(t + 1) & 1], false);
+    __syncthreads();
+  }
+  f32x4 negm[AF_QG];
+#pragma unroll
+  for (int g = 0; g < AF_QG; ++g) {
+    float m = mx[g];
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float c = AF_SHIFT - m;
+    negm[g] = (f32x4){c, c, c, c};
+  }
+
+  // ---------------- pass 2: weights, row sums, O^T = V^T P^T ----------------
+  f32x4 oacc[AF_QG];
+  float lsum[AF_QG];
+#pragma unroll
+  for (int g = 0; g < AF_QG; ++g) {
+    oacc[g] = zero4;
+    lsum[g] = 0.f;
+  }
+  stage_load(0, true);
+  stage_store(tiles[0], true);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const AfTile& tl = tiles[t & 1];
+    if (t + 1 < ntiles) stage_load(t + 1, true);
+#pragma unroll 2
+    for (int k0 = 0; k0 < AF_KT; k0 += 32) {
+      const att_h8 ka0 = k_frag(tl, k0), ka1 = k_frag(tl, k0 + 16);
+      // V^T operand: lane (row i = lane & 15, kg): k-slots 0..3 = keys k0 + 4 kg + (0..3), 4..7 = keys k0 + 16 + 4 kg + (0..3)
+      const att_h4 va = *(const att_h4*)&tl.vt[j][k0 + 4 * kg], vb = *(const att_h4*)&tl.vt[j][k0 + 16 + 4 * kg];
+      const att_h8 vf = (att_h8){va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+#pragma unroll
+      for (int g = 0; g < AF_QG; ++g) {
+        const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka0, bq[g], negm[g], 0, 0, 0);
+        const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka1, bq[g], negm[g], 0, 0, 0);
+        float p[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p[r] = __builtin_amdgcn_exp2f(s0[r]);
+          p[4 + r] = __builtin_amdgcn_exp2f(s1[r]);
+        }
+        lsum[g] += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+        // split p = h + l: packed fp16 conversion for h, one mixed-precision fma per element for l = fp16(p - h)
+        unsigned hw[4], lw[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          hw[r] = __builtin_bit_cast(unsigned, (att_h2){(_Float16)p[2 * r], (_Float16)p[2 * r + 1]});
+          asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+              "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+              : "=&v"(lw[r])
+              : "v"(p[2 * r]), "v"(p[2 * r + 1]), "v"(hw[r]));
+        }
+        typedef unsigned att_u4 __attribute__((ext_vector_type(4)));
+        const att_h8 ph = __builtin_bit_cast(att_h8, (att_u4){hw[0], hw[1], hw[2], hw[3]});
+        const att_h8 pl = __builtin_bit_cast(att_h8, (att_u4){lw[0], lw[1], lw[2], lw[3]});
+        oacc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, ph, oacc[g], 0, 0, 0);
+        oacc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pl, oacc[g], 0, 0, 0);
+      }
+    }
+    if (t + 1 < ntiles) stage_store(tiles[(t + 1) & 1], true);
+    __syncthreads();
+  }
+  // rows dim (v_h) and 8 + dim (v_l) live in lanes kg and kg + 2; the row sum is spread over the 4 kg lanes of a query
+#pragma unroll
+  for (int g = 0; g < AF_QG; ++g) {
+    float l = lsum[g];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    f32x4 o = oacc[g];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] += __shfl_xor(o[r], 32, 64);
+    if (kg < 2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = o[r] / l;
+      *(f32x4*)(out + ((size_t)n * T + q0 + g * 16 + j) * C + h * 8 + 4 * kg) = o;
+    }
+  }
+}
+
 extern "C" int dmd_attention(const float* qkv, float* out, int N, int T, int C, int head_dim, dmd_stream_t stream) {
   DMD_CHECK_ARG(qkv && out, "attention: null");
   DMD_CHECK_ARG(head_dim == 8, "attention: head_dim must be 8 (ATTN_HEAD_DIM), got %d", head_dim);
   DMD_CHECK_ARG(C % 8 == 0 && T % 64 == 0 && N > 0, "attention: need C %% 8 == 0, T %% 64 == 0 (T=%d C=%d)", T, C);
+  static const int use_f16x2 = getenv("DIAMOND_ATTENTION_F16X2") ? atoi(getenv("DIAMOND_ATTENTION_F16X2")) : 1;
+  if (use_f16x2 && T % 256 == 0) {
+    // long sequences (1024 / 4096 tokens of the 256x256 configuration): split-fp16 two-pass kernel
+    hipLaunchKernelGGL(attention_f16x2_kernel, dim3(T / 256, C / 8, N), dim3(256), 0, (hipStream_t)stream, qkv, out, T, C,
+                       1.4426950408889634f / sqrtf((float)head_dim));
+    DMD_LAUNCH_CHECK();
+    return 0;
+  }
   dim3 grid(T / 64, C / 8, N);
   hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, T, C, sqrtf((float)head_dim));
   DMD_LAUNCH_CHECK();

@@ -205,7 +205,7 @@ def test_linear(m, n, k):
     assert rel_err(out3, ref * torch.sigmoid(ref)) < 1e-5
 
 
-@pytest.mark.parametrize("t,c", [(64, 64), (256, 64), (1024, 64), (64, 32)])
+@pytest.mark.parametrize("t,c", [(64, 64), (256, 64), (1024, 64), (64, 32), (4096, 64), (1024, 32)])
 def test_attention(t, c):
     from diamond_amd import engine as E
 
