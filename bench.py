@@ -13,8 +13,8 @@ bookkeeping/resets) + loss.backward() + gradient all-reduce (N > 1) + clip_grad_
 Default workload = BASELINE.json configs[1]: Breakout-shaped 64x64x3 frames, batch 256 per GPU, horizon 15,
 3 Euler denoising steps, synthetic weights/inputs.  value = B_global * 15 / (max-over-ranks seconds per step).
 
-Extra objects on the JSON line: `roofline` for the dominant kernel (found by measured time; HIP events around
-every dmd_conv2d launch in a dedicated instrumented window after the timed region), `exact_fp32` = the same window
+Extra objects on the JSON line: `roofline` for the dominant kernel (found by measured time over EVERY C-ABI launch:
+HIP events around each one in a dedicated instrumented window after the timed region), `exact_fp32` = the same window
 with every convolution on the exact-fp32 MFMA kernels (configs[1] only), and `cpu_baseline` = the CPU oracle
 timed on this box's host cores on one whole window of configs[0] (rank 0, N=1 only).
 """
@@ -209,6 +209,9 @@ def main():
     ap.add_argument("--img-size", type=int, default=None)
     ap.add_argument("--attn-depths", type=str, default=None,
                     help="denoiser attention per level; BASELINE configs[4] (256x256) uses 0,0,1,1")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the distributed code path (RCCL process group, parameter broadcast, gradient all-reduce, replica "
+                         "checksum) even at world size 1 (tests/test_gpu_dist.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-exact-fp32", action="store_true")
@@ -231,19 +234,24 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)  # "nccl" == RCCL on ROCm
 
     import diamond_amd as D
     from diamond_amd import ac_native
     from diamond_amd import engine as E
+    from diamond_amd import native as nv
     from diamond_amd.dist import GradAllReducer, broadcast_parameters, parameter_checksum
 
     torch.manual_seed(1234 + rank)
     attn = tuple(int(v) for v in args.attn_depths.split(","))
     agent = build_agent(device, args.img_size, rank, attn)
-    if world > 1:
+    if use_dist:
         broadcast_parameters(agent, src=0)  # what the DDP constructor does in the reference (utils.py:106)
     env = D.WorldModelEnv(agent.denoiser, agent.rew_end_model, _Loader(args.batch, 100 + rank, args.img_size),
                           D.WorldModelEnvConfig(horizon=args.horizon, num_batches_to_preload=2,
@@ -254,7 +262,7 @@ def main():
                                                  weight_value_loss=1.0, weight_entropy_loss=0.001), env)
     ac = agent.actor_critic
     opt = torch.optim.AdamW(ac.parameters(), lr=1e-4, eps=1e-8, weight_decay=0.0)
-    reducer = GradAllReducer(list(ac.parameters())) if world > 1 else None
+    reducer = GradAllReducer(list(ac.parameters())) if use_dist else None
 
     def window():
         loss, metrics = ac()
@@ -268,7 +276,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -286,7 +294,7 @@ def main():
         window()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -335,20 +343,25 @@ def main():
     }
 
     if not args.no_roofline:
-        # instrumented window (not part of `value`): HIP events around every dmd_conv2d launch
-        E.PROFILER = E.LaunchProfiler()
+        # instrumented window (not part of `value`): HIP events around EVERY C-ABI launch (convolutions, attention, linears,
+        # fused low-resolution levels, pointwise) on the stream they are launched on; the env replays no captured graph
+        # while a profiler is installed (a replay would hide its kernels from the events)
+        nv.PROFILER = nv.LaunchProfiler()
         window()
-        summ = E.PROFILER.summary()
-        E.PROFILER = None
+        summ = nv.PROFILER.summary()
+        nv.PROFILER = None
         key = max(summ, key=lambda k: summ[k]["ms"])
         d = summ[key]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        split = key.startswith("conv_f16ws") or (key.startswith("conv1x1_stream") and key.endswith("true>"))  # split-fp16 kernels
+        # kernels that run split-fp16 arithmetic (3 f16 MFMAs per algorithmic MAC) are priced against the f16 peak
+        split = (key.startswith("conv_f16ws") or key.startswith("attention_f16x2") or key.startswith("lowres_chain")
+                 or ((key.startswith("conv1x1_stream") or key.startswith("conv_mfma")) and key.endswith("true>")))
         peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
         pmc, pmc_set = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_path) and args.config == 1 and world == 1:
             pmc = json.load(open(pmc_path)).get(key)  # keyed by the rocprofv3 kernel name (tools/pmc_to_profile.py)
+        total_ms = sum(v["ms"] for v in summ.values())
         line["roofline"] = {
             "kernel": key, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB units;
@@ -359,13 +372,15 @@ def main():
             "avg_launch_ms": d["ms"] / d["launches"], "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
             "algorithmic_hbm_gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9,
             "frac_hbm_peak": d["bytes"] / (d["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "note": ("achieved = ALGORITHMIC fp32 conv FLOPs (2 per MAC) / measured kernel time; peak = dense f16 MFMA. The kernel "
+            "note": ("achieved = ALGORITHMIC fp32 FLOPs (2 per MAC) / measured kernel time; peak = dense f16 MFMA. The kernel "
                      "splits each fp32 operand into two fp16 pieces and issues 3 f16 MFMAs per algorithmic MAC (fp32-class "
                      "accuracy), so the matrix pipe executes 3x the algorithmic rate: executed_mfma_frac below."
-                     if split else "exact-fp32 MFMA kernel: peak = fp32 MFMA/vector peak"),
+                     if split else "exact-fp32 kernel: peak = fp32 MFMA/vector peak"),
             "executed_mfma_frac": (3.0 if split else 1.0) * achieved / peak,
             "frac_of_fp32_direct_conv_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
-            "conv_share_of_window_ms": {k: v["ms"] for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])},
+            "kernel_share_of_launch_time": d["ms"] / total_ms,
+            # every C-ABI entry point / kernel instantiation of the window, by measured time (the dominant one is chosen over ALL)
+            "launch_time_ms": {k: round(v["ms"], 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])},
         }
         progress("roofline window done")
 
@@ -379,7 +394,7 @@ def main():
         window()
         fence()
         dt = time.perf_counter() - t1
-        if world > 1:
+        if use_dist:
             tt = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
@@ -395,7 +410,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -86,7 +86,8 @@ def _gn_silu_bwd(x: Act, spec: NormSpec, da: Tensor, dskip: Optional[Tensor]) ->
 
 # Arithmetic of the encoder's forward and dgrad convolutions: "f16x2" = split-fp32 on the f16 matrix cores where the
 # shape is covered (fp32-class accuracy, see dmd_conv_f16ws.hip), "f32" = exact fp32 MFMA.  The weight gradient
-# (contraction over pixels) always runs on the exact fp32 MFMA kernel.
+# (contraction over pixels) runs on the split-fp16 instance of the wgrad kernel as well (its operands are pre-scaled to
+# O(1) by the 2^k scaling of the backward), on the exact fp32 instance with "f32" or DIAMOND_WGRAD_EXACT=1.
 AC_PRECISION = os.environ.get("DIAMOND_AC_PRECISION", "f16x2")
 # DIAMOND_WGRAD_EXACT=1: weight gradients on the exact-fp32 instance of the wgrad kernel even where forward / dgrad run split
 WGRAD_EXACT = os.environ.get("DIAMOND_WGRAD_EXACT", "0") == "1"

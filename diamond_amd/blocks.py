@@ -339,7 +339,7 @@ class UNet(nn.Module):
                 cb.wq, cb.wk, cb.wv, cb.wo, cb.gn_gamma, cb.gn_beta, cb.bqkv, cb.bo = (nv.ptr(t) for t in ta)
                 ts += ta
             keep.append(ts)
-        if E.PROFILER is not None:
+        if nv.PROFILER is not None:
             flops = 0.0
             for b in blks:
                 flops += 2.0 * n * 64 * 64 * 9 * (b.conv1.in_channels + 64)
@@ -347,12 +347,7 @@ class UNet(nn.Module):
                     flops += 2.0 * n * 64 * 64 * 128
                 if not isinstance(b.attn, nn.Identity):
                     flops += 2.0 * n * 64 * 64 * 64 * 4 + 4.0 * n * 64 * 64 * 64
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            nv.check(nv.lib().dmd_lowres_chain(C.byref(p), nv.stream()), "dmd_lowres_chain")
-            e1.record()
-            E.PROFILER.records.append(("lowres_chain_kernel", flops, 8.0 * x.t.numel(), e0, e1))
-        else:
-            nv.check(nv.lib().dmd_lowres_chain(C.byref(p), nv.stream()), "dmd_lowres_chain")
+            nv.PROFILER.annotate("lowres_chain_kernel", flops, 8.0 * x.t.numel())
+        nv.check(nv.lib().dmd_lowres_chain(C.byref(p), nv.stream()), "dmd_lowres_chain")
         del keep
         return Act(out)

@@ -364,7 +364,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, in
       for (int c = tid; c < 2 * G::CIN; c += 256) {
         const int s = c / G::CIN, cc = c - s * G::CIN;
         float m, a, ad;
-        norm_entry(p.src.norm, st[s].n, cc, Cx, (double)(Cx < DMD_GN_GROUP ? Cx : DMD_GN_GROUP) * p.H * p.W, &m, &a, &ad);
+        norm_entry(p.src.norm, s ? st[1].n : st[0].n, cc, Cx,  // (select, not st[s]: a per-lane index would put st[] in scratch)
+                   (double)(Cx < DMD_GN_GROUP ? Cx : DMD_GN_GROUP) * p.H * p.W, &m, &a, &ad);
         tab[(s * 3 + 0) * G::CIN + cc] = m;
         tab[(s * 3 + 1) * G::CIN + cc] = a;
         tab[(s * 3 + 2) * G::CIN + cc] = ad;

@@ -53,6 +53,9 @@ struct ConvGeom {
   static constexpr int ITEMS = (NPP * 4 + 255) / 256;
   // stride-2 patches are ~4x larger: single-buffer them to stay under 64 KiB of static LDS
   static constexpr int NBUF = STRIDE_ == 2 ? 1 : 2;
+  // minimum waves per SIMD the kernel is compiled for: the 64-cout 3x3 stride-1 instance on 8x8 patches (8 m-blocks per
+  // wave + nine prefetched weight fragments) does not fit 256 registers -- one workgroup per SIMD set instead of spilling
+  static constexpr int MIN_WAVES = (WN_ == 4 && CFGB_ && TAPS_ == 9 && STRIDE_ == 1) ? 1 : 2;
 };
 
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -98,7 +101,7 @@ __device__ __forceinline__ TileInfo pick_tile(const TileInfo* ti, int s) {
 }
 
 template <class G>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const dmd_conv_params p) {
+__global__ __launch_bounds__(256, G::MIN_WAVES) void conv_mfma_kernel(const dmd_conv_params p) {
   __shared__ f32x4 patch[G::NBUF][G::NPP * 4];
   __shared__ float tab_mean[G::SUB][DMD_CIN_MAX];
   __shared__ float tab_a[G::SUB][DMD_CIN_MAX];

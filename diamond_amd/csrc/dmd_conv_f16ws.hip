@@ -110,6 +110,8 @@ struct WsGeom {
   // compiler-counted loads: with one set in flight hipcc's waits are the exact ones
   static constexpr bool ASM_LOADS = DOUBLE_STAGE;
   static constexpr int HALVES = TAPS_ * 2;         // half-taps of one chunk
+  // address registers of the l pieces (otherwise h ^ 32 at every l read: the 13-item geometry is 3 registers short)
+  static constexpr bool PL_REGS = !(B8_ && NCB_ == 1);
   // patch byte offset of a consumer wave's 32-pixel block `blk` relative to its block 0
   static constexpr int blk_off(int blk) { return (B8_ ? (blk >> 1) * PPS + (blk & 1) * 4 * PW : blk * 2 * PW) * 64; }
 };
@@ -281,7 +283,7 @@ __device__ __forceinline__ void ws_addr_move(WsAddr& ad, int dpar) {  // dpar = 
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx) {
     ad.ph[dx] += dp;
-    ad.pl[dx] += dp;
+    if (G::PL_REGS) ad.pl[dx] += dp;
   }
   ad.w += dw;
 }
@@ -296,7 +298,7 @@ struct WsWin {
 template <class G, int TAP, int BLK, bool LOW>
 __device__ __forceinline__ h8 ws_read_b(const unsigned char* lds, const WsAddr& ad) {
   using Wn = WsWin<G, TAP>;
-  return *(const h8*)(lds + (LOW ? ad.pl[Wn::dx] : ad.ph[Wn::dx]) + (Wn::off + G::blk_off(BLK)));
+  return *(const h8*)(lds + (LOW ? (G::PL_REGS ? ad.pl[Wn::dx] : (ad.ph[Wn::dx] ^ 32)) : ad.ph[Wn::dx]) + (Wn::off + G::blk_off(BLK)));
 }
 template <class G, int TAP, bool LOW>
 __device__ __forceinline__ h8 ws_read_a(const unsigned char* lds, const WsAddr& ad) {
@@ -396,19 +398,36 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
   if (role == 2) {
     // =================================== PRODUCER ===================================
     const int q = tid & 3;
-    int ipos[G::ITEMS];  // (sub << 16) | (py << 8) | px; -1: no item (beyond the patch)
-    // 8-byte unit index of the h half-quad of item `it` in a patch (recomputed where needed: registers are scarce)
-    auto loff_of = [&](int it) { return ((it * (G::NPT / 4) + (tid >> 2)) * 4 + (((q >> 1) + ((ipos[it] & 0xff) >> 1)) & 3)) * 2 + (q & 1); };
-#pragma unroll
-    for (int it = 0; it < G::ITEMS; ++it) {
-      const int id = it * G::NPT + tid;
-      const int pp = id >> 2;
+    // patch position of item `it` of this thread: (sub << 16) | (py << 8) | px; -1: no item (beyond the patch).  Kept in
+    // registers, except in the 13-item geometry (eight 8x8 patches x 32 couts, at the register cap), which recomputes it
+    // from an OPAQUE copy of the thread index wherever it is used (divisions by constants)
+    constexpr bool IPOS_REGS = !(G::B8 && G::NCB == 1);
+    auto ipos_calc = [&](int it, int t) -> int {
+      const int pp = (it * G::NPT + t) >> 2;
       const bool ok = pp < G::NPP;
       const int s = G::SUB == 1 ? 0 : (ok ? pp / G::PPS : 0);
       const int rem = pp - s * G::PPS;
       const int py = rem / G::PW, px = rem - py * G::PW;
-      ipos[it] = ok ? ((s << 16) | (py << 8) | px) : -1;
-    }
+      return ok ? ((s << 16) | (py << 8) | px) : -1;
+    };
+    int ipos_[IPOS_REGS ? G::ITEMS : 1];
+#pragma unroll
+    for (int it = 0; it < (IPOS_REGS ? G::ITEMS : 1); ++it) ipos_[it] = ipos_calc(it, tid);
+    auto ipos = [&](int it) -> int {
+      if (IPOS_REGS) return ipos_[IPOS_REGS ? it : 0];
+      int t = tid;
+      asm volatile("" : "+v"(t));
+      return ipos_calc(it, t);
+    };
+    // 8-byte unit index of the h half-quad of item `it` in a patch.  The 11-13-item geometries are at the register cap:
+    // there the offsets are recomputed at every chunk from an OPAQUE copy of the thread index (left alone, hipcc hoists
+    // one loop-invariant address register per item and piece and spills something else)
+    auto loff_of = [&](int it) {
+      int t = tid;
+      if (G::SUB > 1) asm volatile("" : "+v"(t));
+      const int qq = t & 3;
+      return ((it * (G::NPT / 4) + (t >> 2)) * 4 + (((qq >> 1) + ((ipos(it) & 0xff) >> 1)) & 3)) * 2 + (qq & 1);
+    };
     int gk = -1;          // tile whose descriptors / tables are current
     int tab_n[G::SUB];    // images whose tables are current, and their slot
 #pragma unroll
@@ -419,13 +438,14 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     unsigned gzero = 0;   // bit it = item is conv zero padding / outside the tensor
     int gtile = 0;        // tile index of tile gk
     auto item_source = [&](int it, bool& inb) -> int {
-      const int s = ipos[it] >> 16, py = (ipos[it] >> 8) & 0xff, px = ipos[it] & 0xff;
+      const int ip = ipos(it);
+      const int s = ip >> 16, py = (ip >> 8) & 0xff, px = ip & 0xff;
       // sub-tile of this item: recomputed from its index where a tile has several (selecting from the ti[] registers
       // by a per-lane index turns the array into scratch memory)
       const WsTile t = G::SUB == 1 ? ti[0] : ws_subtile<G>(p, gtile, s);
       const int iy = t.y0 - 1 + py, ix = t.x0 - 1 + px;
       const bool window = G::TAPS == 9 || (py >= 1 && py <= G::TS && px >= 1 && px <= G::TS);  // 1x1: no halo needed
-      inb = ipos[it] >= 0 && window && t.valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      inb = ip >= 0 && window && t.valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
       return inb ? ((t.n * Hs + (iy >> up)) * Ws + (ix >> up)) : 0;
     };
 
@@ -544,7 +564,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           const int it = I0 + i;
           f32x4 ta = ta0, tb = tb0, tc = tc0, td = td0;
           if (G::SUB > 1) {
-            const int to = (slot * G::SUB + (ipos[it] >> 16)) * G::CIN_MAX + cc;
+            const int to = (slot * G::SUB + (ipos(it) >> 16)) * G::CIN_MAX + cc;
             ta = *(const f32x4*)(tab_a + to);
             tb = *(const f32x4*)(tab_b + to);
             if (G::CD_TABLES) {
@@ -599,7 +619,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           const unsigned h23 = __builtin_bit_cast(unsigned, (h2){(_Float16)x[2], (_Float16)x[3]});
           const unsigned l01 = ws_low_pair(x[0], x[1], h01);
           const unsigned l23 = ws_low_pair(x[2], x[3], h23);
-          if ((it + 1) * G::NPT <= G::NPP * 4 || ipos[it] >= 0) {  // only the last item row can fall beyond the patch
+          if ((it + 1) * G::NPT <= G::NPP * 4 || ipos(it) >= 0) {  // only the last item row can fall beyond the patch
             const int lo = loff_of(it);
             pb[lo] = (uint2){h01, h23};
             pb[lo ^ 4] = (uint2){l01, l23};
@@ -692,26 +712,38 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
 
     // ---- write-out state of this group's finished tile ----
     // lane owns couts cb*32 + 8 qd + 4 g + (0..3), qd = 0..3, of pixel n31 of each 32-pixel block
-    int pixoff[4];     // 16-byte unit offset of (pixel, cb*32 + 4 g) per block, -1: sub-tile outside the tensor
+    // 16-byte unit offset of (pixel, cb*32 + 4 g) per block, -1: sub-tile outside the tensor.  16x16 patches: the four
+    // blocks of a wave are rows 2 blk + {0, 1} of ONE sub-tile; 8x8 patches: blocks 2 s + {0, 1} are rows 0-3 / 4-7 of
+    // sub-tile s: one base register per sub-tile + a uniform stride
+    constexpr int NPO = G::B8 ? 2 : 1;
+    int pixoff_[NPO];
+    auto pixoff_of = [&](int blk) {
+      const int base = pixoff_[G::B8 ? (blk >> 1) : 0];
+      const int rows = G::B8 ? (blk & 1) * 4 : blk * 2;
+      return base < 0 ? -1 : base + rows * p.W * (G::COUT / 4);
+    };
     constexpr int NSTAT = G::B8 ? 2 : 1;  // statistics tiles of this wave's 128 pixels (one per 8 rows x 8 | 16 columns)
     int stat_slot[NSTAT];  // out_stats slot per statistics tile of this wave, -1: none
-    double ssum[NSTAT], ssq[NSTAT];
+    // per-lane partial sums of a statistics tile: fp64 across a 16x16 geometry's four blocks; the 8x8 geometries (two blocks
+    // = 32 values per lane and tile, and short of registers) keep them in fp32 -- fp64 from the wave reduction on
+    using StatAcc = std::conditional_t<G::B8, float, double>;
+    StatAcc ssum[NSTAT], ssq[NSTAT];
     int pending = 4;   // next block of the finished tile to write (4 = nothing pending)
     auto epi_begin = [&](int k) {
       const int tile = WS_TILE(k);
 #pragma unroll
-      for (int blk = 0; blk < 4; ++blk) {
-        // sub-tile of this block (wave-uniform index; computed, not selected from a register array)
-        const WsTile t = ws_subtile<G>(p, tile, G::B8 ? ph * 2 + (blk >> 1) : (ph >> 1));
+      for (int s = 0; s < NPO; ++s) {
+        // sub-tile (wave-uniform index; computed, not selected from a register array) and this lane's pixel of its block 0
+        const WsTile t = ws_subtile<G>(p, tile, G::B8 ? ph * 2 + s : (ph >> 1));
         int oy, ox;
         if (G::B8) {
-          oy = t.y0 + (blk & 1) * 4 + (n31 >> 3);
+          oy = t.y0 + (n31 >> 3);
           ox = t.x0 + (n31 & 7);
         } else {
-          oy = t.y0 + (ph & 1) * 8 + blk * 2 + (n31 >> 4);
+          oy = t.y0 + (ph & 1) * 8 + (n31 >> 4);
           ox = t.x0 + (n31 & 15);
         }
-        pixoff[blk] = t.valid ? (((t.n * p.H + oy) * p.W + ox) * (G::COUT / 4) + cb * 8 + g) : -1;  // 16-byte units
+        pixoff_[s] = t.valid ? (((t.n * p.H + oy) * p.W + ox) * (G::COUT / 4) + cb * 8 + g) : -1;  // 16-byte units
       }
 #pragma unroll
       for (int kk = 0; kk < NSTAT; ++kk) {
@@ -727,8 +759,8 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           tt = (t.y0 / 8 + (ph & 1)) * tx16 + t.x0 / 16;
         }
         stat_slot[kk] = t.valid ? ((t.n * G::NCB + cb) * T + tt) : -1;
-        ssum[kk] = 0.0;
-        ssq[kk] = 0.0;
+        ssum[kk] = 0;
+        ssq[kk] = 0;
       }
       pending = 0;
     };
@@ -743,8 +775,8 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         if (G::NCB == 1 && p.out_nchw) {
           // few-channel NCHW output (conv_out: 64 -> 3, weights zero-padded to 32 couts): the real channels are
           // couts 0..3 = quad 0 of the k-group-0 lanes; consecutive lanes = consecutive pixels of a plane
-          if (pixoff[blk] >= 0 && g == 0) {
-            const int pixel = pixoff[blk] >> 3;  // cb == 0, g == 0
+          if (pixoff_of(blk) >= 0 && g == 0) {
+            const int pixel = pixoff_of(blk) >> 3;  // cb == 0, g == 0
             const int HW = p.H * p.W;
             const int n = pixel / HW, rem = pixel - n * HW;
 #pragma unroll
@@ -753,12 +785,13 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           }
           continue;
         }
-        if (pixoff[blk] >= 0) {
-          float* op = p.out + (size_t)pixoff[blk] * 4;
+        const int po = pixoff_of(blk);
+        if (po >= 0) {
+          float* op = p.out + (size_t)po * 4;
           f32x4 rv[4];
 #pragma unroll
           for (int qd = 0; qd < 4; ++qd)
-            rv[qd] = (p.residual && !(WS_ABL & 128)) ? *(const f32x4*)(p.residual + (size_t)pixoff[blk] * 4 + 8 * qd) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            rv[qd] = (p.residual && !(WS_ABL & 128)) ? *(const f32x4*)(p.residual + (size_t)po * 4 + 8 * qd) : (f32x4){0.f, 0.f, 0.f, 0.f};
           if (land) {
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]) : : "memory");
             land = false;
@@ -781,8 +814,8 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
             fq = __builtin_fmaf(v[3], v[3], fq);
           }
           const int slot = G::B8 ? (blk >> 1) : 0;
-          ssum[slot] += (double)fs;
-          ssq[slot] += (double)fq;
+          ssum[slot] += (StatAcc)fs;
+          ssq[slot] += (StatAcc)fq;
         }
       }
       if (land) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no block with stores in this call)
@@ -790,8 +823,8 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       if (last == 4 && first < 4 && p.out_stats) {
 #pragma unroll
         for (int kk = 0; kk < NSTAT; ++kk) {
-          const double a = ws_wave_sum_lane63(ssum[kk]);
-          const double b = ws_wave_sum_lane63(ssq[kk]);
+          const double a = ws_wave_sum_lane63((double)ssum[kk]);
+          const double b = ws_wave_sum_lane63((double)ssq[kk]);
           if (lane == 63 && stat_slot[kk] >= 0) {
             double* o = p.out_stats + (size_t)stat_slot[kk] * 2;
             o[0] = a;

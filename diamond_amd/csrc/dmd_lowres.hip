@@ -836,11 +836,13 @@ extern "C" int dmd_lowres_chain(const dmd_lowres_chain_params* p, dmd_stream_t s
     DMD_CHECK_ARG(!B.wproj || B.bproj, "lowres_chain: block %d: projection bias", b);
     DMD_CHECK_ARG(!B.has_attn || (B.gn_gamma && B.gn_beta && B.wq && B.wk && B.wv && B.wo && B.bqkv && B.bo), "lowres_chain: block %d: attention parameters", b);
   }
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[DMD_MAX_DEVICES] = {};  // the attribute belongs to the DEVICE the launch goes to
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DMD_MAX_DEVICES) dev = 0;
+  if (!attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lowres_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LR_SMEM_BYTES);
     DMD_CHECK_ARG(e == hipSuccess, "lowres_chain: hipFuncSetAttribute(%d bytes): %s", (int)LR_SMEM_BYTES, hipGetErrorString(e));
-    attr_set = true;
+    attr_set[dev] = true;
   }
   hipLaunchKernelGGL(lowres_chain_kernel, dim3(p->N), dim3(256), LR_SMEM_BYTES, (hipStream_t)stream, *p);
   DMD_LAUNCH_CHECK();
@@ -856,11 +858,13 @@ extern "C" int dmd_lowres_chain32(const dmd_lowres_chain_params* p, dmd_stream_t
     DMD_CHECK_ARG(B.skip_slot < 0 && B.save_slot < 0 && !B.wproj, "lowres_chain32: block %d: no concatenated inputs at 32 channels", b);
     DMD_CHECK_ARG(!B.has_attn || (B.gn_gamma && B.gn_beta && B.wq && B.wk && B.wv && B.wo && B.bqkv && B.bo), "lowres_chain32: block %d: attention parameters", b);
   }
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[DMD_MAX_DEVICES] = {};  // the attribute belongs to the DEVICE the launch goes to
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DMD_MAX_DEVICES) dev = 0;
+  if (!attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lowres_chain32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L3_SMEM_BYTES);
     DMD_CHECK_ARG(e == hipSuccess, "lowres_chain32: hipFuncSetAttribute(%d bytes): %s", (int)L3_SMEM_BYTES, hipGetErrorString(e));
-    attr_set = true;
+    attr_set[dev] = true;
   }
   hipLaunchKernelGGL(lowres_chain32_kernel, dim3(p->N), dim3(256), L3_SMEM_BYTES, (hipStream_t)stream, *p);
   DMD_LAUNCH_CHECK();

@@ -116,10 +116,17 @@ class Denoiser(nn.Module):
         return self.inner_model.run(packed, cvec, naive, precision)
 
     @torch.no_grad()
-    def wrap_model_output(self, noisy_next_obs: Tensor, model_output: Tensor, sigma: Union[Tensor, float]) -> Tensor:
-        """quantise(c_skip * x + c_out * F)  (reference :79-84)."""
+    def wrap_model_output(self, noisy_next_obs: Tensor, model_output: Tensor, sigma: Union[Tensor, float],
+                          cond4: Optional[Tensor] = None) -> Tensor:
+        """quantise(c_skip * x + c_out * F)  (reference :79-84).  cond4: an already computed (B, 4) device array of
+        (c_in, c_out, c_skip, c_noise) to use instead of deriving the conditioners from sigma (training step: no host
+        round trip, and the refresh uses exactly the conditioners the loss used)."""
         n = noisy_next_obs.shape[0]
-        cond, stride = self.compute_conditioners(sigma)
+        if cond4 is not None:
+            assert cond4.shape == (n, 4) and cond4.dtype == torch.float32 and cond4.is_contiguous()
+            cond, stride = cond4, 4
+        else:
+            cond, stride = self.compute_conditioners(sigma)
         x = noisy_next_obs.contiguous()
         f = model_output.contiguous()
         out = torch.empty_like(x)
@@ -207,7 +214,7 @@ class Denoiser(nn.Module):
             c_in, c_out, c_skip, c_noise = (v.reshape(-1, 1, 1, 1) for v in cs)
             target = (next_obs - c_skip * noisy_next_obs) / c_out
             loss = loss + F.mse_loss(model_output[mask], target[mask])
-            denoised = self.wrap_model_output(noisy_next_obs, model_output.detach(), sigma)
+            denoised = self.wrap_model_output(noisy_next_obs, model_output.detach(), sigma, cond4=torch.stack(cs, 1).contiguous())
             all_obs[:, n + i] = denoised
         loss = loss / seq_length
         return loss, {"loss_denoising": loss.detach()}

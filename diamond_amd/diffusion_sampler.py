@@ -49,6 +49,7 @@ class DiffusionSampler:
         # test hook: replaces torch.randn for the initial noise / churn draws (host-injected RNG)
         self.noise_fn: Optional[Callable[[Tuple[int, ...], torch.device], Tensor]] = None
         self._graphs: Dict[tuple, "_CapturedSample"] = {}  # latency mode: one hipGraph per (buffers, ring heads)
+        self._graph_stamp = None  # (denoiser parameter versions / pointers, arithmetic switches) the cached graphs were captured with
         self._graph_pool = None                             # ... all drawing their temporaries from one memory pool
 
     def _randn(self, shape, device) -> Tensor:
@@ -69,8 +70,17 @@ class DiffusionSampler:
         The sigma schedule, conditioners and ring heads are launch constants of the captured graph; the context is read
         from the SAME buffers at replay time (WorldModelEnv keeps its rings in place).  Returns fresh copies (the
         graph's output buffers are overwritten by the next replay)."""
-        key = (ctx_obs.data_ptr(), ctx_act.data_ptr(), tuple(ctx_obs.shape), obs_head, act_head,
-               self.denoiser.inner_model.conv_in.weight._version)
+        # A captured graph holds the POINTERS of the packed weights and the kernel choices of capture time: its stamp covers
+        # every denoiser parameter (version + storage pointer, like engine.PackCache), the arithmetic switches and the
+        # fused-level switch.  Graphs of a stale stamp are dropped at once (each holds live pool memory).
+        from . import blocks as BL
+        from . import engine as E
+
+        stamp = (tuple((p._version, p.data_ptr()) for p in self.denoiser.parameters()), E.WORLD_MODEL_PRECISION, BL.LOWRES_CHAIN)
+        if stamp != self._graph_stamp:
+            self._graphs.clear()
+            self._graph_stamp = stamp
+        key = (ctx_obs.data_ptr(), ctx_act.data_ptr(), tuple(ctx_obs.shape), obs_head, act_head)
         cap = self._graphs.get(key)
         if cap is None:
             if len(self._graphs) > 64:

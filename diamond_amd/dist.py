@@ -47,9 +47,12 @@ class GradAllReducer:
     @torch.no_grad()
     def all_reduce_mean(self) -> Tensor:
         self._ensure_views()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        # (also at world size 1: the same RCCL call on the same bucket, so that a 1-GPU run of the distributed path
+        #  exercises everything an N-GPU run does)
+        if dist.is_available() and dist.is_initialized():
             dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group)
-            self.bucket.div_(dist.get_world_size(self.group))
+            if dist.get_world_size(self.group) > 1:
+                self.bucket.div_(dist.get_world_size(self.group))
         return self.bucket
 
 

@@ -25,26 +25,7 @@ _USE_NAIVE = os.environ.get("DIAMOND_CONV_IMPL", "mfma") == "naive"  # debugging
 WORLD_MODEL_PRECISION = os.environ.get("DIAMOND_CONV_PRECISION", "f16x2")
 
 
-class LaunchProfiler:
-    """Optional per-launch HIP-event timing of dmd_conv2d (bench.py's roofline pass).  Events
-    are recorded on torch's current stream == the stream the kernels are launched on."""
-
-    def __init__(self) -> None:
-        self.records: List[Tuple[str, float, float, torch.cuda.Event, torch.cuda.Event]] = []
-
-    def summary(self) -> Dict[str, Dict[str, float]]:
-        torch.cuda.synchronize()
-        out: Dict[str, Dict[str, float]] = {}
-        for key, flops, nbytes, e0, e1 in self.records:
-            d = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
-            d["launches"] += 1
-            d["ms"] += e0.elapsed_time(e1)
-            d["flops"] += flops
-            d["bytes"] += nbytes
-        return out
-
-
-PROFILER: Optional[LaunchProfiler] = None
+LaunchProfiler = nv.LaunchProfiler  # per-launch HIP-event timing of every C-ABI launch: install with `native.PROFILER = ...`
 
 
 @dataclass
@@ -239,17 +220,12 @@ def conv2d(
         p.out_stats = nv.ptr(stats)
     use_naive = _USE_NAIVE if naive is None else naive
     fn = nv.lib().dmd_conv2d_naive if use_naive else nv.lib().dmd_conv2d
-    if PROFILER is not None:
+    if nv.PROFILER is not None:
         cin = sum(a.C for a, _, _ in srcs)
         flops = 2.0 * n * h * w * cout * cin * taps  # algorithmic: MAC = 2, real channels
         nbytes = 4.0 * (sum(a.t.numel() for a, _, _ in srcs) + out.numel() + (residual.t.numel() if residual is not None else 0))
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        nv.check(fn(C.byref(p), nv.stream()), "dmd_conv2d")
-        e1.record()
-        PROFILER.records.append((kernel_key(p), flops, nbytes, e0, e1))
-    else:
-        nv.check(fn(C.byref(p), nv.stream()), "dmd_conv2d")
+        nv.PROFILER.annotate(kernel_key(p), flops, nbytes)
+    nv.check(fn(C.byref(p), nv.stream()), "dmd_conv2d")
     result = Act(out, stats, tiles)
     if TAPE is not None:
         assert module is not None, "recording a conv launch that does not name its nn.Conv2d"
@@ -286,6 +262,9 @@ def attention(qkv: Act, c: int, head_dim: int = 8) -> Tensor:
     n, h, w, c3 = qkv.shape
     assert c3 == 3 * c
     out = torch.empty(n, h, w, c, device=qkv.t.device, dtype=torch.float32)
+    if nv.PROFILER is not None:  # QK^T and PV: 2 x (2 T^2 d) per head
+        t = h * w
+        nv.PROFILER.annotate("attention_f16x2_kernel" if t % 256 == 0 else "attention_kernel", 4.0 * n * t * t * c, 4.0 * n * t * 4 * c)
     nv.check(nv.lib().dmd_attention(nv.fptr(qkv.t), nv.fptr(out), n, h * w, c, head_dim, nv.stream()), "dmd_attention")
     if TAPE is not None:
         TAPE.append(AttnRecord(qkv, out, c, head_dim))

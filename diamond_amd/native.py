@@ -89,10 +89,72 @@ EXPORTS = (
     "dmd_lowres_chain", "dmd_lowres_chain32", "dmd_last_error", "dmd_abi_version",
 )
 
-_lib: Optional[C.CDLL] = None
+# entry points that launch kernels (everything except queries / packing helpers that bench.py does not time)
+LAUNCHERS = frozenset(n for n in EXPORTS if n not in (
+    "dmd_conv2d_kernel_name", "dmd_conv_stat_tiles", "dmd_conv2d_f16x2_eligible", "dmd_conv1x1_stream_eligible",
+    "dmd_attention_bwd_workspace_floats", "dmd_gn_bwd_workspace_bytes", "dmd_wgrad_workspace_floats", "dmd_last_error", "dmd_abi_version"))
 
 
-def lib() -> C.CDLL:
+class LaunchProfiler:
+    """Optional per-launch HIP-event timing of EVERY C-ABI launch (bench.py's roofline pass): set `native.PROFILER` and
+    every call through `lib()` is bracketed by two events on torch's current stream == the stream the kernels are
+    launched on.  A caller that knows more than the entry point's name (dmd_conv2d: the kernel instantiation, the
+    algorithmic FLOPs and bytes) calls `annotate()` right before its launch."""
+
+    def __init__(self) -> None:
+        self.records = []  # (key, flops, bytes, event0, event1)
+        self._pending = None
+
+    def annotate(self, key: str, flops: float, nbytes: float) -> None:
+        self._pending = (key, flops, nbytes)
+
+    def call(self, name: str, fn, args):
+        key, flops, nbytes = self._pending or (name, 0.0, 0.0)
+        self._pending = None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        self.records.append((key, flops, nbytes, e0, e1))
+        return rc
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for key, flops, nbytes, e0, e1 in self.records:
+            d = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        return out
+
+
+PROFILER: Optional[LaunchProfiler] = None
+
+
+class _Lib:
+    """The loaded library; launching entry points go through the profiler when one is installed."""
+
+    def __init__(self, cdll: C.CDLL) -> None:
+        self._cdll = cdll
+
+    def __getattr__(self, name: str):
+        fn = getattr(self._cdll, name)
+        if name not in LAUNCHERS:
+            return fn
+
+        def launch(*args):
+            prof = PROFILER
+            return fn(*args) if prof is None else prof.call(name, fn, args)
+
+        return launch
+
+
+_lib: Optional[_Lib] = None
+
+
+def lib() -> _Lib:
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
@@ -147,7 +209,7 @@ def lib() -> C.CDLL:
         L.dmd_conv2d_wgrad.argtypes = [C.POINTER(WgradParams), C.c_void_p]
         L.dmd_lowres_chain.argtypes = [C.POINTER(LowresChainParams), C.c_void_p]
         L.dmd_lowres_chain32.argtypes = [C.POINTER(LowresChainParams), C.c_void_p]
-        _lib = L
+        _lib = _Lib(L)
     return _lib
 
 
@@ -237,5 +299,8 @@ def linear(a: Tensor, w: Tensor, bias: Optional[Tensor], out: Tensor, accumulate
     p.bias = ptr(bias)
     p.C, p.ldc = ptr(out), out.stride(0)
     p.accumulate, p.silu = int(accumulate), int(silu)
+    if PROFILER is not None:
+        PROFILER.annotate(f"linear_mfma_kernel<{'true' if p.K >= 512 else 'false'}>", 2.0 * p.M * p.N * p.K,
+                          4.0 * (p.M * p.K + p.N * p.K + p.M * p.N))
     check(lib().dmd_linear(C.byref(p), stream()), "dmd_linear")
     return out

@@ -48,6 +48,8 @@ class InitialConditionPool:
     batches; when fewer rows are left than a request needs, the remainder is dropped and fresh batches are
     preloaded (each one burns the reward/end LSTM in on its first T-1 transitions, :123-124)."""
 
+    _warned_fp32 = False  # one warning per process when a pool falls back to fp32 (off-grid frames)
+
     def __init__(self, rew_end_model, data_loader, num_batches: int, device_fn: Callable[[], torch.device]) -> None:
         self._model = rew_end_model
         self._loader = data_loader
@@ -89,6 +91,12 @@ class InitialConditionPool:
         if int(off_grid.item()) == 0:  # one sync per preload round
             self.frames_u8, self.frames_f32 = torch.cat(q_), None
         else:
+            if not InitialConditionPool._warned_fp32:
+                InitialConditionPool._warned_fp32 = True
+                import warnings
+
+                warnings.warn(f"initial-condition pool: {int(off_grid.item())} preloaded values are not on the uint8 grid "
+                              "(x = k / 255 * 2 - 1): keeping this pool in fp32 (4x the memory; results are unchanged)")
             self.frames_u8, self.frames_f32 = None, torch.cat(f_)
         self.act, self.hx, self.cx = torch.cat(act_), torch.cat(hx_), torch.cat(cx_)
         self._cursor = 0
@@ -224,7 +232,9 @@ class WorldModelEnv:
 
     @torch.no_grad()
     def predict_next_obs(self) -> Tuple[Tensor, List[Tensor]]:
-        if self.graph_sampler and self.sampler.noise_fn is None:
+        # (no replay while a launch profiler is installed: a replayed graph issues no launches it could time, and a first
+        #  capture inside the profiled window would record timing events into the graph)
+        if self.graph_sampler and self.sampler.noise_fn is None and nv.PROFILER is None:
             return self.sampler.sample_ring_graphed(self._ctx, self._act, self._head, self._head)
         return self.sampler.sample_ring(self._ctx, self._act, self._head, self._head)
 

@@ -267,13 +267,14 @@ def build_sigmas(spec: SamplerSpec, dtype=torch.float32) -> Tensor:
 
 def sample(sd: SD, dspec: DenoiserSpec, sspec: SamplerSpec, prev_obs: Tensor, prev_act: Tensor, noise: Tensor,
            churn_noise: Optional[Callable[[Tensor], Tensor]] = None,
-           denoise_fn: Optional[Callable] = None) -> Tuple[Tensor, List[Tensor]]:
+           denoise_fn: Optional[Callable] = None, sigmas: Optional[Tensor] = None) -> Tuple[Tensor, List[Tensor]]:
     """DiffusionSampler.sample diffusion_sampler.py:30-58.  `noise` is the injected
     x0 ~ N(0,1) draw (line 36); `churn_noise(x)` supplies randn_like draws (line 42).
-    `denoise_fn(x, sigma, obs, act)` may replace the oracle denoiser (teacher forcing)."""
+    `denoise_fn(x, sigma, obs, act)` may replace the oracle denoiser (teacher forcing); `sigmas` may replace the
+    schedule (a two-element slice of it = ONE step from a teacher-forced trajectory point passed as `noise`)."""
     b, t, c, h, w = prev_obs.shape
     obs = prev_obs.reshape(b, t * c, h, w)
-    sigmas = build_sigmas(sspec, prev_obs.dtype)
+    sigmas = build_sigmas(sspec, prev_obs.dtype) if sigmas is None else sigmas
     dn = denoise_fn or (lambda x, s, o, a: denoise(sd, dspec, x, s, o, a))
     s_in = torch.ones(b, dtype=prev_obs.dtype)
     gamma_ = min(sspec.s_churn / (len(sigmas) - 1), 2 ** 0.5 - 1)

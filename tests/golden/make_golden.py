@@ -91,6 +91,23 @@ def gen_sampler(agent):
     save("sampler.pt", out)
 
 
+def gen_sampler_heun5(agent):
+    """BASELINE configs[3]'s sampler form (2nd-order Heun) at a batch of 2 over 5 steps (9 denoiser calls): the whole
+    reference trajectory, so that every step can be teacher-forced."""
+    from models.diffusion import DiffusionSampler, DiffusionSamplerConfig
+
+    g = torch.Generator().manual_seed(21)
+    b = 2
+    prev_obs = synthetic_frames(g, b, 4, 3, 64, 64)
+    prev_act = synthetic_actions(g, 4, b, 4)
+    sampler = DiffusionSampler(agent.denoiser, DiffusionSamplerConfig(num_steps_denoising=5, order=2))
+    torch.manual_seed(121)  # consumed by torch.randn at diffusion_sampler.py:36
+    with torch.no_grad():
+        x, traj = sampler.sample(prev_obs, prev_act)
+    save("sampler_heun5.pt", {"seed": 21, "noise_seed": 121, "x": x.clone(), "trajectory": torch.stack(traj, 1).clone(),
+                              "sigmas": sampler.sigmas.clone()})
+
+
 def gen_rew_end(agent):
     g = torch.Generator().manual_seed(13)
     b = 2
@@ -318,6 +335,9 @@ def main():
     if "--denoiser-train" in sys.argv:
         gen_denoiser_train()
         return
+    if "--sampler-heun5" in sys.argv:
+        gen_sampler_heun5(ref_agent())
+        return
     if "--denoiser-256" in sys.argv:  # BASELINE configs[4] shape: one 256x256 frame, attention at the two deepest levels
         gen_denoiser(ref_agent(denoiser_attn_depths=(0, 0, 1, 1)), "attn0011_256", h=256, w=256, b=1, only=(1, 3))
         return
@@ -331,6 +351,7 @@ def main():
     save("state_dict_keys.pt", {k: tuple(v.shape) for k, v in agent.state_dict().items()})
     gen_denoiser(agent, "default")
     gen_sampler(agent)
+    gen_sampler_heun5(agent)
     gen_rew_end(agent)
     gen_actor_critic(agent)
     gen_window()

@@ -57,6 +57,25 @@ def _worker(rank, world, port, q):
     flat = red.all_reduce_mean().clone()
     views_ok = all(p.grad.data_ptr() >= red.bucket.data_ptr() and
                    p.grad.data_ptr() < red.bucket.data_ptr() + red.bucket.numel() * 4 for p in ac.parameters())
+    # the world-model parameters go through the same flat bucket (the reference DDP-wraps all three sub-models,
+    # trainer.py:110): rank-dependent gradient pattern -> mean over the ranks; and torch's own DistributedDataParallel
+    # constructor (utils.py:105-106: parameter verification + broadcast from rank 0) accepts the module
+    den = D.Denoiser(D.default_agent_config().denoiser)
+    rem = D.RewEndModel(D.default_agent_config().rew_end_model)
+    wm = list(den.parameters()) + list(rem.parameters())
+    red_wm = GradAllReducer(wm)
+    for i, p in enumerate(wm):
+        p.grad.fill_((rank + 1) * (float(i % 11) - 5.0))
+    red_wm.all_reduce_mean()
+    mean_scale = sum(r + 1 for r in range(world)) / world
+    wm_ok = all(bool(torch.allclose(p.grad, torch.full_like(p.grad, mean_scale * (float(i % 11) - 5.0)))) for i, p in enumerate(wm))
+    torch.manual_seed(100 + rank)
+    ac3 = D.ActorCritic(D.default_agent_config().actor_critic)  # different values per rank
+    ddp = torch.nn.parallel.DistributedDataParallel(ac3)
+    cs3 = torch.tensor([parameter_checksum(ddp.module)], dtype=torch.float64)
+    all_cs3 = [torch.zeros_like(cs3) for _ in range(world)]
+    dist.all_gather(all_cs3, cs3)
+    ddp_ok = all(float(c) == float(all_cs3[0]) for c in all_cs3)
     if rank == 0:
         # single-process reference over the whole batch
         ac2 = D.ActorCritic(D.default_agent_config().actor_critic)
@@ -65,7 +84,7 @@ def _worker(rank, world, port, q):
         (logits.square().mean() + val.mean()).backward()
         ref = torch.cat([p.grad.reshape(-1) for p in ac2.parameters()])
         q.put(float((flat - ref).abs().max() / ref.abs().max()))
-        q.put(bool(views_ok and bumped and same_params))
+        q.put(bool(views_ok and bumped and same_params and wm_ok and ddp_ok))
     dist.barrier()
     dist.destroy_process_group()
 

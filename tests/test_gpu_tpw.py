@@ -188,7 +188,7 @@ def test_denoiser_batch256_tpw16_vs_oracle_sampled_envs():
         assert err < 1e-4, err
         d = ag.denoiser.denoise(x.to(DEV), sigma, obs.to(DEV), act.to(DEV))
         dref = O.denoise(oa.denoiser, oa.dspec, x[s], sigma, obs[s], act[s])
-        check_quantised(u8(d[s.to(DEV)]), u8(dref), max_frac=3e-4)
+        check_quantised(u8(d[s.to(DEV)]), u8(dref), max_frac=1e-4, what="teacher-forced, B=256 sampled envs")
         # the same envs as a B=4 launch (tiles_per_wg == 1 everywhere): same result within rounding of the FiLM GEMM
         f4 = ag.denoiser.compute_model_output(x[s].to(DEV), obs[s].to(DEV), act[s].to(DEV), sigma)
         assert rel_err(f[s.to(DEV)], f4) < 2e-6

@@ -69,6 +69,35 @@ def test_sampler_euler_and_heun():
         check_quantised(u8(x.clamp(-1, 1)), u8(gold[name]["x"].clamp(-1, 1)), max_frac=1e-3)
 
 
+def heun_step_budget(sigmas, i):
+    """A pixel of a quantised denoiser output on the neighbouring uint8 level (2/255) moves the Heun step's result by
+    2/255 * |dt| / (2 sigma) through the first evaluation and 2/255 * |dt| / (2 sigma_next) through the second
+    (reference diffusion_sampler.py:52-56); the last step (sigma_next = 0) is an Euler step."""
+    s0, s1 = float(sigmas[i]), float(sigmas[i + 1])
+    return 2 / 255 * (abs(s1 - s0) / s0 if s1 == 0 else abs(s1 - s0) * (0.5 / s0 + 0.5 / s1))
+
+
+def test_sampler_heun5_every_step_teacher_forced():
+    """BASELINE configs[3]'s sampler form at a batch of 2: each of the 5 Heun steps (9 denoiser calls) starts from the
+    REFERENCE's own trajectory point, so quantisation flips cannot accumulate."""
+    gold = load_golden("sampler_heun5.pt")
+    a = make_oracle_agent()
+    g = torch.Generator().manual_seed(gold["seed"])
+    prev_obs = synthetic_frames(g, 2, 4, 3, 64, 64)
+    prev_act = synthetic_actions(g, 4, 2, 4)
+    sspec = O.SamplerSpec(num_steps_denoising=5, order=2)
+    sig = O.build_sigmas(sspec)
+    assert torch.equal(sig, gold["sigmas"])
+    ref = gold["trajectory"]
+    torch.manual_seed(gold["noise_seed"])
+    assert torch.equal(torch.randn(2, 3, 64, 64), ref[:, 0])
+    for i in range(5):
+        x, _ = O.sample(a.denoiser, a.dspec, sspec, prev_obs, prev_act, ref[:, i], sigmas=sig[i:i + 2])
+        diff = (x - ref[:, i + 1]).abs()
+        assert float(diff.max()) <= heun_step_budget(sig, i) * 2 + 1e-4
+        assert float((diff > 1e-4).float().mean()) <= 2e-4, (i, float((diff > 1e-4).float().mean()))
+
+
 def test_rew_end_model():
     gold = load_golden("rew_end.pt")
     a = make_oracle_agent()

@@ -29,11 +29,11 @@ timed("denoise", lambda: den.denoise(x, 1.0, obs.reshape(B, 12, 64, 64), act), 3
 # host-only launch cost: enqueue without sync
 t0 = time.perf_counter(); den.denoise(x, 1.0, obs.reshape(B, 12, 64, 64), act); t1 = time.perf_counter(); sync()
 print(f"denoise host enqueue time: {(t1-t0)*1e3:.1f} ms", flush=True)
-E.PROFILER = E.LaunchProfiler()
+nv.PROFILER = E.LaunchProfiler()
 den.denoise(x, 1.0, obs.reshape(B, 12, 64, 64), act)
-for k, v in sorted(E.PROFILER.summary().items(), key=lambda kv: -kv[1]["ms"]):
+for k, v in sorted(nv.PROFILER.summary().items(), key=lambda kv: -kv[1]["ms"]):
     print(f"  {k}: {v['launches']} launches {v['ms']:.2f} ms  {v['flops']/v['ms']/1e9:.1f} TF/s  {v['bytes']/v['ms']/1e6:.0f} GB/s", flush=True)
-E.PROFILER = None
+nv.PROFILER = None
 sampler = D.DiffusionSampler(den, D.DiffusionSamplerConfig(num_steps_denoising=3))
 timed("sample (3 Euler)", lambda: sampler.sample(obs, act), 2)
 rem = agent.rew_end_model
