@@ -67,7 +67,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #undef WS_ABL
 #define WS_ABL 0
 #endif
-// WS_ABL (DMD_LAB builds only, WRONG results: timing proxies for profiles/): 2 = no activation global loads,
+// WS_ABL (DMD_LAB builds only, WRONG results: timing proxies for profiles/): 2 = no activation global loads, 4 = no staging arithmetic,
 // 16 = no MFMA loop, 32 = no weight movement, 128 = no epilogue global stores / residual loads.
 
 // NCB = 32-output-channel blocks of the convolution (2: Cout = 64, the U-Net; 1: Cout = 32, the reward/end model and
@@ -198,8 +198,20 @@ __device__ __forceinline__ void ws_aload(f32x4& dst, const f32x4* src) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(src) : "memory");
 }
 // the same with a wave-uniform base (SGPR pair) + a 32-bit per-lane byte offset: no 64-bit address arithmetic per load
+// (FIRST: the base may come straight out of v_readfirstlane -- a VALU write of an SGPR needs 5 wait states before a
+//  vector-memory instruction reads it, and hipcc pads nothing inside an asm statement)
+template <bool FIRST>
 __device__ __forceinline__ void ws_aload(f32x4& dst, const void* base, unsigned voff) {
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(base) : "memory");
+  if constexpr (FIRST)
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(base) : "memory");
+  else
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(base) : "memory");
+}
+// a pointer the compiler must treat as wave-uniform (it is: kernel arguments and the stream position)
+__device__ __forceinline__ const char* ws_uniform_ptr(const char* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const char*)(((unsigned long long)hi << 32) | lo);
 }
 // wait until at most N vector-memory operations of this wave are outstanding; `v` is usable afterwards
 template <int N>
@@ -510,7 +522,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       const dmd_conv_src& sc = p.src[si];
       // source bytes of item `it` = wave-uniform base (source + this chunk's 64 bytes) + pixel * C * 4 + this lane's quad;
       // 24-bit multiply: pixel indices and C * 4 are far below 2^24, the product fits 32 bits (launch check)
-      const char* base = (const char*)sc.x + (si ? ck - nch0 : ck) * 64;
+      const char* base = ws_uniform_ptr((const char*)sc.x + (si ? ck - nch0 : ck) * 64);
       const unsigned cbytes = (unsigned)sc.C * 4u;
       ws_for<0, G::ITEMS>([&](auto ic) {
         constexpr int it = decltype(ic)::value;
@@ -520,7 +532,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         const unsigned voff = __umul24((unsigned)goff[it], cbytes) + 16u * q;
 #endif
         if constexpr (G::ASM_LOADS)
-          ws_aload(st[it], base, voff);
+          ws_aload<it == 0>(st[it], base, voff);
         else
           st[it] = *(const f32x4*)(base + voff);
       });
@@ -532,7 +544,15 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     // before the wait -- where the paths meet.  34 VALU instructions per item (54 in round 2): every VALU instruction
     // of a staging wave delays the MFMA issue of the consumer wave on its SIMD by a few cycles.
     // NEWER (ASM_LOADS) = loads issued after this set's: they may stay in flight.
-    auto stage_S = [&](int e, auto& st, unsigned zmask, int slot) {
+    // e_next >= 0: the register set is re-issued for that element (two steps ahead) as soon as the set has been read -- right
+    // after the first arithmetic phase where one batch covers the whole set: the loads then leave one by one while the
+    // vector-memory queue drains, instead of as a burst at the end of the step
+    auto stage_S = [&](int e, auto& st, unsigned& zm_set, int& sl_set, int e_next) {
+      const unsigned zmask = zm_set;
+      const int slot = sl_set;
+      auto reissue = [&]() __attribute__((always_inline)) {
+        if (e_next >= 0) issue_S(e_next, st, zm_set, sl_set);
+      };
       constexpr int NEWER = G::DOUBLE_STAGE ? G::ITEMS : 0;
       const int ck = e % nchunks;
       const int cc = ck * 16 + 4 * q;
@@ -586,6 +606,11 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (BATCH == G::ITEMS) {
+          reissue();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#if !(WS_ABL & 4)
 #pragma unroll
         for (int i = 0; i < NB; ++i)
 #pragma unroll
@@ -611,6 +636,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           }
         }
         __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
           const int it = I0 + i;
@@ -627,6 +653,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         }
         __builtin_amdgcn_sched_barrier(0);
       });
+      if constexpr (BATCH != G::ITEMS) reissue();
     };
 
     f32x4 stage0[G::ITEMS], stage1[G::DOUBLE_STAGE ? G::ITEMS : 1];
@@ -638,16 +665,14 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       issue_S(0, stage0, zm0, sl0);
       issue_S(1, stage1, zm1, sl1);
       ws_barrier();  // B(-1): the tables written by setup_tile are visible to all producers
-      stage_S(0, stage0, zm0, sl0);
-      issue_S(2, stage0, zm0, sl0);
+      stage_S(0, stage0, zm0, sl0, 2);
       ws_barrier();  // B0: buffer 0 = element 0
       // step j: consumers compute element j, producers fill element j + 1 (register set (j + 1) & 1)
       for (int j = 0; j < S; j += 2) {
         WS_STAMP(2, 0, j);
         if (j + 1 < S) {
-          stage_S(j + 1, stage1, zm1, sl1);
+          stage_S(j + 1, stage1, zm1, sl1, j + 3);
           WS_STAMP(2, 1, j);
-          issue_S(j + 3, stage1, zm1, sl1);
           WS_STAMP(2, 2, j);
         }
         ws_barrier();
@@ -655,9 +680,8 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         if (j + 1 < S) {
           WS_STAMP(2, 0, j + 1);
           if (j + 2 < S) {
-            stage_S(j + 2, stage0, zm0, sl0);
+            stage_S(j + 2, stage0, zm0, sl0, j + 4);
             WS_STAMP(2, 1, j + 1);
-            issue_S(j + 4, stage0, zm0, sl0);
             WS_STAMP(2, 2, j + 1);
           }
           ws_barrier();
@@ -674,13 +698,11 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       // one register set: activations are fetched one step ahead only
       issue_S(0, stage0, zm0, sl0);
       ws_barrier();  // B(-1)
-      stage_S(0, stage0, zm0, sl0);
-      if (S > 1) issue_S(1, stage0, zm0, sl0);
+      stage_S(0, stage0, zm0, sl0, S > 1 ? 1 : -1);
       ws_barrier();  // B0
       for (int j = 0; j < S; ++j) {
         if (j + 1 < S) {
-          stage_S(j + 1, stage0, zm0, sl0);
-          if (j + 2 < S) issue_S(j + 2, stage0, zm0, sl0);
+          stage_S(j + 1, stage0, zm0, sl0, j + 2 < S ? j + 2 : -1);
         }
         ws_barrier();
       }
@@ -729,6 +751,17 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     using StatAcc = std::conditional_t<G::B8, float, double>;
     StatAcc ssum[NSTAT], ssq[NSTAT];
     int pending = 4;   // next block of the finished tile to write (4 = nothing pending)
+    // residual of the NEXT block to write, fetched a chunk step ahead (zeros without a residual): the write-out wave
+    // otherwise sits out an HBM round trip between its DMA issue and its stores, at every step
+    // (32-cout geometries: no registers to spare -- fetched where it is used)
+    constexpr bool RES_PREFETCH = G::NCB == 2;
+    f32x4 rnext[4];
+    auto res_prefetch = [&](int blk) __attribute__((always_inline)) {
+      const int po = pixoff_of(blk);
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd)
+        rnext[qd] = (p.residual && po >= 0 && !(WS_ABL & 128)) ? *(const f32x4*)(p.residual + (size_t)po * 4 + 8 * qd) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
     auto epi_begin = [&](int k) {
       const int tile = WS_TILE(k);
 #pragma unroll
@@ -763,6 +796,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         ssq[kk] = 0;
       }
       pending = 0;
+      if (RES_PREFETCH) res_prefetch(0);
     };
     // blocks [pending, pending + count) of the finished tile: bias, residual, store, statistics
     // `land`: wait for this wave's LDS-DMA (issued before the call) after the residual loads and BEFORE the stores of the
@@ -788,31 +822,34 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         const int po = pixoff_of(blk);
         if (po >= 0) {
           float* op = p.out + (size_t)po * 4;
-          f32x4 rv[4];
+          // the residual of this block was fetched one step ago (res_prefetch at the end of the previous block / epi_begin)
+          if (!RES_PREFETCH) res_prefetch(blk);
+          f32x4 v[4];
 #pragma unroll
-          for (int qd = 0; qd < 4; ++qd)
-            rv[qd] = (p.residual && !(WS_ABL & 128)) ? *(const f32x4*)(p.residual + (size_t)po * 4 + 8 * qd) : (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (land) {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]) : : "memory");
+          for (int qd = 0; qd < 4; ++qd) {
+            v[qd] = (f32x4){acc[blk][4 * qd], acc[blk][4 * qd + 1], acc[blk][4 * qd + 2], acc[blk][4 * qd + 3]};
+            v[qd] += rnext[qd];
+          }
+          if (land) {  // (the waits hipcc emits for `rnext` leave the younger LDS-DMA in flight; this one does not)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             land = false;
           }
           float fs = 0.f, fq = 0.f;  // fp32 over the lane's 16 values of this block, fp64 across
 #pragma unroll
           for (int qd = 0; qd < 4; ++qd) {
-            f32x4 v = (f32x4){acc[blk][4 * qd], acc[blk][4 * qd + 1], acc[blk][4 * qd + 2], acc[blk][4 * qd + 3]};
-            v += rv[qd];
-            if (!(WS_ABL & 128) || v[0] == 1.2345e30f) *(f32x4*)(op + 8 * qd) = v;
-            fs += (v[0] + v[1]) + (v[2] + v[3]);
+            if (!(WS_ABL & 128) || v[qd][0] == 1.2345e30f) *(f32x4*)(op + 8 * qd) = v[qd];
+            fs += (v[qd][0] + v[qd][1]) + (v[qd][2] + v[qd][3]);
             // Sum of squares as an fma chain into its own register, NOT as in-place squares of v: with the squares
             // written over v's registers (`v_mul_f32 v48, v48, v48` right behind the `global_store_dwordx4 v[48:51]`),
             // a slice executed while the other consumer group's MFMAs run on the same SIMD lost one lane's
             // contribution of a block now and then (sum and stored outputs exact, sum of squares short by ~16 values)
             // -- found by tests/test_gpu_tpw.py (tiles_per_wg >= 2), round 2.
-            fq = __builtin_fmaf(v[0], v[0], fq);
-            fq = __builtin_fmaf(v[1], v[1], fq);
-            fq = __builtin_fmaf(v[2], v[2], fq);
-            fq = __builtin_fmaf(v[3], v[3], fq);
+            fq = __builtin_fmaf(v[qd][0], v[qd][0], fq);
+            fq = __builtin_fmaf(v[qd][1], v[qd][1], fq);
+            fq = __builtin_fmaf(v[qd][2], v[qd][2], fq);
+            fq = __builtin_fmaf(v[qd][3], v[qd][3], fq);
           }
+          if (RES_PREFETCH && blk + 1 < 4) res_prefetch(blk + 1);  // behind the stores: in flight across the barrier, used next step
           const int slot = G::B8 ? (blk >> 1) : 0;
           ssum[slot] += (StatAcc)fs;
           ssq[slot] += (StatAcc)fq;

@@ -6,6 +6,7 @@ import torch
 from diamond_amd import engine as E, native as nv
 
 prec = sys.argv[1] if len(sys.argv) > 1 else "f16x2"
+ZERO = os.environ.get("CONV_BENCH_ZERO", "0") == "1"  # zero-filled activations / weights: the DVFS give-back (same instructions, less toggling)
 dev = "cuda"
 SHAPES = [  # N, H, [Cins], prologue, residual, upsample
     (256, 64, [64], 1, True, False),
@@ -27,12 +28,15 @@ for n, h, cins, prologue, res, up in SHAPES:
     hs = h // 2 if up else h
     srcs = []
     for c in cins:
-        a = E.gn_stats(torch.randn(n, hs, hs, c, device=dev)) if prologue else E.Act(torch.randn(n, hs, hs, c, device=dev))
+        xin = torch.zeros(n, hs, hs, c, device=dev) if ZERO else torch.randn(n, hs, hs, c, device=dev)
+        a = E.gn_stats(xin) if prologue else E.Act(xin)
         spec = E.NormSpec(mul=torch.randn(n, c, device=dev) * 0.1, add=torch.randn(n, c, device=dev) * 0.1, mul_stride=c,
                           add_stride=c, plus_one=True) if prologue else None
         srcs.append((a, prologue, spec))
     cin = sum(cins)
     w = torch.randn(COUT, cin, 3, 3, device=dev) / (cin * 9) ** 0.5
+    if ZERO:
+        w.zero_()
     wp = nv.pack_conv_weight(w)
     w16 = nv.pack_conv_weight_f16x2(w) if prec == "f16x2" else None
     b = torch.zeros(COUT, device=dev)
