@@ -194,9 +194,13 @@ class ResBlock(nn.Module):
     def run(self, ctx: RunCtx, xs: Sequence[Act]) -> Act:
         """xs: the channel-concatenated inputs (never materialised: the conv reads both)."""
         cout = self.conv1.out_channels
+        r, proj = None, None
         if isinstance(self.proj, nn.Identity):
             assert len(xs) == 1
             r = xs[0]
+        elif E.proj_fusable(xs, cout, ctx.precision, ctx.naive):
+            # the up path's 128 -> 64 skip projection rides in conv2's write-out (no HBM round trip of its result)
+            proj = (list(xs), ctx.w16(self.proj), ctx.cache.conv_bias(self.proj))
         else:
             r = E.conv2d([(a, nv.PROLOGUE_NONE, None) for a in xs], ctx.cache.conv_weight(self.proj),
                          ctx.cache.conv_bias(self.proj), cout, taps=1, want_stats=False, naive=ctx.naive,
@@ -209,7 +213,7 @@ class ResBlock(nn.Module):
                      w_f16=ctx.w16(self.conv1), fast_math=ctx.fast_math, module=self.conv1)
         h = E.conv2d([(h, nv.PROLOGUE_NORM_SILU, ctx.film_spec(self.norm2))], ctx.cache.conv_weight(self.conv2),
                      ctx.cache.conv_bias(self.conv2), cout, residual=r, naive=ctx.naive, w_f16=ctx.w16(self.conv2),
-                     fast_math=ctx.fast_math, module=self.conv2)
+                     fast_math=ctx.fast_math, module=self.conv2, proj=proj)
         if not isinstance(self.attn, nn.Identity):
             h = self.attn.run(ctx, h)
         return h

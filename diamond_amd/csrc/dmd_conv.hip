@@ -506,6 +506,7 @@ __global__ void pack_weight_kernel(const float* oihw, float* packed, int Cout, i
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+extern "C" int dmd_conv2d_proj_eligible(const dmd_conv_params* p);
 static int validate_conv(const dmd_conv_params* p) {
   DMD_CHECK_ARG(p != nullptr, "conv: null params");
   DMD_CHECK_ARG(p->N > 0 && p->H > 0 && p->W > 0, "conv: bad N/H/W %d %d %d", p->N, p->H, p->W);
@@ -529,6 +530,9 @@ static int validate_conv(const dmd_conv_params* p) {
   if (p->out_stats) DMD_CHECK_ARG(p->Cout % DMD_GN_GROUP == 0 && p->CoutPad == p->Cout, "conv: out_stats needs Cout %% 32 == 0");
   if (p->residual_norm.stats) DMD_CHECK_ARG(p->residual && p->Cout % DMD_GN_GROUP == 0, "conv: residual_norm");
   if (p->upsample) DMD_CHECK_ARG(p->H % 2 == 0 && p->W % 2 == 0, "conv: upsample needs even output");
+  if (p->proj_nsrc)
+    DMD_CHECK_ARG(dmd_conv2d_proj_eligible(p), "conv: fused skip projection on parameters dmd_conv2d_proj_eligible() rejects "
+                  "(needs F16X2 3x3 stride 1, Cout 64, H, W %% 16 == 0, two 64-channel sources, no residual)");
   return 0;
 }
 
@@ -597,6 +601,8 @@ extern "C" int dmd_conv2d_kernel_name(const dmd_conv_params* p, char* buf, int b
     for (int i = 0; i < p->nsrc; ++i) cin += p->src[i].C;
     snprintf(buf, buf_len, "conv1x1_stream_kernel<%d, %d, %s>", cin / 16, cin == 128 ? 2 : 4,
              (p->precision & 0xff) == DMD_PRECISION_F16X2 ? "true" : "false");
+  } else if (p->proj_nsrc) {
+    snprintf(buf, buf_len, "conv_f16ws_kernel<WsGeomProj>");
   } else if (dmd_conv2d_f16x2_eligible(p)) {
     snprintf(buf, buf_len, "conv_f16ws_kernel<WsGeom<%s, %d, %d>>", b8 ? "true" : "false", p->CoutPad == 64 ? 2 : 1, p->taps);
   } else {
@@ -609,6 +615,7 @@ extern "C" int dmd_conv2d_kernel_name(const dmd_conv_params* p, char* buf, int b
 
 extern "C" int dmd_conv2d_naive(const dmd_conv_params* p, dmd_stream_t stream) {
   if (int e = validate_conv(p)) return e;
+  DMD_CHECK_ARG(!p->proj_nsrc, "naive conv: no fused skip projection (run the projection as its own launch)");
   hipStream_t st = (hipStream_t)stream;
   const size_t total = (size_t)p->N * p->H * p->W * p->Cout;
   dmd_conv_params q = *p;

@@ -56,6 +56,7 @@
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -114,6 +115,23 @@ struct WsGeom {
   static constexpr bool PL_REGS = !(B8_ && NCB_ == 1);
   // patch byte offset of a consumer wave's 32-pixel block `blk` relative to its block 0
   static constexpr int blk_off(int blk) { return (B8_ ? (blk >> 1) * PPS + (blk & 1) * 4 * PW : blk * 2 * PW) * 64; }
+  static constexpr bool PROJ = false;  // fused skip projection (WsGeomProj)
+  static constexpr int PROJ_KS = 1;
+};
+
+// PROJECTION.  The up path's ResBlocks compute  proj(cat(x, skip)) + conv2(...)  (blocks.py:133,147) with a 128 -> 64
+// 1x1 projection: on its own that is an HBM-bound pass of 805 MB per launch at the 64x64 level (read 128 channels, write
+// 64, read them back as conv2's residual) and 11 % of the imagination step.  This geometry adds the projection to the
+// write-out of conv2 instead: the write-out wave of a 32-pixel x 32-cout block fetches the block's 128 raw input
+// channels one chunk step ahead (16 x 16 B per lane -- the NHWC row IS the K-contiguous B operand, as in
+// dmd_conv1x1.hip), splits them in registers and runs 8 k-steps x {w_h x_h, w_h x_l, w_l x_h} into the block's
+// accumulators in front of its stores; the projection's 32 KiB of pre-split weights stay in LDS for the lifetime of the
+// workgroup.  Same MACs as the separate launch, 536 MB less HBM traffic, no residual read.
+struct WsGeomProj : WsGeom<false, 2, 9> {
+  static constexpr bool PROJ = true;
+  static constexpr int PROJ_KS = 8;                               // 16-channel k-steps: two 64-channel sources
+  static constexpr int PROJ_BYTES = PROJ_KS * 2 * 2 * COUT * 16;  // [k-step][h|l][k group][cout] x 16 B
+  static constexpr int SMEM_BYTES = WsGeom<false, 2, 9>::SMEM_BYTES + PROJ_BYTES;
 };
 
 struct WsTile {
@@ -385,6 +403,11 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
   float* tab_d = tab_c + G::TAB_FLOATS;
   float* bias_lds = tab_b + (G::CD_TABLES ? 3 : 1) * G::TAB_FLOATS;  // [COUT]
   static_assert(G::SMEM_BYTES <= 160 * 1024, "LDS budget");
+  unsigned char* proj_lds = (unsigned char*)(bias_lds + G::COUT);  // (PROJ) the projection's weights
+  if constexpr (G::PROJ) {
+    const u32x4* pwg = (const u32x4*)p.proj_w_f16;
+    for (int u = (int)threadIdx.x; u < G::PROJ_BYTES / 16; u += 768) ((u32x4*)proj_lds)[u] = pwg[u];  // visible after B(-1)
+  }
 
   // 0, 1: consumer groups (even / odd tiles), 2: producer (staging).  readfirstlane: wave-uniform by construction, and
   // the compiler must know it (scalar branches and scalar loop counters instead of exec-masked ones)
@@ -754,13 +777,73 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     // residual of the NEXT block to write, fetched a chunk step ahead (zeros without a residual): the write-out wave
     // otherwise sits out an HBM round trip between its DMA issue and its stores, at every step
     // (32-cout geometries: no registers to spare -- fetched where it is used)
-    constexpr bool RES_PREFETCH = G::NCB == 2;
+    constexpr bool RES_PREFETCH = G::NCB == 2 && !G::PROJ;  // (PROJ: the projection is the residual)
     f32x4 rnext[4];
     auto res_prefetch = [&](int blk) __attribute__((always_inline)) {
       const int po = pixoff_of(blk);
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd)
         rnext[qd] = (p.residual && po >= 0 && !(WS_ABL & 128)) ? *(const f32x4*)(p.residual + (size_t)po * 4 + 8 * qd) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    // (PROJ) raw input channels of one projection source at this lane's pixel: k-step kk = xq[2 kk], xq[2 kk + 1] =
+    // channels 16 kk + 8 g + (0..7).  Source 0 of a block is fetched one chunk step ahead (behind the previous block's
+    // stores); source 1 goes into the SAME registers once source 0's MFMAs have consumed them, behind the step's weight
+    // DMA, and lands with it.  (Both sources a step ahead = 64 registers next to the 64 accumulators: hipcc spills them.
+    // Touching source 1's cache lines a step ahead -- one dword per line through an LDS-DMA sink -- changes nothing: the
+    // fused launches are bound by the CU's vector-memory path, which now also carries 64 KiB of projection input per
+    // step, not by the latency of these loads.)
+    f32x4 xq[G::PROJ ? G::PROJ_KS : 1];
+    auto proj_fetch = [&](int blk, int src) __attribute__((always_inline)) {
+      if constexpr (G::PROJ) {
+        const int po = pixoff_of(blk);
+        // uniform base (SGPR pair) + 32-bit byte offset: po = pixel * (COUT / 4) + cb * 8 + g  ->  pixel * 256 + 32 g
+        const unsigned boff = po < 0 ? 0u : ((((unsigned)(po - (cb * 8 + g)) >> 4) << 8) + 32u * g);
+        const char* xs = (const char*)p.proj_x[src] + boff;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          xq[kk * 2] = *(const f32x4*)(xs + kk * 64);
+          xq[kk * 2 + 1] = *(const f32x4*)(xs + kk * 64 + 16);
+        }
+      }
+    };
+    // (PROJ) 4 k-steps of projection source SRC (in xq) into the accumulators of block BLK
+    auto proj_mfma = [&](auto blkc, auto srcc) __attribute__((always_inline)) {
+      if constexpr (G::PROJ) {
+        constexpr int blk = decltype(blkc)::value, src = decltype(srcc)::value;
+        const unsigned char* pw = proj_lds + (g * G::COUT + cb * 32 + n31) * 16;
+        ws_for<0, 4>([&](auto kc) {
+          constexpr int kk = decltype(kc)::value, ks = src * 4 + kk;
+          const f32x4 x0 = xq[2 * kk], x1 = xq[2 * kk + 1];
+          const unsigned h01 = __builtin_bit_cast(unsigned, (h2){(_Float16)x0[0], (_Float16)x0[1]});
+          const unsigned h23 = __builtin_bit_cast(unsigned, (h2){(_Float16)x0[2], (_Float16)x0[3]});
+          const unsigned h45 = __builtin_bit_cast(unsigned, (h2){(_Float16)x1[0], (_Float16)x1[1]});
+          const unsigned h67 = __builtin_bit_cast(unsigned, (h2){(_Float16)x1[2], (_Float16)x1[3]});
+          const h8 xh = __builtin_bit_cast(h8, (u32x4){h01, h23, h45, h67});
+          const h8 xl = __builtin_bit_cast(h8, (u32x4){ws_low_pair(x0[0], x0[1], h01), ws_low_pair(x0[2], x0[3], h23),
+                                                       ws_low_pair(x1[0], x1[1], h45), ws_low_pair(x1[2], x1[3], h67)});
+          const h8 wh = *(const h8*)(pw + (ks * 2 + 0) * 2 * G::COUT * 16);
+          const h8 wl = *(const h8*)(pw + (ks * 2 + 1) * 2 * G::COUT * 16);
+          acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc[blk], 0, 0, 0);
+          acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc[blk], 0, 0, 0);
+          acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc[blk], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);  // k-step by k-step (hoisting all the weight reads / splits costs 60+ registers)
+        });
+      }
+    };
+    // (PROJ) first half of block `pending`, run IN FRONT of the step's weight DMA: source 0's MFMAs (operands fetched a
+    // step ago; behind the DMA hipcc's wait for them would be vmcnt(0) = the DMA's latency), then source 1's loads
+    bool proj_half_done = false;
+    auto proj_first = [&]() __attribute__((always_inline)) {
+      if constexpr (G::PROJ) {
+        ws_for<0, 4>([&](auto bc) {
+          constexpr int blk = decltype(bc)::value;
+          if (blk == pending && pixoff_of(blk) >= 0) {
+            proj_mfma(bc, std::integral_constant<int, 0>{});
+            proj_fetch(blk, 1);
+          }
+        });
+        proj_half_done = true;
+      }
     };
     auto epi_begin = [&](int k) {
       const int tile = WS_TILE(k);
@@ -797,6 +880,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       }
       pending = 0;
       if (RES_PREFETCH) res_prefetch(0);
+      proj_fetch(0, 0);
     };
     // blocks [pending, pending + count) of the finished tile: bias, residual, store, statistics
     // `land`: wait for this wave's LDS-DMA (issued before the call) after the residual loads and BEFORE the stores of the
@@ -823,12 +907,26 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         if (po >= 0) {
           float* op = p.out + (size_t)po * 4;
           // the residual of this block was fetched one step ago (res_prefetch at the end of the previous block / epi_begin)
-          if (!RES_PREFETCH) res_prefetch(blk);
+          if (!RES_PREFETCH && !G::PROJ) res_prefetch(blk);
+          if constexpr (G::PROJ) {
+            // the block's skip projection, into its accumulators (first half: proj_first, unless this call writes
+            // several blocks)
+            ws_for<0, 4>([&](auto bc) {
+              if (decltype(bc)::value == blk) {
+                if (!proj_half_done) {
+                  proj_mfma(bc, std::integral_constant<int, 0>{});
+                  proj_fetch(blk, 1);
+                }
+                proj_mfma(bc, std::integral_constant<int, 1>{});
+              }
+            });
+            proj_half_done = false;
+          }
           f32x4 v[4];
 #pragma unroll
           for (int qd = 0; qd < 4; ++qd) {
             v[qd] = (f32x4){acc[blk][4 * qd], acc[blk][4 * qd + 1], acc[blk][4 * qd + 2], acc[blk][4 * qd + 3]};
-            v[qd] += rnext[qd];
+            if (!G::PROJ) v[qd] += rnext[qd];
           }
           if (land) {  // (the waits hipcc emits for `rnext` leave the younger LDS-DMA in flight; this one does not)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -850,6 +948,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
             fq = __builtin_fmaf(v[qd][3], v[qd][3], fq);
           }
           if (RES_PREFETCH && blk + 1 < 4) res_prefetch(blk + 1);  // behind the stores: in flight across the barrier, used next step
+          if (blk + 1 < 4) proj_fetch(blk + 1, 0);
           const int slot = G::B8 ? (blk >> 1) : 0;
           ssum[slot] += (StatAcc)fs;
           ssq[slot] += (StatAcc)fq;
@@ -890,7 +989,8 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     auto cons_land_W = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };  // the DMA writes have landed before the step's barrier
 
     // the bias row of the convolution: accumulators START from it (no bias loads / adds in the write-out)
-    if (role == 0 && tid < G::COUT) bias_lds[tid] = p.bias ? p.bias[tid] : 0.f;
+    if (role == 0 && tid < G::COUT)
+      bias_lds[tid] = (p.bias ? p.bias[tid] : 0.f) + ((G::PROJ && p.proj_bias) ? p.proj_bias[tid] : 0.f);
     ws_barrier();  // B(-1)
     if (role == 1) {  // group 1 is idle during tile 0: it provides the first chunk's weights
       cons_load_W(0, 0);
@@ -901,7 +1001,8 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     for (int k = 0; k < nmy; ++k) {
       if ((k & 1) == role) {
         // ---- this group's tile: fragment reads + MFMAs only ----
-        if (pending < 4) epi_blocks(4);  // (only if the other group's tile had too few steps to finish the write-out)
+        // (only if the other group's tile had too few steps to finish the write-out; PROJ launches have 4 steps per tile)
+        if (!G::PROJ && pending < 4) epi_blocks(4);
         {
           // lane owns couts cb*32 + 8 qd + 4 g + (0..3), qd = 0..3, of its pixel of each block
           f32x4 bq[4];
@@ -947,6 +1048,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         for (int ck = 0; ck < nchunks; ++ck, ++j) {
           const bool wnext = j + 1 < S;  // this (idle) group copies the next step's weights
           WS_STAMP(role, 8, j);
+          if (G::PROJ && pending < 4) proj_first();
           if (wnext) cons_load_W((j + 1) % nchunks, (j + 1) & 1);
           WS_STAMP(role, 9, j);
           if (pending < 4)
@@ -989,9 +1091,15 @@ static int launch_f16ws(const dmd_conv_params& p, int ntiles, hipStream_t st) {
   return 0;
 }
 
+extern "C" int dmd_conv2d_proj_eligible(const dmd_conv_params* p);
 int dmd_launch_conv_f16ws(const dmd_conv_params& p, hipStream_t st) {
   const bool b8 = p.W % 16 != 0;
   const int sub8 = p.N * (p.H / 8) * (p.W / 8), t16 = p.N * (p.H / 16) * (p.W / 16);
+  if (p.proj_nsrc) {
+    DMD_CHECK_ARG(dmd_conv2d_proj_eligible(&p), "conv: the fused skip projection needs a split-fp16 3x3 stride-1 launch with Cout 64, "
+                  "H, W multiples of 16, two 64-channel projection sources and no other residual (dmd_conv2d_proj_eligible)");
+    return launch_f16ws<WsGeomProj>(p, t16, st);
+  }
   if (p.taps == 9) {
     if (p.CoutPad == 64) return b8 ? launch_f16ws<WsGeom<true, 2, 9>>(p, (sub8 + 3) / 4, st) : launch_f16ws<WsGeom<false, 2, 9>>(p, t16, st);
     return b8 ? launch_f16ws<WsGeom<true, 1, 9>>(p, (sub8 + 7) / 8, st) : launch_f16ws<WsGeom<false, 1, 9>>(p, (t16 + 1) / 2, st);
@@ -1054,4 +1162,16 @@ extern "C" int dmd_conv2d_f16x2_eligible(const dmd_conv_params* p) {
   const bool a16 = p->H % 16 == 0 && p->W % 16 == 0;
   const bool b8 = p->W % 16 != 0;
   return (a16 || b8) ? 1 : 0;
+}
+
+// 1: the proj_* fields of these parameters can be fused into the launch (WsGeomProj)
+extern "C" int dmd_conv2d_proj_eligible(const dmd_conv_params* p) {
+  if (!p || !dmd_conv2d_f16x2_eligible(p)) return 0;
+  if (p->taps != 9 || p->upsample || p->Cout != 64 || p->CoutPad != 64 || p->out_nchw || p->residual) return 0;
+  if (p->H % 16 != 0 || p->W % 16 != 0) return 0;
+  // 4 chunk steps per tile = one 32-pixel block of the finished tile per step (the kernel has no catch-up path)
+  if (p->nsrc != 1 || p->src[0].C != 64) return 0;
+  if ((long long)p->N * p->H * p->W * 256 >= (1ll << 32)) return 0;  // 32-bit byte offsets into the projection sources
+  if (p->proj_nsrc != 2 || !p->proj_w_f16 || !p->proj_x[0] || !p->proj_x[1] || p->proj_C[0] != 64 || p->proj_C[1] != 64) return 0;
+  return 1;
 }

@@ -176,6 +176,7 @@ def conv2d(
     w_f16: Optional[Tensor] = None,
     fast_math: bool = False,
     module: Optional[nn.Module] = None,
+    proj: Optional[Tuple[Sequence[Act], Tensor, Optional[Tensor]]] = None,  # fused skip projection: (sources, w_f16 (k = 1), bias)
 ) -> Act:
     a0 = srcs[0][0]
     n, hs, ws, _ = a0.shape
@@ -213,6 +214,18 @@ def conv2d(
         out = torch.empty(n, h, w, cout, device=dev, dtype=torch.float32)
     p.out = nv.ptr(out)
     p.out_nchw = int(out_nchw)
+    if proj is not None:
+        # `proj(cat(sources)) + conv(...)` in one launch (ResBlock.forward, blocks.py:147); dmd_conv2d fails loudly
+        # on parameters dmd_conv2d_proj_eligible() rejects -- the caller asks proj_fusable() first
+        p_srcs, p_w16, p_bias = proj
+        assert TAPE is None and residual is None and len(p_srcs) == 2
+        p.proj_nsrc = len(p_srcs)
+        for i, a in enumerate(p_srcs):
+            assert a.t.is_contiguous() and a.t.dtype == torch.float32 and tuple(a.shape[:3]) == (n, h, w)
+            p.proj_x[i] = nv.ptr(a.t)
+            p.proj_C[i] = a.C
+        p.proj_w_f16 = nv.ptr(p_w16)
+        p.proj_bias = nv.ptr(p_bias)
     stats, tiles = None, 0
     if want_stats:
         tiles = nv.conv_stat_tiles(h, w)
@@ -224,6 +237,9 @@ def conv2d(
         cin = sum(a.C for a, _, _ in srcs)
         flops = 2.0 * n * h * w * cout * cin * taps  # algorithmic: MAC = 2, real channels
         nbytes = 4.0 * (sum(a.t.numel() for a, _, _ in srcs) + out.numel() + (residual.t.numel() if residual is not None else 0))
+        if proj is not None:
+            flops += 2.0 * n * h * w * cout * sum(a.C for a in proj[0])
+            nbytes += 4.0 * sum(a.t.numel() for a in proj[0])
         nv.PROFILER.annotate(kernel_key(p), flops, nbytes)
     nv.check(fn(C.byref(p), nv.stream()), "dmd_conv2d")
     result = Act(out, stats, tiles)
@@ -231,6 +247,19 @@ def conv2d(
         assert module is not None, "recording a conv launch that does not name its nn.Conv2d"
         TAPE.append(ConvRecord(list(srcs), module, taps, stride, upsample, residual, residual_norm, result, out_nchw))
     return result
+
+
+FUSE_PROJ = os.environ.get("DIAMOND_FUSE_PROJ", "1") != "0"  # skip projections inside conv2's launch (dmd_conv_f16ws.hip: PROJECTION)
+
+
+def proj_fusable(xs: Sequence[Act], cout: int, precision: str, naive: Optional[bool]) -> bool:
+    """Mirror of dmd_conv2d_proj_eligible() for a ResBlock whose conv2 is cout -> cout: split-fp16 inference launch (no
+    tape), cout == 64, H, W multiples of 16, two 64-channel projection sources."""
+    if not FUSE_PROJ or precision != "f16x2" or naive or _USE_NAIVE or TAPE is not None:
+        return False
+    n, hh, ww, _ = xs[0].shape
+    return (cout == 64 and hh % 16 == 0 and ww % 16 == 0 and len(xs) == 2 and all(a.C == 64 for a in xs)
+            and n * hh * ww * 256 < 2 ** 32)
 
 
 def gn_stats(t: Tensor) -> Act:

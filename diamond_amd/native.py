@@ -40,7 +40,8 @@ class ConvParams(C.Structure):
                 ("taps", C.c_int32), ("stride", C.c_int32), ("upsample", C.c_int32), ("nsrc", C.c_int32),
                 ("src", ConvSrc * 2), ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p),
                 ("residual_norm", Norm), ("out", C.c_void_p), ("out_nchw", C.c_int32), ("precision", C.c_int32),
-                ("out_stats", C.c_void_p), ("w_f16", C.c_void_p)]
+                ("out_stats", C.c_void_p), ("w_f16", C.c_void_p), ("proj_nsrc", C.c_int32), ("proj_C", C.c_int32 * 2),
+                ("proj_reserved", C.c_int32), ("proj_x", C.c_void_p * 2), ("proj_w_f16", C.c_void_p), ("proj_bias", C.c_void_p)]
 
 
 class LinearParams(C.Structure):
@@ -80,7 +81,7 @@ class LowresChainParams(C.Structure):
 
 EXPORTS = (
     "dmd_conv2d", "dmd_conv2d_kernel_name", "dmd_conv2d_naive", "dmd_conv_stat_tiles", "dmd_pack_conv_weight", "dmd_conv2d_f16x2_eligible",
-    "dmd_conv1x1_stream_eligible",
+    "dmd_conv1x1_stream_eligible", "dmd_conv2d_proj_eligible",
     "dmd_pack_conv_weight_f16x2", "dmd_linear", "dmd_attention", "dmd_attention_bwd", "dmd_attention_bwd_workspace_floats",
     "dmd_edm_pack_input", "dmd_cond_embed", "dmd_edm_denoised", "dmd_euler_step", "dmd_heun_step", "dmd_quantize_u8",
     "dmd_dequant_gather", "dmd_nchw_to_nhwc",
@@ -92,7 +93,7 @@ EXPORTS = (
 # entry points that launch kernels (everything except queries / packing helpers that bench.py does not time)
 LAUNCHERS = frozenset(n for n in EXPORTS if n not in (
     "dmd_conv2d_kernel_name", "dmd_conv_stat_tiles", "dmd_conv2d_f16x2_eligible", "dmd_conv1x1_stream_eligible",
-    "dmd_attention_bwd_workspace_floats", "dmd_gn_bwd_workspace_bytes", "dmd_wgrad_workspace_floats", "dmd_last_error", "dmd_abi_version"))
+    "dmd_conv2d_proj_eligible", "dmd_attention_bwd_workspace_floats", "dmd_gn_bwd_workspace_bytes", "dmd_wgrad_workspace_floats", "dmd_last_error", "dmd_abi_version"))
 
 
 class LaunchProfiler:
@@ -173,6 +174,7 @@ def lib() -> _Lib:
         L.dmd_pack_conv_weight_f16x2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.dmd_conv2d_f16x2_eligible.argtypes = [C.POINTER(ConvParams)]
         L.dmd_conv1x1_stream_eligible.argtypes = [C.POINTER(ConvParams)]
+        L.dmd_conv2d_proj_eligible.argtypes = [C.POINTER(ConvParams)]
         L.dmd_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.dmd_attention_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_void_p]

@@ -72,6 +72,16 @@ typedef struct dmd_conv_params {
   int32_t precision; /* DMD_PRECISION_*: arithmetic of the contraction (see below)       */
   double* out_stats; /* (N, Cout/32, T, 2) partial sums of the output, or NULL          */
   const void* w_f16; /* dmd_pack_conv_weight_f16x2 layout, or NULL (needed for F16X2)    */
+  /* Optional FUSED SKIP PROJECTION (ResBlock.forward, blocks.py:133,147: `self.proj(x) + conv2(...)` with
+   * x = cat(x_up, skip)): a 1x1 convolution of proj_nsrc raw NHWC sources of the OUTPUT's N, H, W, accumulated into the
+   * same fp32 accumulators as the 3x3 contraction -- the (N, H, W, Cout) projection is never written to or read from
+   * HBM.  Honoured only where dmd_conv2d_proj_eligible() says so; dmd_conv2d fails loudly otherwise. */
+  int32_t proj_nsrc;      /* 0: none; 2: two sources                                     */
+  int32_t proj_C[2];      /* channels of each source                                     */
+  int32_t proj_reserved;
+  const float* proj_x[2]; /* NHWC (N, H, W, proj_C[i]), no prologue                      */
+  const void* proj_w_f16; /* dmd_pack_conv_weight_f16x2(k = 1) of the (Cout, sum C, 1, 1) weights */
+  const float* proj_bias; /* [Cout] or NULL                                              */
 } dmd_conv_params;
 
 /* DMD_PRECISION_F32:   v_mfma_f32_16x16x4_f32, bit-for-bit a k-ordered fp32 fma chain.
@@ -85,6 +95,10 @@ typedef struct dmd_conv_params {
 #define DMD_PRECISION_F32 0
 #define DMD_PRECISION_F16X2 1
 int dmd_conv2d_f16x2_eligible(const dmd_conv_params* p);
+/* 1: dmd_conv2d can fuse the skip projection described by the proj_* fields into this launch (split-fp16 3x3 stride 1,
+ * one 64-channel
+ * source, Cout == 64, H, W multiples of 16, two 64-channel projection sources, no other residual) */
+int dmd_conv2d_proj_eligible(const dmd_conv_params* p);
 /* 1: dmd_conv2d runs these parameters on the streaming 1x1 kernel (exact fp32; taps == 1, Cout == 64, no
  * prologue / residual / statistics, Cin in {32, 64, 128}): blocks.py:120,133 skip projections */
 int dmd_conv1x1_stream_eligible(const dmd_conv_params* p);
