@@ -196,12 +196,117 @@ def precision_label(E, ac_native):
     return f"{short} ({wm}; {ac}; LSTM cells / heads: exact fp32 MFMA (dmd_linear))"
 
 
+def latency_run(graph: bool, frames: int, warmup: int = 12):
+    """ms per imagined frame of the B=1 interactive env (reference play.py:105-109, game/play_env.py:113-127): each frame =
+    WorldModelEnv.step(act) (3 Euler denoising steps + reward/end model + bookkeeping) + the play loop's host read of the
+    reward.  Returns (ms per frame, ms per frame of the sampler alone)."""
+    import diamond_amd as D
+
+    dev = torch.device("cuda:0")
+    agent = build_agent(dev, 64, 0)
+    env = D.WorldModelEnv(agent.denoiser, agent.rew_end_model, _Loader(1, 7, 64),
+                          D.WorldModelEnvConfig(horizon=100000, num_batches_to_preload=1,
+                                                diffusion_sampler=D.DiffusionSamplerConfig(num_steps_denoising=3)),
+                          return_denoising_trajectory=True, graph_sampler=graph)
+    env.reset()
+    act = torch.zeros(1, dtype=torch.long, device=dev)
+    for _ in range(max(warmup, 12)):  # caches, and in graph mode one capture per ring head
+        env.step(act)
+    torch.cuda.synchronize()
+    t_s = 0.0
+    for _ in range(frames):
+        ts = time.perf_counter()
+        env.predict_next_obs()
+        torch.cuda.synchronize()
+        t_s += time.perf_counter() - ts
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        _, rew, _, _, _ = env.step(act)
+        float(rew.item())
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / frames, 1e3 * t_s / frames
+
+
+def latency_line(args):
+    frames = args.steps or 200
+    eager, eager_s = latency_run(False, frames, args.warmup)
+    graph, graph_s = latency_run(True, frames, args.warmup)
+    return {"metric": "ms per imagined frame, B=1 interactive world-model env (64x64, 3 Euler denoise steps)", "value": graph,
+            "unit": "ms/frame", "n_gpus": 1, "steps": frames, "warmup": max(args.warmup, 12), "ms_per_step": graph,
+            "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f32 via split-f16 MFMA", "data": "synthetic",
+            "config": {"workload": "SURVEY §8 (f4): play.py's B=1 WorldModelEnv.step + host read of the reward per frame; the "
+                                   "sampler's launches replayed as one hipGraph per ring head", "global_batch": 1},
+            "frames_per_s": 1e3 / graph, "eager_ms_per_frame": eager, "sampler_only_graph_ms": graph_s,
+            "sampler_only_eager_ms": eager_s}
+
+
+def train_line(args):
+    """Denoiser training step (reference trainer.py:349-388, denoiser.py:93-122): forward over a segment of
+    4 conditioning + 1 predicted frame, backward, gradient clipping, AdamW -- at the reference batch of 32 (--batch)."""
+    from types import SimpleNamespace
+
+    import diamond_amd as D
+    from diamond_amd.testing import fill_module_, synthetic_actions, synthetic_frames
+
+    b, steps = args.batch or 32, args.steps or 20
+    dev = torch.device("cuda:0")
+    agent = D.Agent(D.default_agent_config())
+    fill_module_(agent, 0)
+    den = agent.denoiser.to(dev).train()
+    den.setup_training(D.SigmaDistributionConfig(loc=-0.4, scale=1.2, sigma_min=2e-3, sigma_max=20))
+    opt = torch.optim.AdamW(den.parameters(), lr=1e-4)
+    g = torch.Generator().manual_seed(0)
+    t = 5
+    batch = SimpleNamespace(obs=synthetic_frames(g, b, t, 3, 64, 64).to(dev), act=synthetic_actions(g, 4, b, t).to(dev),
+                            mask_padding=torch.ones(b, t, dtype=torch.bool, device=dev))
+
+    def step():
+        loss, _ = den(batch)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(den.parameters(), 1.0)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss.detach()  # (no reference to the autograd graph survives the step: train_graph.py)
+
+    for _ in range(max(args.warmup, 3)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt_eager = (time.perf_counter() - t0) / steps
+    # the same step captured into one hipGraph and replayed on static input buffers (diamond_amd/train_graph.py)
+    from diamond_amd.train_graph import GraphedTrainStep
+
+    opt_g = torch.optim.AdamW(den.parameters(), lr=1e-4, capturable=True)
+    gstep = GraphedTrainStep(den, opt_g, 1.0, batch, warmup_steps=max(args.warmup, 3))
+    for _ in range(2):
+        gstep(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, _ = gstep(batch)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"metric": "denoiser training step (forward + backward + clip + AdamW), 64x64, 1 predicted frame per segment",
+            "value": 1e3 * dt, "unit": "ms/step", "n_gpus": 1, "steps": steps, "warmup": max(args.warmup, 3), "ms_per_step": 1e3 * dt,
+            "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f32 via split-f16 MFMA", "data": "synthetic",
+            "config": {"workload": "SURVEY §8 (f2): Denoiser.forward(batch) + loss.backward() + clip_grad_norm_ + AdamW, the whole step "
+                                   "replayed as one hipGraph (GraphedTrainStep)", "global_batch": b},
+            "frames_per_s": b / dt, "eager_ms_per_step": 1e3 * dt_eager, "loss": float(loss.detach()),
+            "algorithmic_tflops": 3 * 6.0909e9 * b / dt / 1e12}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="BASELINE.json configs[] index (1, 3 or 4)")
+    ap.add_argument("--config", type=str, default="1", choices=[str(k) for k in sorted(CONFIGS)] + ["latency", "train"],
+                    help="BASELINE.json configs[] index (1, 3 or 4), or one of the SURVEY §8 'next' rows: latency = B=1 "
+                         "interactive world-model env (f4, play.py), train = denoiser training step at the reference batch (f2)")
     ap.add_argument("--batch", type=int, default=None, help="imagination batch PER GPU")
     ap.add_argument("--horizon", type=int, default=None)
     ap.add_argument("--denoise-steps", type=int, default=None)
@@ -217,6 +322,13 @@ def main():
     ap.add_argument("--no-exact-fp32", action="store_true")
     ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.config in ("latency", "train"):
+        assert args.gpus == 1, "--config latency / train are single-GPU measurements"
+        torch.cuda.set_device(0)
+        line = latency_line(args) if args.config == "latency" else train_line(args)
+        print(json.dumps(line))
+        return
+    args.config = int(args.config)
     preset = CONFIGS[args.config]
     for k, v in preset.items():
         if getattr(args, k) is None:

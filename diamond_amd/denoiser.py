@@ -181,13 +181,19 @@ class Denoiser(nn.Module):
         nv.check(nv.lib().dmd_edm_pack_input(nv.fptr(xc), nv.fptr(oc), nv.fptr(cond4), 4, float(self.cfg.sigma_data), nv.fptr(packed),
                                              n, cx, cobs, h, w, cpad, 1, 0, nv.stream()), "dmd_edm_pack_input")
         # cond = cond_proj(noise_emb(c_noise) + act_emb(act))  (inner_model.py:45, blocks.py:84-87)
-        f = 2 * math.pi * c_noise.detach().unsqueeze(1) @ im.noise_emb.weight
-        cond = im.cond_proj(torch.cat([f.cos(), f.sin()], dim=-1) + im.act_emb(act))
+        # (an outer product: every element is ONE fp32 product, exactly what the (B, 1) @ (1, C) GEMM computes)
+        f = 2 * math.pi * c_noise.detach().unsqueeze(1) * im.noise_emb.weight
+        # the cond MLP and the FiLM table -- three small GEMMs and their backward -- on dmd_linear (lstm_native.LinearFn)
+        from .lstm_native import LinearFn
+
+        l0, l2 = im.cond_proj[0], im.cond_proj[2]
+        cond = LinearFn.apply(im._cache, torch.cat([f.cos(), f.sin()], dim=-1) + im.act_emb(act), l0.weight, l0.bias)
+        cond = LinearFn.apply(im._cache, F.silu(cond), l2.weight, l2.bias)
         if im._film is None:
             im._film = FilmTable(im.unet)
         w_cat = torch.cat([m.linear.weight for m in im._film.norms], dim=0)
         b_cat = torch.cat([m.linear.bias for m in im._film.norms], dim=0)
-        table = F.linear(cond, w_cat, b_cat)
+        table = LinearFn.apply(im._cache, cond, w_cat, b_cat)
         if self._train_params is None:
             self._train_params = UT.trainable_unet_params(im)
         return UT.UNetTrainFn.apply(im, packed, table, precision or UT.TRAIN_PRECISION, *self._train_params)
@@ -213,7 +219,13 @@ class Denoiser(nn.Module):
             model_output = self.model_output_with_grad(noisy_next_obs, obs, act, cs)
             c_in, c_out, c_skip, c_noise = (v.reshape(-1, 1, 1, 1) for v in cs)
             target = (next_obs - c_skip * noisy_next_obs) / c_out
-            loss = loss + F.mse_loss(model_output[mask], target[mask])
+            # F.mse_loss(model_output[mask], target[mask]) (reference :114) without the boolean gather: the gather's
+            # output shape depends on device data, i.e. a host synchronisation per segment step (and no hipGraph capture
+            # of the training step, train_graph.py); same value up to the fp32 summation order; 0 / 0 = nan for an
+            # all-padding batch, like the mean over an empty selection
+            w = mask.to(model_output.dtype).reshape(-1, 1, 1, 1)
+            per = model_output[0].numel()
+            loss = loss + ((model_output - target).square() * w).sum() / (w.sum() * per)
             denoised = self.wrap_model_output(noisy_next_obs, model_output.detach(), sigma, cond4=torch.stack(cs, 1).contiguous())
             all_obs[:, n + i] = denoised
         loss = loss / seq_length
