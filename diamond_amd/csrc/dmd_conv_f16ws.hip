@@ -131,6 +131,7 @@ struct WsGeomProj : WsGeom<false, 2, 9> {
   static constexpr bool PROJ = true;
   static constexpr int PROJ_KS = 8;                               // 16-channel k-steps: two 64-channel sources
   static constexpr int PROJ_BYTES = PROJ_KS * 2 * 2 * COUT * 16;  // [k-step][h|l][k group][cout] x 16 B
+  static constexpr bool PL_REGS = false;  // at the register cap: the l pieces' addresses are h ^ 32 at every read
   static constexpr int SMEM_BYTES = WsGeom<false, 2, 9>::SMEM_BYTES + PROJ_BYTES;
 };
 
@@ -771,7 +772,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     int stat_slot[NSTAT];  // out_stats slot per statistics tile of this wave, -1: none
     // per-lane partial sums of a statistics tile: fp64 across a 16x16 geometry's four blocks; the 8x8 geometries (two blocks
     // = 32 values per lane and tile, and short of registers) keep them in fp32 -- fp64 from the wave reduction on
-    using StatAcc = std::conditional_t<G::B8, float, double>;
+    using StatAcc = std::conditional_t<G::B8 || G::PROJ, float, double>;  // (PROJ: at the register cap; 4 fp32 block sums per lane)
     StatAcc ssum[NSTAT], ssq[NSTAT];
     int pending = 4;   // next block of the finished tile to write (4 = nothing pending)
     // residual of the NEXT block to write, fetched a chunk step ahead (zeros without a residual): the write-out wave
@@ -785,64 +786,44 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       for (int qd = 0; qd < 4; ++qd)
         rnext[qd] = (p.residual && po >= 0 && !(WS_ABL & 128)) ? *(const f32x4*)(p.residual + (size_t)po * 4 + 8 * qd) : (f32x4){0.f, 0.f, 0.f, 0.f};
     };
-    // (PROJ) raw input channels of one projection source at this lane's pixel: k-step kk = xq[2 kk], xq[2 kk + 1] =
-    // channels 16 kk + 8 g + (0..7).  Source 0 of a block is fetched one chunk step ahead (behind the previous block's
-    // stores); source 1 goes into the SAME registers once source 0's MFMAs have consumed them, behind the step's weight
-    // DMA, and lands with it.  (Both sources a step ahead = 64 registers next to the 64 accumulators: hipcc spills them.
-    // Touching source 1's cache lines a step ahead -- one dword per line through an LDS-DMA sink -- changes nothing: the
-    // fused launches are bound by the CU's vector-memory path, which now also carries 64 KiB of projection input per
-    // step, not by the latency of these loads.)
-    f32x4 xq[G::PROJ ? G::PROJ_KS : 1];
-    auto proj_fetch = [&](int blk, int src) __attribute__((always_inline)) {
+    // (PROJ) raw input channels of the block being projected at this lane's pixel: unit u (= 16-channel k-step u of
+    // cat(proj_x[0], proj_x[1])) = xq[2 u], xq[2 u + 1] = channels 16 u + 8 g + (0..7).  All 8 units of a block are fetched
+    // one chunk step ahead, ROLLING: unit u of block s + 1 is requested into unit u's registers right behind the MFMAs
+    // that consumed unit u of block s, so every request is a whole block of MFMAs + the stores + the barrier old when
+    // it is needed (under load a vector-memory round trip takes ~3,000 cycles here, L2 hit or not: the first version --
+    // source 0 a step ahead, source 1 inside the step -- had two exposed round trips per step and ran at half speed,
+    // profiles/r03_ws_timeline_trace.txt).
+    f32x4 xq[G::PROJ ? 2 * G::PROJ_KS : 1];
+    auto proj_fetch_unit = [&](int blk, auto uc) __attribute__((always_inline)) {
       if constexpr (G::PROJ) {
+        constexpr int u = decltype(uc)::value;
         const int po = pixoff_of(blk);
         // uniform base (SGPR pair) + 32-bit byte offset: po = pixel * (COUT / 4) + cb * 8 + g  ->  pixel * 256 + 32 g
         const unsigned boff = po < 0 ? 0u : ((((unsigned)(po - (cb * 8 + g)) >> 4) << 8) + 32u * g);
-        const char* xs = (const char*)p.proj_x[src] + boff;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          xq[kk * 2] = *(const f32x4*)(xs + kk * 64);
-          xq[kk * 2 + 1] = *(const f32x4*)(xs + kk * 64 + 16);
-        }
+        const char* xs = (const char*)p.proj_x[u / 4] + boff + (u % 4) * 64;
+        xq[2 * u] = *(const f32x4*)xs;
+        xq[2 * u + 1] = *(const f32x4*)(xs + 16);
       }
     };
-    // (PROJ) 4 k-steps of projection source SRC (in xq) into the accumulators of block BLK
-    auto proj_mfma = [&](auto blkc, auto srcc) __attribute__((always_inline)) {
+    // (PROJ) k-step u of the projection (operands in xq) into the accumulators of block BLK
+    auto proj_mfma_unit = [&](f32x16& dacc, auto uc) __attribute__((always_inline)) {
       if constexpr (G::PROJ) {
-        constexpr int blk = decltype(blkc)::value, src = decltype(srcc)::value;
-        const unsigned char* pw = proj_lds + (g * G::COUT + cb * 32 + n31) * 16;
-        ws_for<0, 4>([&](auto kc) {
-          constexpr int kk = decltype(kc)::value, ks = src * 4 + kk;
-          const f32x4 x0 = xq[2 * kk], x1 = xq[2 * kk + 1];
-          const unsigned h01 = __builtin_bit_cast(unsigned, (h2){(_Float16)x0[0], (_Float16)x0[1]});
-          const unsigned h23 = __builtin_bit_cast(unsigned, (h2){(_Float16)x0[2], (_Float16)x0[3]});
-          const unsigned h45 = __builtin_bit_cast(unsigned, (h2){(_Float16)x1[0], (_Float16)x1[1]});
-          const unsigned h67 = __builtin_bit_cast(unsigned, (h2){(_Float16)x1[2], (_Float16)x1[3]});
-          const h8 xh = __builtin_bit_cast(h8, (u32x4){h01, h23, h45, h67});
-          const h8 xl = __builtin_bit_cast(h8, (u32x4){ws_low_pair(x0[0], x0[1], h01), ws_low_pair(x0[2], x0[3], h23),
-                                                       ws_low_pair(x1[0], x1[1], h45), ws_low_pair(x1[2], x1[3], h67)});
-          const h8 wh = *(const h8*)(pw + (ks * 2 + 0) * 2 * G::COUT * 16);
-          const h8 wl = *(const h8*)(pw + (ks * 2 + 1) * 2 * G::COUT * 16);
-          acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc[blk], 0, 0, 0);
-          acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc[blk], 0, 0, 0);
-          acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc[blk], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);  // k-step by k-step (hoisting all the weight reads / splits costs 60+ registers)
-        });
-      }
-    };
-    // (PROJ) first half of block `pending`, run IN FRONT of the step's weight DMA: source 0's MFMAs (operands fetched a
-    // step ago; behind the DMA hipcc's wait for them would be vmcnt(0) = the DMA's latency), then source 1's loads
-    bool proj_half_done = false;
-    auto proj_first = [&]() __attribute__((always_inline)) {
-      if constexpr (G::PROJ) {
-        ws_for<0, 4>([&](auto bc) {
-          constexpr int blk = decltype(bc)::value;
-          if (blk == pending && pixoff_of(blk) >= 0) {
-            proj_mfma(bc, std::integral_constant<int, 0>{});
-            proj_fetch(blk, 1);
-          }
-        });
-        proj_half_done = true;
+        constexpr int ks = decltype(uc)::value;
+        // (this lane's unit inside a weight row is the one of the 3x3 weights: derived from ad.w, no register of its own)
+        const unsigned char* pw = proj_lds + (ad.w - G::W_BASE - apar * G::W_BYTES);
+        const f32x4 x0 = xq[2 * ks], x1 = xq[2 * ks + 1];
+        const unsigned h01 = __builtin_bit_cast(unsigned, (h2){(_Float16)x0[0], (_Float16)x0[1]});
+        const unsigned h23 = __builtin_bit_cast(unsigned, (h2){(_Float16)x0[2], (_Float16)x0[3]});
+        const unsigned h45 = __builtin_bit_cast(unsigned, (h2){(_Float16)x1[0], (_Float16)x1[1]});
+        const unsigned h67 = __builtin_bit_cast(unsigned, (h2){(_Float16)x1[2], (_Float16)x1[3]});
+        const h8 xh = __builtin_bit_cast(h8, (u32x4){h01, h23, h45, h67});
+        const h8 xl = __builtin_bit_cast(h8, (u32x4){ws_low_pair(x0[0], x0[1], h01), ws_low_pair(x0[2], x0[3], h23),
+                                                     ws_low_pair(x1[0], x1[1], h45), ws_low_pair(x1[2], x1[3], h67)});
+        const h8 wh = *(const h8*)(pw + (ks * 2 + 0) * 2 * G::COUT * 16);
+        const h8 wl = *(const h8*)(pw + (ks * 2 + 1) * 2 * G::COUT * 16);
+        dacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, dacc, 0, 0, 0);
+        dacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, dacc, 0, 0, 0);
+        dacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, dacc, 0, 0, 0);
       }
     };
     auto epi_begin = [&](int k) {
@@ -852,12 +833,18 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         // sub-tile (wave-uniform index; computed, not selected from a register array) and this lane's pixel of its block 0
         const WsTile t = ws_subtile<G>(p, tile, G::B8 ? ph * 2 + s : (ph >> 1));
         int oy, ox;
+        int n31e = n31;
+        if constexpr (G::PROJ) {  // at the register cap: recomputed per tile from an OPAQUE copy of the thread index
+          int te = tid;           // (left alone, hipcc keeps the row term in a register of its own and spills it)
+          asm volatile("" : "+v"(te));
+          n31e = te & 31;
+        }
         if (G::B8) {
-          oy = t.y0 + (n31 >> 3);
-          ox = t.x0 + (n31 & 7);
+          oy = t.y0 + (n31e >> 3);
+          ox = t.x0 + (n31e & 7);
         } else {
-          oy = t.y0 + (ph & 1) * 8 + (n31 >> 4);
-          ox = t.x0 + (n31 & 15);
+          oy = t.y0 + (ph & 1) * 8 + (n31e >> 4);
+          ox = t.x0 + (n31e & 15);
         }
         pixoff_[s] = t.valid ? (((t.n * p.H + oy) * p.W + ox) * (G::COUT / 4) + cb * 8 + g) : -1;  // 16-byte units
       }
@@ -880,7 +867,6 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       }
       pending = 0;
       if (RES_PREFETCH) res_prefetch(0);
-      proj_fetch(0, 0);
     };
     // blocks [pending, pending + count) of the finished tile: bias, residual, store, statistics
     // `land`: wait for this wave's LDS-DMA (issued before the call) after the residual loads and BEFORE the stores of the
@@ -909,18 +895,16 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           // the residual of this block was fetched one step ago (res_prefetch at the end of the previous block / epi_begin)
           if (!RES_PREFETCH && !G::PROJ) res_prefetch(blk);
           if constexpr (G::PROJ) {
-            // the block's skip projection, into its accumulators (first half: proj_first, unless this call writes
-            // several blocks)
+            // (stream tail only -- the steady state is proj_step below) the block's skip projection into its accumulators
             ws_for<0, 4>([&](auto bc) {
               if (decltype(bc)::value == blk) {
-                if (!proj_half_done) {
-                  proj_mfma(bc, std::integral_constant<int, 0>{});
-                  proj_fetch(blk, 1);
-                }
-                proj_mfma(bc, std::integral_constant<int, 1>{});
+                ws_for<0, G::PROJ_KS>([&](auto uc) { proj_fetch_unit(blk, uc); });
+                ws_for<0, G::PROJ_KS>([&](auto uc) {
+                  proj_mfma_unit(acc[blk], uc);
+                  __builtin_amdgcn_sched_barrier(0);
+                });
               }
             });
-            proj_half_done = false;
           }
           f32x4 v[4];
 #pragma unroll
@@ -948,7 +932,6 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
             fq = __builtin_fmaf(v[qd][3], v[qd][3], fq);
           }
           if (RES_PREFETCH && blk + 1 < 4) res_prefetch(blk + 1);  // behind the stores: in flight across the barrier, used next step
-          if (blk + 1 < 4) proj_fetch(blk + 1, 0);
           const int slot = G::B8 ? (blk >> 1) : 0;
           ssum[slot] += (StatAcc)fs;
           ssq[slot] += (StatAcc)fq;
@@ -965,6 +948,59 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
             double* o = p.out_stats + (size_t)stat_slot[kk] * 2;
             o[0] = a;
             o[1] = b;
+          }
+        }
+      }
+    };
+    // (PROJ) chunk step S of the write-out: block S's projection (its operands were requested a step ago), the rolling
+    // requests for block S + 1, then bias / store / statistics like epi_blocks.  The weight DMA of the step was issued
+    // just before: it is older than the 16 rolling loads, so `vmcnt(16)` = "the DMA has landed" (loads return in order).
+    auto proj_step = [&](auto sc, bool wnext) __attribute__((always_inline)) {
+      if constexpr (G::PROJ) {
+        constexpr int blk = decltype(sc)::value;
+        const int po = pixoff_of(blk);
+        // (hipcc waits for the operands with vmcnt(0) behind the step's LDS-DMA, guide: "while a glds is in flight ...":
+        //  the DMA's round trip sits in front of the MFMAs instead of under them.  Hand-counted inline-asm loads with
+        //  `s_waitcnt vmcnt(23)` per unit were measured and changed nothing -- 64.1 vs 64.0 ms over the bench window:
+        //  the write-out wave is then bound by the issue of its 24 MFMAs and 25 vector-memory instructions between the
+        //  other group's, not by that wait -- so the loads stay compiler-tracked.)
+        ws_for<0, G::PROJ_KS>([&](auto uc) {
+          proj_mfma_unit(acc[blk], uc);
+          if constexpr (blk + 1 < 4) proj_fetch_unit(blk + 1, uc);
+          __builtin_amdgcn_sched_barrier(0);  // unit by unit (hoisting the weight reads / splits of all units costs 60+ registers)
+        });
+        if (wnext) {
+          if constexpr (blk + 1 < 4)
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (po >= 0) {
+          float* op = p.out + (size_t)po * 4;
+          float fs = 0.f, fq = 0.f;
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            const f32x4 v = (f32x4){acc[blk][4 * qd], acc[blk][4 * qd + 1], acc[blk][4 * qd + 2], acc[blk][4 * qd + 3]};
+            if (!(WS_ABL & 128) || v[0] == 1.2345e30f) *(f32x4*)(op + 8 * qd) = v;
+            fs += (v[0] + v[1]) + (v[2] + v[3]);
+            fq = __builtin_fmaf(v[0], v[0], fq);  // (an fma chain into its own register: see epi_blocks)
+            fq = __builtin_fmaf(v[1], v[1], fq);
+            fq = __builtin_fmaf(v[2], v[2], fq);
+            fq = __builtin_fmaf(v[3], v[3], fq);
+          }
+          ssum[0] += (StatAcc)fs;
+          ssq[0] += (StatAcc)fq;
+        }
+        pending = blk + 1;
+        if constexpr (blk == 3) {
+          if (p.out_stats) {
+            const double a = ws_wave_sum_lane63((double)ssum[0]);
+            const double b = ws_wave_sum_lane63((double)ssq[0]);
+            if (lane == 63 && stat_slot[0] >= 0) {
+              double* o = p.out_stats + (size_t)stat_slot[0] * 2;
+              o[0] = a;
+              o[1] = b;
+            }
           }
         }
       }
@@ -998,19 +1034,37 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     }
     ws_barrier();  // B0
     int j = 0;
-    for (int k = 0; k < nmy; ++k) {
-      if ((k & 1) == role) {
+    // The two groups take alternate tiles: group `role` computes tiles k = role, role + 2, ... and, while the other group
+    // computes tile k + 1, writes tile k out.  The alternation is spelled out structurally (not as `(k & 1) == role`
+    // inside one loop): PROJ's write-out requests are inline-asm loads, and on this skeleton every one of them is provably
+    // awaited on every path (tools/asm_lint.py follows the control-flow graph).
+    // group 1 has nothing to write during tile 0: it only provides the weights of tile 0's chunk steps
+    int k = role;
+    if (role == 1 && nmy > 0) {
+      for (int ck = 0; ck < nchunks; ++ck, ++j) {
+        const bool wnext = j + 1 < S;
+        WS_STAMP(role, 8, j);
+        if (wnext) {
+          cons_load_W((j + 1) % nchunks, (j + 1) & 1);
+          cons_land_W();
+        }
+        WS_STAMP(role, 10, j);
+        ws_barrier();  // B(j + 1)
+        WS_STAMP(role, 11, j);
+      }
+    }
+    for (; k < nmy; k += 2) {
         // ---- this group's tile: fragment reads + MFMAs only ----
         // (only if the other group's tile had too few steps to finish the write-out; PROJ launches have 4 steps per tile)
         if (!G::PROJ && pending < 4) epi_blocks(4);
         {
           // lane owns couts cb*32 + 8 qd + 4 g + (0..3), qd = 0..3, of its pixel of each block
           f32x4 bq[4];
-#pragma unroll
+  #pragma unroll
           for (int qd = 0; qd < 4; ++qd) bq[qd] = *(const f32x4*)(bias_lds + cb * 32 + 8 * qd + 4 * g);
-#pragma unroll
+  #pragma unroll
           for (int blk = 0; blk < 4; ++blk)
-#pragma unroll
+  #pragma unroll
             for (int r = 0; r < 16; ++r) acc[blk][r] = bq[r >> 2][r & 3];
         }
         // operands of the tile's first half-tap (the one exposed LDS round trip per tile)
@@ -1043,23 +1097,40 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           b = bn;
         }
         epi_begin(k);  // written out while the other group computes the next tile
-      } else {
+      if (k + 1 >= nmy) break;
         // ---- the other group's tile: write our finished tile out, a slice per chunk step, and move the weights ----
-        for (int ck = 0; ck < nchunks; ++ck, ++j) {
-          const bool wnext = j + 1 < S;  // this (idle) group copies the next step's weights
-          WS_STAMP(role, 8, j);
-          if (G::PROJ && pending < 4) proj_first();
-          if (wnext) cons_load_W((j + 1) % nchunks, (j + 1) & 1);
-          WS_STAMP(role, 9, j);
-          if (pending < 4)
-            epi_blocks(blocks_per_step, wnext);
-          else if (wnext)
-            cons_land_W();
-          WS_STAMP(role, 10, j);
-          ws_barrier();  // B(j + 1)
-          WS_STAMP(role, 11, j);
+        if constexpr (G::PROJ) {
+          // 4 chunk steps per tile (eligibility), block s of the finished tile in step s: straight-line code, so that
+          // hipcc sees which accumulators are dead and counts the loads in flight exactly
+          ws_for<0, 4>([&](auto sc) {
+            const bool wnext = j + 1 < S;
+            WS_STAMP(role, 8, j);
+            // block 0's operands: requested here, not in epi_begin -- nothing separates the two in time (the tile's last
+            // MFMAs are right in front of this step), and every request and its wait then sit in one straight line
+            if constexpr (decltype(sc)::value == 0) ws_for<0, G::PROJ_KS>([&](auto uc) { proj_fetch_unit(0, uc); });
+            if (wnext) cons_load_W((j + 1) % nchunks, (j + 1) & 1);
+            WS_STAMP(role, 9, j);
+            proj_step(sc, wnext);  // (a finished tile is always waiting here: epi_begin was the previous statement)
+            WS_STAMP(role, 10, j);
+            ws_barrier();  // B(j + 1)
+            WS_STAMP(role, 11, j);
+            ++j;
+          });
+        } else {
+          for (int ck = 0; ck < nchunks; ++ck, ++j) {
+            const bool wnext = j + 1 < S;  // this (idle) group copies the next step's weights
+            WS_STAMP(role, 8, j);
+            if (wnext) cons_load_W((j + 1) % nchunks, (j + 1) & 1);
+            WS_STAMP(role, 9, j);
+            if (pending < 4)
+              epi_blocks(blocks_per_step, wnext);
+            else if (wnext)
+              cons_land_W();
+            WS_STAMP(role, 10, j);
+            ws_barrier();  // B(j + 1)
+            WS_STAMP(role, 11, j);
+          }
         }
-      }
     }
     if (pending < 4) epi_blocks(4);  // tail: the last tile(s) of the range
   }

@@ -1,7 +1,8 @@
 """Timeline of one workgroup of conv_f16ws_kernel (s_memtime stamps of a DMD_LAB -DWS_TRACE build): who waits for whom
 in a chunk step.
    bash tools/build_ws_ablations.sh trace   (WS_EXTRA=-DWS_TRACE)
-   DIAMOND_LIB=diamond_amd/ablate/libdiamond_hip_wstrace.so python tools/ws_trace.py [cin] [res]"""
+   DIAMOND_LIB=diamond_amd/ablate/libdiamond_hip_wstrace.so python tools/ws_trace.py [cin] [res]
+   res = 2: the fused skip projection (WsGeomProj) instead of a residual"""
 import collections
 import ctypes as C
 import os
@@ -24,8 +25,12 @@ for c in [64] * (cin // 64):
 w = torch.randn(64, cin, 3, 3, device=dev) / (cin * 9) ** 0.5
 wp, w16 = nv.pack_conv_weight(w), nv.pack_conv_weight_f16x2(w)
 b = torch.zeros(64, device=dev)
-r = E.Act(torch.randn(n, h, h, 64, device=dev)) if res else None
-run = lambda: E.conv2d(srcs, wp, b, 64, residual=r, w_f16=w16)
+r = E.Act(torch.randn(n, h, h, 64, device=dev)) if res == 1 else None
+proj = None
+if res == 2:
+    wpj = torch.randn(64, 128, 1, 1, device=dev) / 128 ** 0.5
+    proj = ([E.Act(torch.randn(n, h, h, 64, device=dev)), E.Act(torch.randn(n, h, h, 64, device=dev))], nv.pack_conv_weight_f16x2(wpj), b)
+run = lambda: E.conv2d(srcs, wp, b, 64, residual=r, w_f16=w16, proj=proj)
 L = nv.lib()
 L.dmd_ws_trace_dump.argtypes = [C.c_void_p, C.c_void_p]
 NMAX = 4096
@@ -59,7 +64,7 @@ for s in sorted(rows)[4:-4]:
     oth = 1 - act
     vals = {"P.await": d(r, (2, 0), (2, 7)), "P.math": d(r, (2, 7), (2, 1)), "P.issue": d(r, (2, 1), (2, 2)), "P.wait": d(r, (2, 2), (2, 3)),
             "C.mfma": d(r, (act, 4), (act, 5)), "C.wait": d(r, (act, 5), (act, 6)),
-            "W.dma": d(r, (oth, 8), (oth, 9)), "W.epi": d(r, (oth, 9), (oth, 10)), "W.wait": d(r, (oth, 10), (oth, 11))}
+            "W.proj0": d(r, (oth, 8), (oth, 12)), "W.dma": d(r, (oth, 12) if (oth, 12) in r else (oth, 8), (oth, 9)), "W.epi": d(r, (oth, 9), (oth, 10)), "W.wait": d(r, (oth, 10), (oth, 11))}
     prev = rows.get(s - 1, {})
     if (2, 3) in r and (2, 3) in prev:
         vals["step"] = r[(2, 3)] - prev[(2, 3)]
