@@ -320,6 +320,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-exact-fp32", action="store_true")
+    ap.add_argument("--pmc-calibrate", action="store_true",
+                    help="two Heun updates over 256 MiB arrays before the window (tools/pmc_collect.sh: a known byte count for the FETCH_SIZE / "
+                         "WRITE_SIZE unit corrections in the same rocprofv3 pass)")
     ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.config in ("latency", "train"):
@@ -360,6 +363,14 @@ def main():
     from diamond_amd import native as nv
     from diamond_amd.dist import GradAllReducer, broadcast_parameters, parameter_checksum
 
+    if args.pmc_calibrate:
+        # a kernel the window itself never launches (configs[1] is Euler-only), with a known byte count: 2 launches x
+        # (4 x 256 MiB read, 256 MiB written)
+        cal = [torch.randn(64 * 1024 * 1024, device=device) for _ in range(4)]
+        for _ in range(2):
+            D.DiffusionSampler._heun(cal[0], cal[1], cal[2], cal[3], 1.0, 0.5, -0.5)
+        torch.cuda.synchronize()
+        del cal
     torch.manual_seed(1234 + rank)
     attn = tuple(int(v) for v in args.attn_depths.split(","))
     agent = build_agent(device, args.img_size, rank, attn)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: parity tests, the bench lines, rocprofv3 kernel stats and the PMC traffic passes.
-#   gpurun --timeout 1500 -- 'bash tools/gpu_round.sh r02a'
+#   gpurun --timeout 2400 -- 'bash tools/gpu_round.sh r03'
 # Everything lands in gpurun_out/<tag>/ (copy what should be judged into profiles/ afterwards).
 set -u
 TAG=${1:-r02}

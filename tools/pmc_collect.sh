@@ -1,7 +1,9 @@
 #!/bin/bash
 # HBM traffic counters for the hot kernels, one counter per pass (FETCH_SIZE uses 3 of the 4 TCC
 # slots, WRITE_SIZE 2: they cannot share a pass; no trace domains besides --kernel-trace).
-# Run on the GPU box:  bash tools/pmc_collect.sh   -> gpurun_out/pmc/{fetch,write}_counter_collection.csv
+# The profiled workload is ONE BENCH WINDOW of configs[1] (bench.py --steps 1 --warmup 1, preceded by a calibration copy of
+# known size), i.e. the launches bench.py's roofline averages over -- not a stand-in.
+# Run on the GPU box:  bash tools/pmc_collect.sh   -> gpurun_out/pmc/{FETCH,WRITE}_SIZE.json
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 export TMPDIR=/tmp
@@ -9,7 +11,7 @@ cd /tmp
 mkdir -p $R/gpurun_out/pmc
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  timeout 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o pmc -- python $R/tools/pmc_target.py 256 > $R/gpurun_out/pmc/$c.log 2>&1
+  timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o pmc -- python $R/bench.py --steps 1 --warmup 1 --pmc-calibrate --no-cpu-baseline --no-exact-fp32 --no-roofline > $R/gpurun_out/pmc/$c.log 2>&1
   echo "rc=$?" >> $R/gpurun_out/pmc/$c.log
   ls -la /tmp/pmc_$c >> $R/gpurun_out/pmc/$c.log
   f=$(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1)

@@ -4,7 +4,7 @@ dmd_conv2d_kernel_name() spells it, so bench.py finds its dominant kernel by nam
 
     python tools/pmc_to_profile.py r02a        (after `bash tools/pmc_collect.sh` on the GPU box)
 
-Corrections (MI355X_MICROARCH.md, HBM section; re-checked by the calibration copy in tools/pmc_target.py):
+Corrections (MI355X_MICROARCH.md, HBM section; re-checked by the calibration copy of `bench.py --pmc-calibrate`):
 FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads -> x2;
 WRITE_SIZE matches a known byte count 1:1.  The measured calibration factors are stored under "_calibration"."""
 import json
@@ -42,19 +42,20 @@ def main() -> None:
     w = json.load(open(os.path.join(src, "WRITE_SIZE.json")))
     out = {}
     for name, fv in f.items():
-        if name not in w or not any(s in name for s in ("conv", "wgrad", "attention", "linear", "edm_", "gn_")):
+        if name not in w or not any(s in name for s in ("conv", "wgrad", "attention", "linear", "edm_", "gn_", "lowres", "maxpool")):
             continue
         wv = w[name]
         out[normalise(name)] = {
             "launches": fv["launches"], "fetch_bytes_per_launch": fv["mean"] * 2 * 1024, "write_bytes_per_launch": wv["mean"] * 1024,
             "hbm_bytes_per_launch": fv["mean"] * 2 * 1024 + wv["mean"] * 1024,
-            "workload": "2 x Denoiser.denoise at B=256, 64x64 (tools/pmc_target.py), separate --pmc passes", "profile_set": tag}
-    cp = "__amd_rocclr_copyBuffer"
-    if cp in f and cp in w:
-        out["_calibration"] = {"kernel": cp, "known_bytes_read": 2 * 2 ** 30, "known_bytes_written": 2 * 2 ** 30,
+            "workload": "one bench window of configs[1] + its warm-up window (bench.py --steps 1 --warmup 1), separate --pmc passes", "profile_set": tag}
+    cal = [k for k in f if "heun_step_kernel" in k and k in w]  # bench.py --pmc-calibrate: 2 x (4 x 256 MiB read, 256 MiB written)
+    if cal:
+        cp = cal[0]
+        out["_calibration"] = {"kernel": cp, "known_bytes_read": 2 * 2 ** 30, "known_bytes_written": 2 ** 29,
                                "FETCH_SIZE_total_KiB": f[cp]["total"], "WRITE_SIZE_total_KiB": w[cp]["total"],
                                "fetch_factor": 2 * 2 ** 30 / (f[cp]["total"] * 1024),
-                               "write_factor": 2 * 2 ** 30 / (w[cp]["total"] * 1024)}
+                               "write_factor": 2 ** 29 / (w[cp]["total"] * 1024)}
     dst = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
     json.dump(out, open(dst, "w"), indent=1)
     shutil.copyfile(dst, os.path.join(ROOT, "profiles", "pmc_traffic.json"))
