@@ -25,4 +25,9 @@ fi
 if [ "${SKIP_CONFIGS:-0}" != "1" ]; then
   timeout 300 python bench.py --config 4 --no-cpu-baseline > $O/bench_config4.json 2> $O/bench_config4.err; echo "cfg4 rc=$?"; tail -c 300 $O/bench_config4.json
   timeout 400 python bench.py --config 3 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_config3.json 2> $O/bench_config3.err; echo "cfg3 rc=$?"; tail -c 300 $O/bench_config3.json
+  timeout 300 python bench.py --config latency > $O/bench_latency.json 2> $O/bench_latency.err; echo "latency rc=$?"; tail -c 400 $O/bench_latency.json
+  timeout 300 python bench.py --config train > $O/bench_train.json 2> $O/bench_train.err; echo "train rc=$?"; tail -c 400 $O/bench_train.json
+  timeout 300 python bench.py --config train --batch 256 --steps 5 >> $O/bench_train.json 2>> $O/bench_train.err
 fi
+# which box: GPU name / clocks as the driver reports them (boxes differ by a few per cent at identical code)
+(rocm-smi --showproductname --showclocks --showpower 2>/dev/null | head -40) > $O/box.txt

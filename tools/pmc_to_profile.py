@@ -42,7 +42,7 @@ def main() -> None:
     w = json.load(open(os.path.join(src, "WRITE_SIZE.json")))
     out = {}
     for name, fv in f.items():
-        if name not in w or not any(s in name for s in ("conv", "wgrad", "attention", "linear", "edm_", "gn_", "lowres", "maxpool")):
+        if name not in w or not normalise(name).startswith(("conv", "wgrad", "attention", "linear_mfma", "edm_", "gn_", "lowres", "maxpool2")):
             continue
         wv = w[name]
         out[normalise(name)] = {
