@@ -137,7 +137,7 @@ class SelfAttention2d(nn.Module):
         qkv = E.conv2d([(x, nv.PROLOGUE_NORM, spec)], ctx.cache.conv_weight(self.qkv_proj), ctx.cache.conv_bias(self.qkv_proj),
                        3 * c, taps=1, want_stats=False, naive=ctx.naive, fast_math=ctx.fast_math, module=self.qkv_proj)
         y = E.attention(qkv, c, c // self.n_head)
-        return E.conv2d([(Act(y), nv.PROLOGUE_NONE, None)], ctx.cache.conv_weight(self.out_proj),
+        return E.conv2d([(Act(y, valid=x.valid), nv.PROLOGUE_NONE, None)], ctx.cache.conv_weight(self.out_proj),
                         ctx.cache.conv_bias(self.out_proj), c, taps=1, residual=x, residual_norm=spec, naive=ctx.naive,
                         fast_math=ctx.fast_math, module=self.out_proj)
 
@@ -253,10 +253,16 @@ class UNet(nn.Module):
 
     def run(self, ctx: RunCtx, x: Act) -> Act:
         m = 8 * 2 ** self._num_down  # every level must itself be a multiple of the kernels' 8-pixel tile
-        assert x.shape[1] % m == 0 and x.shape[2] % m == 0, \
-            (f"the native U-Net needs H, W multiples of {m} (8 x 2**num_down: every level is tiled in 8x8 pixel blocks); got "
-             f"{x.shape[1]}x{x.shape[2]}.  The reference pads to a multiple of 2**num_down and crops (blocks.py:227-229,247): "
-             "sizes that are not multiples of 8 at every level are not supported by this implementation")
+        if x.valid is None:
+            assert x.shape[1] % m == 0 and x.shape[2] % m == 0, \
+                (f"the native U-Net tiles every level in 8x8 pixel blocks: H, W must be multiples of {m} (8 x 2**num_down), got "
+                 f"{x.shape[1]}x{x.shape[2]}; other sizes go in as the VALID EXTENT of a larger buffer "
+                 "(engine.padded_extent, InnerModel.run(valid=...))")
+        else:
+            # the reference pads to a multiple of 2**num_down and crops (blocks.py:227-229,247): InnerModel.run has done the
+            # padding (zero rows / columns inside the valid extent); every level halves the extent exactly
+            m2 = 2 ** self._num_down
+            assert x.valid[0] % m2 == 0 and x.valid[1] % m2 == 0 and x.shape[1] % (2 * m) == 0 and x.shape[2] % (2 * m) == 0, (x.valid, x.shape)
         skips: List[List[Act]] = []
         last = len(self.d_blocks) - 1
         chained = False
@@ -291,7 +297,7 @@ class UNet(nn.Module):
         level with 64-channel neighbours, at most two down blocks (three skip slots) and eight blocks in all."""
         if not (int(LOWRES_CHAIN) & 1) or ctx.precision != "f16x2" or ctx.naive or E.TAPE is not None or E._USE_NAIVE:
             return False
-        if len(self.d_blocks) < 2 or tuple(x.shape[1:]) != (8, 8, 64):
+        if len(self.d_blocks) < 2 or tuple(x.shape[1:]) != (8, 8, 64) or x.valid is not None:
             return False
         blks = self._chain_blocks()
         nd = len(self.d_blocks[-1].resblocks)

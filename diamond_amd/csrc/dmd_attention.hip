@@ -18,8 +18,10 @@
 #define ATT_KB 256          // keys per LDS tile
 #define ATT_VSTRIDE (ATT_KB + 16)
 
+// Wp > 0 (dmd_attention_valid): the T tokens are a row-major (T / Wp) x Wp grid of which only rows < hv, columns < wv
+// exist; the other keys get the score -inf (token 0 always exists, so the running maximum is finite from the first block on).
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T,
-                                                        int C, float inv_scale_den) {
+                                                        int C, float inv_scale_den, int Wp, int hv, int wv) {
   __shared__ float Ks[ATT_KB][8];
   __shared__ float Vt[8][ATT_VSTRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -64,6 +66,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         s[r] = s[r] / inv_scale_den;  // (q @ k^T) / sqrt(d), blocks.py:68
+        if (Wp > 0) {
+          const int key = kt + k0 + 4 * kg + r, ky = key / Wp, kx = key - ky * Wp;
+          if (ky >= hv || kx >= wv) s[r] = -INFINITY;
+        }
         bmax = fmaxf(bmax, s[r]);
       }
       bmax = fmaxf(bmax, __shfl_xor(bmax, 16, 64));
@@ -313,7 +319,22 @@ extern "C" int dmd_attention(const float* qkv, float* out, int N, int T, int C, 
     return 0;
   }
   dim3 grid(T / 64, C / 8, N);
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, T, C, sqrtf((float)head_dim));
+  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, T, C, sqrtf((float)head_dim), 0, 0, 0);
+  DMD_LAUNCH_CHECK();
+  return 0;
+}
+
+// The same over an (H, W) token grid of which only (valid_h, valid_w) exists (dmd_conv_params: VALID EXTENT): keys outside
+// it do not take part in the softmax; the outputs of queries outside it are unspecified.
+extern "C" int dmd_attention_valid(const float* qkv, float* out, int N, int H, int W, int valid_h, int valid_w, int C, int head_dim,
+                                   dmd_stream_t stream) {
+  DMD_CHECK_ARG(qkv && out, "attention: null");
+  DMD_CHECK_ARG(head_dim == 8, "attention: head_dim must be 8 (ATTN_HEAD_DIM), got %d", head_dim);
+  const int T = H * W;
+  DMD_CHECK_ARG(C % 8 == 0 && T % 64 == 0 && N > 0, "attention: need C %% 8 == 0, T %% 64 == 0 (T=%d C=%d)", T, C);
+  DMD_CHECK_ARG(valid_h > 0 && valid_h <= H && valid_w > 0 && valid_w <= W, "attention: valid extent %d x %d of %d x %d", valid_h, valid_w, H, W);
+  dim3 grid(T / 64, C / 8, N);
+  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, out, T, C, sqrtf((float)head_dim), W, valid_h, valid_w);
   DMD_LAUNCH_CHECK();
   return 0;
 }

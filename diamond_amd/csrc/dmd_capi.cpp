@@ -14,4 +14,4 @@ void dmd_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* dmd_last_error(void) { return g_err; }
-extern "C" int dmd_abi_version(void) { return 5; }
+extern "C" int dmd_abi_version(void) { return 6; }

@@ -126,6 +126,10 @@ __global__ __launch_bounds__(256, G::MIN_WAVES) void conv_mfma_kernel(const dmd_
   const int up = p.upsample;
   const int Hin = p.H * G::S, Win = p.W * G::S;  // conv-input extent
   const int Hs = Hin >> up, Ws = Win >> up;      // stored source extent
+  // valid extent (include/diamond_hip.h): of the output, of the conv input, of the stored sources
+  const int Hvo = p.valid_h ? p.valid_h : p.H, Wvo = p.valid_w ? p.valid_w : p.W;
+  const int Hvi = Hvo * G::S, Wvi = Wvo * G::S;
+  const int Hvs = Hvi >> up, Wvs = Wvi >> up;
   const int C0 = p.src[0].C;
   const int C1 = p.nsrc > 1 ? p.src[1].C : 0;
   const int nch0 = C0 >> 4;
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(256, G::MIN_WAVES) void conv_mfma_kernel(const dmd_
     for (int s = 0; s < G::SUB; ++s) {
       float m = 0.f, a = 1.f, ad = 0.f;
       if (sc.prologue != DMD_PROLOGUE_NONE && ti[s].valid)
-        norm_entry(sc.norm, ti[s].n, cl, sc.C, (double)DMD_GN_GROUP * Hs * Ws, &m, &a, &ad);
+        norm_entry(sc.norm, ti[s].n, cl, sc.C, (double)DMD_GN_GROUP * Hvs * Wvs, &m, &a, &ad);
       tab_mean[s][c] = m;
       tab_a[s][c] = a;
       tab_add[s][c] = ad;
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(256, G::MIN_WAVES) void conv_mfma_kernel(const dmd_
         float m = 0.f, a = 1.f, ad = 0.f;
         const int cc = cout_group0 + c;
         if (ti[s].valid && cc < p.Cout)
-          norm_entry(p.residual_norm, ti[s].n, cc, p.Cout, (double)DMD_GN_GROUP * p.H * p.W, &m, &a, &ad);
+          norm_entry(p.residual_norm, ti[s].n, cc, p.Cout, (double)DMD_GN_GROUP * Hvo * Wvo, &m, &a, &ad);
         rtab[s][0][c] = m;
         rtab[s][1][c] = a;
         rtab[s][2][c] = ad;
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(256, G::MIN_WAVES) void conv_mfma_kernel(const dmd_
     const int px = rem - py * G::PW;
     const int iy = t.y0 * G::S - G::PAD + py;
     const int ix = t.x0 * G::S - G::PAD + px;
-    const bool inb = ok && t.valid && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
+    const bool inb = ok && t.valid && iy >= 0 && iy < Hvi && ix >= 0 && ix < Wvi;
     goff[it] = inb ? ((t.n * Hs + (iy >> up)) * Ws + (ix >> up)) : -1;
     loff[it] = ok ? pp * 4 + ((q + 2 * (pp >> 2)) & 3) : -1;
     isub[it] = s;
@@ -361,9 +365,10 @@ __global__ __launch_bounds__(256, G::MIN_WAVES) void conv_mfma_kernel(const dmd_
     // a wave covers both subtiles only when WM == 1 (then s is a compile-time constant);
     // otherwise all of its m-blocks belong to ONE subtile and slot 0 is used.
     constexpr bool kBoth = G::CFGB && G::WM == 1;
+    const bool counted = oy < Hvo && ox < Wvo;  // outside the valid extent: stored, not counted
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const double d = (double)v[e];
+      const double d = counted ? (double)v[e] : 0.0;
       if (kBoth && mb >= G::MB / 2) {
         ssum[G::SUB - 1] += d;
         ssq[G::SUB - 1] += d * d;
@@ -429,18 +434,20 @@ __global__ void conv_naive_kernel(const dmd_conv_params p, int stat_tw) {
   const int n = pixel / ((size_t)p.W * p.H);
   const int S = p.stride, up = p.upsample, pad = p.taps == 9 ? 1 : 0, k = p.taps == 9 ? 3 : 1;
   const int Hin = p.H * S, Win = p.W * S, Hs = Hin >> up, Ws = Win >> up;
+  const int Hvo = p.valid_h ? p.valid_h : p.H, Wvo = p.valid_w ? p.valid_w : p.W;
+  const int Hvi = Hvo * S, Wvi = Wvo * S, Hvs = Hvi >> up, Wvs = Wvi >> up;
   float acc = 0.f;
   int cbase = 0;
   for (int si = 0; si < p.nsrc; ++si) {
     const dmd_conv_src& sc = p.src[si];
     for (int c = 0; c < sc.C; ++c) {
       float m = 0.f, a = 1.f, ad = 0.f;
-      if (sc.prologue != DMD_PROLOGUE_NONE) norm_entry(sc.norm, n, c, sc.C, (double)DMD_GN_GROUP * Hs * Ws, &m, &a, &ad);
+      if (sc.prologue != DMD_PROLOGUE_NONE) norm_entry(sc.norm, n, c, sc.C, (double)DMD_GN_GROUP * Hvs * Wvs, &m, &a, &ad);
       const int cc = cbase + c;
       for (int dy = 0; dy < k; ++dy)
         for (int dx = 0; dx < k; ++dx) {
           const int iy = oy * S - pad + dy, ix = ox * S - pad + dx;
-          if (iy < 0 || iy >= Hin || ix < 0 || ix >= Win) continue;
+          if (iy < 0 || iy >= Hvi || ix < 0 || ix >= Wvi) continue;
           float v = sc.x[(((size_t)n * Hs + (iy >> up)) * Ws + (ix >> up)) * sc.C + c];
           if (sc.prologue != DMD_PROLOGUE_NONE) {
             v = (v - m) * a + ad;
@@ -457,7 +464,7 @@ __global__ void conv_naive_kernel(const dmd_conv_params p, int stat_tw) {
     float r = p.residual[pixel * p.Cout + co];
     if (p.residual_norm.stats) {
       float m, a, ad;
-      norm_entry(p.residual_norm, n, co, p.Cout, (double)DMD_GN_GROUP * p.H * p.W, &m, &a, &ad);
+      norm_entry(p.residual_norm, n, co, p.Cout, (double)DMD_GN_GROUP * Hvo * Wvo, &m, &a, &ad);
       r = (r - m) * a + ad;
     }
     acc += r;
@@ -469,7 +476,7 @@ __global__ void conv_naive_kernel(const dmd_conv_params p, int stat_tw) {
 }
 
 // stats for the naive path: one thread per (n, group, tile), same tiling as the MFMA kernel
-__global__ void conv_naive_stats_kernel(const float* out, double* stats, int N, int H, int W, int C, int TW) {
+__global__ void conv_naive_stats_kernel(const float* out, double* stats, int N, int H, int W, int C, int TW, int Hv, int Wv) {
   const int tiles_x = W / TW, tiles_y = H / 8, T = tiles_x * tiles_y, G = C / DMD_GN_GROUP;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= N * G * T) return;
@@ -479,6 +486,7 @@ __global__ void conv_naive_stats_kernel(const float* out, double* stats, int N, 
   for (int y = 0; y < 8; ++y)
     for (int x = 0; x < TW; ++x)
       for (int c = 0; c < DMD_GN_GROUP; ++c) {
+        if (y0 + y >= Hv || x0 + x >= Wv) continue;  // outside the valid extent
         const double v = out[(((size_t)n * H + y0 + y) * W + x0 + x) * C + g * DMD_GN_GROUP + c];
         s += v;
         ss += v * v;
@@ -530,6 +538,9 @@ static int validate_conv(const dmd_conv_params* p) {
   if (p->out_stats) DMD_CHECK_ARG(p->Cout % DMD_GN_GROUP == 0 && p->CoutPad == p->Cout, "conv: out_stats needs Cout %% 32 == 0");
   if (p->residual_norm.stats) DMD_CHECK_ARG(p->residual && p->Cout % DMD_GN_GROUP == 0, "conv: residual_norm");
   if (p->upsample) DMD_CHECK_ARG(p->H % 2 == 0 && p->W % 2 == 0, "conv: upsample needs even output");
+  DMD_CHECK_ARG(p->valid_h >= 0 && p->valid_h <= p->H && p->valid_w >= 0 && p->valid_w <= p->W && (p->valid_h == 0) == (p->valid_w == 0),
+                "conv: valid extent %d x %d outside the %d x %d buffer", p->valid_h, p->valid_w, p->H, p->W);
+  if (p->upsample) DMD_CHECK_ARG(p->valid_h % 2 == 0 && p->valid_w % 2 == 0, "conv: upsample needs an even valid extent");
   if (p->proj_nsrc)
     DMD_CHECK_ARG(dmd_conv2d_proj_eligible(p), "conv: fused skip projection on parameters dmd_conv2d_proj_eligible() rejects "
                   "(needs F16X2 3x3 stride 1, Cout 64, H, W %% 16 == 0, two 64-channel sources, no residual)");
@@ -626,7 +637,7 @@ extern "C" int dmd_conv2d_naive(const dmd_conv_params* p, dmd_stream_t stream) {
     const int TW = (p->W % 16) ? 8 : 16;
     const int n = p->N * (p->Cout / DMD_GN_GROUP) * dmd_conv_stat_tiles(p->H, p->W);
     hipLaunchKernelGGL(conv_naive_stats_kernel, dim3((n + 63) / 64), dim3(64), 0, st, tmp_out, p->out_stats, p->N, p->H,
-                       p->W, p->Cout, TW);
+                       p->W, p->Cout, TW, p->valid_h ? p->valid_h : p->H, p->valid_w ? p->valid_w : p->W);
   }
   DMD_LAUNCH_CHECK();
   return 0;

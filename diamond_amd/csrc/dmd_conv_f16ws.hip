@@ -418,6 +418,9 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int up = p.upsample;
   const int Hs = p.H >> up, Ws = p.W >> up;
+  // valid extent (include/diamond_hip.h): conv-input coordinates (= output coordinates: stride 1) and stored-source ones
+  const int Hv = p.valid_h ? p.valid_h : p.H, Wv = p.valid_w ? p.valid_w : p.W;
+  const int Hvs = Hv >> up, Wvs = Wv >> up;
   const int C0 = p.src[0].C;
   const int C1 = p.nsrc > 1 ? p.src[1].C : 0;
   const int nch0 = C0 >> 4;
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       const WsTile t = G::SUB == 1 ? ti[0] : ws_subtile<G>(p, gtile, s);
       const int iy = t.y0 - 1 + py, ix = t.x0 - 1 + px;
       const bool window = G::TAPS == 9 || (py >= 1 && py <= G::TS && px >= 1 && px <= G::TS);  // 1x1: no halo needed
-      inb = ip >= 0 && window && t.valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      inb = ip >= 0 && window && t.valid && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
       return inb ? ((t.n * Hs + (iy >> up)) * Ws + (ix >> up)) : 0;
     };
 
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         for (int s = 0; s < G::SUB; ++s) {
           float m = 0.f, a = 1.f, ad = 0.f;
           if (sc.prologue != DMD_PROLOGUE_NONE && ti[s].valid)
-            norm_entry(sc.norm, ti[s].n, cl, sc.C, (double)DMD_GN_GROUP * Hs * Ws, &m, &a, &ad);
+            norm_entry(sc.norm, ti[s].n, cl, sc.C, (double)DMD_GN_GROUP * Hvs * Wvs, &m, &a, &ad);
           const float bb = ad - m * a;
           const bool silu = sc.prologue == DMD_PROLOGUE_NORM_SILU;
           const int ti_ = (slot * G::SUB + s) * G::CIN_MAX + c;
@@ -768,6 +771,9 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       const int rows = G::B8 ? (blk & 1) * 4 : blk * 2;
       return base < 0 ? -1 : base + rows * p.W * (G::COUT / 4);
     };
+    // bit blk: this lane's pixel of block blk lies outside the valid extent (its output is stored, but stays out of the
+    // GroupNorm partial sums); always 0 without a valid extent.  (PROJ launches have none: eligibility.)
+    int dead = 0;
     constexpr int NSTAT = G::B8 ? 2 : 1;  // statistics tiles of this wave's 128 pixels (one per 8 rows x 8 | 16 columns)
     int stat_slot[NSTAT];  // out_stats slot per statistics tile of this wave, -1: none
     // per-lane partial sums of a statistics tile: fp64 across a 16x16 geometry's four blocks; the 8x8 geometries (two blocks
@@ -847,6 +853,15 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           ox = t.x0 + (n31e & 15);
         }
         pixoff_[s] = t.valid ? (((t.n * p.H + oy) * p.W + ox) * (G::COUT / 4) + cb * 8 + g) : -1;  // 16-byte units
+        if constexpr (!G::PROJ) {
+          if (s == 0) dead = 0;
+#pragma unroll
+          for (int b = 0; b < (G::B8 ? 2 : 4); ++b) {
+            const int blk = G::B8 ? 2 * s + b : b;
+            const int row = oy + (G::B8 ? b * 4 : b * 2);
+            dead |= (row >= Hv || ox >= Wv) ? (1 << blk) : 0;
+          }
+        }
       }
 #pragma unroll
       for (int kk = 0; kk < NSTAT; ++kk) {
@@ -930,6 +945,10 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
             fq = __builtin_fmaf(v[qd][1], v[qd][1], fq);
             fq = __builtin_fmaf(v[qd][2], v[qd][2], fq);
             fq = __builtin_fmaf(v[qd][3], v[qd][3], fq);
+          }
+          if (!G::PROJ && ((dead >> blk) & 1)) {  // outside the valid extent: stored, not counted
+            fs = 0.f;
+            fq = 0.f;
           }
           if (RES_PREFETCH && blk + 1 < 4) res_prefetch(blk + 1);  // behind the stores: in flight across the barrier, used next step
           const int slot = G::B8 ? (blk >> 1) : 0;
@@ -1239,7 +1258,7 @@ extern "C" int dmd_conv2d_f16x2_eligible(const dmd_conv_params* p) {
 extern "C" int dmd_conv2d_proj_eligible(const dmd_conv_params* p) {
   if (!p || !dmd_conv2d_f16x2_eligible(p)) return 0;
   if (p->taps != 9 || p->upsample || p->Cout != 64 || p->CoutPad != 64 || p->out_nchw || p->residual) return 0;
-  if (p->H % 16 != 0 || p->W % 16 != 0) return 0;
+  if (p->H % 16 != 0 || p->W % 16 != 0 || p->valid_h || p->valid_w) return 0;
   // 4 chunk steps per tile = one 32-pixel block of the finished tile per step (the kernel has no catch-up path)
   if (p->nsrc != 1 || p->src[0].C != 64) return 0;
   if ((long long)p->N * p->H * p->W * 256 >= (1ll << 32)) return 0;  // 32-bit byte offsets into the projection sources

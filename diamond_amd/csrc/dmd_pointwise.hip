@@ -182,13 +182,19 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restr
 
 // ---- GroupNorm partial statistics of an NHWC tensor: one tile per image ----------------------
 // grid (G, N), 256 threads: thread -> (pixel stripe, channel quad of the group)
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int HW, int C) {
+// W > 0: the HW pixels are an (HW / W) x W grid of which only rows < hv, columns < wv are counted (VALID EXTENT)
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int HW, int C, int W, int hv,
+                                                       int wv) {
   __shared__ double red[4][2];
   const int g = blockIdx.x, n = blockIdx.y, G = gridDim.x;
   const int tid = threadIdx.x;
   const int quad = tid & 7;  // 8 quads = 32 channels
   double s = 0.0, ss = 0.0;
   for (int pix = tid >> 3; pix < HW; pix += 32) {
+    if (W > 0) {
+      const int py = pix / W;
+      if (py >= hv || pix - py * W >= wv) continue;
+    }
     const f32x4 v = *(const f32x4*)(x + ((size_t)n * HW + pix) * C + g * DMD_GN_GROUP + quad * 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -415,7 +421,15 @@ extern "C" int dmd_nhwc_to_nchw(const float* in, float* out, int N, int C, int H
 
 extern "C" int dmd_gn_stats(const float* x, double* stats, int N, int HW, int C, dmd_stream_t stream) {
   DMD_CHECK_ARG(x && stats && C % DMD_GN_GROUP == 0, "gn_stats: C %% 32");
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(C / DMD_GN_GROUP, N), dim3(256), 0, (hipStream_t)stream, x, stats, HW, C);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(C / DMD_GN_GROUP, N), dim3(256), 0, (hipStream_t)stream, x, stats, HW, C, 0, 0, 0);
+  DMD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dmd_gn_stats_valid(const float* x, double* stats, int N, int H, int W, int valid_h, int valid_w, int C, dmd_stream_t stream) {
+  DMD_CHECK_ARG(x && stats && C % DMD_GN_GROUP == 0, "gn_stats: C %% 32");
+  DMD_CHECK_ARG(valid_h > 0 && valid_h <= H && valid_w > 0 && valid_w <= W, "gn_stats: valid extent %d x %d of %d x %d", valid_h, valid_w, H, W);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(C / DMD_GN_GROUP, N), dim3(256), 0, (hipStream_t)stream, x, stats, H * W, C, W, valid_h, valid_w);
   DMD_LAUNCH_CHECK();
   return 0;
 }

@@ -12,6 +12,7 @@ from typing import Optional, Tuple, Union
 import torch
 from torch import Tensor, nn
 
+from . import engine as E
 from . import native as nv
 from .inner_model import InnerModel, InnerModelConfig
 
@@ -105,6 +106,17 @@ class Denoiser(nn.Module):
         cond, stride = self.compute_conditioners(sigma)
         assert stride == 0 or cond.shape[0] == n, "sigma must be a scalar or one value per sample"
         cpad = (cx + cobs + 15) // 16 * 16
+        # image sizes whose U-Net levels are not multiples of the kernels' tiles (e.g. 72x72: 72 / 36 / 18 / 9) run as the
+        # VALID EXTENT of a larger zero-padded buffer (include/diamond_hip.h); the result is cropped back below
+        valid = None
+        hp, wp = E.padded_extent(h, w, self.inner_model.unet._num_down)
+        if (hp, wp) != (h, w):
+            import torch.nn.functional as F
+
+            valid = (h, w)
+            noisy_next_obs = F.pad(noisy_next_obs, (0, wp - w, 0, hp - h))
+            obs = F.pad(obs, (0, wp - w, 0, hp - h))
+            h, w = hp, wp
         packed = torch.empty(n, h, w, cpad, device=self.device, dtype=torch.float32)
         # NOTE: pointers are only taken from tensors bound to a name -- a temporary made inside the
         # argument list would be freed (and its block re-used) before the kernel is even launched.
@@ -113,7 +125,8 @@ class Denoiser(nn.Module):
                                              nv.fptr(packed), n, cx, cobs, h, w, cpad, t_ring, obs_head, nv.stream()),
                  "dmd_edm_pack_input")
         cvec = self.inner_model.cond_vector(cond, stride, act, act_head)
-        return self.inner_model.run(packed, cvec, naive, precision)
+        out = self.inner_model.run(packed, cvec, naive, precision, valid=valid)
+        return out if valid is None else out[:, :, :valid[0], :valid[1]].contiguous()
 
     @torch.no_grad()
     def wrap_model_output(self, noisy_next_obs: Tensor, model_output: Tensor, sigma: Union[Tensor, float],

@@ -159,7 +159,8 @@ class _CapturedSample:
         if sampler._graph_pool is None:
             sampler._graph_pool = torch.cuda.graph_pool_handle()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, pool=sampler._graph_pool):  # replays are sequential and outputs are copied out
+        # thread_local: other threads' HIP calls (the RCCL watchdog polls its events) must not invalidate this capture
+        with torch.cuda.graph(self.graph, pool=sampler._graph_pool, capture_error_mode="thread_local"):  # replays are sequential, outputs are copied out
             self.x, self.trajectory = sampler.sample_ring(ctx_obs, ctx_act, obs_head, act_head)
 
     def replay(self) -> Tuple[Tensor, List[Tensor]]:

@@ -69,6 +69,9 @@ class Act:
     stats: Optional[Tensor] = None
     tiles: int = 0
     needs_grad: bool = True  # False: network input (the training backward stops here)
+    # (vh, vw): the part of the (H, W) buffer that exists (include/diamond_hip.h: VALID EXTENT) -- image sizes whose U-Net
+    # levels are not multiples of the kernels' tiles live inside a larger buffer; None: all of it
+    valid: Optional[Tuple[int, int]] = None
 
     @property
     def shape(self):
@@ -197,6 +200,17 @@ def conv2d(
         p.src[i].prologue = prologue
         if prologue != nv.PROLOGUE_NONE:
             p.src[i].norm = norm.to_native(a)
+    # valid extent of the output from the sources' (all sources, and the residual, cover the same part)
+    valid = None
+    src_valid = {a.valid for a, _, _ in srcs}
+    assert len(src_valid) == 1, f"sources with different valid extents: {src_valid}"
+    sv = src_valid.pop()
+    if sv is not None:
+        assert TAPE is None, "valid extents are an inference-path feature (no recorded backward)"
+        valid = (sv[0] * 2, sv[1] * 2) if upsample else ((sv[0] // stride, sv[1] // stride))
+        assert stride == 1 or (sv[0] % 2 == 0 and sv[1] % 2 == 0), f"stride-2 conv over an odd valid extent {sv}"
+        p.valid_h, p.valid_w = valid
+        assert residual is None or residual.valid == valid
     p.w = nv.ptr(w_packed)
     if w_f16 is not None:
         p.w_f16 = nv.ptr(w_f16)
@@ -242,7 +256,7 @@ def conv2d(
             nbytes += 4.0 * sum(a.t.numel() for a in proj[0])
         nv.PROFILER.annotate(kernel_key(p), flops, nbytes)
     nv.check(fn(C.byref(p), nv.stream()), "dmd_conv2d")
-    result = Act(out, stats, tiles)
+    result = Act(out, stats, tiles, valid=valid)
     if TAPE is not None:
         assert module is not None, "recording a conv launch that does not name its nn.Conv2d"
         TAPE.append(ConvRecord(list(srcs), module, taps, stride, upsample, residual, residual_norm, result, out_nchw))
@@ -258,16 +272,32 @@ def proj_fusable(xs: Sequence[Act], cout: int, precision: str, naive: Optional[b
     if not FUSE_PROJ or precision != "f16x2" or naive or _USE_NAIVE or TAPE is not None:
         return False
     n, hh, ww, _ = xs[0].shape
+    if any(a.valid is not None for a in xs):
+        return False
     return (cout == 64 and hh % 16 == 0 and ww % 16 == 0 and len(xs) == 2 and all(a.C == 64 for a in xs)
             and n * hh * ww * 256 < 2 ** 32)
 
 
-def gn_stats(t: Tensor) -> Act:
-    """Attach (single-tile) GroupNorm statistics to an NHWC tensor no dmd kernel produced."""
+def gn_stats(t: Tensor, valid: Optional[Tuple[int, int]] = None) -> Act:
+    """Attach (single-tile) GroupNorm statistics to an NHWC tensor no dmd kernel produced (valid: of that part of it)."""
     n, h, w, c = t.shape
     stats = new_stats(n, c, 1, t.device)
-    nv.check(nv.lib().dmd_gn_stats(nv.fptr(t), nv.ptr(stats), n, h * w, c, nv.stream()), "dmd_gn_stats")
-    return Act(t, stats, 1)
+    if valid is None:
+        nv.check(nv.lib().dmd_gn_stats(nv.fptr(t), nv.ptr(stats), n, h * w, c, nv.stream()), "dmd_gn_stats")
+    else:
+        nv.check(nv.lib().dmd_gn_stats_valid(nv.fptr(t), nv.ptr(stats), n, h, w, valid[0], valid[1], c, nv.stream()), "dmd_gn_stats_valid")
+    return Act(t, stats, 1, valid=valid)
+
+
+def padded_extent(h: int, w: int, num_down: int) -> Tuple[int, int]:
+    """Buffer size for an (h, w) image through a U-Net with num_down stride-2 levels: (h, w) itself when every level is a
+    multiple of the kernels' 8-pixel tiles, else the next multiple of 16 * 2**num_down (every level on the 16x16 tiles), in
+    which the image is the VALID EXTENT."""
+    m = 8 * 2 ** num_down
+    if h % m == 0 and w % m == 0:
+        return h, w
+    m *= 2
+    return (h + m - 1) // m * m, (w + m - 1) // m * m
 
 
 def nchw_to_nhwc(x: Tensor, cpad: Optional[int] = None) -> Tensor:
@@ -291,6 +321,11 @@ def attention(qkv: Act, c: int, head_dim: int = 8) -> Tensor:
     n, h, w, c3 = qkv.shape
     assert c3 == 3 * c
     out = torch.empty(n, h, w, c, device=qkv.t.device, dtype=torch.float32)
+    if qkv.valid is not None:  # keys outside the valid extent stay out of the softmax
+        assert TAPE is None
+        nv.check(nv.lib().dmd_attention_valid(nv.fptr(qkv.t), nv.fptr(out), n, h, w, qkv.valid[0], qkv.valid[1], c, head_dim, nv.stream()),
+                 "dmd_attention_valid")
+        return out
     if nv.PROFILER is not None:  # QK^T and PV: 2 x (2 T^2 d) per head
         t = h * w
         nv.PROFILER.annotate("attention_f16x2_kernel" if t % 256 == 0 else "attention_kernel", 4.0 * n * t * t * c, 4.0 * n * t * 4 * c)

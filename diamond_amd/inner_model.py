@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import os
 from dataclasses import dataclass
-from typing import List, Optional
+from typing import Tuple, List, Optional
 
 import torch
 from torch import Tensor, nn
@@ -67,18 +67,37 @@ class InnerModel(nn.Module):
         return E.linear(y, self._cache.f32(l2.weight), self._cache.f32(l2.bias))
 
     def run(self, packed_in: Tensor, cond: Optional[Tensor], naive: Optional[bool] = None, precision: Optional[str] = None,
-            table: Optional[Tensor] = None) -> Tensor:
+            table: Optional[Tensor] = None, valid: Optional[Tuple[int, int]] = None) -> Tensor:
         """packed_in: NHWC16 [obs/sigma_data | noisy*c_in | 0]; returns F as NCHW (N,3,H,W).
-        table: the batched FiLM table if the caller already has it (the training path computes it under autograd)."""
+        table: the batched FiLM table if the caller already has it (the training path computes it under autograd).
+        valid = (h, w): the image is that part of the (H, W) buffer, the rest of which is ZERO (engine.padded_extent): the
+        reference's forward for sizes whose U-Net levels are not multiples of the kernels' tiles, including its
+        pad-to-2**num_down / crop (inner_model.py:44-49, blocks.py:227-229,247).  The returned (N, 3, H, W) is meaningful
+        in [:h, :w] only."""
         if self._film is None:
             self._film = FilmTable(self.unet)
         if table is None:
             table = self._film.compute(cond)
         ctx = RunCtx(self._cache, self._film, table, naive, precision)
-        x = E.conv2d([(E.Act(packed_in, needs_grad=False), nv.PROLOGUE_NONE, None)], self._cache.conv_weight(self.conv_in),
+        x = E.conv2d([(E.Act(packed_in, needs_grad=False, valid=valid), nv.PROLOGUE_NONE, None)], self._cache.conv_weight(self.conv_in),
                      self._cache.conv_bias(self.conv_in), self.conv_in.out_channels, naive=naive, w_f16=ctx.w16(self.conv_in),
                      module=self.conv_in)
+        padded = None
+        if valid is not None:
+            # UNet.forward pads conv_in's output with zeros to a multiple of 2**num_down (blocks.py:227-229) and treats the
+            # padding as data from then on: zero those rows / columns (conv_in's partial sums are unaffected by zeros) and
+            # widen the valid extent to the padded size
+            m = 2 ** self.unet._num_down
+            h, w = valid
+            padded = ((h + m - 1) // m * m, (w + m - 1) // m * m)
+            if padded != valid:
+                x.t[:, h:padded[0], :padded[1]] = 0
+                x.t[:, :h, w:padded[1]] = 0
+                x.valid = padded
         x = self.unet.run(ctx, x)
+        if padded is not None and padded != valid:
+            # ... and crops before norm_out (blocks.py:247): GroupNorm statistics of the cropped tensor
+            x = E.gn_stats(x.t, valid)
         co = self.conv_out
         w16 = self._cache.conv_weight_f16x2_head(co) if (ctx.precision == "f16x2" and not naive) else None
         cpad = 32 if w16 is not None else None  # the split kernel's 32-cout instance, real channels stored as NCHW

@@ -41,7 +41,8 @@ class ConvParams(C.Structure):
                 ("src", ConvSrc * 2), ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p),
                 ("residual_norm", Norm), ("out", C.c_void_p), ("out_nchw", C.c_int32), ("precision", C.c_int32),
                 ("out_stats", C.c_void_p), ("w_f16", C.c_void_p), ("proj_nsrc", C.c_int32), ("proj_C", C.c_int32 * 2),
-                ("proj_reserved", C.c_int32), ("proj_x", C.c_void_p * 2), ("proj_w_f16", C.c_void_p), ("proj_bias", C.c_void_p)]
+                ("proj_reserved", C.c_int32), ("proj_x", C.c_void_p * 2), ("proj_w_f16", C.c_void_p), ("proj_bias", C.c_void_p),
+                ("valid_h", C.c_int32), ("valid_w", C.c_int32)]
 
 
 class LinearParams(C.Structure):
@@ -82,10 +83,10 @@ class LowresChainParams(C.Structure):
 EXPORTS = (
     "dmd_conv2d", "dmd_conv2d_kernel_name", "dmd_conv2d_naive", "dmd_conv_stat_tiles", "dmd_pack_conv_weight", "dmd_conv2d_f16x2_eligible",
     "dmd_conv1x1_stream_eligible", "dmd_conv2d_proj_eligible",
-    "dmd_pack_conv_weight_f16x2", "dmd_linear", "dmd_attention", "dmd_attention_bwd", "dmd_attention_bwd_workspace_floats",
+    "dmd_pack_conv_weight_f16x2", "dmd_linear", "dmd_attention", "dmd_attention_valid", "dmd_attention_bwd", "dmd_attention_bwd_workspace_floats",
     "dmd_edm_pack_input", "dmd_cond_embed", "dmd_edm_denoised", "dmd_euler_step", "dmd_heun_step", "dmd_quantize_u8",
     "dmd_dequant_gather", "dmd_nchw_to_nhwc",
-    "dmd_nhwc_to_nchw", "dmd_gn_stats", "dmd_maxpool2", "dmd_lstm_pointwise", "dmd_lstm_pointwise_bwd", "dmd_categorical_sample",
+    "dmd_nhwc_to_nchw", "dmd_gn_stats", "dmd_gn_stats_valid", "dmd_maxpool2", "dmd_lstm_pointwise", "dmd_lstm_pointwise_bwd", "dmd_categorical_sample",
     "dmd_maxpool2_bwd", "dmd_gn_bwd_workspace_bytes", "dmd_gn_silu_bwd", "dmd_wgrad_workspace_floats", "dmd_conv2d_wgrad",
     "dmd_lowres_chain", "dmd_lowres_chain32", "dmd_last_error", "dmd_abi_version",
 )
@@ -176,6 +177,7 @@ def lib() -> _Lib:
         L.dmd_conv1x1_stream_eligible.argtypes = [C.POINTER(ConvParams)]
         L.dmd_conv2d_proj_eligible.argtypes = [C.POINTER(ConvParams)]
         L.dmd_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.dmd_attention_valid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.dmd_attention_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_void_p]
         L.dmd_attention_bwd_workspace_floats.argtypes = [C.c_int, C.c_int, C.c_int]
@@ -195,6 +197,7 @@ def lib() -> _Lib:
         L.dmd_nchw_to_nhwc.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.dmd_nhwc_to_nchw.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.dmd_gn_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.dmd_gn_stats_valid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.dmd_maxpool2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p]
         L.dmd_lstm_pointwise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]

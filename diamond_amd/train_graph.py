@@ -61,7 +61,8 @@ class GraphedTrainStep:
         _drop_weight_caches(model)
         optimizer.zero_grad(set_to_none=True)  # the gradients of the captured step come from the graph's own pool
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: other threads' HIP calls (the RCCL watchdog polls its events) must not invalidate this capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss, self.metrics = self._eager(zero=False)
         # (gradients stay allocated: the captured backward writes, not accumulates, into them at every replay)
 

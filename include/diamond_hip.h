@@ -82,6 +82,15 @@ typedef struct dmd_conv_params {
   const float* proj_x[2]; /* NHWC (N, H, W, proj_C[i]), no prologue                      */
   const void* proj_w_f16; /* dmd_pack_conv_weight_f16x2(k = 1) of the (Cout, sum C, 1, 1) weights */
   const float* proj_bias; /* [Cout] or NULL                                              */
+  /* VALID EXTENT (ABI v6).  The kernels tile in 8 / 16-pixel blocks; the reference's U-Net runs on any size that is a
+   * multiple of 2^num_down (it pads to that and crops, blocks.py:227-229,247), e.g. 72x72 with levels 72/36/18/9.  Such a
+   * tensor is stored inside a larger (N, H, W, C) buffer whose H, W satisfy the tiling rule, and (valid_h, valid_w) <= (H, W)
+   * is the part that exists: conv-input positions outside the valid extent read as ZERO (like the convolution's own
+   * padding, whatever the buffer holds there and before any fused normalisation), GroupNorm counts and the emitted
+   * partial statistics cover the valid extent only.  Everything is still WRITTEN for the whole (H, W) buffer: positions
+   * outside the valid extent hold unspecified values that no consumer reads unmasked.  The valid extent is the OUTPUT's;
+   * a source's is (2 valid_h, 2 valid_w) at stride 2 and (valid_h / 2, valid_w / 2) under `upsample`.  0, 0 = (H, W). */
+  int32_t valid_h, valid_w;
 } dmd_conv_params;
 
 /* DMD_PRECISION_F32:   v_mfma_f32_16x16x4_f32, bit-for-bit a k-ordered fp32 fma chain.
@@ -137,6 +146,10 @@ int dmd_linear(const dmd_linear_params* p, dmd_stream_t stream);
  * K/V tiles through LDS with an online softmax.  qkv is NHWC (N, T, 3C): q | k | v channel
  * thirds, head h = channels [h*d, (h+1)*d) of each third (blocks.py:66-71).  d == 8. */
 int dmd_attention(const float* qkv, float* out, int N, int T, int C, int head_dim, dmd_stream_t stream);
+/* ... over an (H, W) token grid of which only (valid_h, valid_w) exists (see dmd_conv_params: VALID EXTENT): keys outside it
+ * do not take part in the softmax; outputs of queries outside it are unspecified */
+int dmd_attention_valid(const float* qkv, float* out, int N, int H, int W, int valid_h, int valid_w, int C, int head_dim,
+                        dmd_stream_t stream);
 /* Backward of dmd_attention (autograd of blocks.py:66-71 under the denoiser training loss, denoiser.py:93-122):
  * y = the forward's output, dy its gradient -> dqkv (N, T, 3C) in the qkv layout.  workspace: dmd_attention_bwd_workspace_floats. */
 int64_t dmd_attention_bwd_workspace_floats(int N, int T, int C);
@@ -238,6 +251,8 @@ int dmd_nhwc_to_nchw(const float* in, float* out, int N, int C, int H, int W, in
 /* GroupNorm partial statistics of an NHWC tensor (one tile per image): for tensors that
  * no dmd_* kernel produced. */
 int dmd_gn_stats(const float* x, double* stats, int N, int HW, int C, dmd_stream_t stream);
+/* ... of the (valid_h, valid_w) part of an (N, H, W, C) buffer (dmd_conv_params: VALID EXTENT) */
+int dmd_gn_stats_valid(const float* x, double* stats, int N, int H, int W, int valid_h, int valid_w, int C, dmd_stream_t stream);
 
 /* 2x2 max pooling, NHWC, also emits GroupNorm stats of the pooled output and the argmax
  * (0..3) for the backward pass (actor_critic.py:108-109). */

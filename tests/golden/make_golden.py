@@ -338,6 +338,13 @@ def main():
     if "--sampler-heun5" in sys.argv:
         gen_sampler_heun5(ref_agent())
         return
+    if "--denoiser-ragged" in sys.argv:
+        # sizes whose U-Net levels are not multiples of the kernels' tiles: 72x72 (levels 72 / 36 / 18 / 9: the reference pads
+        # nothing) and 68x76 (padded to 72x80 inside UNet.forward and cropped back, blocks.py:227-229,247); the second one also
+        # with attention at the two deepest levels
+        gen_denoiser(ref_agent(), "72x72", h=72, w=72, b=2, only=(0, 3))
+        gen_denoiser(ref_agent(denoiser_attn_depths=(0, 0, 1, 1)), "attn0011_68x76", h=68, w=76, b=1, only=(1, 3))
+        return
     if "--denoiser-256" in sys.argv:  # BASELINE configs[4] shape: one 256x256 frame, attention at the two deepest levels
         gen_denoiser(ref_agent(denoiser_attn_depths=(0, 0, 1, 1)), "attn0011_256", h=256, w=256, b=1, only=(1, 3))
         return
@@ -361,6 +368,8 @@ def main():
     # attention at 16x16 and 8x8 inside the U-Net (BASELINE config 5 uses attn_depths=[0,0,1,1])
     gen_denoiser(ref_agent(denoiser_attn_depths=(0, 0, 1, 1)), "attn0011", b=1)
     gen_denoiser(ref_agent(denoiser_attn_depths=(0, 0, 1, 1)), "attn0011_256", h=256, w=256, b=1, only=(1, 3))
+    gen_denoiser(ref_agent(), "72x72", h=72, w=72, b=2, only=(0, 3))
+    gen_denoiser(ref_agent(denoiser_attn_depths=(0, 0, 1, 1)), "attn0011_68x76", h=68, w=76, b=1, only=(1, 3))
 
 
 if __name__ == "__main__":

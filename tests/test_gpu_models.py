@@ -72,6 +72,44 @@ def test_denoiser_vs_reference_golden(tag, attn, b):
         check_quantised(u8(d), gold[f"denoised_u8_{i}"], max_frac=1e-4, what=f"teacher-forced sigma#{i}")
 
 
+@pytest.mark.parametrize("tag,attn,b,h,w", [("72x72", (0, 0, 0, 0), 2, 72, 72), ("attn0011_68x76", (0, 0, 1, 1), 1, 68, 76)])
+def test_denoiser_sizes_off_the_tile_grid_vs_reference_golden(tag, attn, b, h, w):
+    """Image sizes whose U-Net levels are not multiples of the kernels' tiles run as the VALID EXTENT of a larger buffer
+    (include/diamond_hip.h): 72x72 has levels 72 / 36 / 18 / 9 (the reference pads nothing); 68x76 is padded to 72x80 by
+    UNet.forward and cropped back (/root/reference/src/models/blocks.py:227-229,247), with attention over 18x20 and 9x10
+    tokens.  Same bars as the 64x64 goldens, f16x2 (default) and exact fp32."""
+    gold = load_golden(f"denoiser_{tag}.pt")
+    ag = make_agent(attn)
+    obs, act, noise = _denoiser_inputs(gold, b, h, w)
+    sig = gold["sigmas"]
+    for i, sigma in enumerate(list(sig[:-1]) + [torch.tensor([0.7, 1.9][:b])]):
+        if f"model_output_{i}" not in gold:
+            continue
+        x = noise * sigma.reshape(-1, 1, 1, 1) + obs[:, -3:] * 0.5
+        for precision in ("f16x2", "f32"):
+            f = ag.denoiser.compute_model_output(x.to(DEV), obs.to(DEV), act.to(DEV), sigma, precision=precision)
+            assert tuple(f.shape) == (b, 3, h, w)
+            err = rel_err(f, gold[f"model_output_{i}"])
+            print(f"{tag} sigma#{i} [{precision}]: model_output rel err {err:.3e}")
+            assert err < 1e-4, f"{tag} sigma#{i} [{precision}]: model_output rel err {err:.3e}"
+        d = ag.denoiser.denoise(x.to(DEV), sigma, obs.to(DEV), act.to(DEV))
+        # 15-31k pixels: a budget of 1e-4 would be 1-3 pixels, i.e. the Poisson noise of the count itself (the fp32 error of
+        # 1-4e-6 puts ~1e-4 of all values within reach of a rounding boundary).  So: at most 2.5e-4 of the pixels off by one
+        # level AND every such pixel is a boundary case -- the reference's own value before `.byte()` (truncation,
+        # denoiser.py:82) lies within 2e-3 levels of an integer
+        mine, ref = u8(d), gold[f"denoised_u8_{i}"]
+        check_quantised(mine, ref, max_frac=2.5e-4, what=f"{tag} teacher-forced sigma#{i}")
+        from oracle import diamond_oracle as O
+
+        _, c_out, c_skip, _ = O.conditioners(O.DenoiserSpec(), sigma)
+        levels = ((c_skip * x + c_out * gold[f"model_output_{i}"]).clamp(-1, 1) + 1) / 2 * 255
+        flipped = mine != ref
+        if flipped.any():
+            frac = levels[flipped] - levels[flipped].floor()
+            dist = torch.minimum(frac, 1 - frac)
+            assert float(dist.max()) < 2e-3, f"a flipped pixel is {float(dist.max()):.2e} levels away from a truncation boundary"
+
+
 def test_denoiser_not_further_from_fp64_than_cpu_fp32(agent):
     """error of the HIP path vs an fp64 evaluation is of the same order as the
     error of the fp32 CPU oracle vs fp64."""
