@@ -7,6 +7,7 @@ injected by tests).
 """
 from __future__ import annotations
 
+import os
 import random
 from functools import wraps
 from typing import Callable, Optional
@@ -50,25 +51,59 @@ def make_env_loop(env, model, epsilon: float = 0.0, expo_fn: Optional[Callable[[
     seed = random.randint(0, 2 ** 31 - 1)
     obs, _ = env.reset(seed=[seed + i for i in range(env.num_envs)])
 
+    # Two-phase env (WorldModelEnv.step_begin / step_end): the policy's NEXT step is issued between the imagined frame and
+    # the reward / end model, i.e. BEFORE the step's one host synchronisation (`if dead.any()`), on the assumption that no
+    # episode ends.  The device then already holds the next action when the host comes back from that wait and the
+    # denoiser can be launched at once; without this the GPU idles ~1 ms per step while the host issues the policy's ~40
+    # small launches.  If an episode did end, the speculative result is dropped and the step is recomputed after the reset,
+    # with the SAME exponential draws: every random stream is consumed in the reference's order either way.
+    two_phase = hasattr(env, "step_begin") and os.environ.get("DIAMOND_SPECULATIVE_POLICY", "1") != "0"
+
+    def draw_expo(logits: Tensor) -> Tensor:
+        if expo_fn is not None:
+            return expo_fn(logits)
+        return torch.empty(logits.shape, device=logits.device, dtype=torch.float32).exponential_(1)
+
     while True:
         hx, cx = hx.detach(), cx.detach()  # BPTT window boundary
         rows, infos = [], []
         dead = val_final_obs = None
+        any_dead = False
+        spec = None        # (logits, val, (hx, cx), act) of this step, issued during the previous one
+        saved_expo = None  # draws of a dropped speculative step, to be used by its recomputation
         for n in range(num_steps):
-            logits_act, val, (hx, cx) = model.predict_act_value(obs, (hx, cx))
-            act = sample_categorical(logits_act, None if expo_fn is None else expo_fn(logits_act))
+            if spec is not None:
+                logits_act, val, (hx, cx), act = spec
+                spec = None
+            else:
+                logits_act, val, (hx, cx) = model.predict_act_value(obs, (hx, cx))
+                expo = saved_expo if saved_expo is not None else draw_expo(logits_act)
+                saved_expo = None
+                act = sample_categorical(logits_act, expo)
             if random.random() < epsilon:  # python RNG consumed every step, like the reference (:34)
                 act = torch.randint(low=0, high=env.num_actions, size=(obs.size(0),), device=obs.device)
-            next_obs, rew, end, trunc, info = env.step(act)
+            cand = None
+            if two_phase:
+                nxt = env.step_begin(act)
+                if n + 1 < num_steps:
+                    s_logits, s_val, s_hc = model.predict_act_value(nxt, (hx, cx))
+                    s_expo = draw_expo(s_logits)
+                    cand = (s_logits, s_val, s_hc, sample_categorical(s_logits, s_expo))
+                next_obs, rew, end, trunc, info = env.step_end()
+            else:
+                next_obs, rew, end, trunc, info = env.step(act)
 
             if n > 0:  # the bootstrap value of step n-1 is this step's value (:39-43)
                 vb = val.detach().clone()
-                if dead.any():
+                if any_dead:
                     vb[dead] = val_final_obs
                 rows[-1][-1] = vb
 
             dead = torch.logical_or(end, trunc)
-            if dead.any():
+            any_dead = info["any_dead"] if "any_dead" in info else bool(dead.any())
+            if any_dead:
+                if cand is not None:
+                    saved_expo, cand = s_expo, None  # an episode ended: this step's policy output is recomputed after the reset
                 with torch.no_grad():
                     _, val_final_obs, _ = model.predict_act_value(info["final_observation"], (hx[dead], cx[dead]))
                 gate = 1 - dead.float().unsqueeze(1)
@@ -77,6 +112,7 @@ def make_env_loop(env, model, epsilon: float = 0.0, expo_fn: Optional[Callable[[
                     burnin = info["burnin_obs"]
                     for i in range(burnin.size(1)):
                         _, _, (hx[dead], cx[dead]) = model.predict_act_value(burnin[:, i], (hx[dead], cx[dead]))
+            spec = cand
 
             rows.append([obs, act, rew, end, trunc, logits_act, val, None])
             infos.append(info)
@@ -84,7 +120,7 @@ def make_env_loop(env, model, epsilon: float = 0.0, expo_fn: Optional[Callable[[
 
         with torch.no_grad():
             _, vb, _ = model.predict_act_value(obs, (hx, cx))
-        if dead.any():
+        if any_dead:
             vb[dead] = val_final_obs
         rows[-1][-1] = vb
         stacked = tuple(torch.stack(col, dim=1) for col in zip(*rows))

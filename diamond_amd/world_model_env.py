@@ -204,10 +204,34 @@ class WorldModelEnv:
 
     @torch.no_grad()
     def step(self, act: Tensor):
+        self.step_begin(act)
+        return self.step_end()
+
+    @torch.no_grad()
+    def step_begin(self, act: Tensor) -> Tensor:
+        """First half of `step`: the imagined next frame.  Nothing here waits for the device.  The random draws of the second
+        half (reward / end samples) are made NOW, so that a caller may interleave its own draws between the two halves
+        without changing the order in which the streams are consumed (env_loop issues the policy's next step in between)."""
         newest = self._slot(-1)
         self._act[:, newest] = act
         next_obs, denoising_trajectory = self.predict_next_obs()
-        rew, end = self.predict_rew_end(next_obs.unsqueeze(1))
+        b, dev = next_obs.shape[0], next_obs.device
+        if self.expo_fn is None:
+            e_rew = torch.empty(b, 3, device=dev).exponential_(1)
+            e_end = torch.empty(b, 2, device=dev).exponential_(1)
+        else:  # (test hook: draws injected in the reference's order -- the hook looks at the shape only)
+            e_rew = self.expo_fn(torch.empty(b, 1, 3, device=dev))
+            e_end = self.expo_fn(torch.empty(b, 1, 2, device=dev))
+        self._pending = (next_obs, denoising_trajectory, e_rew, e_end)
+        return next_obs
+
+    @torch.no_grad()
+    def step_end(self):
+        """Second half of `step`: reward / termination, ring bookkeeping and -- the one host synchronisation of a step -- the
+        check for finished episodes (`if dead.any()`, world_model_env.py:77-83)."""
+        next_obs, denoising_trajectory, e_rew, e_end = self._pending
+        self._pending = None
+        rew, end = self.predict_rew_end(next_obs.unsqueeze(1), e_rew, e_end)
 
         self.ep_len += 1
         trunc = (self.ep_len >= self.horizon).long()
@@ -222,7 +246,9 @@ class WorldModelEnv:
         if self.return_denoising_trajectory:
             info["denoising_trajectory"] = torch.stack(denoising_trajectory, dim=1)
         obs = next_obs  # a fresh tensor every step: never aliases the ring
-        if dead.any():
+        any_dead = bool(dead.any())
+        info["any_dead"] = any_dead  # (so that the caller does not have to synchronise again for the same answer)
+        if any_dead:
             rows = self.reset_dead(dead)
             info["final_observation"] = next_obs[rows]
             cols = self._cols()
@@ -239,12 +265,14 @@ class WorldModelEnv:
         return self.sampler.sample_ring(self._ctx, self._act, self._head, self._head)
 
     @torch.no_grad()
-    def predict_rew_end(self, next_obs: Tensor) -> Tuple[Tensor, Tensor]:
+    def predict_rew_end(self, next_obs: Tensor, e_rew: Optional[Tensor] = None, e_end: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+        """e_rew / e_end: exponential draws made earlier (step_begin); None: drawn here."""
         newest = self._slot(-1)
         logits_rew, logits_end, (self.hx_rew_end, self.cx_rew_end) = self.rew_end_model.predict_rew_end(
             self._ctx[:, newest:newest + 1], self._act[:, newest:newest + 1], next_obs, (self.hx_rew_end, self.cx_rew_end))
-        e_rew = None if self.expo_fn is None else self.expo_fn(logits_rew)
-        e_end = None if self.expo_fn is None else self.expo_fn(logits_end)
+        if e_rew is None:
+            e_rew = None if self.expo_fn is None else self.expo_fn(logits_rew)
+            e_end = None if self.expo_fn is None else self.expo_fn(logits_end)
         rew = sample_categorical(logits_rew, e_rew).squeeze(1) - 1.0  # {-1, 0, 1}
         end = sample_categorical(logits_end, e_end).squeeze(1)
         return rew, end

@@ -669,3 +669,40 @@ def test_sampler_branches_bit_exact_vs_oracle_control_flow(agent, name, steps, o
     for i, (a, r) in enumerate(zip(traj, traj_ref)):
         assert torch.equal(a.cpu(), r), f"{name}: trajectory point {i} differs"
     assert torch.equal(x.cpu(), x_ref)
+
+
+def test_speculative_policy_step_is_bitwise_the_sequential_one(monkeypatch):
+    """env_loop issues the policy's next step between WorldModelEnv.step_begin and step_end (before the step's host
+    synchronisation) and drops it when an episode ended: two windows with many mid-window resets (the golden's unbiased
+    synthetic end-logits), same seeds, with and without the speculation -- every output bitwise identical."""
+    import random
+    import diamond_amd as D
+
+    gold = load_golden("window.pt")
+    b, t = gold["b"], gold["backup_every"]
+    runs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DIAMOND_SPECULATIVE_POLICY", mode)
+        ag = make_agent()
+        env = D.WorldModelEnv(ag.denoiser, ag.rew_end_model, _Loader(b, gold["pool_seed"]),
+                              D.WorldModelEnvConfig(horizon=gold["horizon"], num_batches_to_preload=gold["preload"],
+                                                    diffusion_sampler=D.DiffusionSamplerConfig(num_steps_denoising=3)))
+        ag.setup_training(D.SigmaDistributionConfig(-0.4, 1.2, 2e-3, 20),
+                          D.ActorCriticLossConfig(backup_every=t, gamma=0.985, lambda_=0.95, weight_value_loss=1.0,
+                                                  weight_entropy_loss=0.001), env)
+        torch.manual_seed(gold["rng_seed"])
+        random.seed(0)
+        expo = lambda logits: torch.empty(logits.shape, dtype=torch.float32).exponential_(1)
+        ag.actor_critic.expo_fn = expo
+        env.expo_fn = expo
+        env.sampler.noise_fn = lambda shape, dev: torch.randn(*shape).to(dev)
+        outs = []
+        for _ in range(2):
+            all_obs, act, rew, end, trunc, logits_act, val, vb, _ = ag.actor_critic.env_loop.send(t)
+            outs.append([x.detach().cpu() for x in (all_obs, act, rew, end, trunc, logits_act, val, vb)])
+        runs.append(outs)
+    deaths = int(sum(o[3].sum() for o in runs[0]))
+    assert deaths > 0, "the comparison needs mid-window resets"
+    for wa, wb in zip(*runs):
+        for a, b_ in zip(wa, wb):
+            assert torch.equal(a, b_)

@@ -1,19 +1,22 @@
 """GPU idle-gap analysis of a rocprofv3 kernel trace CSV (development aid).
-usage: python tools/trace_gaps.py kernel_trace.csv[.gz]"""
+usage: python tools/trace_gaps.py kernel_trace.csv[.gz] [min_gap_us]
+Prints the busy fraction, a gap histogram, the largest (previous kernel -> next kernel) gap classes and every individual gap
+above min_gap_us (default 500) with its time before the end of the trace -- for `bench.py --steps K --warmup W` the timed
+windows are the last K x ~330 ms."""
 import csv, gzip, sys
 from collections import defaultdict
 path = sys.argv[1]
+min_gap = float(sys.argv[2]) * 1e3 if len(sys.argv) > 2 else 5e5
 f = gzip.open(path, "rt") if path.endswith(".gz") else open(path)
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(f)]
 rows.sort()
-# restrict to the last 40 % of the trace (steady-state windows)
-t0 = rows[0][0] + int(0.6 * (rows[-1][1] - rows[0][0]))
-rows = [r for r in rows if r[0] >= t0]
+end = rows[-1][1]
 span = rows[-1][1] - rows[0][0]
 busy = sum(e - s for s, e, _ in rows)
 print(f"span {span/1e6:.1f} ms, kernel busy {busy/1e6:.1f} ms ({100*busy/span:.1f} %), {len(rows)} kernels")
 gaps = defaultdict(lambda: [0, 0])
 hist = defaultdict(lambda: [0, 0])
+big = []
 prev_end, prev_name = rows[0][1], rows[0][2]
 for s, e, n in rows[1:]:
     g = s - prev_end
@@ -24,7 +27,12 @@ for s, e, n in rows[1:]:
         b = "<5us" if g < 5e3 else "<20us" if g < 2e4 else "<100us" if g < 1e5 else "<1ms" if g < 1e6 else ">=1ms"
         hist[b][0] += 1
         hist[b][1] += g
+        if g >= min_gap:
+            big.append(((end - s) / 1e6, g / 1e6, prev_name[:60], n[:60]))
     prev_end, prev_name = max(prev_end, e), n
 print("gap histogram:", {k: (v[0], round(v[1] / 1e6, 2)) for k, v in hist.items()})
-for (a, b), (c, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:25]:
+for (a, b), (c, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:12]:
     print(f"{t/1e6:8.2f} ms  {c:6d}x  {a}  ->  {b}")
+print(f"individual gaps >= {min_gap/1e3:.0f} us (ms before the end of the trace, gap ms, previous -> next):")
+for t, g, a, b in big[-80:]:
+    print(f"  -{t:8.1f}  {g:7.2f}  {a}  ->  {b}")
