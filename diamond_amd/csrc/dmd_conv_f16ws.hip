@@ -1075,83 +1075,83 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       }
     }
     for (; k < nmy; k += 2) {
-        // ---- this group's tile: fragment reads + MFMAs only ----
-        // (only if the other group's tile had too few steps to finish the write-out; PROJ launches have 4 steps per tile)
-        if (!G::PROJ && pending < 4) epi_blocks(4);
-        {
-          // lane owns couts cb*32 + 8 qd + 4 g + (0..3), qd = 0..3, of its pixel of each block
-          f32x4 bq[4];
-  #pragma unroll
-          for (int qd = 0; qd < 4; ++qd) bq[qd] = *(const f32x4*)(bias_lds + cb * 32 + 8 * qd + 4 * g);
-  #pragma unroll
-          for (int blk = 0; blk < 4; ++blk)
-  #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[blk][r] = bq[r >> 2][r & 3];
-        }
-        // operands of the tile's first half-tap (the one exposed LDS round trip per tile)
-        ws_addr_move<G>(ad, (j & 1) - apar);
-        apar = j & 1;
-        WsA a, an;
-        WsB b, bn;
-        a.h = ws_read_a<G, 0, false>(lds, ad);
-        b.h0 = ws_read_b<G, 0, 0, false>(lds, ad);
-        b.h1 = ws_read_b<G, 0, 1, false>(lds, ad);
-        b.l0 = ws_read_b<G, 0, 0, true>(lds, ad);
-        b.l1 = ws_read_b<G, 0, 1, true>(lds, ad);
-        a.l = ws_read_a<G, 0, true>(lds, ad);
-        an = a;
-        bn = b;
-        constexpr int LH = (G::HALVES - 1) % 2;
-        for (int ck = 0; ck < nchunks; ++ck, ++j) {
-          WS_STAMP(role, 4, j);
-          ws_chunk_body<G>(acc, a, b, lds, ad);
-          WS_STAMP(role, 5, j);
-          ws_barrier();  // B(j + 1): every fragment of buffer j is in registers; buffer j + 1 is complete
-          WS_STAMP(role, 6, j);
-          // the held-back last half-tap, under the first fragment reads of the next chunk (other buffer pair).  After
-          // the tile's last chunk these reads fetch the other group's first fragments (or, at the end of the stream,
-          // stale LDS) and are simply dropped: unconditional, so that the accumulators stay in one set of registers
-          ws_addr_move<G>(ad, 1 - 2 * apar);
-          apar ^= 1;
-          ws_halftap<G, 2 * LH, 3, 0, 0>(acc, a, b, lds, ad, an, bn);
-          a = an;
-          b = bn;
-        }
-        epi_begin(k);  // written out while the other group computes the next tile
+      // ---- this group's tile: fragment reads + MFMAs only ----
+      // (only if the other group's tile had too few steps to finish the write-out; PROJ launches have 4 steps per tile)
+      if (!G::PROJ && pending < 4) epi_blocks(4);
+      {
+        // lane owns couts cb*32 + 8 qd + 4 g + (0..3), qd = 0..3, of its pixel of each block
+        f32x4 bq[4];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) bq[qd] = *(const f32x4*)(bias_lds + cb * 32 + 8 * qd + 4 * g);
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[blk][r] = bq[r >> 2][r & 3];
+      }
+      // operands of the tile's first half-tap (the one exposed LDS round trip per tile)
+      ws_addr_move<G>(ad, (j & 1) - apar);
+      apar = j & 1;
+      WsA a, an;
+      WsB b, bn;
+      a.h = ws_read_a<G, 0, false>(lds, ad);
+      b.h0 = ws_read_b<G, 0, 0, false>(lds, ad);
+      b.h1 = ws_read_b<G, 0, 1, false>(lds, ad);
+      b.l0 = ws_read_b<G, 0, 0, true>(lds, ad);
+      b.l1 = ws_read_b<G, 0, 1, true>(lds, ad);
+      a.l = ws_read_a<G, 0, true>(lds, ad);
+      an = a;
+      bn = b;
+      constexpr int LH = (G::HALVES - 1) % 2;
+      for (int ck = 0; ck < nchunks; ++ck, ++j) {
+        WS_STAMP(role, 4, j);
+        ws_chunk_body<G>(acc, a, b, lds, ad);
+        WS_STAMP(role, 5, j);
+        ws_barrier();  // B(j + 1): every fragment of buffer j is in registers; buffer j + 1 is complete
+        WS_STAMP(role, 6, j);
+        // the held-back last half-tap, under the first fragment reads of the next chunk (other buffer pair).  After
+        // the tile's last chunk these reads fetch the other group's first fragments (or, at the end of the stream,
+        // stale LDS) and are simply dropped: unconditional, so that the accumulators stay in one set of registers
+        ws_addr_move<G>(ad, 1 - 2 * apar);
+        apar ^= 1;
+        ws_halftap<G, 2 * LH, 3, 0, 0>(acc, a, b, lds, ad, an, bn);
+        a = an;
+        b = bn;
+      }
+      epi_begin(k);  // written out while the other group computes the next tile
       if (k + 1 >= nmy) break;
-        // ---- the other group's tile: write our finished tile out, a slice per chunk step, and move the weights ----
-        if constexpr (G::PROJ) {
-          // 4 chunk steps per tile (eligibility), block s of the finished tile in step s: straight-line code, so that
-          // hipcc sees which accumulators are dead and counts the loads in flight exactly
-          ws_for<0, 4>([&](auto sc) {
-            const bool wnext = j + 1 < S;
-            WS_STAMP(role, 8, j);
-            // block 0's operands: requested here, not in epi_begin -- nothing separates the two in time (the tile's last
-            // MFMAs are right in front of this step), and every request and its wait then sit in one straight line
-            if constexpr (decltype(sc)::value == 0) ws_for<0, G::PROJ_KS>([&](auto uc) { proj_fetch_unit(0, uc); });
-            if (wnext) cons_load_W((j + 1) % nchunks, (j + 1) & 1);
-            WS_STAMP(role, 9, j);
-            proj_step(sc, wnext);  // (a finished tile is always waiting here: epi_begin was the previous statement)
-            WS_STAMP(role, 10, j);
-            ws_barrier();  // B(j + 1)
-            WS_STAMP(role, 11, j);
-            ++j;
-          });
-        } else {
-          for (int ck = 0; ck < nchunks; ++ck, ++j) {
-            const bool wnext = j + 1 < S;  // this (idle) group copies the next step's weights
-            WS_STAMP(role, 8, j);
-            if (wnext) cons_load_W((j + 1) % nchunks, (j + 1) & 1);
-            WS_STAMP(role, 9, j);
-            if (pending < 4)
-              epi_blocks(blocks_per_step, wnext);
-            else if (wnext)
-              cons_land_W();
-            WS_STAMP(role, 10, j);
-            ws_barrier();  // B(j + 1)
-            WS_STAMP(role, 11, j);
-          }
+      // ---- the other group's tile: write our finished tile out, a slice per chunk step, and move the weights ----
+      if constexpr (G::PROJ) {
+        // 4 chunk steps per tile (eligibility), block s of the finished tile in step s: straight-line code, so that
+        // hipcc sees which accumulators are dead and counts the loads in flight exactly
+        ws_for<0, 4>([&](auto sc) {
+          const bool wnext = j + 1 < S;
+          WS_STAMP(role, 8, j);
+          // block 0's operands: requested here, not in epi_begin -- nothing separates the two in time (the tile's last
+          // MFMAs are right in front of this step), and every request and its wait then sit in one straight line
+          if constexpr (decltype(sc)::value == 0) ws_for<0, G::PROJ_KS>([&](auto uc) { proj_fetch_unit(0, uc); });
+          if (wnext) cons_load_W((j + 1) % nchunks, (j + 1) & 1);
+          WS_STAMP(role, 9, j);
+          proj_step(sc, wnext);  // (a finished tile is always waiting here: epi_begin was the previous statement)
+          WS_STAMP(role, 10, j);
+          ws_barrier();  // B(j + 1)
+          WS_STAMP(role, 11, j);
+          ++j;
+        });
+      } else {
+        for (int ck = 0; ck < nchunks; ++ck, ++j) {
+          const bool wnext = j + 1 < S;  // this (idle) group copies the next step's weights
+          WS_STAMP(role, 8, j);
+          if (wnext) cons_load_W((j + 1) % nchunks, (j + 1) & 1);
+          WS_STAMP(role, 9, j);
+          if (pending < 4)
+            epi_blocks(blocks_per_step, wnext);
+          else if (wnext)
+            cons_land_W();
+          WS_STAMP(role, 10, j);
+          ws_barrier();  // B(j + 1)
+          WS_STAMP(role, 11, j);
         }
+      }
     }
     if (pending < 4) epi_blocks(4);  // tail: the last tile(s) of the range
   }
