@@ -1,0 +1,107 @@
+"""Host logic of env_loop's speculative policy step on the CPU (no kernel: a torch toy policy, a toy two-phase env and a torch
+stand-in for the categorical-sample kernel): the policy's step n + 1 is issued between env.step_begin and env.step_end and dropped
+when an episode ended.  With ONE shared random stream for every draw (policy exponentials, env noise, reward / end
+exponentials) the rollout must be bitwise the sequential one -- i.e. the stream is consumed in the same order -- and the env
+must see exactly the same sequence of calls.  (The GPU twin with the real models: tests/test_gpu_models.py.)"""
+import random
+
+import pytest
+import torch
+
+import diamond_amd.env_loop as EL
+
+
+class ToyPolicy:
+    lstm_dim = 5
+
+    def __init__(self):
+        g = torch.Generator().manual_seed(3)
+        self.w = torch.randn(4, 6, generator=g)
+        self.device = torch.device("cpu")
+        self.calls = 0
+
+    def predict_act_value(self, obs, hx_cx):
+        self.calls += 1
+        hx, cx = hx_cx
+        feat = obs.flatten(1)[:, :6] + hx[:, :1]
+        logits = feat @ self.w.t()
+        val = feat.sum(1)
+        return logits, val, (torch.tanh(hx + feat[:, :5]), cx + 1)
+
+
+class ToyEnv:
+    """WorldModelEnv's protocol: step = step_begin + step_end, deaths reset the row, info carries final_observation / any_dead."""
+    num_actions = 4
+
+    def __init__(self, b, p_end, two_phase):
+        self.num_envs, self.p_end = b, p_end
+        if not two_phase:
+            self.step_begin = None  # (hasattr is what env_loop looks at)
+            del self.step_begin
+        self.log = []
+
+    def reset(self, **kw):
+        self.state = torch.randn(self.num_envs, 2, 3)
+        self.t = torch.zeros(self.num_envs, dtype=torch.long)
+        return self.state.clone(), {}
+
+    def _begin(self, act):
+        self.log.append("begin")
+        nxt = self.state * 0.5 + act.float().view(-1, 1, 1) * 0.1 + torch.randn(self.num_envs, 2, 3)  # "denoiser noise"
+        self._pending = (nxt, torch.empty(self.num_envs, 3).exponential_(1), torch.empty(self.num_envs, 2).exponential_(1))
+        return nxt
+
+    def _end(self):
+        self.log.append("end")
+        nxt, e_rew, e_end = self._pending
+        rew = (torch.zeros(self.num_envs, 3) / e_rew).argmax(1).float() - 1
+        end = ((torch.tensor([1 - self.p_end, self.p_end]).log().expand(self.num_envs, 2).exp()) / e_end).argmax(1)
+        self.t += 1
+        trunc = (self.t >= (7 if self.p_end > 0 else 10 ** 6)).long()
+        dead = torch.logical_or(end, trunc)
+        info = {"any_dead": bool(dead.any())}
+        self.state = nxt
+        obs = nxt
+        if info["any_dead"]:
+            info["final_observation"] = nxt[dead]
+            self.state = nxt.clone()
+            self.state[dead] = 7.0  # "fresh episode"
+            self.t[dead] = 0
+            obs = self.state.clone()
+        return obs, rew, end, trunc, info
+
+
+def _make_env(b, p_end, two_phase):
+    env = ToyEnv(b, p_end, two_phase)
+    if two_phase:
+        env.step_begin, env.step_end = env._begin, env._end
+    env.step = lambda act: (env._begin(act), env._end())[1]
+    return env
+
+
+def _rollout(monkeypatch, two_phase, p_end, windows=3, t=6, b=5):
+    monkeypatch.setattr(EL, "sample_categorical", lambda logits, expo: (torch.softmax(logits.detach(), -1) / expo).argmax(-1))
+    torch.manual_seed(11)
+    random.seed(5)
+    env, pol = _make_env(b, p_end, two_phase), ToyPolicy()
+    loop = EL.make_env_loop(env, pol, epsilon=0.2)
+    outs = []
+    for _ in range(windows):
+        *cols, infos = loop.send(t)
+        outs.append([c.clone() for c in cols])
+    return outs, env, pol
+
+
+@pytest.mark.parametrize("p_end", [0.0, 0.35])
+def test_speculative_policy_step_consumes_the_streams_in_the_sequential_order(monkeypatch, p_end):
+    seq, env_s, pol_s = _rollout(monkeypatch, False, p_end)
+    spec, env_p, pol_p = _rollout(monkeypatch, True, p_end)
+    for wa, wb in zip(seq, spec):
+        for a, b in zip(wa, wb):
+            assert torch.equal(a, b)
+    assert env_s.log == env_p.log
+    deaths = sum(int(w[3].sum() + w[4].sum()) for w in seq)
+    if p_end == 0.0:
+        assert deaths == 0 and pol_p.calls == pol_s.calls  # nobody ends mid-window: every speculative step is used
+    else:
+        assert deaths > 0 and pol_p.calls > pol_s.calls  # dropped speculative steps were recomputed
