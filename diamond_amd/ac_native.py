@@ -99,7 +99,7 @@ def _transposed(w: Tensor) -> Tensor:
 
 def _dgrad_weight(cache: E.PackCache, conv: nn.Conv2d) -> Tensor:
     """Packed weight of the transposed convolution: w_t[ci][co][ky][kx] = w[co][ci][2-ky][2-kx]."""
-    return cache.get(conv.weight, "dgradw", lambda w: nv.pack_conv_weight(_transposed(w)))
+    return cache.dgrad_weight(conv, 0, conv.in_channels)
 
 
 def _w16(cache: E.PackCache, conv: nn.Conv2d) -> Optional[Tensor]:
@@ -113,7 +113,7 @@ def _dgrad_w16(cache: E.PackCache, conv: nn.Conv2d) -> Optional[Tensor]:
     cout_t, cin_t = conv.in_channels, conv.out_channels
     if cout_t not in (32, 64) or cin_t > (128 if cout_t == 64 else 64):
         return None
-    return cache.get(conv.weight, "dgradw_f16x2", lambda w: nv.pack_conv_weight_f16x2(_transposed(w)))
+    return cache.dgrad_weight(conv, 0, conv.in_channels, f16x2=True)
 
 
 class _Plan:

@@ -101,31 +101,101 @@ class NormSpec:
         return nv.make_norm(a.stats, a.tiles, self.mul, self.add, self.mul_stride, self.add_stride, self.plus_one)
 
 
+class _PackEntry:
+    """One kernel-layout copy of a convolution parameter: the job that rebuilds it and the stamp it was last built from."""
+    __slots__ = ("ref", "out", "stamp", "job", "elems")
+
+    def __init__(self, p: Tensor, out: Tensor, job: "nv.PackJob", elems: int) -> None:
+        self.ref, self.out, self.stamp, self.job, self.elems = weakref.ref(p), out, None, job, elems
+
+
+def _stamp(p: Tensor) -> Tuple:
+    # storage pointer: catches `p.data = other`; the entry's weakref: an id() re-used by a new tensor is not a hit
+    return (p._version, p.data_ptr(), p.device)
+
+
 class PackCache:
     """Kernel-layout copies of nn.Module parameters, refreshed when a parameter changes
     (optimizer steps bump `Tensor._version`).  Parameters keep the reference's OIHW / (out,in)
-    layouts so checkpoints stay interchangeable (agent.py:48-62)."""
+    layouts so checkpoints stay interchangeable (agent.py:48-62).
+
+    The convolution copies (packed fp32, split-fp16 pieces, padded biases, and the transposed / sliced weights of the data
+    gradient) are JOBS of one table in device memory, all rebuilt together by ONE launch (dmd_pack_jobs) as soon as any of
+    them is stale: a training step changes every parameter, and packing copy by copy was ~640 launches per denoiser step.
+    The outputs are rebuilt in place (stable pointers: a captured training step keeps reading the same buffers)."""
 
     def __init__(self) -> None:
         self._store: Dict[Tuple[int, str], Tuple[Tuple, "weakref.ref", Tensor]] = {}
+        self._jobs: Dict[Tuple, _PackEntry] = {}
+        self._table: Optional[Tensor] = None  # (njobs * sizeof(dmd_pack_job)) bytes on the device
+        self._table_entries: List[_PackEntry] = []
+        self._max_elems = 0
 
     def invalidate(self) -> None:
-        """Drop every packed copy.  Needed after writes that do not bump `Tensor._version` (anything done through
-        `p.data`: `.data.copy_`, `.data.fill_`, collectives on `.data`)."""
+        """Every packed copy is stale.  Needed after writes that do not bump `Tensor._version` (anything done through
+        `p.data`: `.data.copy_`, `.data.fill_`, collectives on `.data`; a replayed training-step graph).  Buffers and the
+        job table are kept: the next use rebuilds the copies in place with one launch."""
         self._store.clear()
+        for ent in self._jobs.values():
+            ent.stamp = None
 
     def get(self, p: Tensor, kind: str, fn):
         key = (id(p), kind)
         hit = self._store.get(key)
-        # storage pointer: catches `p.data = other`; weakref: an id() re-used by a new tensor is not a hit
-        stamp = (p._version, p.data_ptr(), p.device)
+        stamp = _stamp(p)
         if hit is None or hit[0] != stamp or hit[1]() is not p:
             hit = (stamp, weakref.ref(p), fn(p))
             self._store[key] = hit
         return hit[2]
 
+    # -- convolution copies: one table, one launch --------------------------------------------------------------------
+    def _conv_job(self, p: Tensor, kind: int, cout_pad: int, transposed: bool = False, c0: int = 0, c1: int = 0,
+                  cin_pad_to: int = 0) -> Tensor:
+        key = (id(p), kind, cout_pad, transposed, c0, c1, cin_pad_to)
+        ent = self._jobs.get(key)
+        if ent is not None and ent.ref() is p and ent.stamp == _stamp(p):
+            return ent.out
+        if ent is None or ent.ref() is not p or ent.job.src != p.data_ptr() or ent.out.device != p.device:
+            assert p.dtype == torch.float32 and p.is_contiguous(), "convolution parameters are contiguous fp32"
+            job = nv.PackJob()
+            job.src, job.kind, job.transposed, job.c0, job.c1 = p.data_ptr(), kind, int(transposed), c0, c1
+            if kind == nv.PACK_BIAS:
+                job.Cout, job.Cin, job.k, job.CoutPad, job.CinPad = p.numel(), 1, 1, cout_pad, 16
+                out = torch.empty(cout_pad, device=p.device, dtype=torch.float32)
+                elems = cout_pad
+            else:
+                cout, cin, k, _ = p.shape
+                job.Cout, job.Cin, job.k = cout, cin, k
+                cin_l = max(cout, cin_pad_to) if transposed else cin  # input channels of the (transposed) weight
+                job.CoutPad, job.CinPad = cout_pad, (cin_l + 15) // 16 * 16
+                elems = job.CinPad * k * k * cout_pad
+                out = torch.empty(elems * (2 if kind == nv.PACK_F16X2 else 1), device=p.device,
+                                  dtype=torch.float16 if kind == nv.PACK_F16X2 else torch.float32)
+            job.dst = out.data_ptr()
+            ent = _PackEntry(p, out, job, elems)
+            self._jobs[key] = ent
+            self._table = None
+        self._refresh()
+        return ent.out
+
+    def _refresh(self) -> None:
+        """Rebuild every registered copy with one launch (all of them: whoever changed one parameter changed them all)."""
+        if self._table is None:
+            dead = [k for k, e in self._jobs.items() if e.ref() is None]
+            for k in dead:
+                del self._jobs[k]
+            self._table_entries = list(self._jobs.values())
+            raw = b"".join(bytes(e.job) for e in self._table_entries)
+            dev = self._table_entries[0].out.device
+            self._table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+            self._max_elems = max(e.elems for e in self._table_entries)
+        nv.check(nv.lib().dmd_pack_jobs(nv.ptr(self._table), len(self._table_entries), self._max_elems, nv.stream()), "dmd_pack_jobs")
+        for e in self._table_entries:
+            p = e.ref()
+            e.stamp = None if p is None else _stamp(p)
+
     def conv_weight(self, conv: nn.Conv2d, cout_padded: Optional[int] = None) -> Tensor:
-        return self.get(conv.weight, f"convw{cout_padded}", lambda w: nv.pack_conv_weight(w, cout_padded))
+        return self._conv_job(conv.weight, nv.PACK_F32, cout_padded or nv.cout_pad(conv.out_channels))
 
     def conv_weight_f16x2(self, conv: nn.Conv2d) -> Optional[Tensor]:
         """Split-fp16 pieces of a 3x3 / 1x1 stride-1 weight with 32 or 64 output channels (None for other shapes)."""
@@ -133,25 +203,30 @@ class PackCache:
             return None
         if conv.in_channels > (128 if conv.out_channels == 64 else 64):
             return None
-        return self.get(conv.weight, "convw_f16x2", nv.pack_conv_weight_f16x2)
+        return self._conv_job(conv.weight, nv.PACK_F16X2, conv.out_channels)
 
     def conv_weight_f16x2_head(self, conv: nn.Conv2d) -> Optional[Tensor]:
         """Split-fp16 pieces of a few-output-channel 3x3 head (conv_out: 64 -> 3), zero-padded to 32 couts."""
         if conv.out_channels > 4 or conv.kernel_size != (3, 3) or conv.stride != (1, 1) or conv.in_channels > 64:
             return None
-
-        def pack(w: Tensor) -> Tensor:
-            wp = torch.zeros(32, *w.shape[1:], device=w.device, dtype=torch.float32)
-            wp[: w.shape[0]] = w.detach().float()
-            return nv.pack_conv_weight_f16x2(wp)
-
-        return self.get(conv.weight, "convw_f16x2_head", pack)
+        return self._conv_job(conv.weight, nv.PACK_F16X2, 32)
 
     def conv_bias(self, conv: nn.Conv2d, cout_padded: Optional[int] = None) -> Optional[Tensor]:
         if conv.bias is None:
             return None
         n = cout_padded or nv.cout_pad(conv.out_channels)
-        return self.get(conv.bias, f"convb{n}", lambda b: nv.pad_vector(b, n))
+        b = conv.bias
+        if n == b.numel() and b.dtype == torch.float32 and b.is_contiguous():
+            return b.detach()  # nothing to pad: the kernels read the parameter itself
+        return self._conv_job(b, nv.PACK_BIAS, n)
+
+    def dgrad_weight(self, conv: nn.Conv2d, c0: int, c1: int, cin_pad_to: int = 0, f16x2: bool = False) -> Tensor:
+        """Packed weight of the data-gradient (transposed) convolution restricted to input channels [c0, c1) of `conv`:
+        W'[ci - c0][co][ky][kx] = W[co][ci][K-1-ky][K-1-kx], its input channels (= conv's outputs) zero-padded to
+        `cin_pad_to` (conv_out: 3 -> 16)."""
+        cout_t = c1 - c0
+        return self._conv_job(conv.weight, nv.PACK_F16X2 if f16x2 else nv.PACK_F32, cout_t if f16x2 else nv.cout_pad(cout_t),
+                              True, c0, c1, cin_pad_to)
 
     def f32(self, p: Tensor) -> Tensor:
         return self.get(p, "f32", lambda t: t.detach().float().contiguous())

@@ -17,7 +17,8 @@ stream with it (torch warns "AccumulateGrad node's stream does not match"; the c
 
 What is captured is exactly the eager step's launch sequence.  Weight packing (engine.PackCache, blocks.FilmTable) is keyed
 on parameter versions: the warm-up steps' optimizer updates bump every version, so every pack / transpose kernel is recorded
-too and re-runs at each replay on the updated weights; the caches are additionally dropped right before the capture.
+too and re-runs at each replay on the updated weights (one dmd_pack_jobs launch per cache); the copies are additionally
+marked stale right before the capture and after every replay.
 """
 from __future__ import annotations
 
@@ -27,12 +28,13 @@ import torch
 from torch import Tensor, nn
 
 
-def _drop_weight_caches(model: nn.Module) -> None:
+def _mark_weight_caches_stale(model: nn.Module) -> None:
+    """Every packed copy of the model's parameters is stale (buffers and job tables are kept: engine.PackCache.invalidate)."""
     from . import engine as E
 
     for m in model.modules():
         if isinstance(getattr(m, "_cache", None), E.PackCache):
-            m._cache = E.PackCache()
+            m._cache.invalidate()
         film = getattr(m, "_film", None)
         if film is not None and hasattr(film, "_packed"):
             film._packed = None
@@ -58,7 +60,7 @@ class GraphedTrainStep:
                 self._eager()
         cur.wait_stream(side)
         torch.cuda.synchronize()
-        _drop_weight_caches(model)
+        _mark_weight_caches_stale(model)  # (nothing is allocated or uploaded during the capture: the tables exist)
         optimizer.zero_grad(set_to_none=True)  # the gradients of the captured step come from the graph's own pool
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: other threads' HIP calls (the RCCL watchdog polls its events) must not invalidate this capture
@@ -83,4 +85,7 @@ class GraphedTrainStep:
                 f"batch.{k}: {tuple(src.shape)} {src.dtype}, captured with {tuple(buf.shape)} {buf.dtype} (static shapes)"
             buf.copy_(src, non_blocking=True)
         self.graph.replay()
+        # the replayed optimizer update changed every parameter without bumping its `_version`: code that reads the packed
+        # copies outside this graph (imagination with the same denoiser, evaluation) must rebuild them first
+        _mark_weight_caches_stale(self.model)
         return self.loss, self.metrics

@@ -62,19 +62,12 @@ def _dgrad_weights(cache: E.PackCache, conv: nn.Conv2d, c0: int, c1: int, cout_p
     """Packed weight of the transposed convolution restricted to input channels [c0, c1) of `conv`:
     w_t[ci - c0][co][ky][kx] = w[co][ci][K-1-ky][K-1-kx]; co zero-padded to `cout_pad` (conv_out: 3 -> 16)."""
 
-    def transposed(w: Tensor) -> Tensor:
-        wt = _transposed(w[:, c0:c1])  # (c1 - c0, Cout, k, k)
-        if cout_pad is not None and cout_pad > wt.shape[1]:
-            pad = torch.zeros(wt.shape[0], cout_pad - wt.shape[1], *wt.shape[2:], device=wt.device, dtype=wt.dtype)
-            wt = torch.cat((wt, pad), dim=1)
-        return wt
-
-    wp = cache.get(conv.weight, f"dgradw[{c0}:{c1}]p{cout_pad}", lambda w: nv.pack_conv_weight(transposed(w)))
+    wp = cache.dgrad_weight(conv, c0, c1, cout_pad or 0)
     w16 = None
     ci, co = c1 - c0, cout_pad or conv.out_channels
     k = conv.kernel_size[0]
     if use_f16 and ci in (32, 64) and co <= (128 if ci == 64 else 64) and k in (1, 3):
-        w16 = cache.get(conv.weight, f"dgradw16[{c0}:{c1}]p{cout_pad}", lambda w: nv.pack_conv_weight_f16x2(transposed(w)))
+        w16 = cache.dgrad_weight(conv, c0, c1, cout_pad or 0, f16x2=True)
     return wp, w16
 
 

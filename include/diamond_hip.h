@@ -114,6 +114,27 @@ int dmd_conv1x1_stream_eligible(const dmd_conv_params* p);
 /* OIHW (Cout in {32, 64}, Cin, k, k) fp32, k in {1, 3} -> [CinPad/16][k*k][h|l][2][Cout][8] fp16 pieces */
 int dmd_pack_conv_weight_f16x2(const float* oihw, void* packed, int Cout, int Cin, int k, int CinPad, dmd_stream_t stream);
 
+/* Every kernel-layout copy of a model's convolution parameters in ONE launch (a training step changes all of them:
+ * trainer.py:366-388).  A job = one copy; the table lives in DEVICE memory and is reusable as long as the pointers are.
+ *   kind DMD_PACK_F32   : dmd_pack_conv_weight's layout        kind DMD_PACK_F16X2: dmd_pack_conv_weight_f16x2's
+ *   kind DMD_PACK_BIAS  : (CoutPad) fp32 <- bias (Cout), zero beyond
+ *   transposed = 1      : the weight of the data-gradient convolution restricted to input channels [c0, c1):
+ *                         W'[ci - c0][co][ky][kx] = W[co][ci][k-1-ky][k-1-kx]; CoutPad / CinPad then refer to W'
+ *                         (outputs c1 - c0, inputs Cout zero-padded to CinPad).
+ * max_elems = the largest job's element count (fp32: CinPad * taps * CoutPad, f16x2: CinPad * taps * CoutPad, bias: CoutPad). */
+#define DMD_PACK_F32 0
+#define DMD_PACK_F16X2 1
+#define DMD_PACK_BIAS 2
+typedef struct dmd_pack_job {
+  const float* src;      /* OIHW (Cout, Cin, k, k) fp32, or the bias (Cout) */
+  void* dst;
+  int32_t Cout, Cin, k;  /* of src */
+  int32_t kind, transposed, c0, c1;
+  int32_t CoutPad, CinPad; /* of the packed (possibly transposed) weight */
+  int32_t reserved;
+} dmd_pack_job;
+int dmd_pack_jobs(const dmd_pack_job* jobs_device, int njobs, int64_t max_elems, dmd_stream_t stream);
+
 int dmd_conv2d(const dmd_conv_params* p, dmd_stream_t stream);
 /* name of the kernel instantiation dmd_conv2d launches for these parameters, spelled like rocprofv3's kernel trace
  * (e.g. "conv_f16ws_kernel<WsGeom<false, 2, 9>>"): measurement plumbing for bench.py / profiles */

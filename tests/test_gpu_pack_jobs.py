@@ -1,0 +1,92 @@
+"""dmd_pack_jobs / engine.PackCache: every kernel-layout copy of the convolution parameters in one launch -- bitwise the
+copies the single-tensor entry points (dmd_pack_conv_weight, dmd_pack_conv_weight_f16x2) build from the torch-transformed
+weights, including the transposed / sliced / zero-padded weights of the data gradient (autograd of F.conv2d,
+/root/reference/src/trainer.py:366); refreshed in place when a parameter changes."""
+import pytest
+import torch
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _transposed(w, c0, c1, cin_pad_to=0):
+    wt = w.detach()[:, c0:c1].flip(2, 3).transpose(0, 1).contiguous()
+    if cin_pad_to > wt.shape[1]:
+        wt = torch.cat((wt, torch.zeros(wt.shape[0], cin_pad_to - wt.shape[1], *wt.shape[2:], device=wt.device)), 1)
+    return wt
+
+
+def test_every_kind_of_copy_matches_the_single_tensor_packs_and_refreshes_in_place():
+    from diamond_amd import engine as E, native as nv
+
+    torch.manual_seed(0)
+    convs = {
+        "c64": nn.Conv2d(64, 64, 3, padding=1), "cat128": nn.Conv2d(128, 64, 3, padding=1), "c32": nn.Conv2d(32, 32, 3, padding=1),
+        "proj": nn.Conv2d(128, 64, 1), "in": nn.Conv2d(15, 64, 3, padding=1), "out": nn.Conv2d(64, 3, 3, padding=1),
+        "down": nn.Conv2d(64, 64, 3, stride=2, padding=1), "qkv": nn.Conv2d(64, 192, 1),
+    }
+    for c in convs.values():
+        c.to(DEV)
+    cache = E.PackCache()
+
+    def expect():
+        out = {}
+        for k, c in convs.items():
+            out[k, "w"] = nv.pack_conv_weight(c.weight)
+            if k in ("c64", "cat128", "c32", "proj"):
+                out[k, "w16"] = nv.pack_conv_weight_f16x2(c.weight)
+        wp = torch.zeros(32, 64, 3, 3, device=DEV)
+        wp[:3] = convs["out"].weight.detach()
+        out["out", "head16"] = nv.pack_conv_weight_f16x2(wp)
+        out["out", "w32"] = nv.pack_conv_weight(convs["out"].weight, 32)
+        out["out", "b32"] = nv.pad_vector(convs["out"].bias, 32)
+        out["c64", "d"] = nv.pack_conv_weight(_transposed(convs["c64"].weight, 0, 64))
+        out["c64", "d16"] = nv.pack_conv_weight_f16x2(_transposed(convs["c64"].weight, 0, 64))
+        out["cat128", "d_hi"] = nv.pack_conv_weight(_transposed(convs["cat128"].weight, 64, 128))
+        out["cat128", "d16_hi"] = nv.pack_conv_weight_f16x2(_transposed(convs["cat128"].weight, 64, 128))
+        out["out", "d_pad16"] = nv.pack_conv_weight(_transposed(convs["out"].weight, 0, 64, 16))
+        out["out", "d16_pad16"] = nv.pack_conv_weight_f16x2(_transposed(convs["out"].weight, 0, 64, 16))
+        out["in", "d"] = nv.pack_conv_weight(_transposed(convs["in"].weight, 0, 15))
+        return out
+
+    def mine():
+        out = {}
+        for k, c in convs.items():
+            out[k, "w"] = cache.conv_weight(c)
+            if k in ("c64", "cat128", "c32", "proj"):
+                out[k, "w16"] = cache.conv_weight_f16x2(c)
+        out["out", "head16"] = cache.conv_weight_f16x2_head(convs["out"])
+        out["out", "w32"] = cache.conv_weight(convs["out"], 32)
+        out["out", "b32"] = cache.conv_bias(convs["out"], 32)
+        out["c64", "d"] = cache.dgrad_weight(convs["c64"], 0, 64)
+        out["c64", "d16"] = cache.dgrad_weight(convs["c64"], 0, 64, f16x2=True)
+        out["cat128", "d_hi"] = cache.dgrad_weight(convs["cat128"], 64, 128)
+        out["cat128", "d16_hi"] = cache.dgrad_weight(convs["cat128"], 64, 128, f16x2=True)
+        out["out", "d_pad16"] = cache.dgrad_weight(convs["out"], 0, 64, 16)
+        out["out", "d16_pad16"] = cache.dgrad_weight(convs["out"], 0, 64, 16, f16x2=True)
+        out["in", "d"] = cache.dgrad_weight(convs["in"], 0, 15)
+        return out
+
+    a, b = mine(), expect()
+    assert a.keys() == b.keys()
+    for k in a:
+        assert a[k].shape == b[k].shape and a[k].dtype == b[k].dtype, k
+        assert torch.equal(a[k], b[k]), k
+    assert cache.conv_bias(convs["c64"]).data_ptr() == convs["c64"].bias.data_ptr()  # nothing to pad: the parameter itself
+    ptrs = {k: v.data_ptr() for k, v in a.items()}
+    # an optimizer-like in-place update of ONE parameter: every copy is rebuilt by the next lookup, in place
+    with torch.no_grad():
+        for c in convs.values():
+            c.weight.mul_(1.5)
+            c.bias.add_(0.25)
+    a2, b2 = mine(), expect()
+    for k in a2:
+        assert torch.equal(a2[k], b2[k]), k
+        assert a2[k].data_ptr() == ptrs[k], f"{k}: rebuilt into a new buffer"
+    # a write that does not bump the version is invisible until invalidate()
+    convs["c64"].weight.data.mul_(2.0)
+    assert torch.equal(cache.conv_weight(convs["c64"]), b2["c64", "w"])
+    cache.invalidate()
+    assert torch.equal(cache.conv_weight(convs["c64"]), nv.pack_conv_weight(convs["c64"].weight))
+    assert torch.equal(cache.dgrad_weight(convs["c64"], 0, 64, f16x2=True), nv.pack_conv_weight_f16x2(_transposed(convs["c64"].weight, 0, 64)))
