@@ -506,14 +506,14 @@ __global__ void wgrad_reduce1_kernel(const float* __restrict__ ws, int num_wg, i
   ws2[(size_t)sl * per_total + idx] = s;
 }
 
-__global__ void wgrad_reduce2_kernel(const float* __restrict__ ws2, int NB, int NCO, int NCI, int taps, int cin_real,
+__global__ void wgrad_reduce2_kernel(const float* __restrict__ ws2, int nslices, int NB, int NCO, int NCI, int taps, int cin_real,
                                      float* __restrict__ dw, float* __restrict__ dbias) {
   const int per = NB * NCO * 256;
   const int per_total = per + NCO * 16;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= per_total) return;
   double s = 0.0;
-  for (int sl = 0; sl < WGRAD_SLICES; ++sl) s += (double)ws2[(size_t)sl * per_total + idx];
+  for (int sl = 0; sl < nslices; ++sl) s += (double)ws2[(size_t)sl * per_total + idx];
   if (idx < per) {
     const int r = idx & 3, lane = (idx >> 2) & 63;
     const int blk = idx >> 8;
@@ -564,10 +564,17 @@ static int launch_wgrad(const dmd_wgrad_params& p, hipStream_t st) {
     hipLaunchKernelGGL((wgrad_kernel<G, false>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
   const int per_total = G::NB * NCO * 256 + NCO * 16;
   float* ws2 = p.workspace + (size_t)num_wg * per_total;
+  if (num_wg <= 4 * WGRAD_SLICES) {
+    // few partials (the low-resolution levels at the training batch): summed directly, in fp64, in workgroup order -- one
+    // launch less per weight gradient (the training step is a chain of ~600 small kernels)
+    hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3((per_total + 255) / 256), dim3(256), 0, st, (const float*)p.workspace, num_wg, G::NB,
+                       NCO, NCI, TAPS, p.cin_real, p.dw, p.dbias);
+    return 0;
+  }
   hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((per_total + 255) / 256, WGRAD_SLICES), dim3(256), 0, st, p.workspace, num_wg,
                      per_total, ws2);
-  hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3((per_total + 255) / 256), dim3(256), 0, st, (const float*)ws2, G::NB, NCO, NCI,
-                     TAPS, p.cin_real, p.dw, p.dbias);
+  hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3((per_total + 255) / 256), dim3(256), 0, st, (const float*)ws2, WGRAD_SLICES, G::NB,
+                     NCO, NCI, TAPS, p.cin_real, p.dw, p.dbias);
   return 0;
 }
 
