@@ -268,10 +268,19 @@ class UNetTrainFn(torch.autograd.Function):
 
 
 def _unscale(pg: "_ParamGrads", params, inv: Tensor):
-    """Gradients of the scaled problem times 2^-k: ONE multi-tensor launch instead of one multiply per parameter (236 of
-    them for the denoiser, each a 3 us launch of the launch-bound training step)."""
+    """Gradients of the scaled problem times 2^-k.  One multiply per parameter would be 236 launches of 4 us for the
+    denoiser (torch._foreach_mul with a device scalar falls back to exactly that): the gradients are gathered into one flat
+    buffer (torch.cat: two launches), scaled there, and handed out as views of it."""
     have = [pg.by_param[id(p)] for p in params if pg.by_param.get(id(p)) is not None]
-    scaled = iter(torch._foreach_mul(have, inv) if have else [])
+    if not have:
+        return tuple(None for _ in params)
+    flat = torch.cat([g.reshape(-1) for g in have])
+    flat *= inv
+    out, off = [], 0
+    for g in have:
+        out.append(flat[off:off + g.numel()].view(g.shape))
+        off += g.numel()
+    scaled = iter(out)
     return tuple(None if pg.by_param.get(id(p)) is None else next(scaled) for p in params)
 
 
