@@ -549,14 +549,16 @@ static int launch_wgrad(const dmd_wgrad_params& p, hipStream_t st) {
   using G = WgradGeom<NCO, NCI, TAPS>;
   int tiles, num_wg, tpw;
   wgrad_plan(&p, &tiles, &num_wg, &tpw);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[DMD_MAX_DEVICES] = {};  // per instantiation AND per device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DMD_MAX_DEVICES) dev = 0;
+  if (!attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<G, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        G::SMEM_BYTES);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM_BYTES);
     DMD_CHECK_ARG(e == hipSuccess, "wgrad: hipFuncSetAttribute(%d bytes): %s", G::SMEM_BYTES, hipGetErrorString(e));
-    attr_set = true;
+    attr_set[dev] = true;
   }
   if ((p.precision & 0xff) == DMD_PRECISION_F16X2)
     hipLaunchKernelGGL((wgrad_kernel<G, true>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
