@@ -126,6 +126,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 typedef _Float16 att_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 att_h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 att_h2 __attribute__((ext_vector_type(2)));
+// lw = {fp16(p0 - h0), fp16(p1 - h1)} for hw = {h0, h1}: one mixed-precision fma per element (tests/simt, the host build of
+// these sources, defines the macro with the same arithmetic in C++ before this point)
+#ifndef ATT_SPLIT_LOW_PAIR
+#define ATT_SPLIT_LOW_PAIR(lw, p0, p1, hw)                                          \
+  asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"       \
+      "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"           \
+      : "=&v"(lw)                                                                   \
+      : "v"(p0), "v"(p1), "v"(hw))
+#endif
 
 #define AF_KT 256                   // keys per LDS tile
 #define AF_VS (AF_KT + 8)           // V^T row stride in halfs (+16 bytes: rows start on different banks)
@@ -274,10 +283,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16x2_kernel(const float* __
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           hw[r] = __builtin_bit_cast(unsigned, (att_h2){(_Float16)p[2 * r], (_Float16)p[2 * r + 1]});
-          asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
-              "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-              : "=&v"(lw[r])
-              : "v"(p[2 * r]), "v"(p[2 * r + 1]), "v"(hw[r]));
+          ATT_SPLIT_LOW_PAIR(lw[r], p[2 * r], p[2 * r + 1], hw[r]);
         }
         typedef unsigned att_u4 __attribute__((ext_vector_type(4)));
         const att_h8 ph = __builtin_bit_cast(att_h8, (att_u4){hw[0], hw[1], hw[2], hw[3]});

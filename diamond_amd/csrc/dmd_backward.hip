@@ -323,7 +323,7 @@ __device__ __forceinline__ void wg_unpack4(const float (&r)[4], wg_h4& h, wg_h4&
 // group (the same two-lanes-per-bank ds_read_b32 pattern as the exact path).  The bias gradient sums the raw dy.
 template <class G, bool SPLIT>
 __global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, int tiles_total, int tiles_per_wg) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  DMD_DYNAMIC_LDS(float, smem);
   float* patch = smem;                        // [2][PP][SB]
   float* dyt = smem + G::PATCH_FLOATS;        // [128][SA]
   float* tab = dyt + G::DY_FLOATS;            // [2][3][CIN]: mean, a, add

@@ -11,6 +11,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define DMD_GN_EPS 1e-5  // models/blocks.py:13
 #define DMD_MAX_DEVICES 16  // per-device launch state (function attributes, CU counts) is indexed by hipGetDevice()
 
+// The dynamic-LDS array of a kernel.  One spelling for all of them: tests/simt compiles these sources for the host, where
+// LDS is ordinary memory, and defines the macro before this header is read.
+#ifndef DMD_DYNAMIC_LDS
+#define DMD_DYNAMIC_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
+#endif
+
 void dmd_set_error(const char* fmt, ...);
 
 #define DMD_CHECK_ARG(cond, ...)  \

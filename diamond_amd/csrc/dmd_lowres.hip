@@ -91,7 +91,7 @@ __device__ __forceinline__ float lr_wave_sum(float x) {
 }
 
 __global__ __launch_bounds__(256) void lowres_chain_kernel(const dmd_lowres_chain_params p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lr_smem[];
+  DMD_DYNAMIC_LDS(unsigned char, lr_smem);
   float* slots = (float*)lr_smem;
   u32x4* P = (u32x4*)(slots + LR_NSLOT * LR_SLOT);
   float* QKV = (float*)P;               // overlay during attention
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256) void lowres_chain_kernel(const dmd_lowres_chai
 #define L3_SMEM_BYTES ((2 * L3_SLOT + L3_REGION_FLOATS + 64 + 32) * 4 + 64)
 
 __global__ __launch_bounds__(256) void lowres_chain32_kernel(const dmd_lowres_chain_params p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lr_smem[];
+  DMD_DYNAMIC_LDS(unsigned char, lr_smem);
   float* X = (float*)lr_smem;
   float* H = X + L3_SLOT;
   u32x4* P = (u32x4*)(H + L3_SLOT);

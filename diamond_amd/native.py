@@ -161,6 +161,62 @@ class _Lib:
         return launch
 
 
+def declare_signatures(L: C.CDLL) -> None:
+    """restype / argtypes of every entry point of include/diamond_hip.h on a loaded library; AttributeError if the ABI is
+    incomplete.  (tests/simt declares the same signatures on its host build of the kernels.)"""
+    L.dmd_last_error.restype = C.c_char_p
+    for name in EXPORTS:
+        getattr(L, name)  # AttributeError if the ABI is incomplete
+    L.dmd_conv2d.argtypes = [C.POINTER(ConvParams), C.c_void_p]
+    L.dmd_conv2d_naive.argtypes = [C.POINTER(ConvParams), C.c_void_p]
+    L.dmd_conv2d_kernel_name.argtypes = [C.POINTER(ConvParams), C.c_char_p, C.c_int]
+    L.dmd_linear.argtypes = [C.POINTER(LinearParams), C.c_void_p]
+    L.dmd_pack_conv_weight.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.dmd_pack_conv_weight_f16x2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.dmd_conv2d_f16x2_eligible.argtypes = [C.POINTER(ConvParams)]
+    L.dmd_conv1x1_stream_eligible.argtypes = [C.POINTER(ConvParams)]
+    L.dmd_conv2d_proj_eligible.argtypes = [C.POINTER(ConvParams)]
+    L.dmd_pack_jobs.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
+    L.dmd_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.dmd_attention_valid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.dmd_attention_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_void_p]
+    L.dmd_attention_bwd_workspace_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.dmd_attention_bwd_workspace_floats.restype = C.c_int64
+    L.dmd_edm_pack_input.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.dmd_cond_embed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.dmd_heun_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
+                                C.c_void_p, C.c_int64, C.c_void_p]
+    L.dmd_quantize_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.dmd_dequant_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64,
+                                     C.c_int, C.c_void_p]
+    L.dmd_edm_denoised.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64,
+                                   C.c_void_p]
+    L.dmd_euler_step.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]
+    L.dmd_nchw_to_nhwc.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.dmd_nhwc_to_nchw.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.dmd_gn_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.dmd_gn_stats_valid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.dmd_maxpool2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_void_p]
+    L.dmd_lstm_pointwise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.dmd_lstm_pointwise_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int, C.c_int, C.c_void_p]
+    L.dmd_categorical_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.dmd_conv_stat_tiles.argtypes = [C.c_int, C.c_int]
+    L.dmd_maxpool2_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.dmd_gn_bwd_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.dmd_gn_bwd_workspace_bytes.restype = C.c_int64
+    L.dmd_gn_silu_bwd.argtypes = [C.POINTER(GnBwdParams), C.c_void_p]
+    L.dmd_wgrad_workspace_floats.argtypes = [C.POINTER(WgradParams)]
+    L.dmd_wgrad_workspace_floats.restype = C.c_int64
+    L.dmd_conv2d_wgrad.argtypes = [C.POINTER(WgradParams), C.c_void_p]
+    L.dmd_lowres_chain.argtypes = [C.POINTER(LowresChainParams), C.c_void_p]
+    L.dmd_lowres_chain32.argtypes = [C.POINTER(LowresChainParams), C.c_void_p]
+
+
 _lib: Optional[_Lib] = None
 
 
@@ -172,57 +228,11 @@ def lib() -> _Lib:
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(diamond_amd has no CPU/PyTorch fallback for its kernels)")
         L = C.CDLL(LIB_PATH)
-        L.dmd_last_error.restype = C.c_char_p
-        for name in EXPORTS:
-            getattr(L, name)  # AttributeError if the ABI is incomplete
-        L.dmd_conv2d.argtypes = [C.POINTER(ConvParams), C.c_void_p]
-        L.dmd_conv2d_naive.argtypes = [C.POINTER(ConvParams), C.c_void_p]
-        L.dmd_conv2d_kernel_name.argtypes = [C.POINTER(ConvParams), C.c_char_p, C.c_int]
-        L.dmd_linear.argtypes = [C.POINTER(LinearParams), C.c_void_p]
-        L.dmd_pack_conv_weight.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-        L.dmd_pack_conv_weight_f16x2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-        L.dmd_conv2d_f16x2_eligible.argtypes = [C.POINTER(ConvParams)]
-        L.dmd_conv1x1_stream_eligible.argtypes = [C.POINTER(ConvParams)]
-        L.dmd_conv2d_proj_eligible.argtypes = [C.POINTER(ConvParams)]
-        L.dmd_pack_jobs.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
-        L.dmd_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-        L.dmd_attention_valid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-        L.dmd_attention_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                        C.c_int, C.c_void_p]
-        L.dmd_attention_bwd_workspace_floats.argtypes = [C.c_int, C.c_int, C.c_int]
-        L.dmd_attention_bwd_workspace_floats.restype = C.c_int64
-        L.dmd_edm_pack_input.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_int,
-                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-        L.dmd_cond_embed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-        L.dmd_heun_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
-                                    C.c_void_p, C.c_int64, C.c_void_p]
-        L.dmd_quantize_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
-        L.dmd_dequant_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64,
-                                         C.c_int, C.c_void_p]
-        L.dmd_edm_denoised.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64,
-                                       C.c_void_p]
-        L.dmd_euler_step.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]
-        L.dmd_nchw_to_nhwc.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-        L.dmd_nhwc_to_nchw.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-        L.dmd_gn_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
-        L.dmd_gn_stats_valid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-        L.dmd_maxpool2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                   C.c_void_p]
-        L.dmd_lstm_pointwise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
-        L.dmd_lstm_pointwise_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                             C.c_int, C.c_int, C.c_void_p]
-        L.dmd_categorical_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
-        L.dmd_conv_stat_tiles.argtypes = [C.c_int, C.c_int]
-        L.dmd_maxpool2_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-        L.dmd_gn_bwd_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
-        L.dmd_gn_bwd_workspace_bytes.restype = C.c_int64
-        L.dmd_gn_silu_bwd.argtypes = [C.POINTER(GnBwdParams), C.c_void_p]
-        L.dmd_wgrad_workspace_floats.argtypes = [C.POINTER(WgradParams)]
-        L.dmd_wgrad_workspace_floats.restype = C.c_int64
-        L.dmd_conv2d_wgrad.argtypes = [C.POINTER(WgradParams), C.c_void_p]
-        L.dmd_lowres_chain.argtypes = [C.POINTER(LowresChainParams), C.c_void_p]
-        L.dmd_lowres_chain32.argtypes = [C.POINTER(LowresChainParams), C.c_void_p]
+        if hasattr(L, "dmd_simt_host_build"):
+            raise NativeLibraryMissing(
+                f"{LIB_PATH} is the SIMT-interpreter build of the kernels (tests/simt, test infrastructure): "
+                "diamond_amd runs on libdiamond_hip.so only, there is no CPU path")
+        declare_signatures(L)
         _lib = _Lib(L)
     return _lib
 
