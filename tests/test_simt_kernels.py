@@ -44,3 +44,156 @@ def test_gn_stats_valid_extent():
     S.check(S.lib().dmd_gn_stats_valid(S.ptr(x), S.ptr(stats), 2, 16, 16, 9, 13, 64, None), "dmd_gn_stats_valid")
     np.testing.assert_allclose(stats, _group_sums(x, 9, 13), rtol=1e-12, atol=1e-10)
     assert S.lib().dmd_gn_stats_valid(S.ptr(x), S.ptr(stats), 2, 16, 16, 17, 13, 64, None) != 0  # extent beyond the buffer
+
+
+# ---- dmd_conv2d (conv_mfma_kernel instances; dmd_conv_f16ws.hip is not in the host build) ------------------------------------------
+from diamond_amd import native as nv  # struct layouts only
+
+
+def _norm(stats=None, tiles=0, mul=None, add=None, plus_one=False):
+    n = nv.Norm()
+    n.stats, n.stat_tiles, n.mul_plus_one = S.ptr(stats), tiles, int(plus_one)
+    n.mul, n.add = S.ptr(mul), S.ptr(add)
+    n.mul_stride = 0 if mul is None else mul.shape[-1]
+    n.add_stride = 0 if add is None else add.shape[-1]
+    return n
+
+
+def _apply_norm(x, hv, wv, mul, add, plus_one, silu):
+    """GroupNorm(32-channel groups, eps 1e-5, statistics of the valid extent) * (1 +) mul + add [, SiLU], fp64."""
+    n, h, w, c = x.shape
+    v = x[:, :hv, :wv].astype(np.float64).reshape(n, hv * wv, c // 32, 32)
+    mean = v.mean(axis=(1, 3))
+    var = (v * v).mean(axis=(1, 3)) - mean * mean
+    rstd = 1.0 / np.sqrt(np.maximum(var, 0) + 1e-5)
+    m = np.ones((n, c)) if mul is None else mul.astype(np.float64)
+    if plus_one:
+        m = 1.0 + m
+    a = np.repeat(rstd, 32, axis=1) * m
+    y = (x.astype(np.float64) - np.repeat(mean, 32, axis=1)[:, None, None]) * a[:, None, None]
+    if add is not None:
+        y = y + add.astype(np.float64)[:, None, None]
+    return y / (1.0 + np.exp(-y)) if silu else y
+
+
+def _partial_stats(x, hv, wv, tiles, rng):
+    """(N, G, T, 2) partial sums whose total is the valid extent's; split unevenly over T tiles on purpose."""
+    tot = _group_sums(x, hv, wv)  # (N, G, 2)
+    wgt = rng.random((1, 1, tiles, 1)) + 0.1
+    wgt = wgt / wgt.sum()
+    return np.ascontiguousarray(tot[:, :, None, :] * wgt)
+
+
+def _ref_conv(xs, w, bias, k, stride, upsample, hv_out, wv_out):
+    """fp64 F.conv2d(cat(xs), w, bias, stride, padding=k//2) on NHWC arrays already in the conv's input domain; input
+    positions beyond the sources' valid extent are zero."""
+    x = np.concatenate(xs, axis=-1)
+    if upsample:
+        x = x.repeat(2, axis=1).repeat(2, axis=2)
+    n, h, w_, c = x.shape
+    hv_in, wv_in = (hv_out * stride, wv_out * stride)
+    x = x.copy()
+    x[:, hv_in:] = 0
+    x[:, :, wv_in:] = 0
+    pad = k // 2
+    xp = np.pad(x, ((0, 0), (pad, pad), (pad, pad), (0, 0)))
+    ho, wo = h // stride, w_ // stride
+    out = np.zeros((n, ho, wo, w.shape[0]))
+    for dy in range(k):
+        for dx in range(k):
+            patch = xp[:, dy:dy + h:stride, dx:dx + w_:stride][:, :ho, :wo]
+            out += patch @ w[:, :, dy, dx].astype(np.float64).T
+    return out + (0 if bias is None else bias.astype(np.float64))
+
+
+CONV_CASES = [
+    # N, H, W (output), [Cin...], Cout, k, stride, upsample, prologues, residual, precision, valid
+    dict(n=2, h=8, w=16, cin=[32], cout=64, k=3),
+    dict(n=1, h=16, w=8, cin=[64], cout=32, k=3, prologue=[1], film=True),                       # W % 16 != 0 geometry
+    dict(n=1, h=8, w=16, cin=[32, 64], cout=64, k=3, prologue=[1, 1], film=True, residual="raw", stats=True),
+    dict(n=2, h=8, w=8, cin=[32], cout=16, k=3, stride=2),
+    dict(n=1, h=16, w=16, cin=[64], cout=64, k=3, upsample=1, prologue=[1]),
+    dict(n=1, h=8, w=16, cin=[64], cout=96, k=1, prologue=[2], residual="norm"),                  # attention-style 1x1s
+    dict(n=1, h=8, w=16, cin=[32], cout=3, k=3, prologue=[1], nchw=True),                         # few-channel NCHW head
+    dict(n=1, h=16, w=16, cin=[32], cout=64, k=3, prologue=[1], valid=(9, 13), stats=True),       # valid extent
+    dict(n=1, h=16, w=16, cin=[64], cout=64, k=3, stride=2, valid=(5, 7), stats=True),
+    dict(n=1, h=8, w=16, cin=[32, 32], cout=64, k=3, prologue=[1, 0], precision=1, stats=True),   # split-fp16 conv_mfma instance
+    dict(n=1, h=16, w=8, cin=[64], cout=32, k=3, stride=2, precision=1, residual="raw"),
+    dict(n=1, h=8, w=16, cin=[128], cout=64, k=1),                                                # streaming 1x1 kernel
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items() if k not in ("n",)).replace(" ", ""))
+def test_conv2d(case):
+    rng = np.random.default_rng(7)
+    L = S.lib()
+    n, h, w, cins, cout, k = case["n"], case["h"], case["w"], case["cin"], case["cout"], case["k"]
+    stride, up = case.get("stride", 1), case.get("upsample", 0)
+    prol = case.get("prologue", [0] * len(cins))
+    hv, wv = case.get("valid", (h, w))
+    hs, ws = (h * stride, w * stride) if not up else (h // 2, w // 2)         # source buffer size
+    hvs, wvs = (hv * stride, wv * stride) if not up else (hv // 2, wv // 2)   # source valid extent
+    cout_pad = (cout + 15) // 16 * 16
+    cin = sum(cins)
+
+    p = nv.ConvParams()
+    p.N, p.H, p.W, p.Cout, p.CoutPad, p.taps, p.stride, p.upsample, p.nsrc = n, h, w, cout, cout_pad, k * k, stride, up, len(cins)
+    p.precision = case.get("precision", 0)
+    if "valid" in case:
+        p.valid_h, p.valid_w = hv, wv
+    keep, xs_ref = [], []
+    for i, c in enumerate(cins):
+        x = (rng.standard_normal((n, hs, ws, c)) * 1.5 + 0.3).astype(np.float32)
+        p.src[i].x, p.src[i].C, p.src[i].prologue = S.ptr(x), c, prol[i]
+        if prol[i]:
+            tiles = 3
+            st = _partial_stats(x, hvs, wvs, tiles, rng)
+            mul = (rng.standard_normal((n, c)) * 0.3).astype(np.float32) if case.get("film") or prol[i] == 2 else None
+            add = (rng.standard_normal((n, c)) * 0.3).astype(np.float32) if case.get("film") or prol[i] == 2 else None
+            plus_one = bool(case.get("film"))
+            p.src[i].norm = _norm(st, tiles, mul, add, plus_one)
+            xs_ref.append(_apply_norm(x, hvs, wvs, mul, add, plus_one, silu=prol[i] == 1))
+            keep += [st, mul, add]
+        else:
+            xs_ref.append(x.astype(np.float64))
+        keep.append(x)
+
+    wt = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    bias = rng.standard_normal(cout_pad).astype(np.float32)
+    bias[cout:] = 0
+    packed = np.full((cin // 16) * k * k * cout_pad * 16, np.nan, dtype=np.float32)
+    S.check(L.dmd_pack_conv_weight(S.ptr(wt), S.ptr(packed), cout, cin, k, cout_pad, cin, None), "dmd_pack_conv_weight")
+    assert np.isfinite(packed).all()
+    p.w, p.bias = S.ptr(packed), S.ptr(bias)
+
+    ref = _ref_conv(xs_ref, wt, bias[:cout], k, stride, up, hv, wv)
+    if case.get("residual"):
+        r = rng.standard_normal((n, h, w, cout)).astype(np.float32)
+        p.residual = S.ptr(r)
+        if case["residual"] == "norm":
+            rst = _partial_stats(r, hv, wv, 2, rng)
+            g, b = rng.standard_normal((1, cout)).astype(np.float32), rng.standard_normal((1, cout)).astype(np.float32)
+            g, b = np.ascontiguousarray(np.repeat(g, n, 0)), np.ascontiguousarray(np.repeat(b, n, 0))
+            p.residual_norm = _norm(rst, 2, g, b)
+            ref = ref + _apply_norm(r, hv, wv, g, b, False, silu=False)
+            keep += [rst, g, b]
+        else:
+            ref = ref + r
+        keep.append(r)
+
+    nchw = bool(case.get("nchw"))
+    out = np.full((n, cout, h, w) if nchw else (n, h, w, cout), np.nan, dtype=np.float32)
+    p.out, p.out_nchw = S.ptr(out), int(nchw)
+    tiles = L.dmd_conv_stat_tiles(h, w)
+    stats = np.full((n, cout // 32, tiles, 2), np.nan) if case.get("stats") else None
+    p.out_stats = S.ptr(stats)
+
+    name = (b" " * 160)
+    S.check(L.dmd_conv2d(p, None), "dmd_conv2d")
+    got = out.transpose(0, 2, 3, 1) if nchw else out
+    # the exact instance is an fp32 fma chain, the split instance carries fp32-class error (2^-22 per operand)
+    err = np.abs(got[:, :hv, :wv] - ref[:, :hv, :wv]).max()
+    assert err <= 2e-5 * max(1.0, np.abs(ref).max()), err
+    if stats is not None:
+        want = _group_sums(np.ascontiguousarray(got.astype(np.float32)), hv, wv)
+        np.testing.assert_allclose(stats.sum(axis=2), want, rtol=1e-9, atol=1e-6)
