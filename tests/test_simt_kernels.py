@@ -197,3 +197,112 @@ def test_conv2d(case):
     if stats is not None:
         want = _group_sums(np.ascontiguousarray(got.astype(np.float32)), hv, wv)
         np.testing.assert_allclose(stats.sum(axis=2), want, rtol=1e-9, atol=1e-6)
+
+
+# ---- dmd_conv2d_wgrad ------------------------------------------------------------------------------------------------------------
+WGRAD_CASES = [
+    dict(n=2, h=8, w=16, cin=64, cout=64, k=3),
+    dict(n=3, h=8, w=8, cin=32, cout=64, k=3, prologue=1, film=True),          # odd number of 8x8 sub-blocks: a half-empty tile
+    dict(n=1, h=16, w=16, cin=64, cout=64, k=3, prologue=1, precision=1),
+    dict(n=2, h=8, w=8, cin=16, cin_real=15, cout=64, k=3),                     # denoiser conv_in: 15 real input channels
+    dict(n=1, h=8, w=16, cin=64, cout=16, k=3, prologue=1, precision=1),        # denoiser conv_out (dy padded to 16)
+    dict(n=2, h=8, w=8, cin=32, cout=64, k=1, prologue=2),
+    dict(n=1, h=16, w=8, cin=64, cout=64, k=1, precision=1),
+    dict(n=2, h=8, w=8, cin=32, cout=32, k=3, no_bias=True),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_conv2d_wgrad(case):
+    rng = np.random.default_rng(11)
+    L = S.lib()
+    n, h, w, cin, cout, k = case["n"], case["h"], case["w"], case["cin"], case["cout"], case["k"]
+    cin_real, prol = case.get("cin_real", cin), case.get("prologue", 0)
+    x = (rng.standard_normal((n, h, w, cin)) * 1.2 - 0.2).astype(np.float32)
+    x[..., cin_real:] = 0
+    dy = rng.standard_normal((n, h, w, cout)).astype(np.float32)
+    p = nv.WgradParams()
+    p.N, p.H, p.W, p.Cout, p.taps, p.cin_real, p.precision = n, h, w, cout, k * k, cin_real, case.get("precision", 0)
+    p.src.x, p.src.C, p.src.prologue = S.ptr(x), cin, prol
+    a = x.astype(np.float64)
+    keep = []
+    if prol:
+        st = _partial_stats(x, h, w, 2, rng)
+        film = case.get("film") or prol == 2
+        mul = (rng.standard_normal((n, cin)) * 0.3).astype(np.float32) if film else None
+        add = (rng.standard_normal((n, cin)) * 0.3).astype(np.float32) if film else None
+        p.src.norm = _norm(st, 2, mul, add, bool(case.get("film")))
+        a = _apply_norm(x, h, w, mul, add, bool(case.get("film")), silu=prol == 1)
+        keep += [st, mul, add]
+    p.dy = S.ptr(dy)
+    ws = np.full(L.dmd_wgrad_workspace_floats(p), np.nan, dtype=np.float32)
+    dw = np.full((cout, cin_real, k, k), np.nan, dtype=np.float32)
+    db = None if case.get("no_bias") else np.full(cout, np.nan, dtype=np.float32)
+    p.workspace, p.dw, p.dbias = S.ptr(ws), S.ptr(dw), S.ptr(db)
+    S.check(L.dmd_conv2d_wgrad(p, None), "dmd_conv2d_wgrad")
+
+    pad = k // 2
+    ap = np.pad(a, ((0, 0), (pad, pad), (pad, pad), (0, 0)))
+    want = np.zeros((cout, cin_real, k, k))
+    g = dy.astype(np.float64).reshape(-1, cout)
+    for ky in range(k):
+        for kx in range(k):
+            want[:, :, ky, kx] = g.T @ ap[:, ky:ky + h, kx:kx + w, :cin_real].reshape(-1, cin_real)
+    scale = np.abs(want).max()
+    assert np.abs(dw - want).max() <= 3e-6 * scale * np.sqrt(n * h * w / 64), np.abs(dw - want).max() / scale
+    if db is not None:
+        np.testing.assert_allclose(db, g.sum(axis=0), rtol=0, atol=2e-5 * np.abs(g.sum(axis=0)).max() + 1e-5)
+
+
+# ---- attention -------------------------------------------------------------------------------------------------------------------
+def _ref_attention(qkv, c, mask=None):
+    n, t, _ = qkv.shape
+    q, k, v = (qkv[..., i * c:(i + 1) * c].astype(np.float64).reshape(n, t, c // 8, 8).transpose(0, 2, 1, 3) for i in range(3))
+    s = q @ k.transpose(0, 1, 3, 2) / np.sqrt(8.0)
+    if mask is not None:
+        s = np.where(mask[None, None, None, :], s, -np.inf)
+    p = np.exp(s - s.max(axis=-1, keepdims=True))
+    p /= p.sum(axis=-1, keepdims=True)
+    return (p @ v).transpose(0, 2, 1, 3).reshape(n, t, c), p, (q, k, v)
+
+
+@pytest.mark.parametrize("t", [64, 128, 256, 512])  # 64 / 128: attention_kernel; 256 / 512: the split-fp16 two-pass kernel
+def test_attention(t):
+    rng = np.random.default_rng(3)
+    n, c = 2, 16
+    qkv = (rng.standard_normal((n, t, 3 * c)) * 1.5).astype(np.float32)
+    out = np.full((n, t, c), np.nan, dtype=np.float32)
+    S.check(S.lib().dmd_attention(S.ptr(qkv), S.ptr(out), n, t, c, 8, None), "dmd_attention")
+    ref, _, _ = _ref_attention(qkv, c)
+    assert np.abs(out - ref).max() <= 5e-6 * np.abs(ref).max(), np.abs(out - ref).max()
+
+
+def test_attention_valid_extent():
+    rng = np.random.default_rng(4)
+    n, h, w, c, hv, wv = 1, 8, 16, 8, 5, 11
+    qkv = (rng.standard_normal((n, h * w, 3 * c)) * 1.5).astype(np.float32)
+    out = np.full((n, h * w, c), np.nan, dtype=np.float32)
+    S.check(S.lib().dmd_attention_valid(S.ptr(qkv), S.ptr(out), n, h, w, hv, wv, c, 8, None), "dmd_attention_valid")
+    yy, xx = np.divmod(np.arange(h * w), w)
+    mask = (yy < hv) & (xx < wv)
+    ref, _, _ = _ref_attention(qkv, c, mask)
+    assert np.abs(out[:, mask] - ref[:, mask]).max() <= 5e-6 * np.abs(ref).max()
+
+
+def test_attention_bwd():
+    rng = np.random.default_rng(5)
+    n, t, c = 2, 64, 16
+    qkv = rng.standard_normal((n, t, 3 * c)).astype(np.float32)
+    dy = rng.standard_normal((n, t, c)).astype(np.float32)
+    y64, p, (q, k, v) = _ref_attention(qkv, c)
+    y = y64.astype(np.float32)
+    L = S.lib()
+    ws = np.full(L.dmd_attention_bwd_workspace_floats(n, t, c), np.nan, dtype=np.float32)
+    dqkv = np.full_like(qkv, np.nan)
+    S.check(L.dmd_attention_bwd(S.ptr(qkv), S.ptr(y), S.ptr(dy), S.ptr(dqkv), S.ptr(ws), n, t, c, 8, None), "dmd_attention_bwd")
+    g = dy.astype(np.float64).reshape(n, t, c // 8, 8).transpose(0, 2, 1, 3)
+    dp = g @ v.transpose(0, 1, 3, 2)
+    ds = p * (dp - (dp * p).sum(axis=-1, keepdims=True))
+    dq, dk, dv = ds @ k / np.sqrt(8.0), ds.transpose(0, 1, 3, 2) @ q / np.sqrt(8.0), p.transpose(0, 1, 3, 2) @ g
+    want = np.concatenate([a.transpose(0, 2, 1, 3).reshape(n, t, c) for a in (dq, dk, dv)], axis=-1)
+    assert np.abs(dqkv - want).max() <= 1e-5 * np.abs(want).max()
