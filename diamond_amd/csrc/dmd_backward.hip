@@ -9,6 +9,8 @@
 //     (nothing but x and the pooling argmax is saved by the forward);
 //   * GroupNorm+SiLU backward = two passes (group reductions, then elementwise apply);
 //   * MaxPool backward = scatter by the saved argmax.
+#include <stdlib.h>
+
 #include "dmd_common.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -316,13 +318,73 @@ __device__ __forceinline__ void wg_unpack4(const float (&r)[4], wg_h4& h, wg_h4&
   l = __builtin_bit_cast(wg_h4, ll);
 }
 
+typedef _Float16 wg_h8 __attribute__((ext_vector_type(8)));
+// eight packed values (k = 0..7) -> the h and the l operand of v_mfma_f32_16x16x32_f16
+__device__ __forceinline__ void wg_unpack8(const float (&r)[8], wg_h8& h, wg_h8& l) {
+  unsigned u[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) u[e] = __builtin_bit_cast(unsigned, r[e]);
+  const uint4 hh = {__builtin_amdgcn_perm(u[1], u[0], 0x05040100u), __builtin_amdgcn_perm(u[3], u[2], 0x05040100u),
+                    __builtin_amdgcn_perm(u[5], u[4], 0x05040100u), __builtin_amdgcn_perm(u[7], u[6], 0x05040100u)};
+  const uint4 ll = {__builtin_amdgcn_perm(u[1], u[0], 0x07060302u), __builtin_amdgcn_perm(u[3], u[2], 0x07060302u),
+                    __builtin_amdgcn_perm(u[5], u[4], 0x07060302u), __builtin_amdgcn_perm(u[7], u[6], 0x07060302u)};
+  h = __builtin_bit_cast(wg_h8, hh);
+  l = __builtin_bit_cast(wg_h8, ll);
+}
+
+// MODE (template parameter of wgrad_kernel):
+//   0  exact: v_mfma_f32_16x16x4_f32, an fp32 fma chain over the pixels
+//   1  SPLIT, 16 pixels per v_mfma_f32_16x16x16_f16 x 3 (what dmd_wgrad_params.precision == DMD_PRECISION_F16X2 runs)
+//   2  SPLIT, 32 pixels per v_mfma_f32_16x16x32_f16 x 3: the gfx950 instruction with twice the K per matrix-pipe cycle; same
+//      LDS layout and the same ds_read_b32 pattern, lane (i, kg) supplies pixels (row r, column kg + 4 h), r < 4, h < 2
+//   3  mode 2 with the NEXT tile's global loads issued before the MFMA phase of the current one and held in registers
+//      (the kernel runs one workgroup per CU, 512 registers per lane: ~84 of them carry the tile in flight)
+// Modes 2 and 3 are STAGED: selected only by DIAMOND_WGRAD_MODE, checked on the SIMT interpreter (tests/test_simt_kernels.py)
+// and by tests/test_gpu_staged.py, not yet measured on the GPU -- the default stays mode 1 until they are.
+//
 // SPLIT (dmd_wgrad_params.precision == DMD_PRECISION_F16X2): the staged activations and dy are kept as packed split-fp16
 // pairs (same 4 bytes per value, same LDS layout) and 16 pixels are contracted per MFMA -- three
 // v_mfma_f32_16x16x16_f16 per (cout block, column block) instead of four v_mfma_f32_16x16x4_f32 per 4 pixels: 24 instead
 // of 128 matrix-pipe cycles per 16 pixels.  Lane (i, kg) supplies pixels {kg, kg + 4, kg + 8, kg + 12} of a 2 x 8 pixel
 // group (the same two-lanes-per-bank ds_read_b32 pattern as the exact path).  The bias gradient sums the raw dy.
-template <class G, bool SPLIT>
+// the 32-pixel contraction of modes 2 / 3 over the staged tile
+template <class G>
+__device__ __forceinline__ void wgrad_mfma_k32(f32x4 (&acc)[G::NCO][G::CB], const float* dyt, const float* patch, const int (&boff)[G::CB],
+                                               int aoff) {
+#pragma unroll 1
+  for (int kq = 0; kq < 4; ++kq) {
+    const int s = kq >> 1, j = kq & 1;
+    const float* ap = dyt + (size_t)(s * 64 + j * 32) * G::SA + aoff;
+    const float* bp = patch + (size_t)(s * G::PP + 4 * j * G::PW) * G::SB;
+    wg_h8 ah[G::NCO], al[G::NCO];
+#pragma unroll
+    for (int a = 0; a < G::NCO; ++a) {
+      float r[8];
+#pragma unroll
+      for (int v = 0; v < 8; ++v) r[v] = ap[a * 16 + ((v >> 1) * 8 + 4 * (v & 1)) * G::SA];
+      wg_unpack8(r, ah[a], al[a]);
+    }
+#pragma unroll
+    for (int b = 0; b < G::CB; ++b) {
+      const float* q0 = bp + boff[b];
+      float r[8];
+#pragma unroll
+      for (int v = 0; v < 8; ++v) r[v] = q0[((v >> 1) * G::PW + 4 * (v & 1)) * G::SB];
+      wg_h8 bh, bl;
+      wg_unpack8(r, bh, bl);
+#pragma unroll
+      for (int a = 0; a < G::NCO; ++a) {
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bl, acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[a], bh, acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bh, acc[a][b], 0, 0, 0);
+      }
+    }
+  }
+}
+
+template <class G, int MODE>
 __global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, int tiles_total, int tiles_per_wg) {
+  constexpr bool SPLIT = MODE != 0;
   DMD_DYNAMIC_LDS(float, smem);
   float* patch = smem;                        // [2][PP][SB]
   float* dyt = smem + G::PATCH_FLOATS;        // [128][SA]
@@ -355,6 +417,96 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, in
   const int tile_end = min(tiles_total, tile_begin + tiles_per_wg);
   int tab_n0 = -1, tab_n1 = -1;
 
+  if constexpr (MODE == 3) {
+    // ---- software-pipelined tile loop: raw loads of tile t + 1 fly under the MFMA phase of tile t ----
+    constexpr int NPQ = 2 * G::PP * CQI;           // patch quads of a tile
+    constexpr int NP = (NPQ + 255) / 256;          // ... per thread
+    constexpr int ND = (128 * CQO) / 256;
+    f32x4 px[NP], pd[ND];
+    auto fetch = [&](int tile) {
+      const SubTile f0 = wgrad_subtile(p.N, p.H, p.W, 2 * tile), f1 = wgrad_subtile(p.N, p.H, p.W, 2 * tile + 1);
+#pragma unroll
+      for (int it = 0; it < NP; ++it) {
+        const int id = it * 256 + tid;
+        const int q = id % CQI, pp2 = id / CQI;
+        const int s = pp2 >= G::PP ? 1 : 0;
+        const int pp = pp2 - s * G::PP;
+        const int py = pp / G::PW, pxx = pp - py * G::PW;
+        const SubTile t = s ? f1 : f0;
+        const int iy = t.y0 - G::PAD + py, ix = t.x0 - G::PAD + pxx;
+        px[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (id < NPQ && t.valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+          px[it] = *(const f32x4*)(p.src.x + (((size_t)t.n * p.H + iy) * p.W + ix) * Cx + 4 * q);
+      }
+#pragma unroll
+      for (int it = 0; it < ND; ++it) {
+        const int id = it * 256 + tid;
+        const int q = id % CQO, pix = id / CQO;
+        const int s = pix >> 6, r = pix & 63;
+        const SubTile t = s ? f1 : f0;
+        pd[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (t.valid) pd[it] = *(const f32x4*)(p.dy + (((size_t)t.n * p.H + t.y0 + (r >> 3)) * p.W + t.x0 + (r & 7)) * G::COUT + 4 * q);
+      }
+    };
+    if (tile_begin < tile_end) fetch(tile_begin);
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+      SubTile st[2];
+      st[0] = wgrad_subtile(p.N, p.H, p.W, 2 * tile);
+      st[1] = wgrad_subtile(p.N, p.H, p.W, 2 * tile + 1);
+      __syncthreads();  // previous tile's MFMA reads are done
+      if (p.src.prologue != DMD_PROLOGUE_NONE && (st[0].n != tab_n0 || st[1].n != tab_n1)) {
+        for (int c = tid; c < 2 * G::CIN; c += 256) {
+          const int s = c / G::CIN, cc = c - s * G::CIN;
+          float m, a, ad;
+          norm_entry(p.src.norm, s ? st[1].n : st[0].n, cc, Cx, (double)(Cx < DMD_GN_GROUP ? Cx : DMD_GN_GROUP) * p.H * p.W, &m, &a, &ad);
+          tab[(s * 3 + 0) * G::CIN + cc] = m;
+          tab[(s * 3 + 1) * G::CIN + cc] = a;
+          tab[(s * 3 + 2) * G::CIN + cc] = ad;
+        }
+        tab_n0 = st[0].n;
+        tab_n1 = st[1].n;
+        __syncthreads();
+      }
+      // ---- the tile in registers -> activated, split, into LDS ----
+#pragma unroll
+      for (int it = 0; it < NP; ++it) {
+        const int id = it * 256 + tid;
+        if (id >= NPQ) continue;
+        const int q = id % CQI, pp2 = id / CQI;
+        const int s = pp2 >= G::PP ? 1 : 0;
+        const int pp = pp2 - s * G::PP;
+        const int py = pp / G::PW, pxx = pp - py * G::PW;
+        const SubTile t = s ? st[1] : st[0];
+        const int iy = t.y0 - G::PAD + py, ix = t.x0 - G::PAD + pxx;
+        f32x4 v = px[it];
+        if (p.src.prologue != DMD_PROLOGUE_NONE && t.valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int cc = 4 * q + e;
+            float u = (v[e] - tab[(s * 3 + 0) * G::CIN + cc]) * tab[(s * 3 + 1) * G::CIN + cc] + tab[(s * 3 + 2) * G::CIN + cc];
+            if (p.src.prologue == DMD_PROLOGUE_NORM_SILU) u = dmd_silu(u);
+            v[e] = u;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = wg_pack_hl(v[e]);
+        *(f32x4*)(patch + (size_t)pp2 * G::SB + 4 * q) = v;
+      }
+#pragma unroll
+      for (int it = 0; it < ND; ++it) {
+        const int id = it * 256 + tid;
+        const int q = id % CQO, pix = id / CQO;
+        f32x4 v = pd[it];
+        bsum += v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = wg_pack_hl(v[e]);
+        *(f32x4*)(dyt + (size_t)pix * G::SA + 4 * q) = v;
+      }
+      __syncthreads();
+      if (tile + 1 < tile_end) fetch(tile + 1);
+      wgrad_mfma_k32<G>(acc, dyt, patch, boff, aoff);
+    }
+  } else
   for (int tile = tile_begin; tile < tile_end; ++tile) {
     SubTile st[2];
     st[0] = wgrad_subtile(p.N, p.H, p.W, 2 * tile);
@@ -418,6 +570,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, in
       *(f32x4*)(dyt + (size_t)pix * G::SA + 4 * q) = v;
     }
     __syncthreads();
+    if constexpr (MODE == 2) {
+      wgrad_mfma_k32<G>(acc, dyt, patch, boff, aoff);
+      continue;
+    }
     if (SPLIT) {
       // ---- 8 k-groups of 16 pixels (2 rows x 8 columns of a subtile) ----
       // boff[] carries + kg * SB and aoff + kg * SA (pixel kg of the group); the other three pixels of this lane are
@@ -530,7 +686,15 @@ __global__ void wgrad_reduce2_kernel(const float* __restrict__ ws2, int nslices,
 static int wgrad_plan(const dmd_wgrad_params* p, int* tiles, int* num_wg, int* tpw) {
   const int sub = p->N * (p->H / 8) * (p->W / 8);
   *tiles = (sub + 1) / 2;
-  int n = *tiles < 1024 ? *tiles : 1024;
+  // at most `cap` workgroups, each walking a contiguous range of tiles with its accumulators in registers: every workgroup
+  // writes one partial of the whole gradient, so fewer of them is less reduction traffic.  DIAMOND_WGRAD_MAX_WG (STAGED, like
+  // the kernel modes above) lowers the cap from 1024; the workspace is always sized for 1024.
+  int cap = 1024;
+  if (const char* e = getenv("DIAMOND_WGRAD_MAX_WG")) {
+    const int v = atoi(e);
+    if (v >= 1 && v < cap) cap = v;
+  }
+  int n = *tiles < cap ? *tiles : cap;
   *tpw = (*tiles + n - 1) / n;
   *num_wg = (*tiles + *tpw - 1) / *tpw;
   return 0;
@@ -538,10 +702,11 @@ static int wgrad_plan(const dmd_wgrad_params* p, int* tiles, int* num_wg, int* t
 
 extern "C" int64_t dmd_wgrad_workspace_floats(const dmd_wgrad_params* p) {
   if (!p) return -1;
-  int tiles, num_wg, tpw;
-  wgrad_plan(p, &tiles, &num_wg, &tpw);
+  const int sub = p->N * (p->H / 8) * (p->W / 8);
+  const int tiles = (sub + 1) / 2;
+  const int max_wg = tiles < 1024 ? tiles : 1024;  // the largest plan wgrad_plan can make (see DIAMOND_WGRAD_MAX_WG)
   const int64_t NB = (int64_t)p->taps * (p->src.C / 16), NCO = p->Cout / 16;
-  return (int64_t)(num_wg + WGRAD_SLICES) * (NB * NCO * 256 + p->Cout);
+  return (int64_t)(max_wg + WGRAD_SLICES) * (NB * NCO * 256 + p->Cout);
 }
 
 template <int NCO, int NCI, int TAPS>
@@ -553,17 +718,29 @@ static int launch_wgrad(const dmd_wgrad_params& p, hipStream_t st) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DMD_MAX_DEVICES) dev = 0;
   if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<G, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<G, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        G::SMEM_BYTES);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM_BYTES);
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<G, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<G, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<G, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM_BYTES);
     DMD_CHECK_ARG(e == hipSuccess, "wgrad: hipFuncSetAttribute(%d bytes): %s", G::SMEM_BYTES, hipGetErrorString(e));
     attr_set[dev] = true;
   }
-  if ((p.precision & 0xff) == DMD_PRECISION_F16X2)
-    hipLaunchKernelGGL((wgrad_kernel<G, true>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
-  else
-    hipLaunchKernelGGL((wgrad_kernel<G, false>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
+  if ((p.precision & 0xff) == DMD_PRECISION_F16X2) {
+    int mode = 1;
+    if (const char* e = getenv("DIAMOND_WGRAD_MODE")) mode = atoi(e);  // STAGED modes 2 / 3 (see MODE above); anything else: 1
+    if (mode == 2)
+      hipLaunchKernelGGL((wgrad_kernel<G, 2>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
+    else if (mode == 3)
+      hipLaunchKernelGGL((wgrad_kernel<G, 3>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
+    else
+      hipLaunchKernelGGL((wgrad_kernel<G, 1>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
+  } else {
+    hipLaunchKernelGGL((wgrad_kernel<G, 0>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
+  }
   const int per_total = G::NB * NCO * 256 + NCO * 16;
   float* ws2 = p.workspace + (size_t)num_wg * per_total;
   if (num_wg <= 4 * WGRAD_SLICES) {

@@ -209,11 +209,25 @@ WGRAD_CASES = [
     dict(n=2, h=8, w=8, cin=32, cout=64, k=1, prologue=2),
     dict(n=1, h=16, w=8, cin=64, cout=64, k=1, precision=1),
     dict(n=2, h=8, w=8, cin=32, cout=32, k=3, no_bias=True),
+    dict(n=3, h=16, w=16, cin=64, cout=64, k=3, prologue=1, film=True, precision=1),  # 6 tiles, three images: table refreshes
+    dict(n=5, h=8, w=8, cin=32, cout=64, k=3, prologue=1, precision=1),                # 2.5 tiles: a tile spanning two images
 ]
 
 
+# what the launcher reads per call: DIAMOND_WGRAD_MODE (the staged 32-pixel / prefetching kernels, split precision only) and
+# DIAMOND_WGRAD_MAX_WG (fewer workgroups, each walking several tiles with its accumulators in registers)
+WGRAD_PLANS = [dict(), dict(mode=2), dict(mode=3), dict(mode=2, max_wg=1), dict(mode=3, max_wg=3), dict(max_wg=2)]
+
+
+@pytest.mark.parametrize("plan", WGRAD_PLANS, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()) or "default")
 @pytest.mark.parametrize("case", WGRAD_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
-def test_conv2d_wgrad(case):
+def test_conv2d_wgrad(case, plan, monkeypatch):
+    if "mode" in plan and not case.get("precision"):
+        pytest.skip("the staged modes are split-precision kernels")
+    if "mode" in plan:
+        monkeypatch.setenv("DIAMOND_WGRAD_MODE", str(plan["mode"]))
+    if "max_wg" in plan:
+        monkeypatch.setenv("DIAMOND_WGRAD_MAX_WG", str(plan["max_wg"]))
     rng = np.random.default_rng(11)
     L = S.lib()
     n, h, w, cin, cout, k = case["n"], case["h"], case["w"], case["cin"], case["cout"], case["k"]
