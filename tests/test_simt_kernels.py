@@ -320,3 +320,273 @@ def test_attention_bwd():
     dq, dk, dv = ds @ k / np.sqrt(8.0), ds.transpose(0, 1, 3, 2) @ q / np.sqrt(8.0), p.transpose(0, 1, 3, 2) @ g
     want = np.concatenate([a.transpose(0, 2, 1, 3).reshape(n, t, c) for a in (dq, dk, dv)], axis=-1)
     assert np.abs(dqkv - want).max() <= 1e-5 * np.abs(want).max()
+
+
+# ---- dmd_linear ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,k,acc,silu", [(5, 70, 48, 0, 0), (64, 64, 256, 1, 0), (3, 33, 512, 0, 1), (37, 96, 1024, 1, 0)])
+def test_linear(m, n, k, acc, silu):
+    rng = np.random.default_rng(m + n)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    w = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    c0 = rng.standard_normal((m, n)).astype(np.float32)
+    c = c0.copy()
+    p = nv.LinearParams()
+    p.M, p.N, p.K, p.A, p.lda, p.W, p.ldw, p.bias, p.C, p.ldc = m, n, k, S.ptr(a), k, S.ptr(w), k, S.ptr(b), S.ptr(c), n
+    p.accumulate, p.silu = acc, silu
+    S.check(S.lib().dmd_linear(p, None), "dmd_linear")
+    ref = a.astype(np.float64) @ w.astype(np.float64).T + b + (c0 if acc else 0)
+    if silu:
+        ref = ref / (1 + np.exp(-ref))
+    assert np.abs(c - ref).max() <= 3e-6 * max(1.0, np.abs(ref).max())
+
+
+# ---- dmd_gn_silu_bwd: fp64 finite-difference-free truth from the closed form in the header --------------------------------------
+@pytest.mark.parametrize("n,hw,c,identity,skip", [(2, 64, 64, 0, True), (1, 300, 32, 0, False), (2, 256, 128, 1, True), (1, 64, 16, 0, False)])
+def test_gn_silu_bwd(n, hw, c, identity, skip):
+    rng = np.random.default_rng(hw + c)
+    L = S.lib()
+    x = (rng.standard_normal((n, hw, 1, c)) * 1.4 + 0.3).astype(np.float32)
+    da = rng.standard_normal((n, hw, 1, c)).astype(np.float32)
+    dskip = rng.standard_normal((n, hw, 1, c)).astype(np.float32) if skip else None
+    mul = (rng.standard_normal((n, c)) * 0.3).astype(np.float32)
+    add = (rng.standard_normal((n, c)) * 0.3).astype(np.float32)
+    gsz = min(c, 32)
+    g = c // gsz
+    v = x.astype(np.float64).reshape(n, hw, g, gsz)
+    tot = np.stack([v.sum(axis=(1, 3)), (v * v).sum(axis=(1, 3))], axis=-1)
+    st = np.ascontiguousarray(np.stack([tot * 0.25, tot * 0.75], axis=2))  # (N, G, 2 tiles, 2)
+    p = nv.GnBwdParams()
+    p.N, p.HW, p.C, p.identity_activation = n, hw, c, identity
+    p.x, p.norm, p.da, p.dskip = S.ptr(x), _norm(st, 2, mul, add, plus_one=True), S.ptr(da), S.ptr(dskip)
+    dx = np.full_like(x, np.nan)
+    dmul, dadd = np.full((n, c), np.nan, dtype=np.float32), np.full((n, c), np.nan, dtype=np.float32)
+    ws = np.zeros(L.dmd_gn_bwd_workspace_bytes(n, hw, c), dtype=np.uint8)
+    p.dx, p.workspace, p.dmul, p.dadd = S.ptr(dx), S.ptr(ws), S.ptr(dmul), S.ptr(dadd)
+    S.check(L.dmd_gn_silu_bwd(p, None), "dmd_gn_silu_bwd")
+
+    mean = v.mean(axis=(1, 3), keepdims=True)
+    rstd = 1 / np.sqrt((v * v).mean(axis=(1, 3), keepdims=True) - mean ** 2 + 1e-5)
+    xh = ((v - mean) * rstd).reshape(n, hw, c)
+    m1 = 1.0 + mul.astype(np.float64)[:, None]
+    u = xh * m1 + add.astype(np.float64)[:, None]
+    sg = 1 / (1 + np.exp(-u))
+    du = da.astype(np.float64).reshape(n, hw, c) * (1 if identity else sg * (1 + u * (1 - sg)))
+    dxh = (du * m1).reshape(n, hw, g, gsz)
+    xhg = xh.reshape(n, hw, g, gsz)
+    want = rstd * (dxh - dxh.mean(axis=(1, 3), keepdims=True) - xhg * (dxh * xhg).mean(axis=(1, 3), keepdims=True))
+    want = want.reshape(n, hw, 1, c) + (dskip if skip else 0)
+    assert np.abs(dx - want).max() <= 1e-5 * np.abs(want).max()
+    np.testing.assert_allclose(dmul, (du * xh).sum(axis=1), rtol=0, atol=2e-5 * np.abs(du * xh).sum(axis=1).max())
+    np.testing.assert_allclose(dadd, du.sum(axis=1), rtol=0, atol=2e-5 * np.abs(du).sum(axis=1).max())
+
+
+# ---- dmd_pack_jobs: every packed layout against its definition -------------------------------------------------------------------
+def _packed_f32(wl, cout_pad, cin_pad):
+    """[CinPad/16][taps][CoutPad][16] of a logical (co, c, tap) weight"""
+    co, c, taps = wl.shape
+    full = np.zeros((cout_pad, cin_pad, taps), dtype=np.float32)
+    full[:co, :c] = wl
+    return np.ascontiguousarray(full.reshape(cout_pad, cin_pad // 16, 16, taps).transpose(1, 3, 0, 2))
+
+
+def _packed_f16x2(wl, cout, cin_pad):
+    """[CinPad/16][taps][h|l][2][Cout][8] split-fp16 pieces"""
+    co, c, taps = wl.shape
+    full = np.zeros((cout, cin_pad, taps), dtype=np.float32)
+    full[:co, :c] = wl
+    h = full.astype(np.float16)
+    l = (full - h.astype(np.float32)).astype(np.float16)
+    out = np.stack([h, l])  # (2, Cout, CinPad, taps)
+    out = out.reshape(2, cout, cin_pad // 16, 2, 8, taps).transpose(2, 5, 0, 3, 1, 4)
+    return np.ascontiguousarray(out)
+
+
+def test_pack_jobs():
+    rng = np.random.default_rng(21)
+    L = S.lib()
+    w3 = rng.standard_normal((64, 40, 3, 3)).astype(np.float32)     # Cin 40 -> padded to 48
+    w1 = rng.standard_normal((64, 128, 1, 1)).astype(np.float32)
+    wsm = rng.standard_normal((3, 64, 3, 3)).astype(np.float32)     # conv_out: Cout 3
+    bias = rng.standard_normal(3).astype(np.float32)
+    jobs, outs, wants = [], [], []
+
+    def add(src, dst_shape, dtype, want, **kw):
+        dst = np.full(dst_shape, np.nan if dtype == np.float32 else 0, dtype=dtype)
+        if dtype == np.float16:
+            dst[...] = np.float16(np.nan)
+        j = nv.PackJob()
+        j.src, j.dst = S.ptr(src), S.ptr(dst)
+        for k, v in kw.items():
+            setattr(j, k, v)
+        jobs.append(j)
+        outs.append(dst)
+        wants.append(want)
+
+    lw3 = w3.reshape(64, 40, 9)
+    add(w3, (3, 9, 64, 16), np.float32, _packed_f32(lw3, 64, 48), Cout=64, Cin=40, k=3, kind=nv.PACK_F32, CoutPad=64, CinPad=48)
+    add(w3, (3, 9, 2, 2, 64, 8), np.float16, _packed_f16x2(lw3, 64, 48), Cout=64, Cin=40, k=3, kind=nv.PACK_F16X2, CoutPad=64, CinPad=48)
+    add(w1, (8, 1, 2, 2, 64, 8), np.float16, _packed_f16x2(w1.reshape(64, 128, 1), 64, 128), Cout=64, Cin=128, k=1, kind=nv.PACK_F16X2,
+        CoutPad=64, CinPad=128)
+    add(wsm, (4, 9, 16, 16), np.float32, _packed_f32(wsm.reshape(3, 64, 9), 16, 64), Cout=3, Cin=64, k=3, kind=nv.PACK_F32, CoutPad=16, CinPad=64)
+    add(bias, (16,), np.float32, np.concatenate([bias, np.zeros(13, np.float32)]), Cout=3, Cin=0, k=1, kind=nv.PACK_BIAS, CoutPad=16, CinPad=0)
+    # data-gradient weights: W'[co][c][tap] = W[c][c0 + co][taps - 1 - tap], co < c1 - c0 input channels of the slice, c < Cout
+    for c0, c1 in ((0, 40), (8, 40)):
+        wt = lw3[:, c0:c1, ::-1].transpose(1, 0, 2)  # (c1 - c0, 64, 9)
+        cp = (c1 - c0 + 15) // 16 * 16
+        add(w3, (4, 9, cp, 16), np.float32, _packed_f32(wt, cp, 64), Cout=64, Cin=40, k=3, kind=nv.PACK_F32, transposed=1, c0=c0, c1=c1,
+            CoutPad=cp, CinPad=64)
+    wt = w1.reshape(64, 128, 1)[:, 64:128].transpose(1, 0, 2)  # second half of a concatenated input: (64, 64, 1)
+    add(w1, (4, 1, 2, 2, 64, 8), np.float16, _packed_f16x2(wt, 64, 64), Cout=64, Cin=128, k=1, kind=nv.PACK_F16X2, transposed=1, c0=64, c1=128,
+        CoutPad=64, CinPad=64)
+
+    table = (nv.PackJob * len(jobs))(*jobs)
+    S.check(L.dmd_pack_jobs(table, len(jobs), max(o.size for o in outs), None), "dmd_pack_jobs")
+    for i, (got, want) in enumerate(zip(outs, wants)):
+        assert got.shape == want.shape, (i, got.shape, want.shape)
+        assert np.array_equal(got.view(np.uint16 if got.dtype == np.float16 else np.uint32),
+                              want.astype(got.dtype).view(np.uint16 if got.dtype == np.float16 else np.uint32)), f"job {i}"
+    # dmd_pack_conv_weight is the same layout
+    single = np.full((3, 9, 64, 16), np.nan, dtype=np.float32)
+    S.check(L.dmd_pack_conv_weight(S.ptr(w3), S.ptr(single), 64, 40, 3, 64, 48, None), "dmd_pack_conv_weight")
+    assert np.array_equal(single, wants[0])
+
+
+# ---- pointwise family --------------------------------------------------------------------------------------------------------------
+f32 = np.float32
+
+
+def _quantise(d):
+    """denoiser.py:81-83 in fp32, op by op: clamp(-1, 1).add(1).div(2).mul(255).byte().div(255).mul(2).sub(1)"""
+    d = np.clip(d, f32(-1), f32(1))
+    d = ((d + f32(1)) / f32(2)) * f32(255)
+    q = d.astype(np.uint8).astype(np.float32)  # truncation
+    return (q / f32(255)) * f32(2) - f32(1)
+
+
+def test_edm_pointwise_ops_are_bit_exact():
+    rng = np.random.default_rng(31)
+    L = S.lib()
+    n, cx, frames, h, w = 3, 3, 4, 8, 8
+    cobs = frames * 3
+    x = rng.standard_normal((n, cx, h, w)).astype(f32)
+    ring = (rng.random((n, frames, 3, h, w)) * 2 - 1).astype(f32)
+    cond = rng.random((n, 4)).astype(f32) + f32(0.1)
+    head, sd, cpad = 3, f32(0.5), 16
+    out = np.full((n, h, w, cpad), np.nan, dtype=f32)
+    S.check(L.dmd_edm_pack_input(S.ptr(x), S.ptr(ring), S.ptr(cond), 4, float(sd), S.ptr(out), n, cx, cobs, h, w, cpad, frames, head, None), "pack")
+    logical = np.roll(ring, -head, axis=1).reshape(n, cobs, h, w)  # logical frame t is stored at slot (head + t) % T
+    want = np.zeros((n, cpad, h, w), dtype=f32)
+    want[:, :cobs] = logical / sd
+    want[:, cobs:cobs + cx] = x * cond[:, 0, None, None, None]
+    assert np.array_equal(out, want.transpose(0, 2, 3, 1))
+
+    f = rng.standard_normal((n, cx, h, w)).astype(f32)
+    den = np.full_like(x, np.nan)
+    S.check(L.dmd_edm_denoised(S.ptr(x), S.ptr(f), S.ptr(cond), 4, S.ptr(den), n, cx * h * w, None), "denoised")
+    assert np.array_equal(den, _quantise(cond[:, 2, None, None, None] * x + cond[:, 1, None, None, None] * f))
+
+    sh, sn, dt = f32(2.5), f32(1.25), f32(-1.25)
+    xo = np.full_like(x, np.nan)
+    S.check(L.dmd_euler_step(S.ptr(x), S.ptr(den), float(sh), float(dt), S.ptr(xo), x.size, None), "euler")
+    assert np.array_equal(xo, x + ((x - den) / sh) * dt)
+    x2, den2 = xo.copy(), _quantise(xo * f32(0.7))
+    xh = np.full_like(x, np.nan)
+    S.check(L.dmd_heun_step(S.ptr(x), S.ptr(den), S.ptr(x2), S.ptr(den2), float(sh), float(sn), float(dt), S.ptr(xh), x.size, None), "heun")
+    assert np.array_equal(xh, x + ((((x - den) / sh) + ((x2 - den2) / sn)) / f32(2)) * dt)
+
+
+def test_cond_embed_ring_and_layout_transposes():
+    rng = np.random.default_rng(32)
+    L = S.lib()
+    n, half, t, a_rows = 3, 32, 4, 6
+    e = 2 * half // t
+    cond = rng.random((n, 4)).astype(f32)
+    fw = rng.standard_normal(half).astype(f32)
+    act = rng.integers(0, a_rows, (n, t)).astype(np.int64)
+    emb = rng.standard_normal((a_rows, e)).astype(f32)
+    out = np.full((n, 2 * half), np.nan, dtype=f32)
+    S.check(L.dmd_cond_embed(S.ptr(cond), 4, S.ptr(fw), S.ptr(act), S.ptr(emb), S.ptr(out), n, half, t, e, 1, a_rows, None), "cond_embed")
+    fr = (f32(2.0 * np.pi) * cond[:, 3:4]) * fw[None]
+    want = np.concatenate([np.cos(fr), np.sin(fr)], axis=1) + emb[np.roll(act, -1, axis=1)].reshape(n, -1)
+    assert np.abs(out - want).max() < 2e-6  # cosf / sinf: libm here, ocml on the device
+
+    x = rng.standard_normal((2, 5, 4, 6)).astype(f32)
+    nhwc = np.full((2, 4, 6, 8), np.nan, dtype=f32)
+    S.check(L.dmd_nchw_to_nhwc(S.ptr(x), S.ptr(nhwc), 2, 5, 4, 6, 8, None), "nchw_to_nhwc")
+    assert np.array_equal(nhwc[..., :5], x.transpose(0, 2, 3, 1)) and not nhwc[..., 5:].any()
+    back = np.full_like(x, np.nan)
+    S.check(L.dmd_nhwc_to_nchw(S.ptr(nhwc), S.ptr(back), 2, 5, 4, 6, 8, None), "nhwc_to_nchw")
+    assert np.array_equal(back, x)
+
+
+def test_uint8_pool_round_trip():
+    rng = np.random.default_rng(33)
+    L = S.lib()
+    p_, t, per = 5, 4, 48
+    levels = rng.integers(0, 256, (p_, t, per)).astype(np.uint8)
+    frames = (levels.astype(f32) / f32(255)) * f32(2) - f32(1)
+    q = np.zeros_like(levels)
+    off = np.zeros(1, dtype=np.int32)
+    S.check(L.dmd_quantize_u8(S.ptr(frames), S.ptr(q), S.ptr(off), frames.size, None), "quantize")
+    assert np.array_equal(q, levels) and off[0] == 0
+    bad = frames.copy()
+    bad[2, 1, 7] += f32(1e-3)
+    S.check(L.dmd_quantize_u8(S.ptr(bad), S.ptr(q), S.ptr(off), bad.size, None), "quantize")
+    assert off[0] == 1  # a frame off the 256-level grid cannot live in the uint8 pool
+    idx, rows = np.array([4, 0, 2], dtype=np.int64), np.array([1, 3, 0], dtype=np.int64)
+    dst = np.full((4, t, per), np.nan, dtype=f32)
+    S.check(L.dmd_dequant_gather(S.ptr(levels), S.ptr(idx), S.ptr(rows), S.ptr(dst), 3, t, per, 2, None), "dequant_gather")
+    for i in range(3):
+        assert np.array_equal(np.roll(dst[rows[i]], -2, axis=0), frames[idx[i]])  # logical frame k at slot (head + k) % T
+    assert np.isnan(dst[2]).all()
+
+
+def test_maxpool_lstm_categorical():
+    rng = np.random.default_rng(34)
+    L = S.lib()
+    n, h, w, c = 2, 8, 8, 32
+    x = rng.standard_normal((n, h, w, c)).astype(f32)
+    x[0, 0, 0, 0] = x[0, 0, 1, 0] = 9.0  # a tie: the FIRST maximum in scan order wins
+    out = np.full((n, h // 2, w // 2, c), np.nan, dtype=f32)
+    arg = np.full((n, h // 2, w // 2, c), 255, dtype=np.uint8)
+    stats = np.full((n, 1, 1, 2), np.nan)
+    S.check(L.dmd_maxpool2(S.ptr(x), S.ptr(out), S.ptr(arg), S.ptr(stats), n, h, w, c, None), "maxpool2")
+    win = x.reshape(n, h // 2, 2, w // 2, 2, c).transpose(0, 1, 3, 5, 2, 4).reshape(n, h // 2, w // 2, c, 4)
+    assert np.array_equal(out, win.max(axis=-1)) and np.array_equal(arg, win.argmax(axis=-1))
+    np.testing.assert_allclose(stats[:, 0, 0], _group_sums(out)[:, 0], rtol=1e-12)
+    dp = rng.standard_normal(out.shape).astype(f32)
+    dx = np.full_like(x, np.nan)
+    S.check(L.dmd_maxpool2_bwd(S.ptr(dp), S.ptr(arg), S.ptr(dx), n, h, w, c, None), "maxpool2_bwd")
+    want = np.zeros_like(win)
+    np.put_along_axis(want, win.argmax(axis=-1)[..., None], dp[..., None], axis=-1)
+    assert np.array_equal(dx, want.reshape(n, h // 2, w // 2, c, 2, 2).transpose(0, 1, 4, 2, 5, 3).reshape(n, h, w, c))
+
+    b, hd = 3, 40
+    gates = (rng.standard_normal((b, 4 * hd)) * 2).astype(f32)
+    c0 = rng.standard_normal((b, hd)).astype(f32)
+    hh, cc = np.full((b, hd), np.nan, dtype=f32), np.full((b, hd), np.nan, dtype=f32)
+    S.check(L.dmd_lstm_pointwise(S.ptr(gates), S.ptr(c0), S.ptr(hh), S.ptr(cc), b, hd, None), "lstm")
+    sig = lambda v: 1 / (1 + np.exp(-v.astype(np.float64)))
+    i, f, g, o = (gates[:, k * hd:(k + 1) * hd] for k in range(4))
+    c_ref = sig(f) * c0 + sig(i) * np.tanh(g.astype(np.float64))
+    h_ref = sig(o) * np.tanh(c_ref)
+    assert np.abs(cc - c_ref).max() < 1e-6 and np.abs(hh - h_ref).max() < 1e-6
+    dh, dc = rng.standard_normal((b, hd)).astype(f32), rng.standard_normal((b, hd)).astype(f32)
+    dg, dcp = np.full_like(gates, np.nan), np.full((b, hd), np.nan, dtype=f32)
+    S.check(L.dmd_lstm_pointwise_bwd(S.ptr(gates), S.ptr(c0), S.ptr(cc), S.ptr(dh), S.ptr(dc), S.ptr(dg), S.ptr(dcp), b, hd, None), "lstm_bwd")
+    tc = np.tanh(c_ref)
+    dcv = dc + dh * sig(o) * (1 - tc * tc)
+    gg = np.tanh(g.astype(np.float64))
+    want = np.concatenate([dcv * gg * sig(i) * (1 - sig(i)), dcv * c0 * sig(f) * (1 - sig(f)), dcv * sig(i) * (1 - gg * gg),
+                           dh * tc * sig(o) * (1 - sig(o))], axis=1)
+    assert np.abs(dg - want).max() < 2e-6 and np.abs(dcp - dcv * sig(f)).max() < 2e-6
+
+    logits = (rng.standard_normal((50, 7)) * 2).astype(f32)
+    expo = rng.exponential(size=(50, 7)).astype(f32)
+    act = np.full(50, -1, dtype=np.int64)
+    S.check(L.dmd_categorical_sample(S.ptr(logits), S.ptr(expo), S.ptr(act), 50, 7, None), "categorical")
+    l64 = logits.astype(np.float64)
+    probs = np.exp(l64 - l64.max(axis=1, keepdims=True))
+    probs /= probs.sum(axis=1, keepdims=True)
+    assert np.array_equal(act, (probs / expo).argmax(axis=1))  # torch.multinomial: argmax(probs / E)
