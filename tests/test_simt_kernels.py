@@ -590,3 +590,95 @@ def test_maxpool_lstm_categorical():
     probs = np.exp(l64 - l64.max(axis=1, keepdims=True))
     probs /= probs.sum(axis=1, keepdims=True)
     assert np.array_equal(act, (probs / expo).argmax(axis=1))  # torch.multinomial: argmax(probs / E)
+
+
+# ---- dmd_lowres_chain: a chain of ResBlocks (+ attention, concatenated skips) at the 8x8 level in one launch -----------------------
+def _pack16(w_oihw):
+    """split-fp16 pack of an OIHW weight through dmd_pack_jobs"""
+    co, ci, k, _ = w_oihw.shape
+    dst = np.zeros((ci // 16, k * k, 2, 2, co, 8), dtype=np.float16)
+    j = nv.PackJob()
+    j.src, j.dst, j.Cout, j.Cin, j.k, j.kind, j.CoutPad, j.CinPad = S.ptr(w_oihw), S.ptr(dst), co, ci, k, nv.PACK_F16X2, co, ci
+    S.check(S.lib().dmd_pack_jobs((nv.PackJob * 1)(j), 1, dst.size, None), "dmd_pack_jobs")
+    return dst
+
+
+def _ada_gn_silu(x, scale, shift):
+    return _apply_norm(x, x.shape[1], x.shape[2], scale, shift, True, silu=True)
+
+
+@pytest.mark.parametrize("c", [64, 32], ids=["denoiser-64ch", "rew-end-32ch"])
+def test_lowres_chain(c):
+    rng = np.random.default_rng(41 + c)
+    L = S.lib()
+    n = 2
+    x = rng.standard_normal((n, 8, 8, c)).astype(np.float32)
+    table = (rng.standard_normal((n, 40 * c)) * 0.3).astype(np.float32)
+    col = [0]
+
+    def take(k):
+        col[0] += k
+        return col[0] - k
+
+    def conv_w(co, ci, k):
+        return (rng.standard_normal((co, ci, k, k)) / np.sqrt(ci * k * k)).astype(np.float32)
+
+    # block 0: plain, output kept in slot 1; block 1: attention; block 2 (64-channel chain only): cat(x, slot 1) + projection + attention
+    # (the 32-channel chain has no skip slots)
+    specs = [dict(cat=False, attn=False, save=1 if c == 64 else -1), dict(cat=False, attn=True, save=-1)]
+    if c == 64:
+        specs.append(dict(cat=True, attn=True, save=-1))
+    p = nv.LowresChainParams()
+    p.N, p.nblocks, p.input_save_slot = n, len(specs), (0 if c == 64 else -1)
+    out = np.full_like(x, np.nan)
+    p.x, p.out, p.table, p.table_stride = S.ptr(x), S.ptr(out), S.ptr(table), table.shape[1]
+    keep, blocks = [], []
+    for i, sp in enumerate(specs):
+        cin = 2 * c if sp["cat"] else c
+        b = dict(sp, w1=conv_w(c, cin, 3), w2=conv_w(c, c, 3), b1=rng.standard_normal(c).astype(np.float32),
+                 b2=rng.standard_normal(c).astype(np.float32))
+        cb = p.blocks[i]
+        cb.skip_slot, cb.save_slot = (1 if sp["cat"] else -1), sp["save"]
+        o1 = take(2 * cin)
+        cb.film1_mul[0], cb.film1_add[0] = o1, o1 + cin
+        cb.film1_mul[1], cb.film1_add[1] = o1 + c, o1 + cin + c
+        b["f1"] = (table[:, o1:o1 + cin], table[:, o1 + cin:o1 + 2 * cin])
+        o2 = take(2 * c)
+        cb.film2_mul, cb.film2_add = o2, o2 + c
+        b["f2"] = (table[:, o2:o2 + c], table[:, o2 + c:o2 + 2 * c])
+        packs = [_pack16(b["w1"]), _pack16(b["w2"])]
+        cb.w1, cb.w2, cb.b1, cb.b2 = S.ptr(packs[0]), S.ptr(packs[1]), S.ptr(b["b1"]), S.ptr(b["b2"])
+        if sp["cat"]:
+            b["wp"], b["bp"] = conv_w(c, cin, 1), rng.standard_normal(c).astype(np.float32)
+            packs.append(_pack16(b["wp"]))
+            cb.wproj, cb.bproj = S.ptr(packs[-1]), S.ptr(b["bp"])
+        if sp["attn"]:
+            cb.has_attn = 1
+            b["wqkv"], b["bqkv"] = conv_w(3 * c, c, 1), (rng.standard_normal(3 * c) * 0.2).astype(np.float32)
+            b["wo"], b["bo"] = conv_w(c, c, 1), rng.standard_normal(c).astype(np.float32)
+            b["gam"], b["bet"] = (1 + 0.2 * rng.standard_normal(c)).astype(np.float32), (0.2 * rng.standard_normal(c)).astype(np.float32)
+            qkv = [_pack16(np.ascontiguousarray(b["wqkv"][k * c:(k + 1) * c])) for k in range(3)]
+            packs += qkv + [_pack16(b["wo"])]
+            cb.wq, cb.wk, cb.wv, cb.wo = (S.ptr(t) for t in packs[-4:])
+            cb.gn_gamma, cb.gn_beta, cb.bqkv, cb.bo = S.ptr(b["gam"]), S.ptr(b["bet"]), S.ptr(b["bqkv"]), S.ptr(b["bo"])
+        keep.append(packs)
+        blocks.append(b)
+    S.check((L.dmd_lowres_chain if c == 64 else L.dmd_lowres_chain32)(p, None), "dmd_lowres_chain")
+
+    # fp64 restatement of ResBlock.forward (blocks.py:141-147) / SelfAttention2d.forward (blocks.py:62-72)
+    cur, slots = x.astype(np.float64), {0: x.astype(np.float64)}
+    for b in blocks:
+        inp = np.concatenate([cur, slots[1]], axis=-1) if b["cat"] else cur
+        r = _ref_conv([inp], b["wp"], b["bp"], 1, 1, 0, 8, 8) if b["cat"] else cur
+        h = _ref_conv([_ada_gn_silu(inp, *b["f1"])], b["w1"], b["b1"], 3, 1, 0, 8, 8)
+        cur = _ref_conv([_ada_gn_silu(h, *b["f2"])], b["w2"], b["b2"], 3, 1, 0, 8, 8) + r
+        if b["attn"]:
+            gam, bet = np.repeat(b["gam"][None], n, 0), np.repeat(b["bet"][None], n, 0)
+            xn = _apply_norm(cur, 8, 8, gam, bet, False, silu=False)
+            qkv = _ref_conv([xn], b["wqkv"], b["bqkv"], 1, 1, 0, 8, 8).reshape(n, 64, 3 * c)
+            y, _, _ = _ref_attention(qkv, c)
+            cur = xn + _ref_conv([y.reshape(n, 8, 8, c)], b["wo"], b["bo"], 1, 1, 0, 8, 8)
+        if b["save"] >= 0:
+            slots[b["save"]] = cur
+    err = np.abs(out - cur).max() / np.abs(cur).max()
+    assert err <= 2e-5, err
