@@ -34,3 +34,45 @@ def test_denoiser_training_step_staged_modes(plan, monkeypatch):
     fn = getattr(M, "test_denoiser_training_step_vs_reference_golden", None)
     assert fn is not None, "the golden training-step test moved: update tests/test_gpu_staged.py"
     fn()
+
+
+# ---- conv_lat_kernel (dmd_conv_lat.hip): the few-tile 3x3 for play.py's B = 1 sampler, routed by DIAMOND_CONV_LATENCY_TILES ------
+def test_latency_conv_route_vs_reference_goldens(monkeypatch):
+    """The denoiser at batch 1-2 with every eligible 3x3 on conv_lat_kernel: model output and quantised frames against the
+    reference's goldens (same bars as the shipping route), the 3-step / Heun samplers teacher-forced, and the graphed B = 1
+    sampler bitwise against the eager one."""
+    from tests import test_gpu_env as EV, test_gpu_models as M
+
+    monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", "64")
+    M.test_denoiser_vs_reference_golden("default", (0, 0, 0, 0), 2)
+    M.test_denoiser_vs_reference_golden("attn0011", (0, 0, 1, 1), 1)
+    ag = M.make_agent()
+    M.test_sampler_teacher_forced_vs_golden(ag)
+    M.test_denoiser_deterministic(ag)
+    for name in dir(EV):
+        if name.startswith("test_") and "graph" in name:
+            getattr(EV, name)()
+
+
+def test_latency_conv_route_is_taken_and_close_to_the_throughput_kernel(monkeypatch):
+    """same conv, both routes: the kernel-name query reports the route, outputs agree to split-fp16 rounding, statistics too"""
+    import torch
+
+    from diamond_amd import engine as E, native as nv
+    from tests.test_gpu_kernels import DEV, make_act
+
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 64, 32, 32, generator=g, dtype=torch.float64)
+    w = (torch.randn(64, 64, 3, 3, generator=g) / 24).to(DEV)
+    b = torch.randn(64, generator=g).to(DEV)
+    outs = {}
+    for cap in ("0", "64"):
+        monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", cap)
+        xa = make_act(x)
+        y = E.conv2d([(xa, nv.PROLOGUE_NORM_SILU, E.NormSpec(mul=None, add=None))], nv.pack_conv_weight(w), b, 64,
+                     w_f16=nv.pack_conv_weight_f16x2(w))
+        torch.cuda.synchronize()
+        outs[cap] = (y.t.clone(), y.stats.sum(2).clone())
+    err = float((outs["0"][0] - outs["64"][0]).abs().max() / outs["0"][0].abs().max())
+    assert 0 < err < 1e-5, err  # different summation order (not bitwise), same arithmetic
+    assert torch.allclose(outs["0"][1], outs["64"][1], rtol=1e-5)

@@ -682,3 +682,105 @@ def test_lowres_chain(c):
             slots[b["save"]] = cur
     err = np.abs(out - cur).max() / np.abs(cur).max()
     assert err <= 2e-5, err
+
+
+# ---- conv_lat_kernel: the few-tile split-fp16 3x3 (STAGED; dmd_conv2d routes to it under DIAMOND_CONV_LATENCY_TILES) ---------------
+LAT_CASES = [
+    dict(n=1, h=8, w=16, cin=[64]),
+    dict(n=2, h=16, w=32, cin=[64], prologue=[1], film=True, stats=True, residual=True),
+    dict(n=1, h=16, w=16, cin=[64, 64], prologue=[1, 1], film=True, stats=True),             # ResBlock conv1 on cat(x, skip)
+    dict(n=1, h=8, w=32, cin=[64, 64], prologue=[1, 0]),
+    dict(n=2, h=16, w=16, cin=[64], upsample=1, stats=True),                                  # Upsample's conv
+    dict(n=1, h=16, w=16, cin=[64], upsample=1, prologue=[1]),
+    dict(n=2, h=16, w=16, cin=[64], prologue=[1], film=True, stats=True, proj=True),          # conv2 + fused skip projection
+    dict(n=1, h=8, w=16, cin=[128], prologue=[2]),
+]
+
+
+@pytest.mark.parametrize("case", LAT_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()).replace(" ", ""))
+def test_conv_latency_kernel(case, monkeypatch):
+    monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", "64")
+    rng = np.random.default_rng(17)
+    L = S.lib()
+    n, h, w, cins = case["n"], case["h"], case["w"], case["cin"]
+    up, prol = case.get("upsample", 0), case.get("prologue", [0] * len(cins))
+    hs, ws = (h // 2, w // 2) if up else (h, w)
+    cin, cout = sum(cins), 64
+    p = nv.ConvParams()
+    p.N, p.H, p.W, p.Cout, p.CoutPad, p.taps, p.stride, p.upsample, p.nsrc, p.precision = n, h, w, cout, cout, 9, 1, up, len(cins), 1
+    keep, xs_ref = [], []
+    for i, c in enumerate(cins):
+        x = (rng.standard_normal((n, hs, ws, c)) * 1.5 + 0.3).astype(np.float32)
+        p.src[i].x, p.src[i].C, p.src[i].prologue = S.ptr(x), c, prol[i]
+        if prol[i]:
+            tiles = 70 if i == 0 else 3  # more partial sums than lanes: the finalising wave strides over them
+            st = _partial_stats(x, hs, ws, tiles, rng)
+            film = case.get("film") or prol[i] == 2
+            mul = (rng.standard_normal((n, c)) * 0.3).astype(np.float32) if film else None
+            add = (rng.standard_normal((n, c)) * 0.3).astype(np.float32) if film else None
+            p.src[i].norm = _norm(st, tiles, mul, add, bool(case.get("film")))
+            xs_ref.append(_apply_norm(x, hs, ws, mul, add, bool(case.get("film")), silu=prol[i] == 1))
+            keep += [st, mul, add]
+        else:
+            xs_ref.append(x.astype(np.float64))
+        keep.append(x)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    packed = np.zeros((cin // 16) * 9 * cout * 16, dtype=np.float32)
+    S.check(L.dmd_pack_conv_weight(S.ptr(wt), S.ptr(packed), cout, cin, 3, cout, cin, None), "pack")
+    w16 = _pack16(wt)
+    p.w, p.bias, p.w_f16 = S.ptr(packed), S.ptr(bias), S.ptr(w16)
+    ref = _ref_conv(xs_ref, wt, bias, 3, 1, up, h, w)
+    if case.get("residual"):
+        r = rng.standard_normal((n, h, w, cout)).astype(np.float32)
+        p.residual = S.ptr(r)
+        ref = ref + r
+    if case.get("proj"):
+        j0, j1 = (rng.standard_normal((n, h, w, 64)).astype(np.float32) for _ in range(2))
+        wpj = (rng.standard_normal((cout, 128, 1, 1)) / np.sqrt(128)).astype(np.float32)
+        bpj = rng.standard_normal(cout).astype(np.float32)
+        wpj16 = _pack16(wpj)
+        p.proj_nsrc, p.proj_C[0], p.proj_C[1] = 2, 64, 64
+        p.proj_x[0], p.proj_x[1], p.proj_w_f16, p.proj_bias = S.ptr(j0), S.ptr(j1), S.ptr(wpj16), S.ptr(bpj)
+        ref = ref + _ref_conv([j0.astype(np.float64), j1.astype(np.float64)], wpj, bpj, 1, 1, 0, h, w)
+    out = np.full((n, h, w, cout), np.nan, dtype=np.float32)
+    tiles = L.dmd_conv_stat_tiles(h, w)
+    stats = np.full((n, 2, tiles, 2), np.nan) if case.get("stats") else None
+    p.out, p.out_stats = S.ptr(out), S.ptr(stats)
+
+    assert L.dmd_conv2d_latency_eligible(p) == 1
+    name = bytes(96)
+    buf = (nv.C.c_char * 96)()
+    S.check(L.dmd_conv2d_kernel_name(p, buf, 96), "kernel_name")
+    assert buf.value.decode() == f"conv_lat_kernel<{'true' if case.get('proj') else 'false'}>"
+    S.check(L.dmd_conv2d(p, None), "dmd_conv2d")
+    err = np.abs(out - ref).max()
+    assert err <= 2e-5 * max(1.0, np.abs(ref).max()), err
+    if stats is not None:
+        # one partial per 8 x 16 tile and 32-channel group, in dmd_conv_stat_tiles order
+        t8 = out.reshape(n, h // 8, 8, w // 16, 16, 2, 32).astype(np.float64)
+        want = np.stack([t8.sum(axis=(2, 4, 6)), (t8 * t8).sum(axis=(2, 4, 6))], axis=-1)  # (n, ty, tx, g, 2)
+        np.testing.assert_allclose(stats, want.transpose(0, 3, 1, 2, 4).reshape(n, 2, tiles, 2), rtol=1e-9, atol=1e-6)
+
+    # the route is by tile count: above the cap the launch is not taken (here: the interpreter build has no conv_f16ws, so the
+    # same parameters then run on the conv_mfma instance, or are refused when they carry a fused projection)
+    monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", "0")
+    rc = L.dmd_conv2d_kernel_name(p, buf, 96)
+    assert (rc != 0) if case.get("proj") else (rc == 0 and not buf.value.decode().startswith("conv_lat_kernel"))
+
+
+def test_conv_latency_eligibility():
+    L = S.lib()
+    x = np.zeros((1, 8, 16, 64), dtype=np.float32)
+    p = nv.ConvParams()
+    p.N, p.H, p.W, p.Cout, p.CoutPad, p.taps, p.stride, p.nsrc, p.precision = 1, 8, 16, 64, 64, 9, 1, 1, 1
+    p.src[0].x, p.src[0].C = S.ptr(x), 64
+    p.w_f16 = S.ptr(x)
+    assert L.dmd_conv2d_latency_eligible(p) == 1
+    for field, bad in (("precision", 0), ("taps", 1), ("Cout", 32), ("W", 8), ("valid_h", 4), ("out_nchw", 1), ("stride", 2)):
+        good = getattr(p, field)
+        setattr(p, field, bad)
+        assert L.dmd_conv2d_latency_eligible(p) == 0, field
+        setattr(p, field, good)
+    p.src[0].C = 48
+    assert L.dmd_conv2d_latency_eligible(p) == 0
