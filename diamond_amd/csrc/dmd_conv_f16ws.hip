@@ -211,6 +211,9 @@ extern "C" int dmd_ws_trace_dump(unsigned long long* host, int* counts) {
 #define WS_STAMP(role_, tag_, step_) do {} while (0)
 #endif
 
+// ---- the inline-assembly helpers.  tests/simt (the host build of these sources for the SIMT interpreter) defines
+//      WS_HOST_HELPERS and supplies C++ spellings of the same operations: loads are synchronous there, waits are no-ops ----
+#ifndef WS_HOST_HELPERS
 // ---- activation loads hipcc does not count (header: PRODUCERS) ----
 // "=&v": the destination never overlaps the address pair.  Nothing may read or move `dst` before ws_await names it.
 __device__ __forceinline__ void ws_aload(f32x4& dst, const f32x4* src) {
@@ -225,12 +228,6 @@ __device__ __forceinline__ void ws_aload(f32x4& dst, const void* base, unsigned 
     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(base) : "memory");
   else
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(base) : "memory");
-}
-// a pointer the compiler must treat as wave-uniform (it is: kernel arguments and the stream position)
-__device__ __forceinline__ const char* ws_uniform_ptr(const char* p) {
-  const unsigned long long v = (unsigned long long)p;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return (const char*)(((unsigned long long)hi << 32) | lo);
 }
 // wait until at most N vector-memory operations of this wave are outstanding; `v` is usable afterwards
 template <int N>
@@ -249,7 +246,18 @@ __device__ __forceinline__ unsigned ws_low_pair(float x0, float x1, unsigned h01
       : "v"(x0), "v"(x1), "v"(h01));
   return l01;
 }
+// `t` = an opaque copy of itself: the compiler may not reason about its value (no instruction)
+#define WS_OPAQUE(t) asm volatile("" : "+v"(t))
+// wait until at most n vector-memory operations of this wave are outstanding (a literal)
+#define WS_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#endif
 
+// a pointer the compiler must treat as wave-uniform (it is: kernel arguments and the stream position)
+__device__ __forceinline__ const char* ws_uniform_ptr(const char* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const char*)(((unsigned long long)hi << 32) | lo);
+}
 // wave64 sum of a double on the DPP network (no LDS round trips, unlike __shfl_xor): quad swaps and row mirrors leave
 // the 16-lane row total in every lane of a row, row_bcast:15 / row_bcast:31 chain the four rows; total in lane 63
 template <int CTRL, int ROW_MASK>
@@ -269,6 +277,7 @@ __device__ __forceinline__ double ws_wave_sum_lane63(double x) {
   return x;
 }
 
+#ifndef WS_HOST_HELPERS
 // one wait for a whole register set: the loads were issued two chunk steps earlier and have landed long before; what
 // matters is that the compiler may then interleave the staging arithmetic of ALL items (a staging wave is bound by the
 // latency of its dependent fma -> exp -> add -> rcp -> mul -> cvt chains, tools/probe/simd_share_probe.hip: ~10 cycles
@@ -292,6 +301,7 @@ __device__ __forceinline__ void ws_use_all(f32x4 (&st)[M]) {
 #pragma unroll
   for (int it = 0; it < N; ++it) asm volatile("; drained %0" : : "v"(st[it]));
 }
+#endif
 
 // ---- consumer fragments ----
 struct WsA {
@@ -396,7 +406,7 @@ __device__ __forceinline__ void ws_chunk_body(f32x16 (&acc)[4], WsA& a, WsB& b, 
 
 template <class G>
 __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_params p, int ntiles, int tiles_per_wg) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  DMD_DYNAMIC_LDS(unsigned char, smem_raw);
   // [patch 0][patch 1][weights 0][weights 1]: patch [NPP][4 x 16 B], weights [TAPS][h|l][2][COUT] x 16 B
   float* tab_a = (float*)(smem_raw + 2 * G::BUF_BYTES);  // [slot][SUB][CIN_MAX]
   float* tab_b = tab_a + G::TAB_FLOATS;
@@ -457,7 +467,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     auto ipos = [&](int it) -> int {
       if (IPOS_REGS) return ipos_[IPOS_REGS ? it : 0];
       int t = tid;
-      asm volatile("" : "+v"(t));
+      WS_OPAQUE(t);
       return ipos_calc(it, t);
     };
     // 8-byte unit index of the h half-quad of item `it` in a patch.  The 11-13-item geometries are at the register cap:
@@ -465,7 +475,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     // one loop-invariant address register per item and piece and spills something else)
     auto loff_of = [&](int it) {
       int t = tid;
-      if (G::SUB > 1) asm volatile("" : "+v"(t));
+      if (G::SUB > 1) WS_OPAQUE(t);
       const int qq = t & 3;
       return ((it * (G::NPT / 4) + (t >> 2)) * 4 + (((qq >> 1) + ((ipos(it) & 0xff) >> 1)) & 3)) * 2 + (qq & 1);
     };
@@ -719,7 +729,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       }
       // the two dummy sets of the tail (elements S and S + 1): land, and are "used" here
       if constexpr (G::ASM_LOADS) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WS_WAIT_VM(0);
         ws_use_all<G::ITEMS>(stage0);
         ws_use_all<G::ITEMS>(stage1);
       }
@@ -844,7 +854,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         int n31e = n31;
         if constexpr (G::PROJ) {  // at the register cap: recomputed per tile from an OPAQUE copy of the thread index
           int te = tid;           // (left alone, hipcc keeps the row term in a register of its own and spills it)
-          asm volatile("" : "+v"(te));
+          WS_OPAQUE(te);
           n31e = te & 31;
         }
         if (G::B8) {
@@ -930,7 +940,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
             if (!G::PROJ) v[qd] += rnext[qd];
           }
           if (land) {  // (the waits hipcc emits for `rnext` leave the younger LDS-DMA in flight; this one does not)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            WS_WAIT_VM(0);
             land = false;
           }
           float fs = 0.f, fq = 0.f;  // fp32 over the lane's 16 values of this block, fp64 across
@@ -958,7 +968,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           ssq[slot] += (StatAcc)fq;
         }
       }
-      if (land) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no block with stores in this call)
+      if (land) WS_WAIT_VM(0);  // (no block with stores in this call)
       pending = last;
       if (last == 4 && first < 4 && p.out_stats) {
 #pragma unroll
@@ -992,9 +1002,9 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         });
         if (wnext) {
           if constexpr (blk + 1 < 4)
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            WS_WAIT_VM(16);
           else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            WS_WAIT_VM(0);
         }
         if (po >= 0) {
           float* op = p.out + (size_t)po * 4;
@@ -1043,7 +1053,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w + 256 * i),
                                            (__attribute__((address_space(3))) void*)(wl + 256 * i), 16, 0, 0);
     };
-    auto cons_land_W = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };  // the DMA writes have landed before the step's barrier
+    auto cons_land_W = [&]() { WS_WAIT_VM(0); };  // the DMA writes have landed before the step's barrier
 
     // the bias row of the convolution: accumulators START from it (no bias loads / adds in the write-out)
     if (role == 0 && tid < G::COUT)

@@ -40,6 +40,13 @@ inline const char* hipGetErrorString(hipError_t) { return "simt"; }
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+enum { hipDeviceAttributeMultiprocessorCount = 63 };
+// few "CUs": the persistent kernels then walk several tiles per workgroup in the tests (SIMT_NUM_CUS overrides)
+inline hipError_t hipDeviceGetAttribute(int* v, int, int) {
+  const char* e = getenv("SIMT_NUM_CUS");
+  *v = e ? atoi(e) : 3;
+  return hipSuccess;
+}
 #define HIP_SYMBOL(x) (&(x))
 inline hipError_t hipMemcpyFromSymbol(void* dst, const void* sym, size_t n) { memcpy(dst, sym, n); return hipSuccess; }
 
@@ -81,3 +88,20 @@ inline unsigned simt_split_low_pair(float p0, float p1, unsigned hw) {
   return __builtin_bit_cast(unsigned, l);
 }
 #define ATT_SPLIT_LOW_PAIR(lw, p0, p1, hw) (lw) = simt_split_low_pair((p0), (p1), (hw))
+
+// dmd_conv_f16ws.hip: its inline-assembly helpers in C++ (loads are synchronous here, waits and register ties are no-ops)
+#define WS_SYNCTHREADS 1
+#define WS_HOST_HELPERS 1
+template <class V> inline void ws_aload(V& dst, const V* src) { dst = *src; }
+template <bool FIRST, class V> inline void ws_aload(V& dst, const void* base, unsigned voff) { dst = *(const V*)((const char*)base + voff); }
+template <int N, class V> inline void ws_await(V&) {}
+inline unsigned ws_low_pair(float x0, float x1, unsigned h01) { return simt_split_low_pair(x0, x1, h01); }
+template <int N, class V, int M> inline void ws_await_set(V (&)[M]) {}
+template <int N, class V, int M> inline void ws_use_all(V (&)[M]) {}
+#define WS_OPAQUE(t) ((void)(t))
+#define WS_WAIT_VM(n) ((void)0)
+#define __builtin_amdgcn_readfirstlane(x) simt::readfirstlane(x)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) simt::global_load_lds((const void*)(uintptr_t)(g), (void*)(uintptr_t)(l), (size), (off))
+inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
+inline int __mul24(int a, int b) { return (int)(((a << 8) >> 8) * (unsigned)((b << 8) >> 8)); }

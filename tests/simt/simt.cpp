@@ -300,6 +300,12 @@ void fn_shfl_xor(const unsigned char* in, size_t is, unsigned char* out, size_t 
   }
 }
 
+void fn_readfirstlane(const unsigned char* in, size_t is, unsigned char* out, size_t os, uint64_t live, const int*) {
+  int first = 0;
+  while (first < 63 && !((live >> first) & 1)) ++first;
+  for (int l = 0; l < 64; ++l) memcpy(out + l * os, in + first * is, 4);
+}
+
 void fn_readlane(const unsigned char* in, size_t is, unsigned char* out, size_t os, uint64_t, const int* imm) {
   for (int l = 0; l < 64; ++l) memcpy(out + l * os, in + (imm[0] & 63) * is, 4);
 }

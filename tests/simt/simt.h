@@ -2,7 +2,7 @@
 //
 // A small SIMT interpreter for the host: the kernels of diamond_amd/csrc/*.hip, compiled UNCHANGED as host C++ (the shim
 // tests/simt/include/hip/hip_runtime.h stands in for the HIP headers), run one workgroup at a time with one FIBER per lane.
-// Wave-level operations (MFMA, DPP, readlane, __shfl_xor) and __syncthreads are rendezvous points: a lane deposits its
+// Wave-level operations (MFMA, DPP, readlane, readfirstlane, __shfl_xor) and __syncthreads / s_barrier are rendezvous points: a lane deposits its
 // operands and yields; the last lane of the wave to arrive computes the operation for all 64 and everybody resumes.  That
 // executes the kernels' real index arithmetic, LDS layouts, synchronisation structure and MFMA operand layouts on a CPU,
 // so `pytest -m "not gpu"` can hold them against the oracle; it says nothing about speed, memory ordering hazards or the
@@ -54,12 +54,13 @@ void wave_op(int opcode, const void* in, size_t in_bytes, void* out, size_t out_
 void launch(u3 grid, u3 block, size_t dyn_lds_bytes, const std::function<void()>& body);
 
 enum { OP_SHFL_XOR = 1, OP_READLANE, OP_DPP, OP_MFMA_16x16x4_F32, OP_MFMA_16x16x16_F16, OP_MFMA_16x16x32_F16, OP_MFMA_32x32x16_F16,
-       OP_MFMA_32x32x8_F16, OP_BALLOT };
+       OP_MFMA_32x32x8_F16, OP_BALLOT, OP_READFIRSTLANE };
 
 // ---- the wave-level operations the kernels use ---------------------------------------------------------------------------------
 void fn_shfl_xor(const unsigned char*, size_t, unsigned char*, size_t, uint64_t, const int*);
 void fn_readlane(const unsigned char*, size_t, unsigned char*, size_t, uint64_t, const int*);
 void fn_dpp(const unsigned char*, size_t, unsigned char*, size_t, uint64_t, const int*);
+void fn_readfirstlane(const unsigned char*, size_t, unsigned char*, size_t, uint64_t, const int*);
 void fn_mfma_16x16x4_f32(const unsigned char*, size_t, unsigned char*, size_t, uint64_t, const int*);
 void fn_mfma_16x16xK_f16(const unsigned char*, size_t, unsigned char*, size_t, uint64_t, const int*);
 void fn_mfma_32x32xK_f16(const unsigned char*, size_t, unsigned char*, size_t, uint64_t, const int*);
@@ -78,6 +79,21 @@ inline int readlane(int v, int src) {
   int r;
   wave_op(OP_READLANE, &v, 4, &r, 4, fn_readlane, imm, 1);
   return r;
+}
+
+// v_readfirstlane_b32: the value of the lowest lane still in the kernel
+template <class T>
+inline T readfirstlane(T v) {
+  static_assert(sizeof(T) == 4, "readfirstlane: 32-bit values");
+  T r;
+  wave_op(OP_READFIRSTLANE, &v, 4, &r, 4, fn_readfirstlane, nullptr, 0);
+  return r;
+}
+
+// global_load_lds (LDS-DMA): every lane moves `size` bytes from ITS global address to the wave's LDS base + lane * size (+ offset);
+// synchronous here (on the device it is in flight until the issuing wave's vmcnt says otherwise)
+inline void global_load_lds(const void* gptr, void* lds_base, int size, int offset) {
+  memcpy((unsigned char*)lds_base + offset + (size_t)g_lane->lane * size, gptr, (size_t)size);
 }
 
 inline int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {

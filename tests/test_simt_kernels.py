@@ -1,7 +1,8 @@
 """The kernels' own source, run lane by lane on the CPU (tests/simt: a SIMT interpreter, TEST INFRASTRUCTURE), against numpy
 restatements of what each entry point of include/diamond_hip.h promises.  This checks index arithmetic, LDS layouts,
 synchronisation structure and MFMA operand layouts without a GPU; the `-m gpu` tests remain the parity tests proper (the
-interpreter's MFMA accumulation order is not the hardware's, and dmd_conv_f16ws.hip is not part of the host build)."""
+interpreter's MFMA accumulation order is not the hardware's, loads are synchronous and waits are no-ops here: nothing about
+memory ordering, in-flight LDS-DMA or speed is established)."""
 import os
 
 import numpy as np
@@ -46,7 +47,7 @@ def test_gn_stats_valid_extent():
     assert S.lib().dmd_gn_stats_valid(S.ptr(x), S.ptr(stats), 2, 16, 16, 17, 13, 64, None) != 0  # extent beyond the buffer
 
 
-# ---- dmd_conv2d (conv_mfma_kernel instances; dmd_conv_f16ws.hip is not in the host build) ------------------------------------------
+# ---- dmd_conv2d: conv_mfma_kernel instances and the streaming 1x1 (no w_f16: nothing here is eligible for conv_f16ws) ----------------
 from diamond_amd import native as nv  # struct layouts only
 
 
@@ -762,11 +763,15 @@ def test_conv_latency_kernel(case, monkeypatch):
         want = np.stack([t8.sum(axis=(2, 4, 6)), (t8 * t8).sum(axis=(2, 4, 6))], axis=-1)  # (n, ty, tx, g, 2)
         np.testing.assert_allclose(stats, want.transpose(0, 3, 1, 2, 4).reshape(n, 2, tiles, 2), rtol=1e-9, atol=1e-6)
 
-    # the route is by tile count: above the cap the launch is not taken (here: the interpreter build has no conv_f16ws, so the
-    # same parameters then run on the conv_mfma instance, or are refused when they carry a fused projection)
+    # the route is by tile count: above the cap the same parameters run on conv_f16ws_kernel (8 x 16 images: conv_mfma)
     monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", "0")
-    rc = L.dmd_conv2d_kernel_name(p, buf, 96)
-    assert (rc != 0) if case.get("proj") else (rc == 0 and not buf.value.decode().startswith("conv_lat_kernel"))
+    S.check(L.dmd_conv2d_kernel_name(p, buf, 96), "kernel_name")
+    assert buf.value.decode().startswith("conv_f16ws_kernel<" if h % 16 == 0 else "conv_mfma_kernel<")
+    other = np.full_like(out, np.nan)
+    p.out, p.out_stats = S.ptr(other), None
+    S.check(L.dmd_conv2d(p, None), "dmd_conv2d")
+    d = np.abs(other - out).max() / np.abs(out).max()
+    assert 0 < d < 1e-5, d  # two kernels: same split arithmetic, different summation order
 
 
 def test_conv_latency_eligibility():
@@ -784,3 +789,95 @@ def test_conv_latency_eligibility():
         setattr(p, field, good)
     p.src[0].C = 48
     assert L.dmd_conv2d_latency_eligible(p) == 0
+
+
+# ---- conv_f16ws_kernel: the dominant, wave-specialised persistent kernel (its inline assembly spelled in C++ for this build) --------
+WS_CASES = [
+    dict(n=2, h=16, w=16, cin=[64], cout=64, k=3, prologue=[1], film=True, stats=True, residual="raw"),     # WsGeom<false, 2, 9>
+    dict(n=3, h=16, w=32, cin=[64, 64], cout=64, k=3, prologue=[1, 1], film=True, stats=True),             # cat(x, skip), 6 tiles on 3 "CUs"
+    dict(n=1, h=16, w=16, cin=[16], cout=64, k=3),                                                          # conv_in: one chunk
+    dict(n=2, h=8, w=8, cin=[64], cout=64, k=3, prologue=[1], stats=True),                                  # WsGeom<true, 2, 9>: 8x8 blocks of 2 images in a tile
+    dict(n=5, h=8, w=8, cin=[64, 64], cout=64, k=3, prologue=[1, 0], residual="raw"),                       # ... a tile with one block only
+    dict(n=2, h=16, w=16, cin=[32], cout=32, k=3, prologue=[1], film=True, stats=True, residual="raw"),     # WsGeom<false, 1, 9>
+    dict(n=3, h=8, w=8, cin=[32, 32], cout=32, k=3, prologue=[1, 1], stats=True),                           # WsGeom<true, 1, 9>
+    dict(n=1, h=16, w=16, cin=[64], cout=64, k=1, prologue=[2], residual="raw"),                            # 1x1 with a prologue: WsGeom<false, 2, 1>
+    dict(n=2, h=8, w=8, cin=[32], cout=32, k=1, prologue=[2]),                                              # WsGeom<true, 1, 1>
+    dict(n=2, h=32, w=32, cin=[64], cout=64, k=3, upsample=1, stats=True),                                  # Upsample's conv
+    dict(n=1, h=16, w=16, cin=[64], cout=3, k=3, prologue=[1], nchw=True),                                  # conv_out: few-channel NCHW head
+    dict(n=1, h=32, w=32, cin=[64], cout=64, k=3, prologue=[1], valid=(18, 27), stats=True),                # valid extent
+    dict(n=1, h=16, w=16, cin=[64], cout=64, k=3, prologue=[1], valid=(9, 9), stats=True, force_b8=False),
+    dict(n=2, h=16, w=32, cin=[64], cout=64, k=3, prologue=[1], film=True, stats=True, proj=True),          # WsGeomProj: fused skip projection
+]
+
+
+@pytest.mark.parametrize("case", WS_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()).replace(" ", ""))
+def test_conv_f16ws(case, monkeypatch):
+    monkeypatch.delenv("DIAMOND_CONV_LATENCY_TILES", raising=False)
+    rng = np.random.default_rng(23)
+    L = S.lib()
+    n, h, w, cins, cout, k = case["n"], case["h"], case["w"], case["cin"], case["cout"], case["k"]
+    up, prol = case.get("upsample", 0), case.get("prologue", [0] * len(cins))
+    hv, wv = case.get("valid", (h, w))
+    hs, ws = (h // 2, w // 2) if up else (h, w)
+    hvs, wvs = (hv // 2, wv // 2) if up else (hv, wv)
+    cin = sum(cins)
+    cout_pad = 32 if cout < 32 else cout
+    p = nv.ConvParams()
+    p.N, p.H, p.W, p.Cout, p.CoutPad, p.taps, p.stride, p.upsample, p.nsrc, p.precision = n, h, w, cout, cout_pad, k * k, 1, up, len(cins), 1
+    if "valid" in case:
+        p.valid_h, p.valid_w = hv, wv
+    keep, xs_ref = [], []
+    for i, c in enumerate(cins):
+        x = (rng.standard_normal((n, hs, ws, c)) * 1.5 + 0.3).astype(np.float32)
+        p.src[i].x, p.src[i].C, p.src[i].prologue = S.ptr(x), c, prol[i]
+        if prol[i]:
+            st = _partial_stats(x, hvs, wvs, 3, rng)
+            film = case.get("film") or prol[i] == 2
+            mul = (rng.standard_normal((n, c)) * 0.3).astype(np.float32) if film else None
+            add = (rng.standard_normal((n, c)) * 0.3).astype(np.float32) if film else None
+            p.src[i].norm = _norm(st, 3, mul, add, bool(case.get("film")))
+            xs_ref.append(_apply_norm(x, hvs, wvs, mul, add, bool(case.get("film")), silu=prol[i] == 1))
+            keep += [st, mul, add]
+        else:
+            xs_ref.append(x.astype(np.float64))
+        keep.append(x)
+    wt = np.zeros((cout_pad, cin, k, k), dtype=np.float32)
+    wt[:cout] = rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)
+    bias = np.zeros(cout_pad, dtype=np.float32)
+    bias[:cout] = rng.standard_normal(cout)
+    packed = np.zeros((cin // 16) * k * k * cout_pad * 16, dtype=np.float32)
+    S.check(L.dmd_pack_conv_weight(S.ptr(wt), S.ptr(packed), cout_pad, cin, k, cout_pad, cin, None), "pack")
+    w16 = _pack16(wt)
+    p.w, p.bias, p.w_f16 = S.ptr(packed), S.ptr(bias), S.ptr(w16)
+    ref = _ref_conv(xs_ref, wt[:cout], bias[:cout], k, 1, up, hv, wv)
+    if case.get("residual"):
+        r = rng.standard_normal((n, h, w, cout)).astype(np.float32)
+        p.residual = S.ptr(r)
+        ref = ref + r
+    if case.get("proj"):
+        j0, j1 = (rng.standard_normal((n, h, w, 64)).astype(np.float32) for _ in range(2))
+        wpj = (rng.standard_normal((cout, 128, 1, 1)) / np.sqrt(128)).astype(np.float32)
+        bpj = rng.standard_normal(cout).astype(np.float32)
+        wpj16 = _pack16(wpj)
+        p.proj_nsrc, p.proj_C[0], p.proj_C[1] = 2, 64, 64
+        p.proj_x[0], p.proj_x[1], p.proj_w_f16, p.proj_bias = S.ptr(j0), S.ptr(j1), S.ptr(wpj16), S.ptr(bpj)
+        ref = ref + _ref_conv([j0.astype(np.float64), j1.astype(np.float64)], wpj, bpj, 1, 1, 0, h, w)
+        assert L.dmd_conv2d_proj_eligible(p) == 1
+    nchw = bool(case.get("nchw"))
+    out = np.full((n, cout, h, w) if nchw else (n, h, w, cout), np.nan, dtype=np.float32)
+    p.out, p.out_nchw = S.ptr(out), int(nchw)
+    tiles = L.dmd_conv_stat_tiles(h, w)
+    stats = np.full((n, cout // 32, tiles, 2), np.nan) if case.get("stats") else None
+    p.out_stats = S.ptr(stats)
+
+    assert L.dmd_conv2d_f16x2_eligible(p) == 1
+    buf = (nv.C.c_char * 96)()
+    S.check(L.dmd_conv2d_kernel_name(p, buf, 96), "kernel_name")
+    assert buf.value.decode().startswith("conv_f16ws_kernel<"), buf.value
+    S.check(L.dmd_conv2d(p, None), "dmd_conv2d")
+    got = out.transpose(0, 2, 3, 1) if nchw else out
+    err = np.abs(got[:, :hv, :wv] - ref[:, :hv, :wv]).max()
+    assert err <= 2e-5 * max(1.0, np.abs(ref).max()), (buf.value, err)
+    if stats is not None:
+        want = _group_sums(np.ascontiguousarray(got.astype(np.float32)), hv, wv)
+        np.testing.assert_allclose(stats.sum(axis=2), want, rtol=2e-6, atol=1e-4)  # (fp32 sums of a lane's 16 values inside)
