@@ -5,7 +5,7 @@ set -euo pipefail
 cd "$(dirname "$0")"
 CXX=${SIMT_CXX:-/opt/rocm/lib/llvm/bin/clang++}
 SRC=../../diamond_amd/csrc
-FLAGS="-x c++ -std=c++17 -O1 -g0 -fPIC -mf16c -mfma -ffp-contract=off -Iinclude -Wno-unused-value -Wno-unknown-attributes -Wno-unused-result -Wno-psabi"
+FLAGS="-x c++ -std=c++17 -O2 -g0 -fPIC -mf16c -mfma -mavx2 -ffp-contract=off -Iinclude -Wno-unused-value -Wno-unknown-attributes -Wno-unused-result -Wno-psabi"
 mkdir -p _build
 pids=()
 for f in dmd_conv.hip dmd_conv1x1.hip dmd_conv_f16ws.hip dmd_conv_lat.hip dmd_backward.hip dmd_linear.hip dmd_attention.hip dmd_pointwise.hip dmd_lowres.hip dmd_pack.hip dmd_capi.cpp; do

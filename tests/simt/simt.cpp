@@ -4,6 +4,8 @@
 #include <sys/mman.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -108,7 +110,6 @@ void complete_wave_op(Worker* w, Wave& wv, int wave_index) {
   wv.fn(wv.in, SLOT, wv.out, SLOT, live, wv.imm);
   wv.arrived = 0;
   wv.arrived_mask = 0;
-  memset(wv.in, 0, sizeof(wv.in));
   for (int l = 0; l < 64; ++l) {
     const int t = wave_index * 64 + l;
     if (t < w->nlanes && w->fibers[t].state == WAIT_WAVE) w->fibers[t].state = RUNNABLE;
@@ -178,6 +179,7 @@ void run_block(Worker* w, u3 bid, u3 bdim, u3 gdim, size_t dyn_lds, const std::f
             ++w->done;
             Wave& wv = w->waves[v];
             --wv.live;
+            memset(wv.in + (size_t)l * SLOT, 0, SLOT);  // a lane that has left the kernel contributes zeros from now on
             // the lanes still in the kernel may all be waiting in a wave operation already
             if (wv.live > 0 && wv.arrived == wv.live) {
               complete_wave_op(w, wv, v);
@@ -259,6 +261,59 @@ void wave_op(int opcode, const void* in, size_t in_bytes, void* out, size_t out_
   memcpy(out, wv.out + (size_t)f->lane.lane * SLOT, out_bytes);
 }
 
+// Persistent worker threads: a launch hands them (grid, block, body) and waits; lane stacks and the thread_local LDS arrays of
+// the kernels are set up once per worker, not once per launch.
+namespace {
+struct Pool {
+  std::mutex m;
+  std::condition_variable cv_job, cv_done;
+  std::vector<std::thread> threads;
+  uint64_t generation = 0;
+  int active = 0, wanted = 0;
+  bool stop = false;
+  // the job
+  u3 grid, block;
+  size_t lds = 0, nblocks = 0;
+  const std::function<void()>* body = nullptr;
+  std::atomic<size_t> next{0};
+
+  void work(int index) {
+    static thread_local Worker worker;
+    tl_worker = &worker;
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv_job.wait(lk, [&] { return stop || (generation != seen && index < wanted); });
+        if (stop) return;
+        seen = generation;
+      }
+      for (;;) {
+        const size_t b = next.fetch_add(1);
+        if (b >= nblocks) break;
+        const u3 bid = {(unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((size_t)grid.x * grid.y))};
+        run_block(&worker, bid, block, grid, lds, *body);
+      }
+      std::lock_guard<std::mutex> lk(m);
+      if (--active == 0) cv_done.notify_all();
+    }
+  }
+  ~Pool() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      stop = true;
+    }
+    cv_job.notify_all();
+    for (auto& t : threads) t.join();
+  }
+};
+Pool& pool() {
+  static Pool* p = new Pool;  // never destroyed: worker threads must not be joined from a static destructor at exit
+  return *p;
+}
+std::mutex launch_mutex;  // one launch at a time (a stream)
+}  // namespace
+
 void launch(u3 grid, u3 block, size_t dyn_lds_bytes, const std::function<void()>& body) {
   const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
   if (!nblocks) return;
@@ -270,24 +325,25 @@ void launch(u3 grid, u3 block, size_t dyn_lds_bytes, const std::function<void()>
     if (nthreads < 1) nthreads = 1;
   }
   if ((size_t)nthreads > nblocks) nthreads = (int)nblocks;
-  std::atomic<size_t> next{0};
-  auto work = [&]() {
-    static thread_local Worker worker;
-    tl_worker = &worker;
-    for (;;) {
-      const size_t b = next.fetch_add(1);
-      if (b >= nblocks) break;
-      const u3 bid = {(unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((size_t)grid.x * grid.y))};
-      run_block(&worker, bid, block, grid, dyn_lds_bytes, body);
-    }
-  };
-  if (nthreads == 1) {
-    work();
-  } else {
-    std::vector<std::thread> th;
-    for (int i = 0; i < nthreads; ++i) th.emplace_back(work);
-    for (auto& t : th) t.join();
+  std::lock_guard<std::mutex> one(launch_mutex);
+  Pool& P = pool();
+  std::unique_lock<std::mutex> lk(P.m);
+  while ((int)P.threads.size() < nthreads) {
+    const int index = (int)P.threads.size();
+    P.threads.emplace_back([&P, index] { P.work(index); });
   }
+  P.grid = grid;
+  P.block = block;
+  P.lds = dyn_lds_bytes;
+  P.nblocks = nblocks;
+  P.body = &body;
+  P.next.store(0);
+  P.wanted = nthreads;
+  P.active = nthreads;
+  ++P.generation;
+  P.cv_job.notify_all();
+  P.cv_done.wait(lk, [&] { return P.active == 0; });
+  P.wanted = 0;
 }
 
 // ---- wave-level operations -----------------------------------------------------------------------------------------------------
@@ -347,21 +403,31 @@ struct MfmaIn {
 inline const MfmaIn* lane_in(const unsigned char* in, size_t is, int l) { return (const MfmaIn*)(in + l * is); }
 }  // namespace
 
-// D[i][j] = C[i][j] + sum_k A[i][k] B[k][j]; lane l holds A[l % 16][l / 16], B[l / 16][l % 16], D[4 (l / 16) + r][l % 16] in register r
+// D[i][j] = C[i][j] + sum_k A[i][k] B[k][j], k ascending (one fp32 fma per term).  The loops run i, k, j with j innermost so
+// that the compiler vectorises over the columns; per element the order of the sum is unchanged.
+namespace {
+template <int M, int N, int K>
+inline void mma(const float (&A)[M][K], const float (&B)[K][N], float (&D)[M][N]) {
+  for (int i = 0; i < M; ++i)
+    for (int k = 0; k < K; ++k) {
+      const float a = A[i][k];
+      for (int j = 0; j < N; ++j) D[i][j] = __builtin_fmaf(a, B[k][j], D[i][j]);
+    }
+}
+}  // namespace
+
+// v_mfma_f32_16x16x4_f32: lane l holds A[l % 16][l / 16], B[l / 16][l % 16], D[4 (l / 16) + r][l % 16] in register r
 void fn_mfma_16x16x4_f32(const unsigned char* in, size_t is, unsigned char* out, size_t os, uint64_t, const int*) {
-  float A[16][4], B[4][16];
+  float A[16][4], B[4][16], D[16][16];
   for (int l = 0; l < 64; ++l) {
     memcpy(&A[l % 16][l / 16], lane_in(in, is, l)->a, 4);
     memcpy(&B[l / 16][l % 16], lane_in(in, is, l)->b, 4);
+    for (int r = 0; r < 4; ++r) D[4 * (l / 16) + r][l % 16] = lane_in(in, is, l)->c[r];
   }
+  mma<16, 16, 4>(A, B, D);
   for (int l = 0; l < 64; ++l) {
     float d[4];
-    for (int r = 0; r < 4; ++r) {
-      const int i = 4 * (l / 16) + r, j = l % 16;
-      float acc = lane_in(in, is, l)->c[r];
-      for (int k = 0; k < 4; ++k) acc = fmaf(A[i][k], B[k][j], acc);
-      d[r] = acc;
-    }
+    for (int r = 0; r < 4; ++r) d[r] = D[4 * (l / 16) + r][l % 16];
     memcpy(out + l * os, d, 16);
   }
 }
@@ -369,7 +435,7 @@ void fn_mfma_16x16x4_f32(const unsigned char* in, size_t is, unsigned char* out,
 // K = 16 (4 halves per lane) or 32 (8 per lane): lane l holds A[l % 16][KV (l / 16) + v], B[KV (l / 16) + v][l % 16]
 void fn_mfma_16x16xK_f16(const unsigned char* in, size_t is, unsigned char* out, size_t os, uint64_t, const int* imm) {
   const int K = imm[0], KV = K / 4;
-  float A[16][32], B[32][16];
+  float A[16][32] = {}, B[32][16] = {}, D[16][16];
   for (int l = 0; l < 64; ++l) {
     const _Float16* a = (const _Float16*)lane_in(in, is, l)->a;
     const _Float16* b = (const _Float16*)lane_in(in, is, l)->b;
@@ -377,15 +443,20 @@ void fn_mfma_16x16xK_f16(const unsigned char* in, size_t is, unsigned char* out,
       A[l % 16][KV * (l / 16) + v] = (float)a[v];
       B[KV * (l / 16) + v][l % 16] = (float)b[v];
     }
+    for (int r = 0; r < 4; ++r) D[4 * (l / 16) + r][l % 16] = lane_in(in, is, l)->c[r];
+  }
+  if (K == 32)
+    mma<16, 16, 32>(A, B, D);
+  else {  // the upper half of the K range is zero: stop at 16 (adding +0 products would not change a sum, this is for speed)
+    for (int i = 0; i < 16; ++i)
+      for (int k = 0; k < 16; ++k) {
+        const float a = A[i][k];
+        for (int j = 0; j < 16; ++j) D[i][j] = __builtin_fmaf(a, B[k][j], D[i][j]);
+      }
   }
   for (int l = 0; l < 64; ++l) {
     float d[4];
-    for (int r = 0; r < 4; ++r) {
-      const int i = 4 * (l / 16) + r, j = l % 16;
-      float acc = lane_in(in, is, l)->c[r];
-      for (int k = 0; k < K; ++k) acc = fmaf(A[i][k], B[k][j], acc);
-      d[r] = acc;
-    }
+    for (int r = 0; r < 4; ++r) d[r] = D[4 * (l / 16) + r][l % 16];
     memcpy(out + l * os, d, 16);
   }
 }
@@ -393,7 +464,7 @@ void fn_mfma_16x16xK_f16(const unsigned char* in, size_t is, unsigned char* out,
 // 32x32: lane l holds A[l % 32][KV (l / 32) + v], B[KV (l / 32) + v][l % 32] (KV = K / 2), D[8 (r / 4) + 4 (l / 32) + r % 4][l % 32] in register r
 void fn_mfma_32x32xK_f16(const unsigned char* in, size_t is, unsigned char* out, size_t os, uint64_t, const int* imm) {
   const int K = imm[0], KV = K / 2;
-  float A[32][16], B[16][32];
+  float A[32][16] = {}, B[16][32] = {}, D[32][32];
   for (int l = 0; l < 64; ++l) {
     const _Float16* a = (const _Float16*)lane_in(in, is, l)->a;
     const _Float16* b = (const _Float16*)lane_in(in, is, l)->b;
@@ -401,15 +472,20 @@ void fn_mfma_32x32xK_f16(const unsigned char* in, size_t is, unsigned char* out,
       A[l % 32][KV * (l / 32) + v] = (float)a[v];
       B[KV * (l / 32) + v][l % 32] = (float)b[v];
     }
+    for (int r = 0; r < 16; ++r) D[8 * (r / 4) + 4 * (l / 32) + r % 4][l % 32] = lane_in(in, is, l)->c[r];
+  }
+  if (K == 16)
+    mma<32, 32, 16>(A, B, D);
+  else {
+    for (int i = 0; i < 32; ++i)
+      for (int k = 0; k < K; ++k) {
+        const float a = A[i][k];
+        for (int j = 0; j < 32; ++j) D[i][j] = __builtin_fmaf(a, B[k][j], D[i][j]);
+      }
   }
   for (int l = 0; l < 64; ++l) {
     float d[16];
-    for (int r = 0; r < 16; ++r) {
-      const int i = 8 * (r / 4) + 4 * (l / 32) + r % 4, j = l % 32;
-      float acc = lane_in(in, is, l)->c[r];
-      for (int k = 0; k < K; ++k) acc = fmaf(A[i][k], B[k][j], acc);
-      d[r] = acc;
-    }
+    for (int r = 0; r < 16; ++r) d[r] = D[8 * (r / 4) + 4 * (l / 32) + r % 4][l % 32];
     memcpy(out + l * os, d, 64);
   }
 }

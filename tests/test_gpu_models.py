@@ -476,12 +476,12 @@ def test_denoiser_256x256_attention_bench_batch_vs_oracle_sampled_envs():
         check_quantised(u8(d[sl]), u8(dref), max_frac=1e-4, what=f"teacher-forced, 256x256 B=8 env {e}")
 
 
-def test_denoiser_training_step_vs_reference_golden():
-    """f2: Denoiser.forward (training loss, two autoregressive predictions, one padded step) + loss.backward() on the
-    HIP kernels (recorded forward + hand-written U-Net backward) against the reference's loss and gradients:
-    1e-4 on the loss, on every gradient tensor (max-abs relative) and on every gradient norm."""
+def denoiser_training_step_errors(precisions=("f16x2", "f32")):
+    """Denoiser.forward + loss.backward() against the reference's loss and gradients; {precision: {quantity: relative error}}.
+    (Also driven on the SIMT interpreter by tests/test_simt_host.py, with DEV patched to "cpu".)"""
     from types import SimpleNamespace
     import diamond_amd as D
+    from diamond_amd import unet_train as UT
     from diamond_amd.testing import synthetic_actions, synthetic_frames
 
     gold = load_golden("denoiser_train.pt")
@@ -496,29 +496,39 @@ def test_denoiser_training_step_vs_reference_golden():
     mask = torch.ones(b, t, dtype=torch.bool)
     mask[1, 5] = False
     batch = SimpleNamespace(obs=obs, act=act, mask_padding=mask.to(DEV))
-    torch.manual_seed(gold["rng_seed"])
     den.randn_fn = lambda shape: torch.randn(*shape)  # CPU default generator: the stream the reference consumed
-    for precision in ("f16x2", "f32"):
-        from diamond_amd import unet_train as UT
-        UT.TRAIN_PRECISION = precision
-        torch.manual_seed(gold["rng_seed"])
-        den.zero_grad()
-        loss, logs = den(batch)
-        loss.backward()
-        errs = {"loss": rel_err(loss.detach(), gold["loss"])}
-        for k, p in den.named_parameters():
-            assert p.grad is not None, f"no gradient for {k}"
-            gref = gold["grads"][k]
-            mine = p.grad if gref.shape == p.grad.shape else p.grad.flatten()[::13]
-            errs["grad " + k] = rel_err(mine, gref)
-            n = float(gold["grad_norms"][k])
-            errs["|grad| " + k] = abs(float(p.grad.double().norm()) - n) / (n + 1e-30)
-        worst = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
-        print(f"denoiser training step [{precision}]: loss {float(loss):.6f} (ref {float(gold['loss']):.6f}); worst:",
-              [(k, f"{v:.2e}") for k, v in worst])
+    out = {}
+    try:
+        for precision in precisions:
+            UT.TRAIN_PRECISION = precision
+            torch.manual_seed(gold["rng_seed"])
+            den.zero_grad()
+            loss, logs = den(batch)
+            loss.backward()
+            errs = {"loss": rel_err(loss.detach(), gold["loss"])}
+            for k, p in den.named_parameters():
+                assert p.grad is not None, f"no gradient for {k}"
+                gref = gold["grads"][k]
+                mine = p.grad if gref.shape == p.grad.shape else p.grad.flatten()[::13]
+                errs["grad " + k] = rel_err(mine, gref)
+                n = float(gold["grad_norms"][k])
+                errs["|grad| " + k] = abs(float(p.grad.double().norm()) - n) / (n + 1e-30)
+            worst = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+            print(f"denoiser training step [{precision}]: loss {float(loss.detach()):.6f} (ref {float(gold['loss']):.6f}); worst:",
+                  [(k, f"{v:.2e}") for k, v in worst])
+            out[precision] = errs
+    finally:
+        UT.TRAIN_PRECISION = "f16x2"
+    return out
+
+
+def test_denoiser_training_step_vs_reference_golden():
+    """f2: Denoiser.forward (training loss, two autoregressive predictions, one padded step) + loss.backward() on the
+    HIP kernels (recorded forward + hand-written U-Net backward) against the reference's loss and gradients:
+    1e-4 on the loss, on every gradient tensor (max-abs relative) and on every gradient norm."""
+    for precision, errs in denoiser_training_step_errors().items():
         bad = {k: v for k, v in errs.items() if v >= 1e-4}
         assert not bad, (precision, bad)
-    UT.TRAIN_PRECISION = "f16x2"
 
 
 @pytest.mark.parametrize("attn_depths,b", [((0, 0, 0, 0), 5), ((0, 0, 0, 1), 2)])

@@ -1,0 +1,79 @@
+"""The product's HOST-side orchestration on the CPU: engine.py / blocks.py / inner_model.py / denoiser.py / unet_train.py drive
+the SIMT-interpreter build of the kernels (tests/simt: TEST INFRASTRUCTURE) on CPU tensors, and whole-network results are held
+against the REFERENCE's goldens -- the same fixtures and the same bars as the `-m gpu` tests, whose functions are reused with
+their device patched to "cpu".  This covers what the kernel-level interpreter tests cannot: parameter packing through
+PackCache / dmd_pack_jobs, the batched FiLM table and its strides, statistics plumbing between producers and consumers, the
+fused-projection and fused-8x8-level routing, the recorded-tape backward.  The product itself cannot run this way
+(tests/simt/host_harness.py patches the two guards that prevent it, for the duration of a test)."""
+import pytest
+import torch
+
+from tests.simt.host_harness import engine_on_interpreter
+
+
+class _LaunchCounter:
+    """stands in for native.PROFILER: counts launches per kernel key (no timing)"""
+
+    def __init__(self):
+        self.n = {}
+        self._pending = None
+
+    def annotate(self, key, flops, nbytes):
+        self._pending = key
+
+    def call(self, name, fn, args):
+        key, self._pending = self._pending or name, None
+        self.n[key] = self.n.get(key, 0) + 1
+        return fn(*args)
+
+
+@pytest.fixture
+def models(monkeypatch):
+    from diamond_amd import native as nv
+    from tests import test_gpu_models as M
+
+    monkeypatch.setattr(M, "DEV", "cpu")
+    # quantised frames: the interpreter's exp2f / division / MFMA summation order are the host's, not the device's, and a value
+    # within ~1e-6 of a rounding boundary lands on the other side: 3 of 24,576 pixels at one of the four sigmas where the
+    # device has at most 2 (the contract's 1e-4).  The fp32 bars (model output, gradients: 1e-4) are NOT relaxed.
+    strict = M.check_quantised
+    monkeypatch.setattr(M, "check_quantised", lambda a, b, max_frac, what="": strict(a, b, max_frac=2 * max_frac, what=what))
+    counter = _LaunchCounter()
+    monkeypatch.setattr(nv, "PROFILER", counter)
+    with engine_on_interpreter():
+        yield M, counter
+
+
+def test_denoiser_vs_reference_golden_on_the_interpreter(models, monkeypatch):
+    M, counter = models
+    monkeypatch.delenv("DIAMOND_CONV_LATENCY_TILES", raising=False)
+    M.test_denoiser_vs_reference_golden("attn0011", (0, 0, 1, 1), 1)
+    keys = "\n".join(counter.n)
+    assert "conv_f16ws_kernel<WsGeom<false, 2, 9>>" in keys and "conv_f16ws_kernel<WsGeomProj>" in keys, keys
+    assert "conv_lat_kernel" not in keys
+
+
+def test_denoiser_latency_route_vs_reference_golden_on_the_interpreter(models, monkeypatch):
+    """STAGED conv_lat_kernel behind the real engine: every eligible 3x3 of the B = 2 denoiser on it, same golden, same bar"""
+    M, counter = models
+    monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", "64")
+    M.test_denoiser_vs_reference_golden("default", (0, 0, 0, 0), 2)
+    lat = sum(v for k, v in counter.n.items() if k.startswith("conv_lat_kernel"))
+    ws = sum(v for k, v in counter.n.items() if k.startswith("conv_f16ws_kernel"))
+    print(counter.n)
+    evals = 8  # model output + denoised frame at four sigmas
+    assert lat >= evals * 30 and counter.n.get("conv_lat_kernel<true>", 0) >= evals * 9, counter.n
+    assert ws <= evals * 2, counter.n  # conv_in, conv_out (and nothing else) stay on the throughput kernel
+
+
+@pytest.mark.parametrize("env", [{}, {"DIAMOND_WGRAD_MODE": "3", "DIAMOND_WGRAD_MAX_WG": "7"}], ids=["shipping", "staged-wgrad"])
+def test_denoiser_training_step_vs_reference_golden_on_the_interpreter(models, monkeypatch, env):
+    """loss and all 236 gradient tensors of Denoiser.forward + backward (split-fp16 arithmetic), shipping kernels and the staged
+    weight-gradient kernels (32-pixel MFMA + prefetch, 7 workgroups walking many tiles each)"""
+    M, counter = models
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    errs = M.denoiser_training_step_errors(("f16x2",))["f16x2"]
+    bad = {k: v for k, v in errs.items() if v >= 1e-4}
+    assert not bad, bad
+    assert counter.n.get("dmd_conv2d_wgrad", 0) > 100 and counter.n.get("dmd_gn_silu_bwd", 0) > 50, counter.n
