@@ -226,6 +226,5 @@ class NativeEncoder:
         self.cache = E.PackCache()
 
     def __call__(self, obs: Tensor) -> Tensor:
-        if not obs.is_cuda:
-            raise RuntimeError("diamond_amd kernels need GPU tensors (there is no CPU path)")
+        nv.require_gpu(obs)
         return _EncoderFn.apply(self.plan, self.cache, obs.contiguous(), *self.plan.params)

@@ -38,12 +38,12 @@ typedef float lt_f16v __attribute__((ext_vector_type(16)));
 #define LT_PROJ_RS (2 * LT_PROJ_C + 16)
 
 // weights of one 16-channel chunk in A-operand order: [tap][h | l], lane (cout i = lane & 31, k group g = lane >> 5)
-template <int TAPS>
+template <int TAPS, int COUT>
 __device__ __forceinline__ void lt_load_w(lt_h8 (&w)[2 * TAPS], const lt_h8* __restrict__ wp, int chunk, int unit_lane) {
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-    for (int hl = 0; hl < 2; ++hl) w[2 * t + hl] = wp[(((size_t)chunk * TAPS + t) * 2 + hl) * 128 + unit_lane];
+    for (int hl = 0; hl < 2; ++hl) w[2 * t + hl] = wp[(((size_t)chunk * TAPS + t) * 2 + hl) * (2 * COUT) + unit_lane];
 }
 
 // one chunk of the 3x3 contraction: 9 taps x 3 MFMAs (w_h x_l + w_l x_h + w_h x_h)
@@ -71,15 +71,15 @@ __device__ __forceinline__ void lt_split_store(unsigned char* ph, unsigned char*
   *(lt_h4*)(pl + byte) = l;
 }
 
-// CQ = input channel quads (16: 64 input channels, 32: 128)
-template <bool PROJ, int CQ>
+// CQ = input channel quads (8 / 16 / 32: 32 / 64 / 128 input channels), COUT = 32 | 64 output channels
+template <bool PROJ, int CQ, int COUT>
 __global__ __launch_bounds__(256) void conv_lat_kernel(const dmd_conv_params p) {
   DMD_DYNAMIC_LDS(unsigned char, lt_smem);
   __shared__ float g_mean[4], g_rstd[4];
   __shared__ double red[4][2];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = blockIdx.y;  // which 32 of the 64 output channels
+  const int half = blockIdx.y;  // which 32 of the COUT output channels
   const int tx_n = p.W / 16, per_img = tx_n * (p.H / 8);
   const int n = blockIdx.x / per_img, timg = blockIdx.x - n * per_img;
   const int y0 = (timg / tx_n) * 8, x0 = (timg % tx_n) * 16;
@@ -96,10 +96,10 @@ __global__ __launch_bounds__(256) void conv_lat_kernel(const dmd_conv_params p) 
 
   // ---- weights of chunk 0: requested before anything else, needed after the staging phase ----
   const int g = lane >> 5, ci = lane & 31;
-  const int unit_lane = g * 64 + half * 32 + ci;   // [k group][cout] inside a (chunk, tap, piece) block of 128 16-byte units
+  const int unit_lane = g * COUT + half * 32 + ci;  // [k group][cout] inside a (chunk, tap, piece) block of 2 COUT 16-byte units
   const lt_h8* wp = (const lt_h8*)p.w_f16;
   lt_h8 wa[18], wb[18];
-  lt_load_w<9>(wa, wp, 0, unit_lane);
+  lt_load_w<9, COUT>(wa, wp, 0, unit_lane);
 
   // ---- everything that does not depend on anything else is REQUESTED now, in one batch: this thread's share of the patch,
   //      of the projection sources, its prologue parameters, the bias row and the residual of its output pixel.  (Fields of
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void conv_lat_kernel(const dmd_conv_params p) 
   }
   // accumulators start from the bias row: register r holds cout 8 (r / 4) + 4 g + r % 4 of this half, pixel ci
   const int oy = y0 + 2 * wave + (ci >> 4), ox = x0 + (ci & 15);
-  const size_t obase = (((size_t)n * p.H + oy) * p.W + ox) * 64 + half * 32 + 4 * g;
+  const size_t obase = (((size_t)n * p.H + oy) * p.W + ox) * COUT + half * 32 + 4 * g;
   float bias[16], pbias[PROJ ? 16 : 1], res[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) bias[r] = res[r] = 0.f;
@@ -237,9 +237,9 @@ __global__ __launch_bounds__(256) void conv_lat_kernel(const dmd_conv_params p) 
   constexpr int nch = Cin >> 4;
   lt_h8 wj[16];
   for (int c = 0; c < nch; c += 2) {
-    lt_load_w<9>(wb, wp, c + 1, unit_lane);
+    lt_load_w<9, COUT>(wb, wp, c + 1, unit_lane);
     lt_chunk9(acc, wa, ph, pl, pixbyte, rs, c * 32 + g * 16);
-    if (c + 2 < nch) lt_load_w<9>(wa, wp, c + 2, unit_lane);
+    if (c + 2 < nch) lt_load_w<9, COUT>(wa, wp, c + 2, unit_lane);
     if (PROJ && c + 2 >= nch) {
       const lt_h8* wq = (const lt_h8*)p.proj_w_f16;
 #pragma unroll
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void conv_lat_kernel(const dmd_conv_params p) 
     }
     __syncthreads();
     if (tid == 0) {
-      double* o = p.out_stats + ((size_t)(n * 2 + half) * per_img + timg) * 2;
+      double* o = p.out_stats + ((size_t)(n * (COUT / 32) + half) * per_img + timg) * 2;
       o[0] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
       o[1] = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
     }
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void conv_lat_kernel(const dmd_conv_params p) 
 // 1: these parameters can run on conv_lat_kernel (a subset of what conv_f16ws_kernel takes)
 extern "C" int dmd_conv2d_latency_eligible(const dmd_conv_params* p) {
   if (!p || (p->precision & 0xff) != DMD_PRECISION_F16X2 || !p->w_f16) return 0;
-  if (p->taps != 9 || p->stride != 1 || p->Cout != 64 || p->CoutPad != 64 || p->out_nchw || p->residual_norm.stats) return 0;
+  if (p->taps != 9 || p->stride != 1 || (p->Cout != 64 && p->Cout != 32) || p->CoutPad != p->Cout || p->out_nchw || p->residual_norm.stats) return 0;
   if (p->H % 8 != 0 || p->W % 16 != 0 || p->valid_h || p->valid_w) return 0;
   if (p->nsrc < 1 || p->nsrc > 2) return 0;
   int cin = 0;
@@ -302,11 +302,12 @@ extern "C" int dmd_conv2d_latency_eligible(const dmd_conv_params* p) {
     if (!p->src[i].x || p->src[i].C % 32 != 0) return 0;  // whole GroupNorm groups per source, an even number of 16-channel chunks
     cin += p->src[i].C;
   }
-  if (cin != 64 && cin != 128) return 0;
+  if (cin != 32 && cin != 64 && cin != 128) return 0;
+  if (p->Cout == 32 && cin == 128) return 0;  // (no such layer; not instantiated)
   if ((long long)p->N * p->H * p->W * 128 * 4 >= (1ll << 40)) return 0;
   if (p->proj_nsrc) {
     if (p->proj_nsrc != 2 || !p->proj_w_f16 || !p->proj_x[0] || !p->proj_x[1] || p->proj_C[0] != 64 || p->proj_C[1] != 64) return 0;
-    if (p->upsample || p->residual || cin != 64) return 0;
+    if (p->upsample || p->residual || cin != 64 || p->Cout != 64) return 0;
   }
   return 1;
 }
@@ -327,21 +328,25 @@ int dmd_launch_conv_lat(const dmd_conv_params& p, hipStream_t st) {
   static bool attr_set[DMD_MAX_DEVICES] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DMD_MAX_DEVICES) dev = 0;
-  if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lat_kernel<false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  if (!attr_set[dev]) {  // (the instances that can need more than 64 KiB of LDS)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lat_kernel<false, 32, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lat_kernel<false, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lat_kernel<true, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lat_kernel<true, 16, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     DMD_CHECK_ARG(e == hipSuccess, "conv_lat: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set[dev] = true;
   }
-  const dim3 grid((unsigned)(p.N * (p.H / 8) * (p.W / 16)), 2);
+  const dim3 grid((unsigned)(p.N * (p.H / 8) * (p.W / 16)), (unsigned)(p.Cout / 32));
   if (p.proj_nsrc)
-    hipLaunchKernelGGL((conv_lat_kernel<true, 16>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_lat_kernel<true, 16, 64>), grid, dim3(256), lds, st, p);
+  else if (p.Cout == 64 && cin == 128)
+    hipLaunchKernelGGL((conv_lat_kernel<false, 32, 64>), grid, dim3(256), lds, st, p);
+  else if (p.Cout == 64 && cin == 64)
+    hipLaunchKernelGGL((conv_lat_kernel<false, 16, 64>), grid, dim3(256), lds, st, p);
+  else if (p.Cout == 64)
+    hipLaunchKernelGGL((conv_lat_kernel<false, 8, 64>), grid, dim3(256), lds, st, p);
   else if (cin == 64)
-    hipLaunchKernelGGL((conv_lat_kernel<false, 16>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_lat_kernel<false, 16, 32>), grid, dim3(256), lds, st, p);
   else
-    hipLaunchKernelGGL((conv_lat_kernel<false, 32>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv_lat_kernel<false, 8, 32>), grid, dim3(256), lds, st, p);
   return 0;
 }

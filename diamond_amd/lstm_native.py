@@ -143,8 +143,7 @@ class LstmStepFn(torch.autograd.Function):
 def lstm_heads(cache: E.PackCache, x: Tensor, hx: Tensor, cx: Tensor, lstm, actor_linear, critic_linear
                ) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """(logits_act, val, hx', cx') of reference actor_critic.py:72-73."""
-    if not x.is_cuda:
-        raise RuntimeError("diamond_amd kernels need GPU tensors (there is no CPU path)")
+    nv.require_gpu(x)
     w_heads = torch.cat((actor_linear.weight, critic_linear.weight), dim=0)
     b_heads = torch.cat((actor_linear.bias, critic_linear.bias), dim=0)
     heads, h, c = LstmHeadsFn.apply(cache, x, hx, cx, lstm.weight_ih, lstm.weight_hh, lstm.bias_ih, lstm.bias_hh, w_heads, b_heads)

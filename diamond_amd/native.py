@@ -247,11 +247,16 @@ def stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def require_gpu(t: Tensor) -> None:
+    """The one place that says it: there is no CPU path."""
+    if not t.is_cuda:
+        raise RuntimeError("diamond_amd kernels need GPU tensors (there is no CPU path)")
+
+
 def ptr(t: Optional[Tensor]) -> Optional[int]:
     if t is None:
         return None
-    if not t.is_cuda:
-        raise RuntimeError("diamond_amd kernels need GPU tensors (there is no CPU path)")
+    require_gpu(t)
     return t.data_ptr()
 
 

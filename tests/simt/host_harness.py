@@ -4,7 +4,7 @@ tensors against the SIMT-interpreter build of the kernels, so that `pytest -m "n
 against the reference's goldens.
 
 The product cannot do this by itself -- diamond_amd.native refuses the interpreter library and rejects CPU tensors.  This
-context manager monkeypatches exactly those two guards (and the stream query) for the duration of a test and restores them."""
+context manager monkeypatches exactly those two guards (native._lib, native.require_gpu) and the stream query for the duration of a test and restores them."""
 from __future__ import annotations
 
 import contextlib
@@ -16,11 +16,11 @@ from . import loader as S
 
 @contextlib.contextmanager
 def engine_on_interpreter():
-    saved = (nv._lib, nv.ptr, nv.stream)
+    saved = (nv._lib, nv.require_gpu, nv.stream)
     nv._lib = nv._Lib(S.lib())
-    nv.ptr = lambda t: None if t is None else t.data_ptr()
+    nv.require_gpu = lambda t: None
     nv.stream = lambda: None
     try:
         yield
     finally:
-        nv._lib, nv.ptr, nv.stream = saved
+        nv._lib, nv.require_gpu, nv.stream = saved

@@ -49,6 +49,8 @@ def test_latency_conv_route_vs_reference_goldens(monkeypatch):
     ag = M.make_agent()
     M.test_sampler_teacher_forced_vs_golden(ag)
     M.test_denoiser_deterministic(ag)
+    M.test_rew_end_model_vs_golden(ag)  # its 32-channel 3x3s take the route as well
+    M.test_actor_critic_vs_golden(ag)
     for name in dir(EV):
         if name.startswith("test_") and "graph" in name:
             getattr(EV, name)()

@@ -77,3 +77,17 @@ def test_denoiser_training_step_vs_reference_golden_on_the_interpreter(models, m
     bad = {k: v for k, v in errs.items() if v >= 1e-4}
     assert not bad, bad
     assert counter.n.get("dmd_conv2d_wgrad", 0) > 100 and counter.n.get("dmd_gn_silu_bwd", 0) > 50, counter.n
+
+
+@pytest.mark.parametrize("cap", ["0", "64"], ids=["shipping", "staged-latency-route"])
+def test_rew_end_model_and_actor_critic_vs_goldens_on_the_interpreter(models, monkeypatch, cap):
+    """reward / end model (32-channel AdaGN encoder, fused 8x8 tail, LSTM, head) and the actor-critic (forward + every gradient)
+    against the reference-generated goldens; with the cap, their eligible 32- and 64-channel 3x3s run on conv_lat_kernel"""
+    M, counter = models
+    monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", cap)
+    ag = M.make_agent()
+    M.test_rew_end_model_vs_golden(ag)
+    M.test_actor_critic_vs_golden(ag)
+    lat = sum(v for k, v in counter.n.items() if k.startswith("conv_lat_kernel"))
+    assert (lat >= 30) if cap != "0" else (lat == 0), counter.n
+    assert counter.n.get("dmd_lowres_chain32", 0) >= 2 and counter.n.get("dmd_lstm_pointwise_bwd", 0) >= 1, counter.n

@@ -695,6 +695,9 @@ LAT_CASES = [
     dict(n=1, h=16, w=16, cin=[64], upsample=1, prologue=[1]),
     dict(n=2, h=16, w=16, cin=[64], prologue=[1], film=True, stats=True, proj=True),          # conv2 + fused skip projection
     dict(n=1, h=8, w=16, cin=[128], prologue=[2]),
+    dict(n=2, h=16, w=16, cin=[32], cout=32, prologue=[1], film=True, stats=True, residual=True),   # reward / end encoder ResBlock convs
+    dict(n=1, h=16, w=32, cin=[32], cout=64, prologue=[1], stats=True),                              # actor-critic encoder 32 -> 64
+    dict(n=1, h=8, w=16, cin=[64], cout=32, prologue=[1]),
 ]
 
 
@@ -706,7 +709,7 @@ def test_conv_latency_kernel(case, monkeypatch):
     n, h, w, cins = case["n"], case["h"], case["w"], case["cin"]
     up, prol = case.get("upsample", 0), case.get("prologue", [0] * len(cins))
     hs, ws = (h // 2, w // 2) if up else (h, w)
-    cin, cout = sum(cins), 64
+    cin, cout = sum(cins), case.get("cout", 64)
     p = nv.ConvParams()
     p.N, p.H, p.W, p.Cout, p.CoutPad, p.taps, p.stride, p.upsample, p.nsrc, p.precision = n, h, w, cout, cout, 9, 1, up, len(cins), 1
     keep, xs_ref = [], []
@@ -746,7 +749,7 @@ def test_conv_latency_kernel(case, monkeypatch):
         ref = ref + _ref_conv([j0.astype(np.float64), j1.astype(np.float64)], wpj, bpj, 1, 1, 0, h, w)
     out = np.full((n, h, w, cout), np.nan, dtype=np.float32)
     tiles = L.dmd_conv_stat_tiles(h, w)
-    stats = np.full((n, 2, tiles, 2), np.nan) if case.get("stats") else None
+    stats = np.full((n, cout // 32, tiles, 2), np.nan) if case.get("stats") else None
     p.out, p.out_stats = S.ptr(out), S.ptr(stats)
 
     assert L.dmd_conv2d_latency_eligible(p) == 1
@@ -759,9 +762,9 @@ def test_conv_latency_kernel(case, monkeypatch):
     assert err <= 2e-5 * max(1.0, np.abs(ref).max()), err
     if stats is not None:
         # one partial per 8 x 16 tile and 32-channel group, in dmd_conv_stat_tiles order
-        t8 = out.reshape(n, h // 8, 8, w // 16, 16, 2, 32).astype(np.float64)
+        t8 = out.reshape(n, h // 8, 8, w // 16, 16, cout // 32, 32).astype(np.float64)
         want = np.stack([t8.sum(axis=(2, 4, 6)), (t8 * t8).sum(axis=(2, 4, 6))], axis=-1)  # (n, ty, tx, g, 2)
-        np.testing.assert_allclose(stats, want.transpose(0, 3, 1, 2, 4).reshape(n, 2, tiles, 2), rtol=1e-9, atol=1e-6)
+        np.testing.assert_allclose(stats, want.transpose(0, 3, 1, 2, 4).reshape(n, cout // 32, tiles, 2), rtol=1e-9, atol=1e-6)
 
     # the route is by tile count: above the cap the same parameters run on conv_f16ws_kernel (8 x 16 images: conv_mfma)
     monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", "0")
@@ -782,7 +785,7 @@ def test_conv_latency_eligibility():
     p.src[0].x, p.src[0].C = S.ptr(x), 64
     p.w_f16 = S.ptr(x)
     assert L.dmd_conv2d_latency_eligible(p) == 1
-    for field, bad in (("precision", 0), ("taps", 1), ("Cout", 32), ("W", 8), ("valid_h", 4), ("out_nchw", 1), ("stride", 2)):
+    for field, bad in (("precision", 0), ("taps", 1), ("Cout", 48), ("W", 8), ("valid_h", 4), ("out_nchw", 1), ("stride", 2)):
         good = getattr(p, field)
         setattr(p, field, bad)
         assert L.dmd_conv2d_latency_eligible(p) == 0, field
