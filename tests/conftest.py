@@ -14,7 +14,30 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# DIAMOND_TESTS_ON_INTERPRETER=1 (development aid, off by default): run the `-m gpu` tests WITHOUT a GPU, on the SIMT-interpreter
+# build of the kernels (tests/simt) -- a pre-flight for test logic and host code before GPU minutes are spent on it.  Tests
+# that need the device itself (hipGraphs, events, RCCL, batch-256 shapes) fail or crawl there; it proves nothing about the GPU.
+ON_INTERPRETER = os.environ.get("DIAMOND_TESTS_ON_INTERPRETER") == "1"
+
+
+@pytest.fixture(scope="session", autouse=ON_INTERPRETER)
+def _gpu_tests_on_the_interpreter():
+    if not ON_INTERPRETER:
+        yield
+        return
+    from tests.simt.host_harness import engine_on_interpreter
+
+    torch.cuda.synchronize = lambda *a, **k: None
+    with engine_on_interpreter():
+        yield
+
+
 def pytest_collection_modifyitems(config, items):
+    if ON_INTERPRETER:
+        for item in items:  # the device of the `-m gpu` test modules (module-scoped fixtures read it too)
+            if hasattr(item.module, "DEV"):
+                item.module.DEV = "cpu"
+        return
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="no GPU visible")
