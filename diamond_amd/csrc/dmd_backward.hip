@@ -158,11 +158,29 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const dmd_gn_bwd_par
   }
 }
 
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const dmd_gn_bwd_params p, int T, const double* __restrict__ group_partial) {
+// FOLD (STAGED, DIAMOND_GN_BWD_FOLD=1): workgroup (0, n) also sums the T per-tile channel partials of image n into dmul / dadd,
+// in gn_bwd_chan_kernel's order (bitwise the same sums, one launch less per normalisation)
+template <bool FOLD>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const dmd_gn_bwd_params p, int T, const double* __restrict__ group_partial,
+                                                           const float* __restrict__ chan_partial) {
   __shared__ float g_mean[GN_BWD_MAXG], g_rstd[GN_BWD_MAXG], g_m1[GN_BWD_MAXG], g_m2[GN_BWD_MAXG];
   const int t = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
   const int C = p.C, CQ = C / 4, G = C / DMD_GN_GROUP > 0 ? C / DMD_GN_GROUP : 1;
   const int gsz = C / G;
+  if constexpr (FOLD) {
+    if (t == 0) {
+      for (int c = tid; c < C; c += 256) {
+        float a = 0.f, b = 0.f;
+        for (int tt = 0; tt < T; ++tt) {
+          const float* o = chan_partial + (((size_t)n * T + tt) * C + c) * 2;
+          a += o[0];
+          b += o[1];
+        }
+        p.dmul[(size_t)n * C + c] = a;
+        p.dadd[(size_t)n * C + c] = b;
+      }
+    }
+  }
   if (tid < G) {
     float m, r;
     const double cnt = (double)gsz * p.HW;
@@ -242,9 +260,15 @@ extern "C" int dmd_gn_silu_bwd(const dmd_gn_bwd_params* pp, dmd_stream_t stream)
   float* chan_partial = (float*)((char*)p.workspace + (size_t)p.N * G * T * 2 * 8);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(T, p.N), dim3(256), 0, st, p, T, group_partial, chan_partial);
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(T, p.N), dim3(256), 0, st, p, T, (const double*)group_partial);
-  hipLaunchKernelGGL(gn_bwd_chan_kernel, dim3((p.N * p.C + 255) / 256), dim3(256), 0, st, (const float*)chan_partial, p.dmul,
-                     p.dadd, p.N, T, p.C);
+  const char* fe = getenv("DIAMOND_GN_BWD_FOLD");
+  const int fold = fe && atoi(fe) == 1;
+  if (fold) {
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(T, p.N), dim3(256), 0, st, p, T, (const double*)group_partial, (const float*)chan_partial);
+  } else {
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(T, p.N), dim3(256), 0, st, p, T, (const double*)group_partial, (const float*)chan_partial);
+    hipLaunchKernelGGL(gn_bwd_chan_kernel, dim3((p.N * p.C + 255) / 256), dim3(256), 0, st, (const float*)chan_partial, p.dmul,
+                       p.dadd, p.N, T, p.C);
+  }
   DMD_LAUNCH_CHECK();
   return 0;
 }
@@ -743,7 +767,12 @@ static int launch_wgrad(const dmd_wgrad_params& p, hipStream_t st) {
   }
   const int per_total = G::NB * NCO * 256 + NCO * 16;
   float* ws2 = p.workspace + (size_t)num_wg * per_total;
-  if (num_wg <= 4 * WGRAD_SLICES) {
+  int single = 4 * WGRAD_SLICES;
+  if (const char* e = getenv("DIAMOND_WGRAD_SINGLE_REDUCE")) {  // STAGED: sum up to this many partials in one pass (fp64, workgroup order)
+    const int v = atoi(e);
+    if (v > single && v <= 1024) single = v;
+  }
+  if (num_wg <= single) {
     // few partials (the low-resolution levels at the training batch): summed directly, in fp64, in workgroup order -- one
     // launch less per weight gradient (the training step is a chain of ~600 small kernels)
     hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3((per_total + 255) / 256), dim3(256), 0, st, (const float*)p.workspace, num_wg, G::NB,

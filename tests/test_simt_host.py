@@ -66,10 +66,12 @@ def test_denoiser_latency_route_vs_reference_golden_on_the_interpreter(models, m
     assert ws <= evals * 2, counter.n  # conv_in, conv_out (and nothing else) stay on the throughput kernel
 
 
-@pytest.mark.parametrize("env", [{}, {"DIAMOND_WGRAD_MODE": "3", "DIAMOND_WGRAD_MAX_WG": "7"}], ids=["shipping", "staged-wgrad"])
+@pytest.mark.parametrize("env", [{}, {"DIAMOND_WGRAD_MODE": "3", "DIAMOND_WGRAD_MAX_WG": "7", "DIAMOND_WGRAD_SINGLE_REDUCE": "256",
+                                      "DIAMOND_GN_BWD_FOLD": "1"}], ids=["shipping", "staged-backward"])
 def test_denoiser_training_step_vs_reference_golden_on_the_interpreter(models, monkeypatch, env):
     """loss and all 236 gradient tensors of Denoiser.forward + backward (split-fp16 arithmetic), shipping kernels and the staged
-    weight-gradient kernels (32-pixel MFMA + prefetch, 7 workgroups walking many tiles each)"""
+    backward (weight gradients: 32-pixel MFMA + prefetch, 7 workgroups walking many tiles each, one-pass reduction; GroupNorm
+    backward with the channel sums folded into the apply pass)"""
     M, counter = models
     for k, v in env.items():
         monkeypatch.setenv(k, v)

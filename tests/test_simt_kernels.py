@@ -218,6 +218,7 @@ WGRAD_CASES = [
 # what the launcher reads per call: DIAMOND_WGRAD_MODE (the staged 32-pixel / prefetching kernels, split precision only) and
 # DIAMOND_WGRAD_MAX_WG (fewer workgroups, each walking several tiles with its accumulators in registers)
 WGRAD_PLANS = [dict(), dict(mode=2), dict(mode=3), dict(mode=2, max_wg=1), dict(mode=3, max_wg=3), dict(max_wg=2)]
+# (DIAMOND_WGRAD_SINGLE_REDUCE: test_conv2d_wgrad_many_partials below)
 
 
 @pytest.mark.parametrize("plan", WGRAD_PLANS, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()) or "default")
@@ -267,6 +268,35 @@ def test_conv2d_wgrad(case, plan, monkeypatch):
     assert np.abs(dw - want).max() <= 3e-6 * scale * np.sqrt(n * h * w / 64), np.abs(dw - want).max() / scale
     if db is not None:
         np.testing.assert_allclose(db, g.sum(axis=0), rtol=0, atol=2e-5 * np.abs(g.sum(axis=0)).max() + 1e-5)
+
+
+def test_conv2d_wgrad_many_partials(monkeypatch):
+    """more partials than the single-pass reduction takes by default (64): both reduction forms, and the staged threshold"""
+    rng = np.random.default_rng(12)
+    L = S.lib()
+    n, h, w, c = 20, 16, 16, 32  # 80 8x8 blocks = 40 tiles... times 4 images more: 100 workgroups
+    n = 50
+    x = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    dy = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    g = dy.astype(np.float64).reshape(-1, c)
+    ap = np.pad(x.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
+    want = np.zeros((c, c, 3, 3))
+    for ky in range(3):
+        for kx in range(3):
+            want[:, :, ky, kx] = g.T @ ap[:, ky:ky + h, kx:kx + w].reshape(-1, c)
+    got = {}
+    for single in ("0", "256"):
+        monkeypatch.setenv("DIAMOND_WGRAD_SINGLE_REDUCE", single)
+        p = nv.WgradParams()
+        p.N, p.H, p.W, p.Cout, p.taps, p.cin_real, p.precision = n, h, w, c, 9, c, 1
+        p.src.x, p.src.C, p.src.prologue, p.dy = S.ptr(x), c, 0, S.ptr(dy)
+        ws = np.full(L.dmd_wgrad_workspace_floats(p), np.nan, dtype=np.float32)
+        dw, db = np.full((c, c, 3, 3), np.nan, dtype=np.float32), np.full(c, np.nan, dtype=np.float32)
+        p.workspace, p.dw, p.dbias = S.ptr(ws), S.ptr(dw), S.ptr(db)
+        S.check(L.dmd_conv2d_wgrad(p, None), "dmd_conv2d_wgrad")
+        assert np.abs(dw - want).max() <= 2e-6 * np.abs(want).max() and np.abs(db - g.sum(0)).max() <= 2e-5 * np.abs(g.sum(0)).max()
+        got[single] = dw
+    assert np.abs(got["0"] - got["256"]).max() <= 1e-6 * np.abs(want).max()
 
 
 # ---- attention -------------------------------------------------------------------------------------------------------------------
@@ -343,8 +373,11 @@ def test_linear(m, n, k, acc, silu):
 
 
 # ---- dmd_gn_silu_bwd: fp64 finite-difference-free truth from the closed form in the header --------------------------------------
-@pytest.mark.parametrize("n,hw,c,identity,skip", [(2, 64, 64, 0, True), (1, 300, 32, 0, False), (2, 256, 128, 1, True), (1, 64, 16, 0, False)])
-def test_gn_silu_bwd(n, hw, c, identity, skip):
+@pytest.mark.parametrize("fold", [0, 1], ids=["three-launches", "staged-fold"])
+@pytest.mark.parametrize("n,hw,c,identity,skip", [(2, 64, 64, 0, True), (1, 300, 32, 0, False), (2, 256, 128, 1, True), (1, 64, 16, 0, False),
+                                                  (3, 1024, 64, 0, True)])
+def test_gn_silu_bwd(n, hw, c, identity, skip, fold, monkeypatch):
+    monkeypatch.setenv("DIAMOND_GN_BWD_FOLD", str(fold))
     rng = np.random.default_rng(hw + c)
     L = S.lib()
     x = (rng.standard_normal((n, hw, 1, c)) * 1.4 + 0.3).astype(np.float32)

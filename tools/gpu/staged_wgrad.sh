@@ -23,4 +23,6 @@ for rep in 1 2; do
   run "mode1/wg256 " DIAMOND_WGRAD_MODE=1 DIAMOND_WGRAD_MAX_WG=256
   run "mode3/wg256 " DIAMOND_WGRAD_MODE=3 DIAMOND_WGRAD_MAX_WG=256
   run "mode3/wg512 " DIAMOND_WGRAD_MODE=3 DIAMOND_WGRAD_MAX_WG=512
+  run "mode3/wg256/1pass" DIAMOND_WGRAD_MODE=3 DIAMOND_WGRAD_MAX_WG=256 DIAMOND_WGRAD_SINGLE_REDUCE=256
+  run "mode3/wg256/1pass/gnfold" DIAMOND_WGRAD_MODE=3 DIAMOND_WGRAD_MAX_WG=256 DIAMOND_WGRAD_SINGLE_REDUCE=256 DIAMOND_GN_BWD_FOLD=1
 done
