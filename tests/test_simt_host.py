@@ -5,6 +5,8 @@ their device patched to "cpu".  This covers what the kernel-level interpreter te
 PackCache / dmd_pack_jobs, the batched FiLM table and its strides, statistics plumbing between producers and consumers, the
 fused-projection and fused-8x8-level routing, the recorded-tape backward.  The product itself cannot run this way
 (tests/simt/host_harness.py patches the two guards that prevent it, for the duration of a test)."""
+import os
+
 import pytest
 import torch
 
@@ -69,6 +71,8 @@ def test_denoiser_latency_route_vs_reference_golden_on_the_interpreter(models, m
 @pytest.mark.parametrize("env", [{}, {"DIAMOND_WGRAD_MODE": "3", "DIAMOND_WGRAD_MAX_WG": "7", "DIAMOND_WGRAD_SINGLE_REDUCE": "256",
                                       "DIAMOND_GN_BWD_FOLD": "1"}], ids=["shipping", "staged-backward"])
 def test_denoiser_training_step_vs_reference_golden_on_the_interpreter(models, monkeypatch, env):
+    if env and os.environ.get("DIAMOND_STAGED_TESTS") != "1":
+        pytest.skip("staged backward end to end (55 s): DIAMOND_STAGED_TESTS=1 runs it; its kernels are in test_simt_kernels.py")
     """loss and all 236 gradient tensors of Denoiser.forward + backward (split-fp16 arithmetic), shipping kernels and the staged
     backward (weight gradients: 32-pixel MFMA + prefetch, 7 workgroups walking many tiles each, one-pass reduction; GroupNorm
     backward with the channel sums folded into the apply pass)"""
