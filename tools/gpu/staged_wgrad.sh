@@ -26,3 +26,13 @@ for rep in 1 2; do
   run "mode3/wg256/1pass" DIAMOND_WGRAD_MODE=3 DIAMOND_WGRAD_MAX_WG=256 DIAMOND_WGRAD_SINGLE_REDUCE=256
   run "mode3/wg256/1pass/gnfold" DIAMOND_WGRAD_MODE=3 DIAMOND_WGRAD_MAX_WG=256 DIAMOND_WGRAD_SINGLE_REDUCE=256 DIAMOND_GN_BWD_FOLD=1
 done
+# the same switches on the headline window (configs[1]: the actor-critic backward over 256 x 15 frames has weight gradients
+# and GroupNorm backward too: 3 % + 1.3 % of the window)
+for rep in 1 2; do
+  for setting in "DIAMOND_WGRAD_MODE=1" "DIAMOND_WGRAD_MODE=3 DIAMOND_WGRAD_MAX_WG=256 DIAMOND_WGRAD_SINGLE_REDUCE=256 DIAMOND_GN_BWD_FOLD=1"; do
+    env $setting timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-fp32 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('configs[1]', '$setting', round(d['value'], 1), 'frames/s')" | tee -a $O/ab.txt
+  done
+done
