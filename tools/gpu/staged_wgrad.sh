@@ -1,7 +1,7 @@
 #!/bin/bash
 # The staged weight-gradient kernels (DIAMOND_WGRAD_MODE 2 / 3, DIAMOND_WGRAD_MAX_WG; diamond_amd/csrc/dmd_backward.hip) on the
-# GPU: parity first, then a same-box A/B of the denoiser training step.  ~4 GPU-minutes.
-#   gpurun --timeout 420 -- 'bash tools/gpu/staged_wgrad.sh'
+# GPU: parity first, then same-box A/Bs of the denoiser training step and of the headline window.  ~7 GPU-minutes.
+#   gpurun --timeout 600 -- 'bash tools/gpu/staged_wgrad.sh'
 # Results -> gpurun_out/staged_wgrad/.  Whatever wins becomes the default in launch_wgrad / wgrad_plan; the rest is deleted.
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}; cd $R
