@@ -313,10 +313,16 @@ extern "C" int dmd_conv2d_latency_eligible(const dmd_conv_params* p) {
 }
 
 // DIAMOND_CONV_LATENCY_TILES = the largest number of conv_f16ws tiles (256 pixels each) a launch may have to be routed here;
-// 0 / unset: never (the kernel is staged, see the header of this file)
+// 0 / unset: never (the kernel is staged, see the header of this file).  DIAMOND_CONV_LATENCY_TILES_C32 = the same cap for the
+// 32-output-channel layers only (default: the general cap).  Those are memory-bound at ANY batch (288 MACs per input value:
+// the 256-batch launch of the reward / end encoder runs at 2.5x its HBM time on the pipelined kernel), so a large value there
+// asks whether plain occupancy -- two of these workgroups per CU, every load of a workgroup in flight at once -- streams
+// better than the producer / consumer pipeline does; tools/gpu/staged_latency.sh measures that too.
 int dmd_conv_lat_route(const dmd_conv_params& p) {
   const char* e = getenv("DIAMOND_CONV_LATENCY_TILES");
-  const int cap = e ? atoi(e) : 0;
+  long long cap = e ? atoll(e) : 0;
+  if (p.Cout == 32)
+    if (const char* e32 = getenv("DIAMOND_CONV_LATENCY_TILES_C32")) cap = atoll(e32);
   if (cap <= 0 || !dmd_conv2d_latency_eligible(&p)) return 0;
   const long long tiles16 = (long long)p.N * (p.H / 8) * (p.W / 16) / 2;  // 8 x 16 tiles / 2 = 256-pixel tiles
   return tiles16 <= cap ? 1 : 0;

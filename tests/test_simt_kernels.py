@@ -917,3 +917,30 @@ def test_conv_f16ws(case, monkeypatch):
     if stats is not None:
         want = _group_sums(np.ascontiguousarray(got.astype(np.float32)), hv, wv)
         np.testing.assert_allclose(stats.sum(axis=2), want, rtol=2e-6, atol=1e-4)  # (fp32 sums of a lane's 16 values inside)
+
+
+def test_conv_latency_route_caps(monkeypatch):
+    """the general cap and the one for the 32-output-channel layers (tile count of the launch: N * H * W / 256)"""
+    L = S.lib()
+    x = np.zeros((4, 16, 16, 64), dtype=np.float32)
+    buf = (nv.C.c_char * 96)()
+
+    def route(cout, cin):
+        p = nv.ConvParams()
+        p.N, p.H, p.W, p.Cout, p.CoutPad, p.taps, p.stride, p.nsrc, p.precision = 4, 16, 16, cout, cout, 9, 1, 1, 1
+        p.src[0].x, p.src[0].C, p.w, p.w_f16, p.out = S.ptr(x), cin, S.ptr(x), S.ptr(x), S.ptr(x)
+        S.check(L.dmd_conv2d_kernel_name(p, buf, 96), "kernel_name")
+        return buf.value.decode().startswith("conv_lat_kernel")
+
+    monkeypatch.delenv("DIAMOND_CONV_LATENCY_TILES", raising=False)
+    monkeypatch.delenv("DIAMOND_CONV_LATENCY_TILES_C32", raising=False)
+    assert not route(64, 64) and not route(32, 32)              # staged: off by default
+    monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", "3")        # this launch is 4 tiles of 256 pixels
+    assert not route(64, 64) and not route(32, 32)
+    monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", "4")
+    assert route(64, 64) and route(32, 32) and route(64, 32)
+    monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES_C32", "0")
+    assert route(64, 64) and not route(32, 32)
+    monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", "0")
+    monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES_C32", "1000000000")
+    assert not route(64, 64) and route(32, 32) and route(32, 64)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The staged few-tile convolution (conv_lat_kernel, DIAMOND_CONV_LATENCY_TILES; diamond_amd/csrc/dmd_conv_lat.hip) on the GPU:
-# parity first, then a same-box A/B of the B = 1 frame latency and a kernel census of the graphed frame.  ~4 GPU-minutes.
-#   gpurun --timeout 420 -- 'bash tools/gpu/staged_latency.sh'
+# parity first, then a same-box A/B of the B = 1 frame latency and a kernel census of the graphed frame.  ~7 GPU-minutes.
+#   gpurun --timeout 600 -- 'bash tools/gpu/staged_latency.sh'
 # Results -> gpurun_out/staged_latency/.  If it wins, the cap becomes a default in dmd_conv_lat_route (and the batch-invariance
 # tests pin DIAMOND_CONV_LATENCY_TILES=0 where they compare a small launch bitwise with a large one); if not, the file goes.
 set -u
@@ -16,6 +16,15 @@ for rep in 1 2; do
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('cap $cap', 'ms/frame graph', round(d['value'], 3), {k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items() if 'eager' in k})" | tee -a $O/ab.txt
+  done
+done
+# the 32-channel layers of the headline window (configs[1], batch 256) on the same kernel: occupancy instead of the pipeline
+for rep in 1 2; do
+  for c32 in 0 1000000000; do
+    DIAMOND_CONV_LATENCY_TILES_C32=$c32 timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-fp32 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); r = d['roofline']
+print('configs[1] c32 cap $c32', round(d['value'], 1), 'frames/s;', {k: v for k, v in list(r['launch_time_ms'].items())[:6]})" | tee -a $O/ab.txt
   done
 done
 export TMPDIR=/tmp
