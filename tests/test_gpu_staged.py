@@ -52,6 +52,7 @@ def test_latency_conv_route_vs_reference_goldens(monkeypatch):
     M.test_denoiser_deterministic(ag)
     M.test_rew_end_model_vs_golden(ag)  # its 32-channel 3x3s take the route as well
     M.test_actor_critic_vs_golden(ag)
+    M.test_full_window_vs_reference_golden()  # batch 4: the whole rollout on the route, integer trajectories bit-exact
     for name in dir(EV):
         if name.startswith("test_") and "graph" in name:
             getattr(EV, name)()

@@ -99,12 +99,13 @@ def test_rew_end_model_and_actor_critic_vs_goldens_on_the_interpreter(models, mo
     assert counter.n.get("dmd_lowres_chain32", 0) >= 2 and counter.n.get("dmd_lstm_pointwise_bwd", 0) >= 1, counter.n
 
 
-@pytest.mark.skipif(os.environ.get("DIAMOND_SLOW_CPU_TESTS") != "1", reason="4 minutes on 8 cores: DIAMOND_SLOW_CPU_TESTS=1 runs it")
-def test_full_window_vs_reference_golden_on_the_interpreter(models, monkeypatch):
+@pytest.mark.skipif(os.environ.get("DIAMOND_SLOW_CPU_TESTS") != "1", reason="2-4 minutes on 8 cores: DIAMOND_SLOW_CPU_TESTS=1 runs it")
+@pytest.mark.parametrize("cap", ["0", "64"], ids=["shipping", "staged-latency-route"])
+def test_full_window_vs_reference_golden_on_the_interpreter(models, monkeypatch, cap):
     """The whole north-star path on the CPU: two BPTT windows of ActorCritic.forward() + backward through WorldModelEnv /
     env_loop / DiffusionSampler / reward-end model with resets and burn-in, the reference's RNG order -- sampled actions,
     rewards, ends and truncations BIT-exact against the reference-generated golden, frames on its uint8 levels."""
     M, counter = models
-    monkeypatch.delenv("DIAMOND_CONV_LATENCY_TILES", raising=False)
+    monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", cap)  # batch 4: every level of the U-Net is within 64 tiles
     M.test_full_window_vs_reference_golden()
     assert counter.n.get("dmd_categorical_sample", 0) >= 12 and counter.n.get("lowres_chain_kernel", 0) >= 36, counter.n
