@@ -71,8 +71,9 @@ __device__ __forceinline__ void lt_split_store(unsigned char* ph, unsigned char*
   *(lt_h4*)(pl + byte) = l;
 }
 
-// CQ = input channel quads (8 / 16 / 32: 32 / 64 / 128 input channels), COUT = 32 | 64 output channels
-template <bool PROJ, int CQ, int COUT>
+// CQ = input channel quads (4 / 8 / 16 / 32: 16 / 32 / 64 / 128 input channels), COUT = 32 | 64 output channels (of the packed
+// weights), HEAD: the few-channel NCHW head (conv_out: p.Cout <= 4 real channels of 32 packed ones, no statistics / residual)
+template <bool PROJ, int CQ, int COUT, bool HEAD = false>
 __global__ __launch_bounds__(256) void conv_lat_kernel(const dmd_conv_params p) {
   DMD_DYNAMIC_LDS(unsigned char, lt_smem);
   __shared__ float g_mean[4], g_rstd[4];
@@ -236,7 +237,8 @@ __global__ __launch_bounds__(256) void conv_lat_kernel(const dmd_conv_params p) 
   const int pixbyte = ((2 * wave + (ci >> 4)) * LT_PW + (ci & 15)) * rs;  // top-left tap of this lane's pixel
   constexpr int nch = Cin >> 4;
   lt_h8 wj[16];
-  for (int c = 0; c < nch; c += 2) {
+  if constexpr (nch == 1) lt_chunk9(acc, wa, ph, pl, pixbyte, rs, g * 16);  // conv_in: 16 (15 real) input channels
+  for (int c = 0; c + 1 < nch; c += 2) {
     lt_load_w<9, COUT>(wb, wp, c + 1, unit_lane);
     lt_chunk9(acc, wa, ph, pl, pixbyte, rs, c * 32 + g * 16);
     if (c + 2 < nch) lt_load_w<9, COUT>(wa, wp, c + 2, unit_lane);
@@ -262,6 +264,14 @@ __global__ __launch_bounds__(256) void conv_lat_kernel(const dmd_conv_params p) 
     }
   }
 
+  if constexpr (HEAD) {  // NCHW planes of the real channels: they are registers 0..Cout-1 of the lanes with k group 0
+    if (g == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (r < p.Cout) p.out[(((size_t)n * p.Cout + r) * p.H + oy) * p.W + ox] = acc[r];
+    }
+    return;
+  }
   // ---- write-out: residual, NHWC store, partial statistics of this (tile, 32-channel group) ----
   double s = 0.0, ss = 0.0;
 #pragma unroll
@@ -294,14 +304,22 @@ __global__ __launch_bounds__(256) void conv_lat_kernel(const dmd_conv_params p) 
 // 1: these parameters can run on conv_lat_kernel (a subset of what conv_f16ws_kernel takes)
 extern "C" int dmd_conv2d_latency_eligible(const dmd_conv_params* p) {
   if (!p || (p->precision & 0xff) != DMD_PRECISION_F16X2 || !p->w_f16) return 0;
-  if (p->taps != 9 || p->stride != 1 || (p->Cout != 64 && p->Cout != 32) || p->CoutPad != p->Cout || p->out_nchw || p->residual_norm.stats) return 0;
+  if (p->taps != 9 || p->stride != 1 || p->residual_norm.stats) return 0;
   if (p->H % 8 != 0 || p->W % 16 != 0 || p->valid_h || p->valid_w) return 0;
   if (p->nsrc < 1 || p->nsrc > 2) return 0;
   int cin = 0;
   for (int i = 0; i < p->nsrc; ++i) {
-    if (!p->src[i].x || p->src[i].C % 32 != 0) return 0;  // whole GroupNorm groups per source, an even number of 16-channel chunks
+    if (!p->src[i].x) return 0;
     cin += p->src[i].C;
   }
+  // few-channel NCHW head (conv_out): Cout <= 4 zero-padded to 32 packed channels, 64 normalised input channels
+  const bool head = p->out_nchw && p->Cout <= 4 && p->CoutPad == 32 && !p->residual && !p->out_stats && !p->proj_nsrc;
+  if (head) return (p->nsrc == 1 && cin == 64 && !p->upsample) ? 1 : 0;
+  if ((p->Cout != 64 && p->Cout != 32) || p->CoutPad != p->Cout || p->out_nchw) return 0;
+  // conv_in: one 16-channel source (15 real), nothing to normalise
+  if (cin == 16) return (p->nsrc == 1 && p->Cout == 64 && p->src[0].prologue == DMD_PROLOGUE_NONE && !p->upsample && !p->proj_nsrc) ? 1 : 0;
+  for (int i = 0; i < p->nsrc; ++i)
+    if (p->src[i].C % 32 != 0) return 0;  // whole GroupNorm groups per source, an even number of 16-channel chunks
   if (cin != 32 && cin != 64 && cin != 128) return 0;
   if (p->Cout == 32 && cin == 128) return 0;  // (no such layer; not instantiated)
   if ((long long)p->N * p->H * p->W * 128 * 4 >= (1ll << 40)) return 0;
@@ -341,8 +359,12 @@ int dmd_launch_conv_lat(const dmd_conv_params& p, hipStream_t st) {
     DMD_CHECK_ARG(e == hipSuccess, "conv_lat: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set[dev] = true;
   }
-  const dim3 grid((unsigned)(p.N * (p.H / 8) * (p.W / 16)), (unsigned)(p.Cout / 32));
-  if (p.proj_nsrc)
+  const dim3 grid((unsigned)(p.N * (p.H / 8) * (p.W / 16)), (unsigned)(p.CoutPad / 32));
+  if (p.out_nchw)
+    hipLaunchKernelGGL((conv_lat_kernel<false, 16, 32, true>), grid, dim3(256), lds, st, p);
+  else if (cin == 16)
+    hipLaunchKernelGGL((conv_lat_kernel<false, 4, 64>), grid, dim3(256), lds, st, p);
+  else if (p.proj_nsrc)
     hipLaunchKernelGGL((conv_lat_kernel<true, 16, 64>), grid, dim3(256), lds, st, p);
   else if (p.Cout == 64 && cin == 128)
     hipLaunchKernelGGL((conv_lat_kernel<false, 32, 64>), grid, dim3(256), lds, st, p);

@@ -731,6 +731,8 @@ LAT_CASES = [
     dict(n=2, h=16, w=16, cin=[32], cout=32, prologue=[1], film=True, stats=True, residual=True),   # reward / end encoder ResBlock convs
     dict(n=1, h=16, w=32, cin=[32], cout=64, prologue=[1], stats=True),                              # actor-critic encoder 32 -> 64
     dict(n=1, h=8, w=16, cin=[64], cout=32, prologue=[1]),
+    dict(n=2, h=16, w=16, cin=[16], stats=True),                                                      # conv_in: one chunk, nothing to normalise
+    dict(n=2, h=16, w=32, cin=[64], cout=3, prologue=[1], film=True, nchw=True),                      # conv_out: few-channel NCHW head
 ]
 
 
@@ -743,8 +745,10 @@ def test_conv_latency_kernel(case, monkeypatch):
     up, prol = case.get("upsample", 0), case.get("prologue", [0] * len(cins))
     hs, ws = (h // 2, w // 2) if up else (h, w)
     cin, cout = sum(cins), case.get("cout", 64)
+    nchw = bool(case.get("nchw"))
+    cout_pad = 32 if nchw else cout
     p = nv.ConvParams()
-    p.N, p.H, p.W, p.Cout, p.CoutPad, p.taps, p.stride, p.upsample, p.nsrc, p.precision = n, h, w, cout, cout, 9, 1, up, len(cins), 1
+    p.N, p.H, p.W, p.Cout, p.CoutPad, p.taps, p.stride, p.upsample, p.nsrc, p.precision = n, h, w, cout, cout_pad, 9, 1, up, len(cins), 1
     keep, xs_ref = [], []
     for i, c in enumerate(cins):
         x = (rng.standard_normal((n, hs, ws, c)) * 1.5 + 0.3).astype(np.float32)
@@ -761,13 +765,15 @@ def test_conv_latency_kernel(case, monkeypatch):
         else:
             xs_ref.append(x.astype(np.float64))
         keep.append(x)
-    wt = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
-    bias = rng.standard_normal(cout).astype(np.float32)
-    packed = np.zeros((cin // 16) * 9 * cout * 16, dtype=np.float32)
-    S.check(L.dmd_pack_conv_weight(S.ptr(wt), S.ptr(packed), cout, cin, 3, cout, cin, None), "pack")
+    wt = np.zeros((cout_pad, cin, 3, 3), dtype=np.float32)
+    wt[:cout] = rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)
+    bias = np.zeros(cout_pad, dtype=np.float32)
+    bias[:cout] = rng.standard_normal(cout)
+    packed = np.zeros((cin // 16) * 9 * cout_pad * 16, dtype=np.float32)
+    S.check(L.dmd_pack_conv_weight(S.ptr(wt), S.ptr(packed), cout_pad, cin, 3, cout_pad, cin, None), "pack")
     w16 = _pack16(wt)
     p.w, p.bias, p.w_f16 = S.ptr(packed), S.ptr(bias), S.ptr(w16)
-    ref = _ref_conv(xs_ref, wt, bias, 3, 1, up, h, w)
+    ref = _ref_conv(xs_ref, wt[:cout], bias[:cout], 3, 1, up, h, w)
     if case.get("residual"):
         r = rng.standard_normal((n, h, w, cout)).astype(np.float32)
         p.residual = S.ptr(r)
@@ -780,7 +786,8 @@ def test_conv_latency_kernel(case, monkeypatch):
         p.proj_nsrc, p.proj_C[0], p.proj_C[1] = 2, 64, 64
         p.proj_x[0], p.proj_x[1], p.proj_w_f16, p.proj_bias = S.ptr(j0), S.ptr(j1), S.ptr(wpj16), S.ptr(bpj)
         ref = ref + _ref_conv([j0.astype(np.float64), j1.astype(np.float64)], wpj, bpj, 1, 1, 0, h, w)
-    out = np.full((n, h, w, cout), np.nan, dtype=np.float32)
+    out = np.full((n, cout, h, w) if nchw else (n, h, w, cout), np.nan, dtype=np.float32)
+    p.out_nchw = int(nchw)
     tiles = L.dmd_conv_stat_tiles(h, w)
     stats = np.full((n, cout // 32, tiles, 2), np.nan) if case.get("stats") else None
     p.out, p.out_stats = S.ptr(out), S.ptr(stats)
@@ -791,7 +798,8 @@ def test_conv_latency_kernel(case, monkeypatch):
     S.check(L.dmd_conv2d_kernel_name(p, buf, 96), "kernel_name")
     assert buf.value.decode() == f"conv_lat_kernel<{'true' if case.get('proj') else 'false'}>"
     S.check(L.dmd_conv2d(p, None), "dmd_conv2d")
-    err = np.abs(out - ref).max()
+    got = out.transpose(0, 2, 3, 1) if nchw else out
+    err = np.abs(got - ref).max()
     assert err <= 2e-5 * max(1.0, np.abs(ref).max()), err
     if stats is not None:
         # one partial per 8 x 16 tile and 32-channel group, in dmd_conv_stat_tiles order
