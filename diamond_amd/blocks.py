@@ -156,8 +156,10 @@ class Downsample(nn.Module):
         nn.init.orthogonal_(self.conv.weight)
 
     def run(self, ctx: RunCtx, x: Act) -> Act:
+        # (w_f16: the generic stride-2 instance splits the fp32 pack on the fly and ignores it; the few-tile kernel reads it)
         return E.conv2d([(x, nv.PROLOGUE_NONE, None)], ctx.cache.conv_weight(self.conv), ctx.cache.conv_bias(self.conv),
-                        self.conv.out_channels, stride=2, naive=ctx.naive, fast_math=ctx.fast_math, module=self.conv)
+                        self.conv.out_channels, stride=2, naive=ctx.naive, fast_math=ctx.fast_math, w_f16=ctx.w16(self.conv),
+                        module=self.conv)
 
 
 class Upsample(nn.Module):

@@ -46,12 +46,13 @@ __device__ __forceinline__ void lt_load_w(lt_h8 (&w)[2 * TAPS], const lt_h8* __r
     for (int hl = 0; hl < 2; ++hl) w[2 * t + hl] = wp[(((size_t)chunk * TAPS + t) * 2 + hl) * (2 * COUT) + unit_lane];
 }
 
-// one chunk of the 3x3 contraction: 9 taps x 3 MFMAs (w_h x_l + w_l x_h + w_h x_h)
+// one chunk of the 3x3 contraction: 9 taps x 3 MFMAs (w_h x_l + w_l x_h + w_h x_h); PITCH = patch pixels per row
+template <int PITCH = LT_PW>
 __device__ __forceinline__ void lt_chunk9(lt_f16v& acc, const lt_h8 (&w)[18], const unsigned char* ph, const unsigned char* pl, int pixbyte,
                                           int rs, int kbyte) {
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
-    const int off = pixbyte + ((t / 3) * LT_PW + (t % 3)) * rs + kbyte;
+    const int off = pixbyte + ((t / 3) * PITCH + (t % 3)) * rs + kbyte;
     const lt_h8 bh = *(const lt_h8*)(ph + off);
     const lt_h8 bl = *(const lt_h8*)(pl + off);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[2 * t], bl, acc, 0, 0, 0);
@@ -301,11 +302,123 @@ __global__ __launch_bounds__(256) void conv_lat_kernel(const dmd_conv_params p) 
   }
 }
 
+// ---- stride 2 (Downsample, blocks.py:93-100): the 8 x 16 output tile reads a 17 x 33 input patch, staged 32 channels at a
+// time (two rounds for 64 input channels: 90 KB of LDS instead of 160); the next round's loads fly under this round's MFMAs ----
+#define LT2_PW 33
+#define LT2_NPP 561  // 17 x 33
+#define LT2_RS 80    // 32 channels x 2 bytes + 16
+
+template <int CQ, int COUT>
+__global__ __launch_bounds__(256) void conv_lat_s2_kernel(const dmd_conv_params p) {
+  DMD_DYNAMIC_LDS(unsigned char, lt_smem);
+  __shared__ double red[4][2];
+  constexpr int Cin = 4 * CQ, ROUNDS = Cin / 32, NIT = (LT2_NPP + 31) / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = blockIdx.y;
+  const int tx_n = p.W / 16, per_img = tx_n * (p.H / 8);
+  const int n = blockIdx.x / per_img, timg = blockIdx.x - n * per_img;
+  const int y0 = (timg / tx_n) * 8, x0 = (timg % tx_n) * 16;
+  const int Hi = 2 * p.H, Wi = 2 * p.W;  // input extent
+  unsigned char* ph = lt_smem;
+  unsigned char* pl = ph + LT2_NPP * LT2_RS;
+  const int g = lane >> 5, ci = lane & 31;
+  const int unit_lane = g * COUT + half * 32 + ci;
+  const lt_h8* wp = (const lt_h8*)p.w_f16;
+  lt_h8 wa[18], wb[18];
+  lt_load_w<9, COUT>(wa, wp, 0, unit_lane);
+  lt_load_w<9, COUT>(wb, wp, 1, unit_lane);
+
+  // this thread stages channel quad q (of the round's 8) of patch pixels tid / 8 + 32 it
+  const int q = tid & 7;
+  f32x4 sv[NIT];
+  auto fetch = [&](int round) {
+    const float* sx = p.src[0].x + round * 32 + 4 * q;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int pp = it * 32 + (tid >> 3);
+      const int py = pp / LT2_PW, px = pp - py * LT2_PW;
+      const int iy = 2 * y0 - 1 + py, ix = 2 * x0 - 1 + px;
+      sv[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (pp < LT2_NPP && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi) sv[it] = *(const f32x4*)(sx + (((size_t)n * Hi + iy) * Wi + ix) * Cin);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int pp = it * 32 + (tid >> 3);
+      if (pp < LT2_NPP) lt_split_store(ph, pl, pp * LT2_RS + 8 * q, sv[it]);
+    }
+  };
+  fetch(0);
+  const int oy = y0 + 2 * wave + (ci >> 4), ox = x0 + (ci & 15);
+  const size_t obase = (((size_t)n * p.H + oy) * p.W + ox) * COUT + half * 32 + 4 * g;
+  float bias[16], res[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bias[r] = res[r] = 0.f;
+  if (p.bias) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias[r] = p.bias[half * 32 + 8 * (r >> 2) + 4 * g + (r & 3)];
+  }
+  if (p.residual) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) res[r] = p.residual[obase + 8 * (r >> 2) + (r & 3)];
+  }
+  commit();
+  lt_f16v acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = bias[r];
+  // top-left tap of this lane's output pixel (row 2 wave + ci / 16, column ci % 16) in the stride-2 patch
+  const int pixbyte = ((2 * (2 * wave + (ci >> 4))) * LT2_PW + 2 * (ci & 15)) * LT2_RS;
+#pragma unroll
+  for (int round = 0; round < ROUNDS; ++round) {
+    if (round + 1 < ROUNDS) fetch(round + 1);
+    __syncthreads();
+    lt_chunk9<LT2_PW>(acc, wa, ph, pl, pixbyte, LT2_RS, g * 16);
+    if (round + 1 < ROUNDS) lt_load_w<9, COUT>(wa, wp, 2 * round + 2, unit_lane);
+    lt_chunk9<LT2_PW>(acc, wb, ph, pl, pixbyte, LT2_RS, 32 + g * 16);
+    if (round + 1 < ROUNDS) {
+      lt_load_w<9, COUT>(wb, wp, 2 * round + 3, unit_lane);
+      __syncthreads();  // every wave has read this round's patch
+      commit();
+    }
+  }
+  double s = 0.0, ss = 0.0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e] = acc[4 * k + e] + res[4 * k + e];
+      s += (double)o[e];
+      ss += (double)o[e] * (double)o[e];
+    }
+    *(f32x4*)(p.out + obase + 8 * k) = o;
+  }
+  if (p.out_stats) {
+    s = dmd_wave_sum(s);
+    ss = dmd_wave_sum(ss);
+    if (lane == 0) {
+      red[wave][0] = s;
+      red[wave][1] = ss;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double* o = p.out_stats + ((size_t)(n * (COUT / 32) + half) * per_img + timg) * 2;
+      o[0] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+      o[1] = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
+    }
+  }
+}
+
 // 1: these parameters can run on conv_lat_kernel (a subset of what conv_f16ws_kernel takes)
 extern "C" int dmd_conv2d_latency_eligible(const dmd_conv_params* p) {
   if (!p || (p->precision & 0xff) != DMD_PRECISION_F16X2 || !p->w_f16) return 0;
-  if (p->taps != 9 || p->stride != 1 || p->residual_norm.stats) return 0;
+  if (p->taps != 9 || p->residual_norm.stats) return 0;
   if (p->H % 8 != 0 || p->W % 16 != 0 || p->valid_h || p->valid_w) return 0;
+  if (p->stride == 2)  // Downsample: one raw source, as many outputs as inputs
+    return (p->nsrc == 1 && p->src[0].x && p->src[0].prologue == DMD_PROLOGUE_NONE && (p->src[0].C == 64 || p->src[0].C == 32) &&
+            p->Cout == p->src[0].C && p->CoutPad == p->Cout && !p->out_nchw && !p->upsample && !p->proj_nsrc) ? 1 : 0;
+  if (p->stride != 1) return 0;
   if (p->nsrc < 1 || p->nsrc > 2) return 0;
   int cin = 0;
   for (int i = 0; i < p->nsrc; ++i) {
@@ -360,6 +473,21 @@ int dmd_launch_conv_lat(const dmd_conv_params& p, hipStream_t st) {
     attr_set[dev] = true;
   }
   const dim3 grid((unsigned)(p.N * (p.H / 8) * (p.W / 16)), (unsigned)(p.CoutPad / 32));
+  if (p.stride == 2) {
+    static bool attr2[DMD_MAX_DEVICES] = {};
+    if (!attr2[dev]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lat_s2_kernel<16, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LT2_NPP * LT2_RS);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lat_s2_kernel<8, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LT2_NPP * LT2_RS);
+      DMD_CHECK_ARG(e == hipSuccess, "conv_lat_s2: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      attr2[dev] = true;
+    }
+    if (p.Cout == 64)
+      hipLaunchKernelGGL((conv_lat_s2_kernel<16, 64>), grid, dim3(256), 2 * LT2_NPP * LT2_RS, st, p);
+    else
+      hipLaunchKernelGGL((conv_lat_s2_kernel<8, 32>), grid, dim3(256), 2 * LT2_NPP * LT2_RS, st, p);
+    return 0;
+  }
   if (p.out_nchw)
     hipLaunchKernelGGL((conv_lat_kernel<false, 16, 32, true>), grid, dim3(256), lds, st, p);
   else if (cin == 16)

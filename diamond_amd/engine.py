@@ -198,8 +198,9 @@ class PackCache:
         return self._conv_job(conv.weight, nv.PACK_F32, cout_padded or nv.cout_pad(conv.out_channels))
 
     def conv_weight_f16x2(self, conv: nn.Conv2d) -> Optional[Tensor]:
-        """Split-fp16 pieces of a 3x3 / 1x1 stride-1 weight with 32 or 64 output channels (None for other shapes)."""
-        if conv.out_channels not in (32, 64) or conv.kernel_size not in ((3, 3), (1, 1)) or conv.stride != (1, 1):
+        """Split-fp16 pieces of a 3x3 / 1x1 weight with 32 or 64 output channels (None for other shapes); stride 2 (Downsample)
+        has the same layout -- only the few-tile kernel reads it there."""
+        if conv.out_channels not in (32, 64) or conv.kernel_size not in ((3, 3), (1, 1)) or conv.stride not in ((1, 1), (2, 2)):
             return None
         if conv.in_channels > (128 if conv.out_channels == 64 else 64):
             return None

@@ -65,7 +65,8 @@ def test_denoiser_latency_route_vs_reference_golden_on_the_interpreter(models, m
     print(counter.n)
     evals = 8  # model output + denoised frame at four sigmas
     assert lat >= evals * 30 and counter.n.get("conv_lat_kernel<true>", 0) >= evals * 9, counter.n
-    assert ws <= evals * 2, counter.n  # conv_in, conv_out (and nothing else) stay on the throughput kernel
+    # what is left: the fused 8x8 level and the stride-2 convolution INTO it (8 x 8 outputs are off the 8 x 16 tile grid)
+    assert ws == 0 and [k for k in counter.n if k.startswith("conv_mfma_kernel")] == ["conv_mfma_kernel<ConvGeom<4, true, 9, 2, true>>"], counter.n
 
 
 @pytest.mark.parametrize("env", [{}, {"DIAMOND_WGRAD_MODE": "3", "DIAMOND_WGRAD_MAX_WG": "7", "DIAMOND_WGRAD_SINGLE_REDUCE": "256",

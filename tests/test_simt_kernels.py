@@ -733,6 +733,8 @@ LAT_CASES = [
     dict(n=1, h=8, w=16, cin=[64], cout=32, prologue=[1]),
     dict(n=2, h=16, w=16, cin=[16], stats=True),                                                      # conv_in: one chunk, nothing to normalise
     dict(n=2, h=16, w=32, cin=[64], cout=3, prologue=[1], film=True, nchw=True),                      # conv_out: few-channel NCHW head
+    dict(n=2, h=16, w=16, cin=[64], stride=2, stats=True),                                            # Downsample: two staging rounds
+    dict(n=1, h=8, w=32, cin=[32], cout=32, stride=2, stats=True),
 ]
 
 
@@ -742,13 +744,13 @@ def test_conv_latency_kernel(case, monkeypatch):
     rng = np.random.default_rng(17)
     L = S.lib()
     n, h, w, cins = case["n"], case["h"], case["w"], case["cin"]
-    up, prol = case.get("upsample", 0), case.get("prologue", [0] * len(cins))
-    hs, ws = (h // 2, w // 2) if up else (h, w)
+    up, prol, stride = case.get("upsample", 0), case.get("prologue", [0] * len(cins)), case.get("stride", 1)
+    hs, ws = (h // 2, w // 2) if up else (h * stride, w * stride)
     cin, cout = sum(cins), case.get("cout", 64)
     nchw = bool(case.get("nchw"))
     cout_pad = 32 if nchw else cout
     p = nv.ConvParams()
-    p.N, p.H, p.W, p.Cout, p.CoutPad, p.taps, p.stride, p.upsample, p.nsrc, p.precision = n, h, w, cout, cout_pad, 9, 1, up, len(cins), 1
+    p.N, p.H, p.W, p.Cout, p.CoutPad, p.taps, p.stride, p.upsample, p.nsrc, p.precision = n, h, w, cout, cout_pad, 9, stride, up, len(cins), 1
     keep, xs_ref = [], []
     for i, c in enumerate(cins):
         x = (rng.standard_normal((n, hs, ws, c)) * 1.5 + 0.3).astype(np.float32)
@@ -773,7 +775,7 @@ def test_conv_latency_kernel(case, monkeypatch):
     S.check(L.dmd_pack_conv_weight(S.ptr(wt), S.ptr(packed), cout_pad, cin, 3, cout_pad, cin, None), "pack")
     w16 = _pack16(wt)
     p.w, p.bias, p.w_f16 = S.ptr(packed), S.ptr(bias), S.ptr(w16)
-    ref = _ref_conv(xs_ref, wt[:cout], bias[:cout], 3, 1, up, h, w)
+    ref = _ref_conv(xs_ref, wt[:cout], bias[:cout], 3, stride, up, h, w)
     if case.get("residual"):
         r = rng.standard_normal((n, h, w, cout)).astype(np.float32)
         p.residual = S.ptr(r)
@@ -810,7 +812,7 @@ def test_conv_latency_kernel(case, monkeypatch):
     # the route is by tile count: above the cap the same parameters run on conv_f16ws_kernel (8 x 16 images: conv_mfma)
     monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", "0")
     S.check(L.dmd_conv2d_kernel_name(p, buf, 96), "kernel_name")
-    assert buf.value.decode().startswith("conv_f16ws_kernel<" if h % 16 == 0 else "conv_mfma_kernel<")
+    assert buf.value.decode().startswith("conv_f16ws_kernel<" if h % 16 == 0 and stride == 1 else "conv_mfma_kernel<")
     other = np.full_like(out, np.nan)
     p.out, p.out_stats = S.ptr(other), None
     S.check(L.dmd_conv2d(p, None), "dmd_conv2d")
@@ -826,7 +828,7 @@ def test_conv_latency_eligibility():
     p.src[0].x, p.src[0].C = S.ptr(x), 64
     p.w_f16 = S.ptr(x)
     assert L.dmd_conv2d_latency_eligible(p) == 1
-    for field, bad in (("precision", 0), ("taps", 1), ("Cout", 48), ("W", 8), ("valid_h", 4), ("out_nchw", 1), ("stride", 2)):
+    for field, bad in (("precision", 0), ("taps", 1), ("Cout", 48), ("W", 8), ("valid_h", 4), ("out_nchw", 1), ("stride", 3)):
         good = getattr(p, field)
         setattr(p, field, bad)
         assert L.dmd_conv2d_latency_eligible(p) == 0, field
