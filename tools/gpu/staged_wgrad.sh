@@ -25,6 +25,8 @@ for rep in 1 2; do
   run "mode3/wg512 " DIAMOND_WGRAD_MODE=3 DIAMOND_WGRAD_MAX_WG=512
   run "mode3/wg256/1pass" DIAMOND_WGRAD_MODE=3 DIAMOND_WGRAD_MAX_WG=256 DIAMOND_WGRAD_SINGLE_REDUCE=256
   run "mode3/wg256/1pass/gnfold" DIAMOND_WGRAD_MODE=3 DIAMOND_WGRAD_MAX_WG=256 DIAMOND_WGRAD_SINGLE_REDUCE=256 DIAMOND_GN_BWD_FOLD=1
+  # ... and the few-tile convolution for the forward / data-gradient launches of the 16x16 level (32 tiles at batch 32)
+  run "all + lat64" DIAMOND_WGRAD_MODE=3 DIAMOND_WGRAD_MAX_WG=256 DIAMOND_WGRAD_SINGLE_REDUCE=256 DIAMOND_GN_BWD_FOLD=1 DIAMOND_CONV_LATENCY_TILES=64
 done
 # the same switches on the headline window (configs[1]: the actor-critic backward over 256 x 15 frames has weight gradients
 # and GroupNorm backward too: 3 % + 1.3 % of the window)
