@@ -11,7 +11,9 @@ pytestmark = [pytest.mark.gpu,
 
 PLANS = [dict(DIAMOND_WGRAD_MODE="2"), dict(DIAMOND_WGRAD_MODE="3"), dict(DIAMOND_WGRAD_MAX_WG="256"),
          dict(DIAMOND_WGRAD_MODE="3", DIAMOND_WGRAD_MAX_WG="7"),
-         dict(DIAMOND_WGRAD_MODE="3", DIAMOND_WGRAD_MAX_WG="256", DIAMOND_WGRAD_SINGLE_REDUCE="256", DIAMOND_GN_BWD_FOLD="1")]
+         dict(DIAMOND_WGRAD_MODE="3", DIAMOND_WGRAD_MAX_WG="256", DIAMOND_WGRAD_SINGLE_REDUCE="256", DIAMOND_GN_BWD_FOLD="1"),
+         dict(DIAMOND_WGRAD_MODE="3", DIAMOND_WGRAD_MAX_WG="256", DIAMOND_WGRAD_SINGLE_REDUCE="256", DIAMOND_GN_BWD_FOLD="1",
+              DIAMOND_CONV_LATENCY_TILES="64")]
 
 
 @pytest.mark.parametrize("plan", PLANS, ids=lambda p: ",".join(f"{k[8:]}={v}" for k, v in p.items()))

@@ -70,13 +70,13 @@ def test_denoiser_latency_route_vs_reference_golden_on_the_interpreter(models, m
 
 
 @pytest.mark.parametrize("env", [{}, {"DIAMOND_WGRAD_MODE": "3", "DIAMOND_WGRAD_MAX_WG": "7", "DIAMOND_WGRAD_SINGLE_REDUCE": "256",
-                                      "DIAMOND_GN_BWD_FOLD": "1"}], ids=["shipping", "staged-backward"])
+                                      "DIAMOND_GN_BWD_FOLD": "1", "DIAMOND_CONV_LATENCY_TILES": "64"}], ids=["shipping", "staged-backward"])
 def test_denoiser_training_step_vs_reference_golden_on_the_interpreter(models, monkeypatch, env):
     if env and os.environ.get("DIAMOND_STAGED_TESTS") != "1":
         pytest.skip("staged backward end to end (55 s): DIAMOND_STAGED_TESTS=1 runs it; its kernels are in test_simt_kernels.py")
     """loss and all 236 gradient tensors of Denoiser.forward + backward (split-fp16 arithmetic), shipping kernels and the staged
     backward (weight gradients: 32-pixel MFMA + prefetch, 7 workgroups walking many tiles each, one-pass reduction; GroupNorm
-    backward with the channel sums folded into the apply pass)"""
+    backward with the channel sums folded into the apply pass; forward and data-gradient 3x3s on the few-tile kernel)"""
     M, counter = models
     for k, v in env.items():
         monkeypatch.setenv(k, v)
