@@ -410,11 +410,218 @@ __global__ __launch_bounds__(256) void conv_lat_s2_kernel(const dmd_conv_params 
   }
 }
 
+// ---- images whose width is not a multiple of 16 (the 8 x 8 level: W = 8; 24, 40, ...): a workgroup = TWO 8 x 8 pixel blocks
+// (consecutive in (image, row, column) order, possibly of different images) x one 32-channel half; waves 0, 1 finish the
+// rows 0-3 / 4-7 of block 0, waves 2, 3 those of block 1.  Statistics: one partial per 8 x 8 block (dmd_conv_stat_tiles). ----
+template <int CQ, int COUT>
+__global__ __launch_bounds__(256) void conv_lat_b8_kernel(const dmd_conv_params p, int nsub) {
+  DMD_DYNAMIC_LDS(unsigned char, lt_smem);
+  __shared__ float g_mean[2][4], g_rstd[2][4];
+  __shared__ double red[4][2];
+  constexpr int Cin = 4 * CQ, rs = 2 * Cin + 16, NPP = 200, PPSTEP = 256 / CQ, NIT = (NPP + PPSTEP - 1) / PPSTEP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = blockIdx.y;
+  const int bx = p.W / 8, per_img = bx * (p.H / 8);
+  int sn[2], sy[2], sx0[2], st[2];
+  bool sval[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int gs = 2 * blockIdx.x + s;
+    sval[s] = gs < nsub;
+    const int g2 = sval[s] ? gs : 0;
+    sn[s] = g2 / per_img;
+    st[s] = g2 - sn[s] * per_img;
+    sy[s] = (st[s] / bx) * 8;
+    sx0[s] = (st[s] % bx) * 8;
+  }
+  const int C0 = p.src[0].C;
+  unsigned char* ph = lt_smem;
+  unsigned char* pl = ph + NPP * rs;
+  const int g = lane >> 5, ci = lane & 31;
+  const int unit_lane = g * COUT + half * 32 + ci;
+  const lt_h8* wp = (const lt_h8*)p.w_f16;
+  lt_h8 wa[18], wb[18];
+  lt_load_w<9, COUT>(wa, wp, 0, unit_lane);
+
+  const int q = tid % CQ, c4 = 4 * q;
+  const bool s1 = c4 >= C0;
+  const int cl = c4 - (s1 ? C0 : 0);
+  const float* sx = (s1 ? p.src[1].x : p.src[0].x) + cl;
+  const int Cs = s1 ? p.src[1].C : C0;
+  const int prol = s1 ? p.src[1].prologue : p.src[0].prologue;
+  const float* mulp = s1 ? p.src[1].norm.mul : p.src[0].norm.mul;
+  const float* addp = s1 ? p.src[1].norm.add : p.src[0].norm.add;
+  const int64_t mul_stride = s1 ? p.src[1].norm.mul_stride : p.src[0].norm.mul_stride;
+  const int64_t add_stride = s1 ? p.src[1].norm.add_stride : p.src[0].norm.add_stride;
+  const int plus_one = s1 ? p.src[1].norm.mul_plus_one : p.src[0].norm.mul_plus_one;
+  f32x4 sv[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int pp = it * PPSTEP + tid / CQ;
+    const int sb = pp >= 100 ? 1 : 0, ppl = pp - 100 * sb;
+    const int py = ppl / 10, px = ppl - py * 10;
+    const int iy = (sb ? sy[1] : sy[0]) - 1 + py, ix = (sb ? sx0[1] : sx0[0]) - 1 + px;
+    sv[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (pp < NPP && (sb ? sval[1] : sval[0]) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+      sv[it] = *(const f32x4*)(sx + (((size_t)(sb ? sn[1] : sn[0]) * p.H + iy) * p.W + ix) * Cs);
+  }
+  float mul[2][4], ad[2][4];
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      mul[sb][e] = 1.f;
+      ad[sb][e] = 0.f;
+    }
+  if (prol != DMD_PROLOGUE_NONE) {
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      if (mulp) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mul[sb][e] = mulp[(size_t)sn[sb] * mul_stride + cl + e];
+      }
+      if (addp) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ad[sb][e] = addp[(size_t)sn[sb] * add_stride + cl + e];
+      }
+    }
+  }
+  // this lane's output pixel: block wave / 2, row 4 (wave & 1) + ci / 8, column ci % 8
+  const int ob = wave >> 1, orow = 4 * (wave & 1) + (ci >> 3), ocol = ci & 7;
+  const bool oval = ob ? sval[1] : sval[0];
+  const size_t obase = (((size_t)(ob ? sn[1] : sn[0]) * p.H + (ob ? sy[1] : sy[0]) + orow) * p.W + (ob ? sx0[1] : sx0[0]) + ocol) * COUT + half * 32 + 4 * g;
+  float bias[16], res[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bias[r] = res[r] = 0.f;
+  if (p.bias) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias[r] = p.bias[half * 32 + 8 * (r >> 2) + 4 * g + (r & 3)];
+  }
+  if (p.residual && oval) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) res[r] = p.residual[obase + 8 * (r >> 2) + (r & 3)];
+  }
+
+  // ---- GroupNorm statistics: (block, 32-channel group) combinations over the four waves ----
+  constexpr int ngroups = Cin >> 5;
+  for (int c = wave; c < 2 * ngroups; c += 4) {
+    const int sb = c & 1, k = c >> 1;
+    const bool w1 = k * 32 >= C0;
+    const int wprol = w1 ? p.src[1].prologue : p.src[0].prologue;
+    if (wprol != DMD_PROLOGUE_NONE) {
+      const int Cw = w1 ? p.src[1].C : C0;
+      const int gi = (k * 32 - (w1 ? C0 : 0)) >> 5, G = Cw >> 5;
+      const int T = w1 ? p.src[1].norm.stat_tiles : p.src[0].norm.stat_tiles;
+      const double* stp = (w1 ? p.src[1].norm.stats : p.src[0].norm.stats) + ((size_t)((sb ? sn[1] : sn[0]) * G + gi) * T) * 2;
+      double s = 0.0, ss = 0.0;
+      for (int t = lane; t < T; t += 64) {
+        s += stp[2 * t];
+        ss += stp[2 * t + 1];
+      }
+      s = dmd_wave_sum(s);
+      ss = dmd_wave_sum(ss);
+      if (lane == 0) {
+        const double cnt = (double)DMD_GN_GROUP * p.H * p.W;
+        const double m = s / cnt;
+        double var = ss / cnt - m * m;
+        var = var < 0.0 ? 0.0 : var;
+        g_mean[sb][k] = (float)m;
+        g_rstd[sb][k] = (float)(1.0 / sqrt(var + (double)DMD_GN_EPS));
+      }
+    }
+  }
+  __syncthreads();
+
+  float mean[2] = {0.f, 0.f}, a[2][4];
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[sb][e] = 1.f;
+  if (prol != DMD_PROLOGUE_NONE) {
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      mean[sb] = g_mean[sb][c4 >> 5];
+      const float rstd = g_rstd[sb][c4 >> 5];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[sb][e] = rstd * (plus_one ? 1.0f + mul[sb][e] : mul[sb][e]);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int pp = it * PPSTEP + tid / CQ;
+    if (pp >= NPP) continue;
+    const int sb = pp >= 100 ? 1 : 0, ppl = pp - 100 * sb;
+    const int py = ppl / 10, px = ppl - py * 10;
+    const int iy = (sb ? sy[1] : sy[0]) - 1 + py, ix = (sb ? sx0[1] : sx0[0]) - 1 + px;
+    f32x4 v = sv[it];
+    if (prol != DMD_PROLOGUE_NONE && (sb ? sval[1] : sval[0]) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float u = (v[e] - (sb ? mean[1] : mean[0])) * (sb ? a[1][e] : a[0][e]) + (sb ? ad[1][e] : ad[0][e]);
+        v[e] = prol == DMD_PROLOGUE_NORM_SILU ? dmd_silu_fast(u) : u;
+      }
+    }
+    lt_split_store(ph, pl, pp * rs + 8 * q, v);
+  }
+  lt_f16v acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = bias[r];
+  __syncthreads();
+
+  const int pixbyte = (ob * 100 + orow * 10 + ocol) * rs;
+  constexpr int nch = Cin >> 4;
+  for (int c = 0; c + 1 < nch; c += 2) {
+    lt_load_w<9, COUT>(wb, wp, c + 1, unit_lane);
+    lt_chunk9<10>(acc, wa, ph, pl, pixbyte, rs, c * 32 + g * 16);
+    if (c + 2 < nch) lt_load_w<9, COUT>(wa, wp, c + 2, unit_lane);
+    lt_chunk9<10>(acc, wb, ph, pl, pixbyte, rs, (c + 1) * 32 + g * 16);
+  }
+
+  double s = 0.0, ss = 0.0;
+  if (oval) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = acc[4 * k + e] + res[4 * k + e];
+        s += (double)o[e];
+        ss += (double)o[e] * (double)o[e];
+      }
+      *(f32x4*)(p.out + obase + 8 * k) = o;
+    }
+  }
+  if (p.out_stats) {
+    s = dmd_wave_sum(s);
+    ss = dmd_wave_sum(ss);
+    if (lane == 0) {
+      red[wave][0] = s;
+      red[wave][1] = ss;
+    }
+    __syncthreads();
+    if (tid < 2 && (tid ? sval[1] : sval[0])) {  // thread b: the partial of block b = its two waves
+      double* o = p.out_stats + ((size_t)((tid ? sn[1] : sn[0]) * (COUT / 32) + half) * per_img + (tid ? st[1] : st[0])) * 2;
+      o[0] = red[2 * tid][0] + red[2 * tid + 1][0];
+      o[1] = red[2 * tid][1] + red[2 * tid + 1][1];
+    }
+  }
+}
+
 // 1: these parameters can run on conv_lat_kernel (a subset of what conv_f16ws_kernel takes)
 extern "C" int dmd_conv2d_latency_eligible(const dmd_conv_params* p) {
   if (!p || (p->precision & 0xff) != DMD_PRECISION_F16X2 || !p->w_f16) return 0;
   if (p->taps != 9 || p->residual_norm.stats) return 0;
-  if (p->H % 8 != 0 || p->W % 16 != 0 || p->valid_h || p->valid_w) return 0;
+  if (p->H % 8 != 0 || p->W % 8 != 0 || p->valid_h || p->valid_w) return 0;
+  if (p->W % 16 != 0) {  // 8 x 8 blocks (conv_lat_b8_kernel): the plain stride-1 layers only
+    if (p->stride != 1 || p->upsample || p->proj_nsrc || p->out_nchw || p->nsrc < 1 || p->nsrc > 2) return 0;
+    int c8 = 0;
+    for (int i = 0; i < p->nsrc; ++i) {
+      if (!p->src[i].x || p->src[i].C % 32 != 0) return 0;
+      c8 += p->src[i].C;
+    }
+    if (p->CoutPad != p->Cout) return 0;
+    return ((p->Cout == 64 && (c8 == 64 || c8 == 128)) || (p->Cout == 32 && c8 == 32)) ? 1 : 0;
+  }
   if (p->stride == 2)  // Downsample: one raw source, as many outputs as inputs
     return (p->nsrc == 1 && p->src[0].x && p->src[0].prologue == DMD_PROLOGUE_NONE && (p->src[0].C == 64 || p->src[0].C == 32) &&
             p->Cout == p->src[0].C && p->CoutPad == p->Cout && !p->out_nchw && !p->upsample && !p->proj_nsrc) ? 1 : 0;
@@ -455,7 +662,7 @@ int dmd_conv_lat_route(const dmd_conv_params& p) {
   if (p.Cout == 32)
     if (const char* e32 = getenv("DIAMOND_CONV_LATENCY_TILES_C32")) cap = atoll(e32);
   if (cap <= 0 || !dmd_conv2d_latency_eligible(&p)) return 0;
-  const long long tiles16 = (long long)p.N * (p.H / 8) * (p.W / 16) / 2;  // 8 x 16 tiles / 2 = 256-pixel tiles
+  const long long tiles16 = (long long)p.N * p.H * p.W / 256;  // 256-pixel tiles
   return tiles16 <= cap ? 1 : 0;
 }
 
@@ -471,6 +678,24 @@ int dmd_launch_conv_lat(const dmd_conv_params& p, hipStream_t st) {
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lat_kernel<true, 16, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     DMD_CHECK_ARG(e == hipSuccess, "conv_lat: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set[dev] = true;
+  }
+  if (p.W % 16 != 0) {
+    static bool attr8[DMD_MAX_DEVICES] = {};
+    if (!attr8[dev]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_lat_b8_kernel<32, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      DMD_CHECK_ARG(e == hipSuccess, "conv_lat_b8: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      attr8[dev] = true;
+    }
+    const int nsub = p.N * (p.H / 8) * (p.W / 8);
+    const dim3 grid8((unsigned)((nsub + 1) / 2), (unsigned)(p.Cout / 32));
+    const int lds8 = 2 * 200 * (2 * cin + 16);
+    if (p.Cout == 32)
+      hipLaunchKernelGGL((conv_lat_b8_kernel<8, 32>), grid8, dim3(256), lds8, st, p, nsub);
+    else if (cin == 64)
+      hipLaunchKernelGGL((conv_lat_b8_kernel<16, 64>), grid8, dim3(256), lds8, st, p, nsub);
+    else
+      hipLaunchKernelGGL((conv_lat_b8_kernel<32, 64>), grid8, dim3(256), lds8, st, p, nsub);
+    return 0;
   }
   const dim3 grid((unsigned)(p.N * (p.H / 8) * (p.W / 16)), (unsigned)(p.CoutPad / 32));
   if (p.stride == 2) {

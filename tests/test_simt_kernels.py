@@ -735,6 +735,10 @@ LAT_CASES = [
     dict(n=2, h=16, w=32, cin=[64], cout=3, prologue=[1], film=True, nchw=True),                      # conv_out: few-channel NCHW head
     dict(n=2, h=16, w=16, cin=[64], stride=2, stats=True),                                            # Downsample: two staging rounds
     dict(n=1, h=8, w=32, cin=[32], cout=32, stride=2, stats=True),
+    dict(n=3, h=8, w=8, cin=[64], prologue=[1], film=True, stats=True, residual=True),                # 8 x 8 blocks: images 0 | 1 in one workgroup, image 2 alone
+    dict(n=2, h=8, w=8, cin=[64, 64], prologue=[1, 1], film=True, stats=True),
+    dict(n=1, h=16, w=24, cin=[64], prologue=[1], stats=True),                                        # 2 x 3 blocks per image
+    dict(n=5, h=8, w=8, cin=[32], cout=32, prologue=[1], stats=True, residual=True),
 ]
 
 
@@ -805,14 +809,15 @@ def test_conv_latency_kernel(case, monkeypatch):
     assert err <= 2e-5 * max(1.0, np.abs(ref).max()), err
     if stats is not None:
         # one partial per 8 x 16 tile and 32-channel group, in dmd_conv_stat_tiles order
-        t8 = out.reshape(n, h // 8, 8, w // 16, 16, cout // 32, 32).astype(np.float64)
+        tw = 16 if w % 16 == 0 else 8
+        t8 = out.reshape(n, h // 8, 8, w // tw, tw, cout // 32, 32).astype(np.float64)
         want = np.stack([t8.sum(axis=(2, 4, 6)), (t8 * t8).sum(axis=(2, 4, 6))], axis=-1)  # (n, ty, tx, g, 2)
         np.testing.assert_allclose(stats, want.transpose(0, 3, 1, 2, 4).reshape(n, cout // 32, tiles, 2), rtol=1e-9, atol=1e-6)
 
     # the route is by tile count: above the cap the same parameters run on conv_f16ws_kernel (8 x 16 images: conv_mfma)
     monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", "0")
     S.check(L.dmd_conv2d_kernel_name(p, buf, 96), "kernel_name")
-    assert buf.value.decode().startswith("conv_f16ws_kernel<" if h % 16 == 0 and stride == 1 else "conv_mfma_kernel<")
+    assert buf.value.decode().startswith("conv_f16ws_kernel<" if (h % 16 == 0 or w % 16 != 0) and stride == 1 else "conv_mfma_kernel<")
     other = np.full_like(out, np.nan)
     p.out, p.out_stats = S.ptr(other), None
     S.check(L.dmd_conv2d(p, None), "dmd_conv2d")
@@ -828,7 +833,7 @@ def test_conv_latency_eligibility():
     p.src[0].x, p.src[0].C = S.ptr(x), 64
     p.w_f16 = S.ptr(x)
     assert L.dmd_conv2d_latency_eligible(p) == 1
-    for field, bad in (("precision", 0), ("taps", 1), ("Cout", 48), ("W", 8), ("valid_h", 4), ("out_nchw", 1), ("stride", 3)):
+    for field, bad in (("precision", 0), ("taps", 1), ("Cout", 48), ("W", 12), ("valid_h", 4), ("out_nchw", 1), ("stride", 3)):
         good = getattr(p, field)
         setattr(p, field, bad)
         assert L.dmd_conv2d_latency_eligible(p) == 0, field

@@ -18,6 +18,13 @@ d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('cap $cap', 'ms/frame graph', round(d['value'], 3), {k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items() if 'eager' in k})" | tee -a $O/ab.txt
   done
 done
+# the 8 x 8 level launch by launch on the 8 x 8-block form of the kernel instead of the fused level (144 us per call at B = 1)
+for rep in 1 2; do
+  DIAMOND_CONV_LATENCY_TILES=64 DIAMOND_LOWRES_CHAIN=0 timeout 120 python bench.py --config latency 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('cap 64, no fused 8x8 level', 'ms/frame graph', round(d['value'], 3))" | tee -a $O/ab.txt
+done
 # the 32-channel layers of the headline window (configs[1], batch 256) on the same kernel: occupancy instead of the pipeline
 for rep in 1 2; do
   for c32 in 0 1000000000; do
