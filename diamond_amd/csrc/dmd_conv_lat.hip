@@ -21,6 +21,10 @@
 //     finalised by one wave per group (lanes over the partial sums + butterfly), not by a serial loop per channel;
 //   * optional fused skip projection (dmd_conv_params.proj_*): the 128 raw channels of the tile are staged next to the
 //     patch and contracted as eight more K steps into the same accumulators.
+// Forms: conv_lat_kernel<PROJ, CQ, COUT, HEAD> (stride 1, W % 16 == 0: 16 / 32 / 64 / 128 input and 32 / 64 output channels,
+// two sources, upsampling, the few-channel NCHW head), conv_lat_s2_kernel (stride 2: the 17 x 33 patch staged 32 channels at a
+// time) and conv_lat_b8_kernel (W % 16 != 0: two 8 x 8 blocks per workgroup -- the 8 x 8 level of a recorded forward and its
+// data gradients).  dmd_conv2d_latency_eligible() is the list.
 // Same C ABI, same results to rounding (different summation order than conv_f16ws: a launch routed here is NOT bitwise
 // the large-batch launch, which is why the route is by tile count and off by default), same statistics layout
 // (dmd_conv_stat_tiles: one partial per 8 x 16 tile and 32-channel group = one workgroup).
