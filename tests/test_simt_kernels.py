@@ -959,3 +959,75 @@ def test_conv_latency_route_caps(monkeypatch):
     monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", "0")
     monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES_C32", "1000000000")
     assert not route(64, 64) and route(32, 32) and route(32, 64)
+
+
+def test_conv_routes_agree_on_random_shapes(monkeypatch):
+    """Randomised cross-check of the three 3x3 families behind dmd_conv2d (seeded): whatever conv_lat_kernel is eligible for must
+    come out as on the route the launch takes without it (conv_f16ws / conv_mfma), outputs to split-fp16 rounding and statistics
+    alike -- odd block counts, non-square images, every source / prologue / residual combination the eligibility admits."""
+    rng = np.random.default_rng(2024)
+    L = S.lib()
+    tried = routed = 0
+    buf = (nv.C.c_char * 96)()
+    for _ in range(160):
+        n = int(rng.integers(1, 4))
+        h = int(rng.choice([8, 16, 24]))
+        w = int(rng.choice([8, 16, 24, 32]))
+        stride = int(rng.choice([1, 1, 1, 2]))
+        up = int(stride == 1 and w % 16 == 0 and h % 2 == 0 and rng.random() < 0.2)
+        cins = [[32], [64], [64, 64], [32, 32], [128]][int(rng.integers(0, 5))]
+        cout = int(rng.choice([32, 64]))
+        prol = [int(rng.choice([0, 1, 2])) for _ in cins]
+        if stride == 2:
+            cins, prol, cout = [cout], [0], cout
+        residual = bool(rng.random() < 0.5)
+        want_stats = bool(rng.random() < 0.7)
+        cin = sum(cins)
+        hs, ws = (h // 2, w // 2) if up else (h * stride, w * stride)
+        p = nv.ConvParams()
+        p.N, p.H, p.W, p.Cout, p.CoutPad, p.taps, p.stride, p.upsample, p.nsrc, p.precision = n, h, w, cout, cout, 9, stride, up, len(cins), 1
+        keep = []
+        for i, c in enumerate(cins):
+            x = (rng.standard_normal((n, hs, ws, c)) * 1.3).astype(np.float32)
+            p.src[i].x, p.src[i].C, p.src[i].prologue = S.ptr(x), c, prol[i]
+            if prol[i]:
+                st = _partial_stats(x, hs, ws, 2, rng)
+                mul = (rng.standard_normal((n, c)) * 0.3).astype(np.float32)
+                add = (rng.standard_normal((n, c)) * 0.3).astype(np.float32)
+                p.src[i].norm = _norm(st, 2, mul, add, plus_one=prol[i] == 1)
+                keep += [st, mul, add]
+            keep.append(x)
+        wt = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+        bias = rng.standard_normal(cout).astype(np.float32)
+        packed = np.zeros((cin // 16) * 9 * cout * 16, dtype=np.float32)
+        S.check(L.dmd_pack_conv_weight(S.ptr(wt), S.ptr(packed), cout, cin, 3, cout, cin, None), "pack")
+        w16 = _pack16(wt)
+        p.w, p.bias, p.w_f16 = S.ptr(packed), S.ptr(bias), S.ptr(w16)
+        if residual:
+            r = rng.standard_normal((n, h, w, cout)).astype(np.float32)
+            p.residual = S.ptr(r)
+        tried += 1
+        if not L.dmd_conv2d_latency_eligible(p):
+            continue
+        routed += 1
+        tiles = L.dmd_conv_stat_tiles(h, w)
+        res = {}
+        for cap in ("0", "1000000"):
+            monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", cap)
+            out = np.full((n, h, w, cout), np.nan, dtype=np.float32)
+            stats = np.full((n, cout // 32, tiles, 2), np.nan) if want_stats else None
+            p.out, p.out_stats = S.ptr(out), S.ptr(stats)
+            S.check(L.dmd_conv2d_kernel_name(p, buf, 96), "kernel_name")
+            assert buf.value.decode().startswith("conv_lat_kernel") == (cap != "0")
+            S.check(L.dmd_conv2d(p, None), "dmd_conv2d")
+            res[cap] = (out, stats)
+        a, b = res["0"], res["1000000"]
+        what = (n, h, w, stride, up, cins, cout, prol, residual)
+        assert np.isfinite(b[0]).all(), what
+        assert np.abs(a[0] - b[0]).max() <= 1e-5 * max(1.0, np.abs(a[0]).max()), what
+        if want_stats:
+            np.testing.assert_allclose(a[1].sum(axis=2), b[1].sum(axis=2), rtol=1e-5, atol=1e-3, err_msg=str(what))
+            if w % 16 == 0 or stride == 1:  # same partial layout on both routes: compare tile by tile
+                np.testing.assert_allclose(a[1], b[1], rtol=1e-4, atol=1e-3, err_msg=str(what))
+    print(f"{routed} of {tried} random launches were eligible for the few-tile kernels")
+    assert routed >= 70, (tried, routed)
