@@ -517,6 +517,7 @@ __global__ void pack_weight_kernel(const float* oihw, float* packed, int Cout, i
 extern "C" int dmd_conv2d_proj_eligible(const dmd_conv_params* p);
 int dmd_conv_lat_route(const dmd_conv_params& p);                     // dmd_conv_lat.hip (few-tile launches; STAGED, off by default)
 int dmd_launch_conv_lat(const dmd_conv_params& p, hipStream_t st);
+void dmd_conv_lat_kernel_name(const dmd_conv_params& p, char* buf, int buf_len);
 static int validate_conv(const dmd_conv_params* p) {
   DMD_CHECK_ARG(p != nullptr, "conv: null params");
   DMD_CHECK_ARG(p->N > 0 && p->H > 0 && p->W > 0, "conv: bad N/H/W %d %d %d", p->N, p->H, p->W);
@@ -617,7 +618,7 @@ extern "C" int dmd_conv2d_kernel_name(const dmd_conv_params* p, char* buf, int b
     snprintf(buf, buf_len, "conv1x1_stream_kernel<%d, %d, %s>", cin / 16, cin == 128 ? 2 : 4,
              (p->precision & 0xff) == DMD_PRECISION_F16X2 ? "true" : "false");
   } else if (dmd_conv_lat_route(*p)) {
-    snprintf(buf, buf_len, "conv_lat_kernel<%s>", p->proj_nsrc ? "true" : "false");
+    dmd_conv_lat_kernel_name(*p, buf, buf_len);
   } else if (p->proj_nsrc) {
     snprintf(buf, buf_len, "conv_f16ws_kernel<WsGeomProj>");
   } else if (dmd_conv2d_f16x2_eligible(p)) {

@@ -660,6 +660,7 @@ extern "C" int dmd_conv2d_latency_eligible(const dmd_conv_params* p) {
 // the 256-batch launch of the reward / end encoder runs at 2.5x its HBM time on the pipelined kernel), so a large value there
 // asks whether plain occupancy -- two of these workgroups per CU, every load of a workgroup in flight at once -- streams
 // better than the producer / consumer pipeline does; tools/gpu/staged_latency.sh measures that too.
+// (Read per launch while the kernels are staged: tests and the A/B scripts flip the caps inside one process.)
 int dmd_conv_lat_route(const dmd_conv_params& p) {
   const char* e = getenv("DIAMOND_CONV_LATENCY_TILES");
   long long cap = e ? atoll(e) : 0;
@@ -668,6 +669,19 @@ int dmd_conv_lat_route(const dmd_conv_params& p) {
   if (cap <= 0 || !dmd_conv2d_latency_eligible(&p)) return 0;
   const long long tiles16 = (long long)p.N * p.H * p.W / 256;  // 256-pixel tiles
   return tiles16 <= cap ? 1 : 0;
+}
+
+// the instantiation dmd_launch_conv_lat picks, spelled like rocprofv3's kernel trace (dmd_conv2d_kernel_name)
+void dmd_conv_lat_kernel_name(const dmd_conv_params& p, char* buf, int buf_len) {
+  const int cin = p.src[0].C + (p.nsrc > 1 ? p.src[1].C : 0);
+  if (p.W % 16 != 0)
+    snprintf(buf, buf_len, "conv_lat_b8_kernel<%d, %d>", cin / 4, p.Cout);
+  else if (p.stride == 2)
+    snprintf(buf, buf_len, "conv_lat_s2_kernel<%d, %d>", cin / 4, p.Cout);
+  else if (p.out_nchw)
+    snprintf(buf, buf_len, "conv_lat_kernel<false, 16, 32, true>");
+  else
+    snprintf(buf, buf_len, "conv_lat_kernel<%s, %d, %d, false>", p.proj_nsrc ? "true" : "false", cin / 4, p.Cout);
 }
 
 int dmd_launch_conv_lat(const dmd_conv_params& p, hipStream_t st) {

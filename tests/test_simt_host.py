@@ -60,11 +60,11 @@ def test_denoiser_latency_route_vs_reference_golden_on_the_interpreter(models, m
     M, counter = models
     monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", "64")
     M.test_denoiser_vs_reference_golden("default", (0, 0, 0, 0), 2)
-    lat = sum(v for k, v in counter.n.items() if k.startswith("conv_lat_kernel"))
+    lat = sum(v for k, v in counter.n.items() if k.startswith("conv_lat_"))
     ws = sum(v for k, v in counter.n.items() if k.startswith("conv_f16ws_kernel"))
     print(counter.n)
     evals = 8  # model output + denoised frame at four sigmas
-    assert lat >= evals * 30 and counter.n.get("conv_lat_kernel<true>", 0) >= evals * 9, counter.n
+    assert lat >= evals * 30 and counter.n.get("conv_lat_kernel<true, 16, 64, false>", 0) >= evals * 9, counter.n
     # what is left: the fused 8x8 level and the stride-2 convolution INTO it (8 x 8 outputs are off the 8 x 16 tile grid)
     assert ws == 0 and [k for k in counter.n if k.startswith("conv_mfma_kernel")] == ["conv_mfma_kernel<ConvGeom<4, true, 9, 2, true>>"], counter.n
 
@@ -95,7 +95,7 @@ def test_rew_end_model_and_actor_critic_vs_goldens_on_the_interpreter(models, mo
     ag = M.make_agent()
     M.test_rew_end_model_vs_golden(ag)
     M.test_actor_critic_vs_golden(ag)
-    lat = sum(v for k, v in counter.n.items() if k.startswith("conv_lat_kernel"))
+    lat = sum(v for k, v in counter.n.items() if k.startswith("conv_lat_"))
     assert (lat >= 30) if cap != "0" else (lat == 0), counter.n
     assert counter.n.get("dmd_lowres_chain32", 0) >= 2 and counter.n.get("dmd_lstm_pointwise_bwd", 0) >= 1, counter.n
 

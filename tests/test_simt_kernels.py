@@ -802,7 +802,15 @@ def test_conv_latency_kernel(case, monkeypatch):
     name = bytes(96)
     buf = (nv.C.c_char * 96)()
     S.check(L.dmd_conv2d_kernel_name(p, buf, 96), "kernel_name")
-    assert buf.value.decode() == f"conv_lat_kernel<{'true' if case.get('proj') else 'false'}>"
+    name = buf.value.decode()
+    if w % 16:
+        assert name == f"conv_lat_b8_kernel<{cin // 4}, {cout}>"
+    elif stride == 2:
+        assert name == f"conv_lat_s2_kernel<{cin // 4}, {cout}>"
+    elif nchw:
+        assert name == "conv_lat_kernel<false, 16, 32, true>"
+    else:
+        assert name == f"conv_lat_kernel<{'true' if case.get('proj') else 'false'}, {cin // 4}, {cout}, false>"
     S.check(L.dmd_conv2d(p, None), "dmd_conv2d")
     got = out.transpose(0, 2, 3, 1) if nchw else out
     err = np.abs(got - ref).max()
@@ -945,7 +953,7 @@ def test_conv_latency_route_caps(monkeypatch):
         p.N, p.H, p.W, p.Cout, p.CoutPad, p.taps, p.stride, p.nsrc, p.precision = 4, 16, 16, cout, cout, 9, 1, 1, 1
         p.src[0].x, p.src[0].C, p.w, p.w_f16, p.out = S.ptr(x), cin, S.ptr(x), S.ptr(x), S.ptr(x)
         S.check(L.dmd_conv2d_kernel_name(p, buf, 96), "kernel_name")
-        return buf.value.decode().startswith("conv_lat_kernel")
+        return buf.value.decode().startswith("conv_lat_")
 
     monkeypatch.delenv("DIAMOND_CONV_LATENCY_TILES", raising=False)
     monkeypatch.delenv("DIAMOND_CONV_LATENCY_TILES_C32", raising=False)
@@ -1018,7 +1026,7 @@ def test_conv_routes_agree_on_random_shapes(monkeypatch):
             stats = np.full((n, cout // 32, tiles, 2), np.nan) if want_stats else None
             p.out, p.out_stats = S.ptr(out), S.ptr(stats)
             S.check(L.dmd_conv2d_kernel_name(p, buf, 96), "kernel_name")
-            assert buf.value.decode().startswith("conv_lat_kernel") == (cap != "0")
+            assert buf.value.decode().startswith("conv_lat_") == (cap != "0")
             S.check(L.dmd_conv2d(p, None), "dmd_conv2d")
             res[cap] = (out, stats)
         a, b = res["0"], res["1000000"]
