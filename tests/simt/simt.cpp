@@ -71,10 +71,14 @@ struct Worker {
   Fiber* cur = nullptr;
   const std::function<void()>* body = nullptr;
   int nlanes = 0, nwaves = 0, done = 0;
-  std::vector<unsigned char> dyn_lds;
+  // dynamic LDS: the block ENDS at an inaccessible page, so a kernel that reaches beyond the bytes its launch asked for faults
+  // here instead of reading / writing a neighbour's data unnoticed (on the device: another workgroup's LDS, or a memory fault)
+  unsigned char* lds_map = nullptr;
+  static constexpr size_t LDS_MAP = 192 * 1024, PAGE = 4096;
   Block block;
   ~Worker() {
     if (stacks) munmap(stacks, STACK_BYTES * MAX_LANES);
+    if (lds_map) munmap(lds_map, LDS_MAP + PAGE);
   }
 };
 
@@ -136,11 +140,16 @@ void run_block(Worker* w, u3 bid, u3 bdim, u3 gdim, size_t dyn_lds, const std::f
     w->fibers.resize(MAX_LANES);
     w->waves.resize(MAX_LANES / 64);
   }
-  if (w->dyn_lds.size() < dyn_lds + 64) w->dyn_lds.resize(dyn_lds + 64);
+  if (!w->lds_map) {
+    w->lds_map = (unsigned char*)mmap(nullptr, Worker::LDS_MAP + Worker::PAGE, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (w->lds_map == (unsigned char*)MAP_FAILED) die("mmap of the LDS block failed");
+    if (mprotect(w->lds_map + Worker::LDS_MAP, Worker::PAGE, PROT_NONE) != 0) die("mprotect of the LDS guard page failed");
+  }
+  if (dyn_lds > 160 * 1024) die("a launch asks for more than 160 KiB of dynamic LDS");
   w->block.bid = bid;
   w->block.bdim = bdim;
   w->block.gdim = gdim;
-  w->block.dyn_lds = (unsigned char*)(((uintptr_t)w->dyn_lds.data() + 63) & ~(uintptr_t)63);
+  w->block.dyn_lds = w->lds_map + Worker::LDS_MAP - ((dyn_lds + 15) & ~(size_t)15);  // 16-byte aligned, ends at the guard page
   w->body = &body;
   w->nlanes = n;
   w->nwaves = (n + 63) / 64;

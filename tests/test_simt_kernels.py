@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from tests.simt import loader as S
+from tests.simt.fence import fenced as G  # arrays between inaccessible pages: an out-of-bounds access of a kernel faults
 
 
 def test_product_refuses_the_host_build(monkeypatch):
@@ -144,7 +145,7 @@ def test_conv2d(case):
         p.valid_h, p.valid_w = hv, wv
     keep, xs_ref = [], []
     for i, c in enumerate(cins):
-        x = (rng.standard_normal((n, hs, ws, c)) * 1.5 + 0.3).astype(np.float32)
+        x = G((rng.standard_normal((n, hs, ws, c)) * 1.5 + 0.3).astype(np.float32), tight="start" if (n + hs + c) % 2 else "end")
         p.src[i].x, p.src[i].C, p.src[i].prologue = S.ptr(x), c, prol[i]
         if prol[i]:
             tiles = 3
@@ -169,7 +170,7 @@ def test_conv2d(case):
 
     ref = _ref_conv(xs_ref, wt, bias[:cout], k, stride, up, hv, wv)
     if case.get("residual"):
-        r = rng.standard_normal((n, h, w, cout)).astype(np.float32)
+        r = G(rng.standard_normal((n, h, w, cout)).astype(np.float32))
         p.residual = S.ptr(r)
         if case["residual"] == "norm":
             rst = _partial_stats(r, hv, wv, 2, rng)
@@ -183,10 +184,10 @@ def test_conv2d(case):
         keep.append(r)
 
     nchw = bool(case.get("nchw"))
-    out = np.full((n, cout, h, w) if nchw else (n, h, w, cout), np.nan, dtype=np.float32)
+    out = G(np.full((n, cout, h, w) if nchw else (n, h, w, cout), np.nan, dtype=np.float32))
     p.out, p.out_nchw = S.ptr(out), int(nchw)
     tiles = L.dmd_conv_stat_tiles(h, w)
-    stats = np.full((n, cout // 32, tiles, 2), np.nan) if case.get("stats") else None
+    stats = G(np.full((n, cout // 32, tiles, 2), np.nan)) if case.get("stats") else None
     p.out_stats = S.ptr(stats)
 
     name = (b" " * 160)
@@ -236,7 +237,8 @@ def test_conv2d_wgrad(case, plan, monkeypatch):
     cin_real, prol = case.get("cin_real", cin), case.get("prologue", 0)
     x = (rng.standard_normal((n, h, w, cin)) * 1.2 - 0.2).astype(np.float32)
     x[..., cin_real:] = 0
-    dy = rng.standard_normal((n, h, w, cout)).astype(np.float32)
+    x = G(x, tight="start" if (n + h) % 2 else "end")
+    dy = G(rng.standard_normal((n, h, w, cout)).astype(np.float32))
     p = nv.WgradParams()
     p.N, p.H, p.W, p.Cout, p.taps, p.cin_real, p.precision = n, h, w, cout, k * k, cin_real, case.get("precision", 0)
     p.src.x, p.src.C, p.src.prologue = S.ptr(x), cin, prol
@@ -252,7 +254,7 @@ def test_conv2d_wgrad(case, plan, monkeypatch):
         keep += [st, mul, add]
     p.dy = S.ptr(dy)
     ws = np.full(L.dmd_wgrad_workspace_floats(p), np.nan, dtype=np.float32)
-    dw = np.full((cout, cin_real, k, k), np.nan, dtype=np.float32)
+    dw = G(np.full((cout, cin_real, k, k), np.nan, dtype=np.float32))
     db = None if case.get("no_bias") else np.full(cout, np.nan, dtype=np.float32)
     p.workspace, p.dw, p.dbias = S.ptr(ws), S.ptr(dw), S.ptr(db)
     S.check(L.dmd_conv2d_wgrad(p, None), "dmd_conv2d_wgrad")
@@ -630,7 +632,7 @@ def test_maxpool_lstm_categorical():
 def _pack16(w_oihw):
     """split-fp16 pack of an OIHW weight through dmd_pack_jobs"""
     co, ci, k, _ = w_oihw.shape
-    dst = np.zeros((ci // 16, k * k, 2, 2, co, 8), dtype=np.float16)
+    dst = G(np.zeros((ci // 16, k * k, 2, 2, co, 8), dtype=np.float16))
     j = nv.PackJob()
     j.src, j.dst, j.Cout, j.Cin, j.k, j.kind, j.CoutPad, j.CinPad = S.ptr(w_oihw), S.ptr(dst), co, ci, k, nv.PACK_F16X2, co, ci
     S.check(S.lib().dmd_pack_jobs((nv.PackJob * 1)(j), 1, dst.size, None), "dmd_pack_jobs")
@@ -757,7 +759,7 @@ def test_conv_latency_kernel(case, monkeypatch):
     p.N, p.H, p.W, p.Cout, p.CoutPad, p.taps, p.stride, p.upsample, p.nsrc, p.precision = n, h, w, cout, cout_pad, 9, stride, up, len(cins), 1
     keep, xs_ref = [], []
     for i, c in enumerate(cins):
-        x = (rng.standard_normal((n, hs, ws, c)) * 1.5 + 0.3).astype(np.float32)
+        x = G((rng.standard_normal((n, hs, ws, c)) * 1.5 + 0.3).astype(np.float32), tight="start" if (n + hs + c) % 2 else "end")
         p.src[i].x, p.src[i].C, p.src[i].prologue = S.ptr(x), c, prol[i]
         if prol[i]:
             tiles = 70 if i == 0 else 3  # more partial sums than lanes: the finalising wave strides over them
@@ -781,21 +783,21 @@ def test_conv_latency_kernel(case, monkeypatch):
     p.w, p.bias, p.w_f16 = S.ptr(packed), S.ptr(bias), S.ptr(w16)
     ref = _ref_conv(xs_ref, wt[:cout], bias[:cout], 3, stride, up, h, w)
     if case.get("residual"):
-        r = rng.standard_normal((n, h, w, cout)).astype(np.float32)
+        r = G(rng.standard_normal((n, h, w, cout)).astype(np.float32))
         p.residual = S.ptr(r)
         ref = ref + r
     if case.get("proj"):
-        j0, j1 = (rng.standard_normal((n, h, w, 64)).astype(np.float32) for _ in range(2))
+        j0, j1 = (G(rng.standard_normal((n, h, w, 64)).astype(np.float32)) for _ in range(2))
         wpj = (rng.standard_normal((cout, 128, 1, 1)) / np.sqrt(128)).astype(np.float32)
         bpj = rng.standard_normal(cout).astype(np.float32)
         wpj16 = _pack16(wpj)
         p.proj_nsrc, p.proj_C[0], p.proj_C[1] = 2, 64, 64
         p.proj_x[0], p.proj_x[1], p.proj_w_f16, p.proj_bias = S.ptr(j0), S.ptr(j1), S.ptr(wpj16), S.ptr(bpj)
         ref = ref + _ref_conv([j0.astype(np.float64), j1.astype(np.float64)], wpj, bpj, 1, 1, 0, h, w)
-    out = np.full((n, cout, h, w) if nchw else (n, h, w, cout), np.nan, dtype=np.float32)
+    out = G(np.full((n, cout, h, w) if nchw else (n, h, w, cout), np.nan, dtype=np.float32))
     p.out_nchw = int(nchw)
     tiles = L.dmd_conv_stat_tiles(h, w)
-    stats = np.full((n, cout // 32, tiles, 2), np.nan) if case.get("stats") else None
+    stats = G(np.full((n, cout // 32, tiles, 2), np.nan)) if case.get("stats") else None
     p.out, p.out_stats = S.ptr(out), S.ptr(stats)
 
     assert L.dmd_conv2d_latency_eligible(p) == 1
@@ -887,7 +889,7 @@ def test_conv_f16ws(case, monkeypatch):
         p.valid_h, p.valid_w = hv, wv
     keep, xs_ref = [], []
     for i, c in enumerate(cins):
-        x = (rng.standard_normal((n, hs, ws, c)) * 1.5 + 0.3).astype(np.float32)
+        x = G((rng.standard_normal((n, hs, ws, c)) * 1.5 + 0.3).astype(np.float32), tight="start" if (n + hs + c) % 2 else "end")
         p.src[i].x, p.src[i].C, p.src[i].prologue = S.ptr(x), c, prol[i]
         if prol[i]:
             st = _partial_stats(x, hvs, wvs, 3, rng)
@@ -910,11 +912,11 @@ def test_conv_f16ws(case, monkeypatch):
     p.w, p.bias, p.w_f16 = S.ptr(packed), S.ptr(bias), S.ptr(w16)
     ref = _ref_conv(xs_ref, wt[:cout], bias[:cout], k, 1, up, hv, wv)
     if case.get("residual"):
-        r = rng.standard_normal((n, h, w, cout)).astype(np.float32)
+        r = G(rng.standard_normal((n, h, w, cout)).astype(np.float32))
         p.residual = S.ptr(r)
         ref = ref + r
     if case.get("proj"):
-        j0, j1 = (rng.standard_normal((n, h, w, 64)).astype(np.float32) for _ in range(2))
+        j0, j1 = (G(rng.standard_normal((n, h, w, 64)).astype(np.float32)) for _ in range(2))
         wpj = (rng.standard_normal((cout, 128, 1, 1)) / np.sqrt(128)).astype(np.float32)
         bpj = rng.standard_normal(cout).astype(np.float32)
         wpj16 = _pack16(wpj)
@@ -923,10 +925,10 @@ def test_conv_f16ws(case, monkeypatch):
         ref = ref + _ref_conv([j0.astype(np.float64), j1.astype(np.float64)], wpj, bpj, 1, 1, 0, h, w)
         assert L.dmd_conv2d_proj_eligible(p) == 1
     nchw = bool(case.get("nchw"))
-    out = np.full((n, cout, h, w) if nchw else (n, h, w, cout), np.nan, dtype=np.float32)
+    out = G(np.full((n, cout, h, w) if nchw else (n, h, w, cout), np.nan, dtype=np.float32))
     p.out, p.out_nchw = S.ptr(out), int(nchw)
     tiles = L.dmd_conv_stat_tiles(h, w)
-    stats = np.full((n, cout // 32, tiles, 2), np.nan) if case.get("stats") else None
+    stats = G(np.full((n, cout // 32, tiles, 2), np.nan)) if case.get("stats") else None
     p.out_stats = S.ptr(stats)
 
     assert L.dmd_conv2d_f16x2_eligible(p) == 1
@@ -996,7 +998,7 @@ def test_conv_routes_agree_on_random_shapes(monkeypatch):
         p.N, p.H, p.W, p.Cout, p.CoutPad, p.taps, p.stride, p.upsample, p.nsrc, p.precision = n, h, w, cout, cout, 9, stride, up, len(cins), 1
         keep = []
         for i, c in enumerate(cins):
-            x = (rng.standard_normal((n, hs, ws, c)) * 1.3).astype(np.float32)
+            x = G((rng.standard_normal((n, hs, ws, c)) * 1.3).astype(np.float32), tight="start" if (n + hs) % 2 else "end")
             p.src[i].x, p.src[i].C, p.src[i].prologue = S.ptr(x), c, prol[i]
             if prol[i]:
                 st = _partial_stats(x, hs, ws, 2, rng)
@@ -1012,7 +1014,7 @@ def test_conv_routes_agree_on_random_shapes(monkeypatch):
         w16 = _pack16(wt)
         p.w, p.bias, p.w_f16 = S.ptr(packed), S.ptr(bias), S.ptr(w16)
         if residual:
-            r = rng.standard_normal((n, h, w, cout)).astype(np.float32)
+            r = G(rng.standard_normal((n, h, w, cout)).astype(np.float32))
             p.residual = S.ptr(r)
         tried += 1
         if not L.dmd_conv2d_latency_eligible(p):
@@ -1022,8 +1024,8 @@ def test_conv_routes_agree_on_random_shapes(monkeypatch):
         res = {}
         for cap in ("0", "1000000"):
             monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", cap)
-            out = np.full((n, h, w, cout), np.nan, dtype=np.float32)
-            stats = np.full((n, cout // 32, tiles, 2), np.nan) if want_stats else None
+            out = G(np.full((n, h, w, cout), np.nan, dtype=np.float32))
+            stats = G(np.full((n, cout // 32, tiles, 2), np.nan)) if want_stats else None
             p.out, p.out_stats = S.ptr(out), S.ptr(stats)
             S.check(L.dmd_conv2d_kernel_name(p, buf, 96), "kernel_name")
             assert buf.value.decode().startswith("conv_lat_") == (cap != "0")
