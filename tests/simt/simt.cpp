@@ -169,15 +169,23 @@ void run_block(Worker* w, u3 bid, u3 bdim, u3 gdim, size_t dyn_lds, const std::f
     wv.live = (v == w->nwaves - 1 && n % 64) ? n % 64 : 64;
     memset(wv.in, 0, sizeof(wv.in));
   }
+  // SIMT_SCHEDULE: the order in which runnable waves / lanes are resumed (0: ascending, 1: descending, 2: odd waves first).  A
+  // correctly synchronised kernel computes the same bits under every order; tests run a kernel under several and compare.
+  int schedule = 0;
+  if (const char* e = getenv("SIMT_SCHEDULE")) schedule = atoi(e);
   while (w->done < n) {
     bool progressed = false;
-    for (int v = 0; v < w->nwaves; ++v) {
+    for (int vi = 0; vi < w->nwaves; ++vi) {
+      int v = vi;
+      if (schedule == 1) v = w->nwaves - 1 - vi;
+      else if (schedule == 2) v = (2 * vi + 1 < w->nwaves) ? 2 * vi + 1 : 2 * (vi - w->nwaves / 2);
       bool again = true;
       while (again) {
         again = false;
-        for (int l = 0; l < 64; ++l) {
+        for (int li = 0; li < 64; ++li) {
+          const int l = schedule == 1 ? 63 - li : li;
           const int t = v * 64 + l;
-          if (t >= n) break;
+          if (t >= n) continue;
           Fiber& f = w->fibers[t];
           if (f.state != RUNNABLE) continue;
           w->cur = &f;

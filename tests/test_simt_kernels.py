@@ -23,6 +23,25 @@ def test_product_refuses_the_host_build(monkeypatch):
         nv.lib()
 
 
+# ---- schedule independence: a correctly synchronised kernel computes the SAME BITS in whatever order the interpreter resumes
+#      its waves and lanes (SIMT_SCHEDULE 0: ascending, 1: descending, 2: odd waves first); a missing barrier or a read of LDS
+#      that another wave is still writing shows up as a difference.  Results of schedule 0 are kept and compared by test id. ----
+_BITS = {}
+_COMPARED = [0]
+SCHEDULES = [0, 1, 2]
+
+
+def _same_bits_as_schedule_0(request, schedule, *arrays):
+    key = request.node.name.replace(f"[{schedule}-", "[").replace(f"-{schedule}]", "]")
+    blob = b"".join(np.ascontiguousarray(a).tobytes() for a in arrays if a is not None)
+    if schedule == 0:
+        _BITS[key] = blob
+    elif key in _BITS:  # (absent when a single schedule was selected with -k)
+        _COMPARED[0] += 1
+        assert _BITS[key] == blob, f"{key}: results depend on the wave schedule ({schedule} vs 0)"
+
+
+
 def _group_sums(x, hv=None, wv=None):
     n, h, w, c = x.shape
     v = x[:, :hv, :wv].astype(np.float64).reshape(n, -1, c // 32, 32)
@@ -222,9 +241,11 @@ WGRAD_PLANS = [dict(), dict(mode=2), dict(mode=3), dict(mode=2, max_wg=1), dict(
 # (DIAMOND_WGRAD_SINGLE_REDUCE: test_conv2d_wgrad_many_partials below)
 
 
+@pytest.mark.parametrize("schedule", SCHEDULES)
 @pytest.mark.parametrize("plan", WGRAD_PLANS, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()) or "default")
 @pytest.mark.parametrize("case", WGRAD_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
-def test_conv2d_wgrad(case, plan, monkeypatch):
+def test_conv2d_wgrad(case, plan, schedule, monkeypatch, request):
+    monkeypatch.setenv("SIMT_SCHEDULE", str(schedule))
     if "mode" in plan and not case.get("precision"):
         pytest.skip("the staged modes are split-precision kernels")
     if "mode" in plan:
@@ -258,6 +279,7 @@ def test_conv2d_wgrad(case, plan, monkeypatch):
     db = None if case.get("no_bias") else np.full(cout, np.nan, dtype=np.float32)
     p.workspace, p.dw, p.dbias = S.ptr(ws), S.ptr(dw), S.ptr(db)
     S.check(L.dmd_conv2d_wgrad(p, None), "dmd_conv2d_wgrad")
+    _same_bits_as_schedule_0(request, schedule, dw, db)
 
     pad = k // 2
     ap = np.pad(a, ((0, 0), (pad, pad), (pad, pad), (0, 0)))
@@ -643,8 +665,10 @@ def _ada_gn_silu(x, scale, shift):
     return _apply_norm(x, x.shape[1], x.shape[2], scale, shift, True, silu=True)
 
 
+@pytest.mark.parametrize("schedule", SCHEDULES)
 @pytest.mark.parametrize("c", [64, 32], ids=["denoiser-64ch", "rew-end-32ch"])
-def test_lowres_chain(c):
+def test_lowres_chain(c, schedule, monkeypatch, request):
+    monkeypatch.setenv("SIMT_SCHEDULE", str(schedule))
     rng = np.random.default_rng(41 + c)
     L = S.lib()
     n = 2
@@ -700,6 +724,7 @@ def test_lowres_chain(c):
         keep.append(packs)
         blocks.append(b)
     S.check((L.dmd_lowres_chain if c == 64 else L.dmd_lowres_chain32)(p, None), "dmd_lowres_chain")
+    _same_bits_as_schedule_0(request, schedule, out)
 
     # fp64 restatement of ResBlock.forward (blocks.py:141-147) / SelfAttention2d.forward (blocks.py:62-72)
     cur, slots = x.astype(np.float64), {0: x.astype(np.float64)}
@@ -744,9 +769,11 @@ LAT_CASES = [
 ]
 
 
+@pytest.mark.parametrize("schedule", SCHEDULES)
 @pytest.mark.parametrize("case", LAT_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()).replace(" ", ""))
-def test_conv_latency_kernel(case, monkeypatch):
+def test_conv_latency_kernel(case, schedule, monkeypatch, request):
     monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", "64")
+    monkeypatch.setenv("SIMT_SCHEDULE", str(schedule))
     rng = np.random.default_rng(17)
     L = S.lib()
     n, h, w, cins = case["n"], case["h"], case["w"], case["cin"]
@@ -817,6 +844,7 @@ def test_conv_latency_kernel(case, monkeypatch):
     got = out.transpose(0, 2, 3, 1) if nchw else out
     err = np.abs(got - ref).max()
     assert err <= 2e-5 * max(1.0, np.abs(ref).max()), err
+    _same_bits_as_schedule_0(request, schedule, out, stats)
     if stats is not None:
         # one partial per 8 x 16 tile and 32-channel group, in dmd_conv_stat_tiles order
         tw = 16 if w % 16 == 0 else 8
@@ -871,9 +899,11 @@ WS_CASES = [
 ]
 
 
+@pytest.mark.parametrize("schedule", SCHEDULES)
 @pytest.mark.parametrize("case", WS_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()).replace(" ", ""))
-def test_conv_f16ws(case, monkeypatch):
+def test_conv_f16ws(case, schedule, monkeypatch, request):
     monkeypatch.delenv("DIAMOND_CONV_LATENCY_TILES", raising=False)
+    monkeypatch.setenv("SIMT_SCHEDULE", str(schedule))
     rng = np.random.default_rng(23)
     L = S.lib()
     n, h, w, cins, cout, k = case["n"], case["h"], case["w"], case["cin"], case["cout"], case["k"]
@@ -939,6 +969,7 @@ def test_conv_f16ws(case, monkeypatch):
     got = out.transpose(0, 2, 3, 1) if nchw else out
     err = np.abs(got[:, :hv, :wv] - ref[:, :hv, :wv]).max()
     assert err <= 2e-5 * max(1.0, np.abs(ref).max()), (buf.value, err)
+    _same_bits_as_schedule_0(request, schedule, out[:, :hv, :wv] if not nchw else out[:, :, :hv, :wv], stats)
     if stats is not None:
         want = _group_sums(np.ascontiguousarray(got.astype(np.float32)), hv, wv)
         np.testing.assert_allclose(stats.sum(axis=2), want, rtol=2e-6, atol=1e-4)  # (fp32 sums of a lane's 16 values inside)
@@ -1041,3 +1072,10 @@ def test_conv_routes_agree_on_random_shapes(monkeypatch):
                 np.testing.assert_allclose(a[1], b[1], rtol=1e-4, atol=1e-3, err_msg=str(what))
     print(f"{routed} of {tried} random launches were eligible for the few-tile kernels")
     assert routed >= 70, (tried, routed)
+
+
+def test_zz_schedule_comparisons_took_place():
+    """(runs last in this file) the bitwise comparisons across wave schedules above were made, not skipped by a key mismatch"""
+    if len(_BITS) < 50:
+        pytest.skip("a subset of the file was selected")
+    assert _COMPARED[0] >= 2 * len(_BITS) - 4, (_COMPARED[0], len(_BITS))
