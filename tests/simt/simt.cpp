@@ -150,6 +150,7 @@ void run_block(Worker* w, u3 bid, u3 bdim, u3 gdim, size_t dyn_lds, const std::f
   w->block.bdim = bdim;
   w->block.gdim = gdim;
   w->block.dyn_lds = w->lds_map + Worker::LDS_MAP - ((dyn_lds + 15) & ~(size_t)15);  // 16-byte aligned, ends at the guard page
+  memset(w->block.dyn_lds, 0xff, dyn_lds);  // poison: whatever a kernel reads before it has written it is a NaN (fp32 / fp16 alike)
   w->body = &body;
   w->nlanes = n;
   w->nwaves = (n + 63) / 64;
