@@ -274,7 +274,7 @@ def test_conv2d_wgrad(case, plan, schedule, monkeypatch, request):
         a = _apply_norm(x, h, w, mul, add, bool(case.get("film")), silu=prol == 1)
         keep += [st, mul, add]
     p.dy = S.ptr(dy)
-    ws = np.full(L.dmd_wgrad_workspace_floats(p), np.nan, dtype=np.float32)
+    ws = G(np.full(L.dmd_wgrad_workspace_floats(p), np.nan, dtype=np.float32))  # sized by the library: an overrun faults
     dw = G(np.full((cout, cin_real, k, k), np.nan, dtype=np.float32))
     db = None if case.get("no_bias") else np.full(cout, np.nan, dtype=np.float32)
     p.workspace, p.dw, p.dbias = S.ptr(ws), S.ptr(dw), S.ptr(db)
@@ -314,7 +314,7 @@ def test_conv2d_wgrad_many_partials(monkeypatch):
         p = nv.WgradParams()
         p.N, p.H, p.W, p.Cout, p.taps, p.cin_real, p.precision = n, h, w, c, 9, c, 1
         p.src.x, p.src.C, p.src.prologue, p.dy = S.ptr(x), c, 0, S.ptr(dy)
-        ws = np.full(L.dmd_wgrad_workspace_floats(p), np.nan, dtype=np.float32)
+        ws = G(np.full(L.dmd_wgrad_workspace_floats(p), np.nan, dtype=np.float32))
         dw, db = np.full((c, c, 3, 3), np.nan, dtype=np.float32), np.full(c, np.nan, dtype=np.float32)
         p.workspace, p.dw, p.dbias = S.ptr(ws), S.ptr(dw), S.ptr(db)
         S.check(L.dmd_conv2d_wgrad(p, None), "dmd_conv2d_wgrad")
@@ -366,8 +366,8 @@ def test_attention_bwd():
     y64, p, (q, k, v) = _ref_attention(qkv, c)
     y = y64.astype(np.float32)
     L = S.lib()
-    ws = np.full(L.dmd_attention_bwd_workspace_floats(n, t, c), np.nan, dtype=np.float32)
-    dqkv = np.full_like(qkv, np.nan)
+    ws = G(np.full(L.dmd_attention_bwd_workspace_floats(n, t, c), np.nan, dtype=np.float32))
+    dqkv = G(np.full_like(qkv, np.nan))
     S.check(L.dmd_attention_bwd(S.ptr(qkv), S.ptr(y), S.ptr(dy), S.ptr(dqkv), S.ptr(ws), n, t, c, 8, None), "dmd_attention_bwd")
     g = dy.astype(np.float64).reshape(n, t, c // 8, 8).transpose(0, 2, 1, 3)
     dp = g @ v.transpose(0, 1, 3, 2)
@@ -417,9 +417,9 @@ def test_gn_silu_bwd(n, hw, c, identity, skip, fold, monkeypatch):
     p = nv.GnBwdParams()
     p.N, p.HW, p.C, p.identity_activation = n, hw, c, identity
     p.x, p.norm, p.da, p.dskip = S.ptr(x), _norm(st, 2, mul, add, plus_one=True), S.ptr(da), S.ptr(dskip)
-    dx = np.full_like(x, np.nan)
-    dmul, dadd = np.full((n, c), np.nan, dtype=np.float32), np.full((n, c), np.nan, dtype=np.float32)
-    ws = np.zeros(L.dmd_gn_bwd_workspace_bytes(n, hw, c), dtype=np.uint8)
+    dx = G(np.full_like(x, np.nan))
+    dmul, dadd = G(np.full((n, c), np.nan, dtype=np.float32)), G(np.full((n, c), np.nan, dtype=np.float32))
+    ws = G(np.zeros(L.dmd_gn_bwd_workspace_bytes(n, hw, c), dtype=np.uint8))
     p.dx, p.workspace, p.dmul, p.dadd = S.ptr(dx), S.ptr(ws), S.ptr(dmul), S.ptr(dadd)
     S.check(L.dmd_gn_silu_bwd(p, None), "dmd_gn_silu_bwd")
 
