@@ -73,6 +73,7 @@ struct Worker {
   int nlanes = 0, nwaves = 0, done = 0;
   // dynamic LDS: the block ENDS at an inaccessible page, so a kernel that reaches beyond the bytes its launch asked for faults
   // here instead of reading / writing a neighbour's data unnoticed (on the device: another workgroup's LDS, or a memory fault)
+  unsigned long long n_barriers = 0, n_ops[16] = {};  // SIMT_STATS: wave-level barriers / operations by opcode, of this worker
   unsigned char* lds_map = nullptr;
   static constexpr size_t LDS_MAP = 192 * 1024, PAGE = 4096;
   Block block;
@@ -110,6 +111,7 @@ void fiber_main() {
 }
 
 void complete_wave_op(Worker* w, Wave& wv, int wave_index) {
+  ++w->n_ops[wv.opcode & 15];
   uint64_t live = wv.arrived_mask;
   wv.fn(wv.in, SLOT, wv.out, SLOT, live, wv.imm);
   wv.arrived = 0;
@@ -217,6 +219,7 @@ void run_block(Worker* w, u3 bid, u3 bdim, u3 gdim, size_t dyn_lds, const std::f
     int waiting = 0;
     for (int t = 0; t < n; ++t) waiting += w->fibers[t].state == WAIT_BLOCK;
     if (waiting && waiting == n - w->done) {
+      ++w->n_barriers;
       for (int t = 0; t < n; ++t)
         if (w->fibers[t].state == WAIT_BLOCK) w->fibers[t].state = RUNNABLE;
       progressed = true;
@@ -282,6 +285,7 @@ void wave_op(int opcode, const void* in, size_t in_bytes, void* out, size_t out_
 // Persistent worker threads: a launch hands them (grid, block, body) and waits; lane stacks and the thread_local LDS arrays of
 // the kernels are set up once per worker, not once per launch.
 namespace {
+std::atomic<unsigned long long> g_barriers{0}, g_ops[16];
 struct Pool {
   std::mutex m;
   std::condition_variable cv_job, cv_done;
@@ -311,6 +315,12 @@ struct Pool {
         if (b >= nblocks) break;
         const u3 bid = {(unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((size_t)grid.x * grid.y))};
         run_block(&worker, bid, block, grid, lds, *body);
+      }
+      g_barriers += worker.n_barriers;
+      worker.n_barriers = 0;
+      for (int i = 0; i < 16; ++i) {
+        g_ops[i] += worker.n_ops[i];
+        worker.n_ops[i] = 0;
       }
       std::lock_guard<std::mutex> lk(m);
       if (--active == 0) cv_done.notify_all();
@@ -362,6 +372,20 @@ void launch(u3 grid, u3 block, size_t dyn_lds_bytes, const std::function<void()>
   P.cv_job.notify_all();
   P.cv_done.wait(lk, [&] { return P.active == 0; });
   P.wanted = 0;
+  if (getenv("SIMT_STATS")) {  // per launch: workgroup barriers and wave-level operations (by opcode, simt.h) actually executed
+    fprintf(stderr, "simt: launch grid %u x %u x %u, block %u: %llu workgroup barriers; wave operations:", grid.x, grid.y, grid.z,
+            block.x * block.y * block.z, (unsigned long long)g_barriers.exchange(0));
+    static const char* names[16] = {"", "shfl_xor", "readlane", "dpp", "mfma16x16x4f32", "mfma16x16x16f16", "mfma16x16x32f16", "mfma32x32x16f16",
+                                    "mfma32x32x8f16", "ballot", "readfirstlane", "", "", "", "", ""};
+    for (int i = 1; i < 16; ++i) {
+      const unsigned long long v = g_ops[i].exchange(0);
+      if (v) fprintf(stderr, " %s %llu", names[i], v);
+    }
+    fprintf(stderr, "\n");
+  } else {
+    g_barriers = 0;
+    for (int i = 0; i < 16; ++i) g_ops[i] = 0;
+  }
 }
 
 // ---- wave-level operations -----------------------------------------------------------------------------------------------------
