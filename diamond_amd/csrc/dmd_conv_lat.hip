@@ -65,6 +65,23 @@ __device__ __forceinline__ void lt_chunk9(lt_f16v& acc, const lt_h8 (&w)[18], co
   }
 }
 
+// the same with the weight fragments read tap by tap (TP flavour: no chunk-sized register buffer)
+template <int COUT>
+__device__ __forceinline__ void lt_chunk9_stream(lt_f16v& acc, const lt_h8* __restrict__ wp, int chunk, int unit_lane, const unsigned char* ph,
+                                                 const unsigned char* pl, int pixbyte, int rs, int kbyte) {
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const lt_h8 wh = wp[(((size_t)chunk * 9 + t) * 2 + 0) * (2 * COUT) + unit_lane];
+    const lt_h8 wl = wp[(((size_t)chunk * 9 + t) * 2 + 1) * (2 * COUT) + unit_lane];
+    const int off = pixbyte + ((t / 3) * LT_PW + (t % 3)) * rs + kbyte;
+    const lt_h8 bh = *(const lt_h8*)(ph + off);
+    const lt_h8 bl = *(const lt_h8*)(pl + off);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, acc, 0, 0, 0);
+  }
+}
+
 __device__ __forceinline__ void lt_split_store(unsigned char* ph, unsigned char* pl, int byte, const f32x4 v) {
   lt_h4 h, l;
 #pragma unroll
@@ -78,8 +95,11 @@ __device__ __forceinline__ void lt_split_store(unsigned char* ph, unsigned char*
 
 // CQ = input channel quads (4 / 8 / 16 / 32: 16 / 32 / 64 / 128 input channels), COUT = 32 | 64 output channels (of the packed
 // weights), HEAD: the few-channel NCHW head (conv_out: p.Cout <= 4 real channels of 32 packed ones, no statistics / residual)
-template <bool PROJ, int CQ, int COUT, bool HEAD = false>
-__global__ __launch_bounds__(256) void conv_lat_kernel(const dmd_conv_params p) {
+// TP: the THROUGHPUT flavour for the 32-channel layers at any batch (DIAMOND_CONV_LATENCY_TP=1): those launches are memory-bound,
+// so the registers that buy latency inside ONE workgroup (chunk-sized weight buffers; bias and residual requested up front) are given
+// up for occupancy -- 4 workgroups per CU instead of 2 hide each other's round trips.
+template <bool PROJ, int CQ, int COUT, bool HEAD = false, bool TP = false>
+__global__ __launch_bounds__(256, TP ? 4 : 1) void conv_lat_kernel(const dmd_conv_params p) {
   DMD_DYNAMIC_LDS(unsigned char, lt_smem);
   __shared__ float g_mean[4], g_rstd[4];
   __shared__ double red[4][2];
@@ -105,7 +125,7 @@ __global__ __launch_bounds__(256) void conv_lat_kernel(const dmd_conv_params p) 
   const int unit_lane = g * COUT + half * 32 + ci;  // [k group][cout] inside a (chunk, tap, piece) block of 2 COUT 16-byte units
   const lt_h8* wp = (const lt_h8*)p.w_f16;
   lt_h8 wa[18], wb[18];
-  lt_load_w<9, COUT>(wa, wp, 0, unit_lane);
+  if constexpr (!TP) lt_load_w<9, COUT>(wa, wp, 0, unit_lane);
 
   // ---- everything that does not depend on anything else is REQUESTED now, in one batch: this thread's share of the patch,
   //      of the projection sources, its prologue parameters, the bias row and the residual of its output pixel.  (Fields of
@@ -163,7 +183,7 @@ __global__ __launch_bounds__(256) void conv_lat_kernel(const dmd_conv_params p) 
   for (int r = 0; r < 16; ++r) bias[r] = res[r] = 0.f;
 #pragma unroll
   for (int r = 0; r < (PROJ ? 16 : 1); ++r) pbias[r] = 0.f;
-  if (p.bias) {
+  if (!TP && p.bias) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) bias[r] = p.bias[half * 32 + 8 * (r >> 2) + 4 * g + (r & 3)];
   }
@@ -171,7 +191,7 @@ __global__ __launch_bounds__(256) void conv_lat_kernel(const dmd_conv_params p) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) pbias[r] = p.proj_bias[half * 32 + 8 * (r >> 2) + 4 * g + (r & 3)];
   }
-  if (p.residual) {
+  if (!TP && p.residual) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) res[r] = p.residual[obase + 8 * (r >> 2) + (r & 3)];
   }
@@ -243,6 +263,9 @@ __global__ __launch_bounds__(256) void conv_lat_kernel(const dmd_conv_params p) 
   constexpr int nch = Cin >> 4;
   lt_h8 wj[16];
   if constexpr (nch == 1) lt_chunk9(acc, wa, ph, pl, pixbyte, rs, g * 16);  // conv_in: 16 (15 real) input channels
+  if constexpr (TP) {  // weights tap by tap: their round trips are other workgroups' compute time
+    for (int c = 0; c < nch; ++c) lt_chunk9_stream<COUT>(acc, wp, c, unit_lane, ph, pl, pixbyte, rs, c * 32 + g * 16);
+  } else
   for (int c = 0; c + 1 < nch; c += 2) {
     lt_load_w<9, COUT>(wb, wp, c + 1, unit_lane);
     lt_chunk9(acc, wa, ph, pl, pixbyte, rs, c * 32 + g * 16);
@@ -278,6 +301,16 @@ __global__ __launch_bounds__(256) void conv_lat_kernel(const dmd_conv_params p) 
     return;
   }
   // ---- write-out: residual, NHWC store, partial statistics of this (tile, 32-channel group) ----
+  if constexpr (TP) {  // (bias: the accumulators started from zero here)
+    if (p.bias) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) res[r] = p.bias[half * 32 + 8 * (r >> 2) + 4 * g + (r & 3)];
+    }
+    if (p.residual) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) res[r] += p.residual[obase + 8 * (r >> 2) + (r & 3)];
+    }
+  }
   double s = 0.0, ss = 0.0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -745,6 +778,8 @@ int dmd_launch_conv_lat(const dmd_conv_params& p, hipStream_t st) {
     hipLaunchKernelGGL((conv_lat_kernel<false, 8, 64>), grid, dim3(256), lds, st, p);
   else if (cin == 64)
     hipLaunchKernelGGL((conv_lat_kernel<false, 16, 32>), grid, dim3(256), lds, st, p);
+  else if (getenv("DIAMOND_CONV_LATENCY_TP") && atoi(getenv("DIAMOND_CONV_LATENCY_TP")) == 1)
+    hipLaunchKernelGGL((conv_lat_kernel<false, 8, 32, false, true>), grid, dim3(256), lds, st, p);
   else
     hipLaunchKernelGGL((conv_lat_kernel<false, 8, 32>), grid, dim3(256), lds, st, p);
   return 0;

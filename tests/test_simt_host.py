@@ -86,11 +86,13 @@ def test_denoiser_training_step_vs_reference_golden_on_the_interpreter(models, m
     assert counter.n.get("dmd_conv2d_wgrad", 0) > 100 and counter.n.get("dmd_gn_silu_bwd", 0) > 50, counter.n
 
 
-@pytest.mark.parametrize("cap", ["0", "64"], ids=["shipping", "staged-latency-route"])
+@pytest.mark.parametrize("cap", ["0", "64", "64tp"], ids=["shipping", "staged-latency-route", "staged-throughput-flavour"])
 def test_rew_end_model_and_actor_critic_vs_goldens_on_the_interpreter(models, monkeypatch, cap):
     """reward / end model (32-channel AdaGN encoder, fused 8x8 tail, LSTM, head) and the actor-critic (forward + every gradient)
     against the reference-generated goldens; with the cap, their eligible 32- and 64-channel 3x3s run on conv_lat_kernel"""
     M, counter = models
+    monkeypatch.setenv("DIAMOND_CONV_LATENCY_TP", "1" if cap.endswith("tp") else "0")
+    cap = cap.rstrip("tp")
     monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", cap)
     ag = M.make_agent()
     M.test_rew_end_model_vs_golden(ag)

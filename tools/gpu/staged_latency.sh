@@ -27,11 +27,12 @@ print('cap 64, no fused 8x8 level', 'ms/frame graph', round(d['value'], 3))" | t
 done
 # the 32-channel layers of the headline window (configs[1], batch 256) on the same kernel: occupancy instead of the pipeline
 for rep in 1 2; do
-  for c32 in 0 1000000000; do
-    DIAMOND_CONV_LATENCY_TILES_C32=$c32 timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-fp32 2>/dev/null | python -c "
+  for c32 in "0 0" "1000000000 0" "1000000000 1"; do
+    set -- $c32
+    DIAMOND_CONV_LATENCY_TILES_C32=$1 DIAMOND_CONV_LATENCY_TP=$2 timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-fp32 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); r = d['roofline']
-print('configs[1] c32 cap $c32', round(d['value'], 1), 'frames/s;', {k: v for k, v in list(r['launch_time_ms'].items())[:6]})" | tee -a $O/ab.txt
+print('configs[1] c32 cap / throughput flavour: $c32', round(d['value'], 1), 'frames/s;', {k: v for k, v in list(r['launch_time_ms'].items())[:6]})" | tee -a $O/ab.txt
   done
 done
 export TMPDIR=/tmp
