@@ -81,16 +81,34 @@ class FilmTable:
             off += 2 * m.in_channels
         self.total = off
         self._packed: Optional[Tuple[Tuple[int, ...], Tensor, Tensor]] = None
+        self.stale_epoch = 0  # (see engine.PackCache)
+        self.frees_epoch = 0
 
     def weights(self) -> Tuple[Tensor, Tensor]:
         ver = tuple((m.linear.weight._version, m.linear.weight.data_ptr(), m.linear.bias._version, m.linear.bias.data_ptr())
                     for m in self.norms)
         dev = self.norms[0].linear.weight.device
         if self._packed is None or self._packed[0] != ver or self._packed[1].device != dev:
-            w = torch.cat([m.linear.weight.detach().float() for m in self.norms], dim=0).contiguous()
-            b = torch.cat([m.linear.bias.detach().float() for m in self.norms], dim=0).contiguous()
+            ws, bs = [m.linear.weight.detach().float() for m in self.norms], [m.linear.bias.detach().float() for m in self.norms]
+            if self._packed is not None and self._packed[1].device == dev:
+                # in place: a captured graph that reads the table keeps a valid pointer (engine.PackCache does the same)
+                w, b = self._packed[1], self._packed[2]
+                torch.cat(ws, dim=0, out=w)
+                torch.cat(bs, dim=0, out=b)
+            else:
+                w, b = torch.cat(ws, dim=0).contiguous(), torch.cat(bs, dim=0).contiguous()
+                self.frees_epoch += 1 if self._packed is not None else 0
             self._packed = (ver, w, b)
         return self._packed[1], self._packed[2]
+
+    def invalidate(self) -> None:
+        """The concatenated copy is stale although no parameter version says so (engine.PackCache.invalidate)."""
+        if self._packed is not None:
+            self._packed = (None, self._packed[1], self._packed[2])
+        self.stale_epoch += 1
+
+    def refresh(self) -> None:
+        self.weights()
 
     def compute(self, cond: Tensor) -> Tensor:
         w, b = self.weights()

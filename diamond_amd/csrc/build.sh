@@ -7,7 +7,7 @@ OUT=../libdiamond_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result"
 mkdir -p build
 pids=()
-for f in dmd_conv.hip dmd_conv1x1.hip dmd_conv_f16ws.hip dmd_conv_lat.hip dmd_backward.hip dmd_linear.hip dmd_attention.hip dmd_pointwise.hip dmd_lowres.hip dmd_pack.hip dmd_capi.cpp; do
+for f in dmd_conv.hip dmd_conv1x1.hip dmd_conv_f16ws.hip dmd_backward.hip dmd_linear.hip dmd_attention.hip dmd_pointwise.hip dmd_lowres.hip dmd_pack.hip dmd_capi.cpp; do
   o=build/${f%.*}.o
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ dmd_common.h -nt "$o" ] || [ ../../include/diamond_hip.h -nt "$o" ]; then
     ( hipcc $FLAGS -x hip -c "$f" -o "$o" ${EXTRA_HIPCC_FLAGS:-} ) &

@@ -260,8 +260,8 @@ extern "C" int dmd_gn_silu_bwd(const dmd_gn_bwd_params* pp, dmd_stream_t stream)
   float* chan_partial = (float*)((char*)p.workspace + (size_t)p.N * G * T * 2 * 8);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(T, p.N), dim3(256), 0, st, p, T, group_partial, chan_partial);
-  const char* fe = getenv("DIAMOND_GN_BWD_FOLD");
-  const int fold = fe && atoi(fe) == 1;
+  static DmdEnvInt fold_env{"DIAMOND_GN_BWD_FOLD", 0};
+  const int fold = fold_env.get() == 1;
   if (fold) {
     hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(T, p.N), dim3(256), 0, st, p, T, (const double*)group_partial, (const float*)chan_partial);
   } else {
@@ -594,10 +594,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, in
       *(f32x4*)(dyt + (size_t)pix * G::SA + 4 * q) = v;
     }
     __syncthreads();
-    if constexpr (MODE == 2) {
-      wgrad_mfma_k32<G>(acc, dyt, patch, boff, aoff);
-      continue;
-    }
     if (SPLIT) {
       // ---- 8 k-groups of 16 pixels (2 rows x 8 columns of a subtile) ----
       // boff[] carries + kg * SB and aoff + kg * SA (pixel kg of the group); the other three pixels of this lane are
@@ -713,11 +709,8 @@ static int wgrad_plan(const dmd_wgrad_params* p, int* tiles, int* num_wg, int* t
   // at most `cap` workgroups, each walking a contiguous range of tiles with its accumulators in registers: every workgroup
   // writes one partial of the whole gradient, so fewer of them is less reduction traffic.  DIAMOND_WGRAD_MAX_WG (STAGED, like
   // the kernel modes above) lowers the cap from 1024; the workspace is always sized for 1024.
-  int cap = 1024;
-  if (const char* e = getenv("DIAMOND_WGRAD_MAX_WG")) {
-    const int v = atoi(e);
-    if (v >= 1 && v < cap) cap = v;
-  }
+  static DmdEnvInt cap_env{"DIAMOND_WGRAD_MAX_WG", 256};
+  const int cap = cap_env.get() >= 1 && cap_env.get() <= 1024 ? cap_env.get() : 256;
   int n = *tiles < cap ? *tiles : cap;
   *tpw = (*tiles + n - 1) / n;
   *num_wg = (*tiles + *tpw - 1) / *tpw;
@@ -747,31 +740,23 @@ static int launch_wgrad(const dmd_wgrad_params& p, hipStream_t st) {
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<G, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM_BYTES);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<G, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM_BYTES);
-    if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<G, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM_BYTES);
     DMD_CHECK_ARG(e == hipSuccess, "wgrad: hipFuncSetAttribute(%d bytes): %s", G::SMEM_BYTES, hipGetErrorString(e));
     attr_set[dev] = true;
   }
   if ((p.precision & 0xff) == DMD_PRECISION_F16X2) {
-    int mode = 1;
-    if (const char* e = getenv("DIAMOND_WGRAD_MODE")) mode = atoi(e);  // STAGED modes 2 / 3 (see MODE above); anything else: 1
-    if (mode == 2)
-      hipLaunchKernelGGL((wgrad_kernel<G, 2>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
-    else if (mode == 3)
-      hipLaunchKernelGGL((wgrad_kernel<G, 3>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
-    else
+    static DmdEnvInt mode_env{"DIAMOND_WGRAD_MODE", 3};
+    const int mode = mode_env.get();
+    if (mode == 1)
       hipLaunchKernelGGL((wgrad_kernel<G, 1>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
+    else
+      hipLaunchKernelGGL((wgrad_kernel<G, 3>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
   } else {
     hipLaunchKernelGGL((wgrad_kernel<G, 0>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
   }
   const int per_total = G::NB * NCO * 256 + NCO * 16;
   float* ws2 = p.workspace + (size_t)num_wg * per_total;
-  int single = 4 * WGRAD_SLICES;
-  if (const char* e = getenv("DIAMOND_WGRAD_SINGLE_REDUCE")) {  // STAGED: sum up to this many partials in one pass (fp64, workgroup order)
-    const int v = atoi(e);
-    if (v > single && v <= 1024) single = v;
-  }
+  const int single = 4 * WGRAD_SLICES;
   if (num_wg <= single) {
     // few partials (the low-resolution levels at the training batch): summed directly, in fp64, in workgroup order -- one
     // launch less per weight gradient (the training step is a chain of ~600 small kernels)

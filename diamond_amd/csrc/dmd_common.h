@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/diamond_hip.h"
 
@@ -18,6 +19,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 
 void dmd_set_error(const char* fmt, ...);
+
+// An integer switch from the environment, read ONCE (and again after dmd_reload_env(), the tests' hook): the launchers do
+// not call getenv per launch.     static DmdEnvInt mode{"DIAMOND_WGRAD_MODE", 3};  ...  mode.get()
+int dmd_env_generation();
+struct DmdEnvInt {
+  const char* name;
+  int def;
+  int gen = -1, val = 0;
+  int get() {
+    const int g = dmd_env_generation();
+    if (g != gen) {
+      const char* e = getenv(name);
+      val = e ? atoi(e) : def;
+      gen = g;
+    }
+    return val;
+  }
+};
 
 #define DMD_CHECK_ARG(cond, ...)  \
   do {                            \

@@ -515,9 +515,6 @@ __global__ void pack_weight_kernel(const float* oihw, float* packed, int Cout, i
 // host side
 // ------------------------------------------------------------------------------------------
 extern "C" int dmd_conv2d_proj_eligible(const dmd_conv_params* p);
-int dmd_conv_lat_route(const dmd_conv_params& p);                     // dmd_conv_lat.hip (few-tile launches; STAGED, off by default)
-int dmd_launch_conv_lat(const dmd_conv_params& p, hipStream_t st);
-void dmd_conv_lat_kernel_name(const dmd_conv_params& p, char* buf, int buf_len);
 static int validate_conv(const dmd_conv_params* p) {
   DMD_CHECK_ARG(p != nullptr, "conv: null params");
   DMD_CHECK_ARG(p->N > 0 && p->H > 0 && p->W > 0, "conv: bad N/H/W %d %d %d", p->N, p->H, p->W);
@@ -545,14 +542,19 @@ static int validate_conv(const dmd_conv_params* p) {
                 "conv: valid extent %d x %d outside the %d x %d buffer", p->valid_h, p->valid_w, p->H, p->W);
   if (p->upsample) DMD_CHECK_ARG(p->valid_h % 2 == 0 && p->valid_w % 2 == 0, "conv: upsample needs an even valid extent");
   if (p->proj_nsrc)
-    DMD_CHECK_ARG(dmd_conv_lat_route(*p) || dmd_conv2d_proj_eligible(p), "conv: fused skip projection on parameters dmd_conv2d_proj_eligible() rejects "
+    DMD_CHECK_ARG(dmd_conv2d_proj_eligible(p), "conv: fused skip projection on parameters dmd_conv2d_proj_eligible() rejects "
                   "(needs F16X2 3x3 stride 1, Cout 64, H, W %% 16 == 0, two 64-channel sources, no residual)");
   return 0;
 }
 
+static int conv1x1_stream_on() {
+  static DmdEnvInt on{"DIAMOND_CONV1X1_STREAM", 1};
+  return on.get();
+}
+
 static int conv_mfma_split(const dmd_conv_params& p) {
-  static const int on = getenv("DIAMOND_CONV_MFMA_SPLIT") ? atoi(getenv("DIAMOND_CONV_MFMA_SPLIT")) : 1;
-  return on && (p.precision & 0xff) == DMD_PRECISION_F16X2;
+  static DmdEnvInt on{"DIAMOND_CONV_MFMA_SPLIT", 1};
+  return on.get() && (p.precision & 0xff) == DMD_PRECISION_F16X2;
 }
 
 template <int WN, bool CFGB, int TAPS, int STRIDE>
@@ -587,11 +589,9 @@ extern "C" int dmd_conv1x1_stream_eligible(const dmd_conv_params* p);
 extern "C" int dmd_conv2d(const dmd_conv_params* p, dmd_stream_t stream) {
   if (int e = validate_conv(p)) return e;
   hipStream_t st = (hipStream_t)stream;
-  static const int use_1x1 = getenv("DIAMOND_CONV1X1_STREAM") ? atoi(getenv("DIAMOND_CONV1X1_STREAM")) : 1;
+  const int use_1x1 = conv1x1_stream_on();
   if (use_1x1 && dmd_conv1x1_stream_eligible(p)) {
     dmd_launch_conv1x1_stream(*p, st);
-  } else if (dmd_conv_lat_route(*p)) {
-    if (int e = dmd_launch_conv_lat(*p, st)) return e;
   } else if (dmd_conv2d_f16x2_eligible(p)) {
     if (int e = dmd_launch_conv_f16ws(*p, st)) return e;
   } else if (p->taps == 1)
@@ -610,15 +610,13 @@ extern "C" int dmd_conv2d(const dmd_conv_params* p, dmd_stream_t stream) {
 extern "C" int dmd_conv2d_kernel_name(const dmd_conv_params* p, char* buf, int buf_len) {
   if (int e = validate_conv(p)) return e;
   DMD_CHECK_ARG(buf && buf_len > 0, "kernel_name: buffer");
-  static const int use_1x1 = getenv("DIAMOND_CONV1X1_STREAM") ? atoi(getenv("DIAMOND_CONV1X1_STREAM")) : 1;
+  const int use_1x1 = conv1x1_stream_on();
   const bool b8 = p->W % 16 != 0;
   if (use_1x1 && dmd_conv1x1_stream_eligible(p)) {
     int cin = 0;
     for (int i = 0; i < p->nsrc; ++i) cin += p->src[i].C;
     snprintf(buf, buf_len, "conv1x1_stream_kernel<%d, %d, %s>", cin / 16, cin == 128 ? 2 : 4,
              (p->precision & 0xff) == DMD_PRECISION_F16X2 ? "true" : "false");
-  } else if (dmd_conv_lat_route(*p)) {
-    dmd_conv_lat_kernel_name(*p, buf, buf_len);
   } else if (p->proj_nsrc) {
     snprintf(buf, buf_len, "conv_f16ws_kernel<WsGeomProj>");
   } else if (dmd_conv2d_f16x2_eligible(p)) {

@@ -740,10 +740,14 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       stage_S(0, stage0, zm0, sl0, S > 1 ? 1 : -1);
       ws_barrier();  // B0
       for (int j = 0; j < S; ++j) {
+        WS_STAMP(2, 0, j);
         if (j + 1 < S) {
           stage_S(j + 1, stage0, zm0, sl0, j + 2 < S ? j + 2 : -1);
+          WS_STAMP(2, 1, j);
+          WS_STAMP(2, 2, j);
         }
         ws_barrier();
+        WS_STAMP(2, 3, j);
       }
     }
   } else {

@@ -70,22 +70,39 @@ class DiffusionSampler:
         The sigma schedule, conditioners and ring heads are launch constants of the captured graph; the context is read
         from the SAME buffers at replay time (WorldModelEnv keeps its rings in place).  Returns fresh copies (the
         graph's output buffers are overwritten by the next replay)."""
-        # A captured graph holds the POINTERS of the packed weights and the kernel choices of capture time: its stamp covers
-        # every denoiser parameter (version + storage pointer, like engine.PackCache), the arithmetic switches and the
-        # fused-level switch.  Graphs of a stale stamp are dropped at once (each holds live pool memory).
+        # A captured graph holds the POINTERS of the packed weights and the kernel choices of capture time.  The packed copies
+        # are rebuilt IN PLACE (engine.PackCache, blocks.FilmTable), so a weight update does not void a graph: it only has to
+        # be followed by a refresh of the copies before the next replay -- there is no lookup inside a replay that would do
+        # it.  `versions` notices optimizer steps / loads (and, through the caches' stale_epoch, invalidations that bump no
+        # `Tensor._version`; a replayed GraphedTrainStep refreshes the copies itself).  Graphs are dropped only when a buffer
+        # they point to was replaced (frees_epoch) or an arithmetic / routing switch changed.
         from . import blocks as BL
         from . import engine as E
+        from .train_graph import _refresh_weight_caches, _weight_caches
 
-        stamp = (tuple((p._version, p.data_ptr()) for p in self.denoiser.parameters()), E.WORLD_MODEL_PRECISION, BL.LOWRES_CHAIN)
-        if stamp != self._graph_stamp:
+        # (the module walk of `parameters()` is ~350 us of Python per call, a tenth of a B = 1 frame: the lists are kept and
+        #  re-derived only now and then)
+        self._stamp_calls = getattr(self, "_stamp_calls", 0) + 1
+        if getattr(self, "_stamp_params", None) is None or self._stamp_calls % 256 == 0:
+            self._stamp_params = list(self.denoiser.parameters())
+            self._stamp_caches = list(_weight_caches(self.denoiser))
+        versions = (tuple((p._version, p.data_ptr()) for p in self._stamp_params), sum(c.stale_epoch for c in self._stamp_caches))
+        if versions != getattr(self, "_graph_versions", None):
+            _refresh_weight_caches(self.denoiser)
+            self._graph_versions = versions
+        stamp = lambda: (sum(c.frees_epoch for c in self._stamp_caches), E.WORLD_MODEL_PRECISION, BL.LOWRES_CHAIN)
+        if stamp() != self._graph_stamp:
             self._graphs.clear()
-            self._graph_stamp = stamp
+            self._graph_stamp = stamp()
         key = (ctx_obs.data_ptr(), ctx_act.data_ptr(), tuple(ctx_obs.shape), obs_head, act_head)
         cap = self._graphs.get(key)
         if cap is None:
             if len(self._graphs) > 64:
                 self._graphs.clear()
             cap = _CapturedSample(self, ctx_obs, ctx_act, obs_head, act_head)
+            if stamp() != self._graph_stamp:  # the warm-up replaced a buffer (e.g. copies built on another device before)
+                self._graphs.clear()
+                self._graph_stamp = stamp()
             self._graphs[key] = cap
         x, traj = cap.replay()
         return x.clone(), [t.clone() for t in traj]

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 import weakref
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import torch
 from torch import Tensor, nn
@@ -125,28 +125,61 @@ class PackCache:
     The outputs are rebuilt in place (stable pointers: a captured training step keeps reading the same buffers)."""
 
     def __init__(self) -> None:
-        self._store: Dict[Tuple[int, str], Tuple[Tuple, "weakref.ref", Tensor]] = {}
+        self._store: Dict[Tuple[int, str], Tuple[Optional[Tuple], "weakref.ref", Any, Any]] = {}  # (stamp, param, copy, builder)
         self._jobs: Dict[Tuple, _PackEntry] = {}
         self._table: Optional[Tensor] = None  # (njobs * sizeof(dmd_pack_job)) bytes on the device
         self._table_entries: List[_PackEntry] = []
         self._max_elems = 0
+        # What the owner of a captured graph that reads these copies directly (DiffusionSampler.sample_ring_graphed) watches:
+        # `stale_epoch` counts invalidations no `Tensor._version` shows -- refresh() before the next replay; `frees_epoch`
+        # counts copies whose BUFFER was replaced or dropped -- graphs holding the old pointer are void.  (Rebuilding a copy
+        # in place changes neither: the graph reads the new values through the same pointer.)
+        self.stale_epoch = 0
+        self.frees_epoch = 0
 
     def invalidate(self) -> None:
         """Every packed copy is stale.  Needed after writes that do not bump `Tensor._version` (anything done through
-        `p.data`: `.data.copy_`, `.data.fill_`, collectives on `.data`; a replayed training-step graph).  Buffers and the
-        job table are kept: the next use rebuilds the copies in place with one launch."""
-        self._store.clear()
+        `p.data`: `.data.copy_`, `.data.fill_`, collectives on `.data`).  Buffers and the job table are kept: the next use
+        rebuilds the copies IN PLACE (a captured graph that reads them keeps valid pointers; it is the weights EPOCH that
+        tells its owner that what it captured may be out of date)."""
+        for key, hit in list(self._store.items()):
+            self._store[key] = (None, hit[1], hit[2], hit[3])
         for ent in self._jobs.values():
             ent.stamp = None
+        self.stale_epoch += 1
 
     def get(self, p: Tensor, kind: str, fn):
         key = (id(p), kind)
         hit = self._store.get(key)
-        stamp = _stamp(p)
-        if hit is None or hit[0] != stamp or hit[1]() is not p:
-            hit = (stamp, weakref.ref(p), fn(p))
-            self._store[key] = hit
+        if hit is None or hit[0] != _stamp(p) or hit[1]() is not p:
+            hit = self._rebuild(key, p, fn, hit)
         return hit[2]
+
+    def _rebuild(self, key, p: Tensor, fn, hit):
+        new = fn(p)
+        old = hit[2] if (hit is not None and hit[1]() is p) else None
+        if isinstance(old, Tensor) and isinstance(new, Tensor) and new.data_ptr() != p.data_ptr() and old.data_ptr() != p.data_ptr() \
+                and old.shape == new.shape and old.dtype == new.dtype and old.device == new.device and old.is_contiguous():
+            old.copy_(new)  # same buffer: whoever holds its pointer (a captured graph, a device-side table) sees the update
+            new = old
+        elif hit is not None:
+            self.frees_epoch += 1
+        hit = (_stamp(p), weakref.ref(p), new, fn)
+        self._store[key] = hit
+        return hit
+
+    def refresh(self) -> None:
+        """Rebuild every stale copy NOW (on the current stream, capturable): the captured training step calls this behind its
+        optimizer update, so that a replay leaves the packed copies equal to the parameters it leaves."""
+        if self._jobs and any(e.ref() is not None and e.stamp != _stamp(e.ref()) for e in self._jobs.values()):
+            self._refresh()
+        for key, hit in list(self._store.items()):
+            p = hit[1]()
+            if p is None:
+                del self._store[key]
+                self.frees_epoch += 1
+            elif hit[0] != _stamp(p):
+                self._rebuild(key, p, hit[3], hit)
 
     # -- convolution copies: one table, one launch --------------------------------------------------------------------
     def _conv_job(self, p: Tensor, kind: int, cout_pad: int, transposed: bool = False, c0: int = 0, c1: int = 0,
@@ -155,7 +188,7 @@ class PackCache:
         ent = self._jobs.get(key)
         if ent is not None and ent.ref() is p and ent.stamp == _stamp(p):
             return ent.out
-        if ent is None or ent.ref() is not p or ent.job.src != p.data_ptr() or ent.out.device != p.device:
+        if ent is None or ent.ref() is not p or ent.out.device != p.device:
             assert p.dtype == torch.float32 and p.is_contiguous(), "convolution parameters are contiguous fp32"
             job = nv.PackJob()
             job.src, job.kind, job.transposed, job.c0, job.c1 = p.data_ptr(), kind, int(transposed), c0, c1
@@ -172,19 +205,49 @@ class PackCache:
                 out = torch.empty(elems * (2 if kind == nv.PACK_F16X2 else 1), device=p.device,
                                   dtype=torch.float16 if kind == nv.PACK_F16X2 else torch.float32)
             job.dst = out.data_ptr()
+            if ent is not None:
+                self.frees_epoch += 1
             ent = _PackEntry(p, out, job, elems)
             self._jobs[key] = ent
-            self._table = None
-        self._refresh()
+            self._table = None  # (rebuilt with all rows by the first full refresh)
+            self._pack_one(ent)  # a new copy alone: registration is O(1) launches, not a rebuild of everything so far
+            return ent.out
+        self._refresh()  # stale: an optimizer step / load changed every parameter -> all copies, one launch
         return ent.out
+
+    @staticmethod
+    def _no_capture(what: str) -> None:
+        assert not torch.cuda.is_available() or not torch.cuda.is_current_stream_capturing(), \
+            f"PackCache: {what} inside a hipGraph capture (a synchronous upload; warm the step up eagerly first)"
+
+    def _pack_one(self, e: _PackEntry) -> None:
+        self._no_capture("a new packed copy was requested")
+        table = torch.frombuffer(bytearray(bytes(e.job)), dtype=torch.uint8).to(e.out.device)
+        nv.check(nv.lib().dmd_pack_jobs(nv.ptr(table), 1, e.elems, nv.stream()), "dmd_pack_jobs")
+        e.stamp = _stamp(e.ref())
 
     def _refresh(self) -> None:
         """Rebuild every registered copy with one launch (all of them: whoever changed one parameter changed them all)."""
+        if self._table is not None:
+            # a parameter whose storage was swapped (`p.data = other`, `module.to(...)`) or that died: its rows still name
+            # the old storage -- patch them before anything is rebuilt from it
+            for e in self._table_entries:
+                p = e.ref()
+                if p is None or e.job.src != p.data_ptr() or e.out.device != p.device:
+                    self._table = None
+                    break
         if self._table is None:
-            dead = [k for k, e in self._jobs.items() if e.ref() is None]
-            for k in dead:
-                del self._jobs[k]
+            for k, e in list(self._jobs.items()):
+                p = e.ref()
+                if p is None or e.out.device != p.device:
+                    del self._jobs[k]  # (a moved parameter registers a new job on its next lookup)
+                    self.frees_epoch += 1
+                elif e.job.src != p.data_ptr():
+                    e.job.src = p.data_ptr()
             self._table_entries = list(self._jobs.values())
+            if not self._table_entries:
+                return
+            self._no_capture("the job table has to be uploaded")
             raw = b"".join(bytes(e.job) for e in self._table_entries)
             dev = self._table_entries[0].out.device
             self._table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)

@@ -90,19 +90,19 @@ class LowresChainParams(C.Structure):
 
 EXPORTS = (
     "dmd_conv2d", "dmd_conv2d_kernel_name", "dmd_conv2d_naive", "dmd_conv_stat_tiles", "dmd_pack_conv_weight", "dmd_conv2d_f16x2_eligible",
-    "dmd_conv1x1_stream_eligible", "dmd_conv2d_proj_eligible", "dmd_conv2d_latency_eligible", "dmd_pack_jobs",
+    "dmd_conv1x1_stream_eligible", "dmd_conv2d_proj_eligible", "dmd_pack_jobs",
     "dmd_pack_conv_weight_f16x2", "dmd_linear", "dmd_attention", "dmd_attention_valid", "dmd_attention_bwd", "dmd_attention_bwd_workspace_floats",
     "dmd_edm_pack_input", "dmd_cond_embed", "dmd_edm_denoised", "dmd_euler_step", "dmd_heun_step", "dmd_quantize_u8",
     "dmd_dequant_gather", "dmd_nchw_to_nhwc",
     "dmd_nhwc_to_nchw", "dmd_gn_stats", "dmd_gn_stats_valid", "dmd_maxpool2", "dmd_lstm_pointwise", "dmd_lstm_pointwise_bwd", "dmd_categorical_sample",
     "dmd_maxpool2_bwd", "dmd_gn_bwd_workspace_bytes", "dmd_gn_silu_bwd", "dmd_wgrad_workspace_floats", "dmd_conv2d_wgrad",
-    "dmd_lowres_chain", "dmd_lowres_chain32", "dmd_last_error", "dmd_abi_version",
+    "dmd_lowres_chain", "dmd_lowres_chain32", "dmd_last_error", "dmd_abi_version", "dmd_reload_env",
 )
 
 # entry points that launch kernels (everything except queries / packing helpers that bench.py does not time)
 LAUNCHERS = frozenset(n for n in EXPORTS if n not in (
     "dmd_conv2d_kernel_name", "dmd_conv_stat_tiles", "dmd_conv2d_f16x2_eligible", "dmd_conv1x1_stream_eligible",
-    "dmd_conv2d_proj_eligible", "dmd_attention_bwd_workspace_floats", "dmd_gn_bwd_workspace_bytes", "dmd_wgrad_workspace_floats", "dmd_last_error", "dmd_abi_version"))
+    "dmd_conv2d_proj_eligible", "dmd_attention_bwd_workspace_floats", "dmd_gn_bwd_workspace_bytes", "dmd_wgrad_workspace_floats", "dmd_last_error", "dmd_abi_version", "dmd_reload_env"))
 
 
 class LaunchProfiler:
@@ -165,6 +165,7 @@ def declare_signatures(L: C.CDLL) -> None:
     """restype / argtypes of every entry point of include/diamond_hip.h on a loaded library; AttributeError if the ABI is
     incomplete.  (tests/simt declares the same signatures on its host build of the kernels.)"""
     L.dmd_last_error.restype = C.c_char_p
+    L.dmd_reload_env.restype = None
     for name in EXPORTS:
         getattr(L, name)  # AttributeError if the ABI is incomplete
     L.dmd_conv2d.argtypes = [C.POINTER(ConvParams), C.c_void_p]
@@ -176,7 +177,6 @@ def declare_signatures(L: C.CDLL) -> None:
     L.dmd_conv2d_f16x2_eligible.argtypes = [C.POINTER(ConvParams)]
     L.dmd_conv1x1_stream_eligible.argtypes = [C.POINTER(ConvParams)]
     L.dmd_conv2d_proj_eligible.argtypes = [C.POINTER(ConvParams)]
-    L.dmd_conv2d_latency_eligible.argtypes = [C.POINTER(ConvParams)]
     L.dmd_pack_jobs.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
     L.dmd_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.dmd_attention_valid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]

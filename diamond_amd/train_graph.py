@@ -17,8 +17,9 @@ stream with it (torch warns "AccumulateGrad node's stream does not match"; the c
 
 What is captured is exactly the eager step's launch sequence.  Weight packing (engine.PackCache, blocks.FilmTable) is keyed
 on parameter versions: the warm-up steps' optimizer updates bump every version, so every pack / transpose kernel is recorded
-too and re-runs at each replay on the updated weights (one dmd_pack_jobs launch per cache); the copies are additionally
-marked stale right before the capture and after every replay.
+too: the step ends with an explicit refresh of every cache behind the optimizer update (one dmd_pack_jobs launch per cache,
+in place), so after a replay the packed copies equal the parameters -- also for readers that never look a copy up again (the
+sampler's captured imagination graphs read the packed buffers directly).
 """
 from __future__ import annotations
 
@@ -28,16 +29,28 @@ import torch
 from torch import Tensor, nn
 
 
-def _mark_weight_caches_stale(model: nn.Module) -> None:
-    """Every packed copy of the model's parameters is stale (buffers and job tables are kept: engine.PackCache.invalidate)."""
+def _weight_caches(model: nn.Module):
     from . import engine as E
 
     for m in model.modules():
         if isinstance(getattr(m, "_cache", None), E.PackCache):
-            m._cache.invalidate()
+            yield m._cache
         film = getattr(m, "_film", None)
-        if film is not None and hasattr(film, "_packed"):
-            film._packed = None
+        if film is not None and hasattr(film, "refresh"):
+            yield film
+
+
+def _mark_weight_caches_stale(model: nn.Module) -> None:
+    """Every packed copy of the model's parameters is stale (buffers and job tables are kept: engine.PackCache.invalidate)."""
+    for c in _weight_caches(model):
+        c.invalidate()
+
+
+def _refresh_weight_caches(model: nn.Module) -> None:
+    """Rebuild, in place and on the current stream, every packed copy that is stale (capturable: no allocation of a table,
+    no upload -- the job tables exist after the warm-up)."""
+    for c in _weight_caches(model):
+        c.refresh()
 
 
 class GraphedTrainStep:
@@ -60,7 +73,11 @@ class GraphedTrainStep:
                 self._eager()
         cur.wait_stream(side)
         torch.cuda.synchronize()
-        _mark_weight_caches_stale(model)  # (nothing is allocated or uploaded during the capture: the tables exist)
+        # The packed copies are rebuilt at the END of the captured step, behind the optimizer update (not at its start): a
+        # replay then leaves them equal to the parameters it leaves, and anything that reads them without a lookup -- the
+        # sampler's captured imagination graphs -- is never a step behind.  So they have to be fresh going in:
+        _mark_weight_caches_stale(model)
+        _refresh_weight_caches(model)
         optimizer.zero_grad(set_to_none=True)  # the gradients of the captured step come from the graph's own pool
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: other threads' HIP calls (the RCCL watchdog polls its events) must not invalidate this capture
@@ -74,6 +91,7 @@ class GraphedTrainStep:
         if self.max_grad_norm is not None:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_grad_norm)
         self.optimizer.step()
+        _refresh_weight_caches(self.model)  # one dmd_pack_jobs launch per cache, on the updated weights
         if zero:
             self.optimizer.zero_grad(set_to_none=True)
         return loss.detach(), {k: (v.detach() if isinstance(v, Tensor) else v) for k, v in metrics.items()}
@@ -85,7 +103,8 @@ class GraphedTrainStep:
                 f"batch.{k}: {tuple(src.shape)} {src.dtype}, captured with {tuple(buf.shape)} {buf.dtype} (static shapes)"
             buf.copy_(src, non_blocking=True)
         self.graph.replay()
-        # the replayed optimizer update changed every parameter without bumping its `_version`: code that reads the packed
-        # copies outside this graph (imagination with the same denoiser, evaluation) must rebuild them first
-        _mark_weight_caches_stale(self.model)
+        # The replayed optimizer update changed every parameter without bumping its `_version`; the packed copies were
+        # rebuilt from the new values by the replay itself, in place: the stamps of capture time still describe them, and
+        # graphs captured elsewhere from the same weights (DiffusionSampler.sample_ring_graphed) read the new values through
+        # the same pointers.
         return self.loss, self.metrics

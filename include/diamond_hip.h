@@ -108,12 +108,6 @@ int dmd_conv2d_f16x2_eligible(const dmd_conv_params* p);
  * one 64-channel
  * source, Cout == 64, H, W multiples of 16, two 64-channel projection sources, no other residual) */
 int dmd_conv2d_proj_eligible(const dmd_conv_params* p);
-/* 1: these parameters can run on the few-tile kernel (conv_lat_kernel, dmd_conv_lat.hip: one workgroup per 8 x 16 pixel tile
- * and 32-channel half, no pipeline -- for the launches of play.py's B = 1 sampler, reference play.py:105-109): split-fp16 3x3
- * stride 1 (or stride 2 with one raw source and Cout == Cin), Cout 32 | 64 (or the few-channel NCHW head), 16 | 32 | 64 | 128 input channels in whole 32-channel sources, H % 8 == 0,
- * W % 8 == 0 (fused projection, head, stride 2, upsampling: W % 16 == 0), optional raw residual or fused skip projection.  dmd_conv2d takes it for launches of at most DIAMOND_CONV_LATENCY_TILES 256-pixel tiles
- * (environment; unset / 0: never -- the kernel is STAGED until it has been measured on the GPU). */
-int dmd_conv2d_latency_eligible(const dmd_conv_params* p);
 /* 1: dmd_conv2d runs these parameters on the streaming 1x1 kernel (exact fp32; taps == 1, Cout == 64, no
  * prologue / residual / statistics, Cin in {32, 64, 128}): blocks.py:120,133 skip projections */
 int dmd_conv1x1_stream_eligible(const dmd_conv_params* p);
@@ -346,6 +340,8 @@ int dmd_conv2d_wgrad(const dmd_wgrad_params* p, dmd_stream_t stream);
 
 const char* dmd_last_error(void);
 int dmd_abi_version(void);
+/* The library reads its DIAMOND_* switches from the environment once; this makes it read them again (test hook). */
+void dmd_reload_env(void);
 
 #ifdef __cplusplus
 }

@@ -46,6 +46,30 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+def reload_dmd_env():
+    """The libraries cache their DIAMOND_* switches (DmdEnvInt, csrc/dmd_common.h): re-read them in whichever is loaded."""
+    from diamond_amd import native as nv
+    from tests.simt import loader as S
+
+    for mod in (nv, S):
+        L = getattr(mod, "_lib", None)
+        if L is not None:
+            L.dmd_reload_env()
+
+
+@pytest.fixture
+def dmd_env(monkeypatch):
+    """dmd_env(DIAMOND_WGRAD_MAX_WG=7, ...): library switches for the duration of one test (None = unset)."""
+    def set_(**kv):
+        for k, v in kv.items():
+            monkeypatch.delenv(k, raising=False) if v is None else monkeypatch.setenv(k, str(v))
+        reload_dmd_env()
+
+    yield set_
+    monkeypatch.undo()
+    reload_dmd_env()
+
+
 def load_golden(name):
     return torch.load(os.path.join(GOLDEN, name), map_location="cpu", weights_only=False)
 

@@ -1,8 +1,9 @@
 """Import the upstream DIAMOND reference (read-only, /root/reference) with stub modules.
 
-Only used by `make_golden.py` (fixture generation, build container only) and by the
-optional cross-checks in tests that skip when /root/reference is absent (it does not
-exist on the GPU box).  Nothing in the product path imports this.
+Only used by `make_golden.py` (fixture generation, build container only), by the optional
+cross-checks in tests that skip when /root/reference is absent (it does not exist on the
+GPU box), and by `oracle/reference_window.py` (bench.py's CPU baseline on the reference's
+own bytecode, oracle/_ref).  Nothing in the product path imports this.
 
 The stubs cover third-party packages that are not installable here:
 omegaconf, wandb, gymnasium, ale_py, cv2, torcheval.
@@ -25,9 +26,13 @@ def _mod(name, **attrs):
     return m
 
 
-def install():
-    """Register stubs and put the reference `src/` on sys.path. Idempotent."""
-    if "agent" in sys.modules and getattr(sys.modules["agent"], "__file__", "").startswith(REF_SRC):
+def install(src=None):
+    """Register stubs and put the reference `src/` on sys.path. Idempotent.  `src`: where the reference's modules are
+    (default /root/reference/src; oracle/reference_window.py passes oracle/_ref/src, their bytecode, on the GPU box)."""
+    global REF_SRC
+    if src is not None:
+        REF_SRC = src
+    if "agent" in sys.modules and (getattr(sys.modules["agent"], "__file__", None) or "").startswith(REF_SRC):
         return
     sys.dont_write_bytecode = True  # never drop __pycache__ into the read-only tree
 

@@ -8,7 +8,7 @@ SRC=../../diamond_amd/csrc
 FLAGS="-x c++ -std=c++17 -O2 -g0 -fPIC -mf16c -mfma -mavx2 -ffp-contract=off -Iinclude -Wno-unused-value -Wno-unknown-attributes -Wno-unused-result -Wno-psabi"
 mkdir -p _build
 pids=()
-for f in dmd_conv.hip dmd_conv1x1.hip dmd_conv_f16ws.hip dmd_conv_lat.hip dmd_backward.hip dmd_linear.hip dmd_attention.hip dmd_pointwise.hip dmd_lowres.hip dmd_pack.hip dmd_capi.cpp; do
+for f in dmd_conv.hip dmd_conv1x1.hip dmd_conv_f16ws.hip dmd_backward.hip dmd_linear.hip dmd_attention.hip dmd_pointwise.hip dmd_lowres.hip dmd_pack.hip dmd_capi.cpp; do
   o=_build/${f%.*}.o
   if [ ! -f "$o" ] || [ "$SRC/$f" -nt "$o" ] || [ $SRC/dmd_common.h -nt "$o" ] || [ ../../include/diamond_hip.h -nt "$o" ] || [ simt.h -nt "$o" ] || [ include/hip/hip_runtime.h -nt "$o" ]; then
     ( $CXX $FLAGS -c "$SRC/$f" -o "$o" ) &

@@ -368,10 +368,15 @@ WGRAD_CASES = [
 ]
 
 
+# launch plans: at most DIAMOND_WGRAD_MAX_WG workgroups (default 256) walk contiguous tile ranges; 7: many tiles per workgroup
+# (accumulators carried across tiles, the next tile's loads in flight under the MFMAs), 1024: the two-pass partial reduction
+@pytest.mark.parametrize("max_wg", [None, 7, 1024], ids=["plan256", "plan7", "plan1024"])
+@pytest.mark.parametrize("split", [False, True], ids=["exact", "f16x2"])
 @pytest.mark.parametrize("case", WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
-def test_conv_wgrad(case):
+def test_conv_wgrad(case, split, max_wg, dmd_env):
     from diamond_amd import ac_native as A, engine as E
 
+    dmd_env(DIAMOND_WGRAD_MAX_WG=max_wg)
     name, n, h, w, cin, cin_real, cout, taps, prologue = case
     g = torch.Generator().manual_seed(len(name) * 7 + n)
     k = 3 if taps == 9 else 1
@@ -391,7 +396,7 @@ def test_conv_wgrad(case):
     xa = make_act(x)
     spec = E.NormSpec(mul=gamma.float().to(DEV), add=beta.float().to(DEV)) if prologue else None
     dyd = to_nhwc(dy.float()).to(DEV)
-    dw, db = A._wgrad(xa, prologue, spec, dyd, taps, cin_real)
+    dw, db = A._wgrad(xa, prologue, spec, dyd, taps, cin_real, split=split)
     torch.cuda.synchronize()
     assert rel_err(dw, wgt.grad) < 2e-5, f"{name}: dW rel err {rel_err(dw, wgt.grad):.3e}"
     assert rel_err(db, bias.grad) < 2e-5, f"{name}: db rel err {rel_err(db, bias.grad):.3e}"

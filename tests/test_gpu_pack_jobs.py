@@ -90,3 +90,62 @@ def test_every_kind_of_copy_matches_the_single_tensor_packs_and_refreshes_in_pla
     cache.invalidate()
     assert torch.equal(cache.conv_weight(convs["c64"]), nv.pack_conv_weight(convs["c64"].weight))
     assert torch.equal(cache.dgrad_weight(convs["c64"], 0, 64, f16x2=True), nv.pack_conv_weight_f16x2(_transposed(convs["c64"].weight, 0, 64)))
+
+
+def test_a_swapped_parameter_storage_reaches_every_copy_of_that_parameter():
+    """`p.data = other` (checkpoint surgery, `module.to(...)`): ALL copies of the parameter are rebuilt from the new storage --
+    not only the one that is looked up first (the others' table rows would still name the old, possibly freed, storage and be
+    stamped fresh) -- into the same buffers, and rows of parameters that died leave the table."""
+    from diamond_amd import engine as E, native as nv
+
+    torch.manual_seed(1)
+    conv, other = nn.Conv2d(64, 64, 3, padding=1).to(DEV), nn.Conv2d(128, 64, 3, padding=1).to(DEV)
+    cache = E.PackCache()
+    look = lambda: (cache.conv_weight(conv), cache.conv_weight_f16x2(conv), cache.dgrad_weight(conv, 0, 64, f16x2=True),
+                    cache.conv_weight(other), cache.conv_weight_f16x2(other))
+    before = look()
+    ptrs = [t.data_ptr() for t in before]
+    frees = cache.frees_epoch
+    old_storage = conv.weight.data
+    conv.weight.data = torch.randn_like(conv.weight.data)  # a new storage, same version
+    old_storage.fill_(float("nan"))  # whoever still reads the old storage shows
+    after = look()
+    assert [t.data_ptr() for t in after] == ptrs and cache.frees_epoch == frees, "copies of a swapped parameter are rebuilt in place"
+    assert torch.equal(after[0], nv.pack_conv_weight(conv.weight))
+    assert torch.equal(after[1], nv.pack_conv_weight_f16x2(conv.weight))
+    assert torch.equal(after[2], nv.pack_conv_weight_f16x2(_transposed(conv.weight, 0, 64)))
+    assert torch.equal(after[3], nv.pack_conv_weight(other.weight)) and torch.equal(after[4], nv.pack_conv_weight_f16x2(other.weight))
+    # a parameter that died: its rows are dropped at the next rebuild of the table instead of being packed from freed memory
+    del other, look, before, after
+    import gc
+
+    gc.collect()
+    with torch.no_grad():
+        conv.weight.mul_(0.5)
+    assert torch.equal(cache.conv_weight_f16x2(conv), nv.pack_conv_weight_f16x2(conv.weight))
+    cache.invalidate()
+    assert torch.equal(cache.conv_weight(conv), nv.pack_conv_weight(conv.weight))
+    assert all(e.ref() is not None for e in cache._table_entries) or cache._table is None
+
+
+def test_looked_up_copies_outside_the_job_table_are_rebuilt_in_place_too():
+    """PackCache.get (transposed LSTM weights, per-head qkv pieces): same buffer after an update, and after invalidate() --
+    a captured graph that holds the pointer reads the new values."""
+    from diamond_amd import engine as E
+
+    w = nn.Parameter(torch.randn(48, 32, device=DEV))
+    cache = E.PackCache()
+    t0 = cache.get(w, "T", lambda t: t.detach().t().contiguous())
+    ptr = t0.data_ptr()
+    with torch.no_grad():
+        w.mul_(2.0)
+    t1 = cache.get(w, "T", lambda t: t.detach().t().contiguous())
+    assert t1.data_ptr() == ptr and torch.equal(t1, w.detach().t())
+    w.data.add_(1.0)
+    cache.invalidate()
+    assert cache.stale_epoch == 1
+    cache.refresh()  # what a captured training step / the graphed sampler call: no lookup needed
+    assert t1.data_ptr() == ptr and torch.equal(t1, w.detach().t()) and cache.frees_epoch == 0
+    # a view of the parameter itself stays a view (nothing to copy, the pointer follows the parameter)
+    v = cache.f32(w)
+    assert v.data_ptr() == w.data_ptr()

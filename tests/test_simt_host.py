@@ -48,67 +48,40 @@ def models(monkeypatch):
 
 def test_denoiser_vs_reference_golden_on_the_interpreter(models, monkeypatch):
     M, counter = models
-    monkeypatch.delenv("DIAMOND_CONV_LATENCY_TILES", raising=False)
     M.test_denoiser_vs_reference_golden("attn0011", (0, 0, 1, 1), 1)
     keys = "\n".join(counter.n)
     assert "conv_f16ws_kernel<WsGeom<false, 2, 9>>" in keys and "conv_f16ws_kernel<WsGeomProj>" in keys, keys
-    assert "conv_lat_kernel" not in keys
 
 
-def test_denoiser_latency_route_vs_reference_golden_on_the_interpreter(models, monkeypatch):
-    """STAGED conv_lat_kernel behind the real engine: every eligible 3x3 of the B = 2 denoiser on it, same golden, same bar"""
+@pytest.mark.parametrize("env", [{}, {"DIAMOND_WGRAD_MAX_WG": "7", "DIAMOND_GN_BWD_FOLD": "1"}], ids=["shipping", "few-workgroups+gn-fold"])
+def test_denoiser_training_step_vs_reference_golden_on_the_interpreter(models, dmd_env, env):
+    """loss and all 236 gradient tensors of Denoiser.forward + backward (split-fp16 arithmetic): the shipping plan, and 7
+    workgroups walking many tiles each with GroupNorm backward's channel sums folded into the apply pass"""
+    if env and os.environ.get("DIAMOND_SLOW_CPU_TESTS") != "1":
+        pytest.skip("a second 55 s end-to-end run: DIAMOND_SLOW_CPU_TESTS=1 runs it; the kernels' plans are in test_simt_kernels.py")
     M, counter = models
-    monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", "64")
-    M.test_denoiser_vs_reference_golden("default", (0, 0, 0, 0), 2)
-    lat = sum(v for k, v in counter.n.items() if k.startswith("conv_lat_"))
-    ws = sum(v for k, v in counter.n.items() if k.startswith("conv_f16ws_kernel"))
-    print(counter.n)
-    evals = 8  # model output + denoised frame at four sigmas
-    assert lat >= evals * 30 and counter.n.get("conv_lat_kernel<true, 16, 64, false>", 0) >= evals * 9, counter.n
-    # what is left: the fused 8x8 level and the stride-2 convolution INTO it (8 x 8 outputs are off the 8 x 16 tile grid)
-    assert ws == 0 and [k for k in counter.n if k.startswith("conv_mfma_kernel")] == ["conv_mfma_kernel<ConvGeom<4, true, 9, 2, true>>"], counter.n
-
-
-@pytest.mark.parametrize("env", [{}, {"DIAMOND_WGRAD_MODE": "3", "DIAMOND_WGRAD_MAX_WG": "7", "DIAMOND_WGRAD_SINGLE_REDUCE": "256",
-                                      "DIAMOND_GN_BWD_FOLD": "1", "DIAMOND_CONV_LATENCY_TILES": "64"}], ids=["shipping", "staged-backward"])
-def test_denoiser_training_step_vs_reference_golden_on_the_interpreter(models, monkeypatch, env):
-    if env and os.environ.get("DIAMOND_STAGED_TESTS") != "1":
-        pytest.skip("staged backward end to end (55 s): DIAMOND_STAGED_TESTS=1 runs it; its kernels are in test_simt_kernels.py")
-    """loss and all 236 gradient tensors of Denoiser.forward + backward (split-fp16 arithmetic), shipping kernels and the staged
-    backward (weight gradients: 32-pixel MFMA + prefetch, 7 workgroups walking many tiles each, one-pass reduction; GroupNorm
-    backward with the channel sums folded into the apply pass; forward and data-gradient 3x3s on the few-tile kernel)"""
-    M, counter = models
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    dmd_env(**env)
     errs = M.denoiser_training_step_errors(("f16x2",))["f16x2"]
     bad = {k: v for k, v in errs.items() if v >= 1e-4}
     assert not bad, bad
     assert counter.n.get("dmd_conv2d_wgrad", 0) > 100 and counter.n.get("dmd_gn_silu_bwd", 0) > 50, counter.n
 
 
-@pytest.mark.parametrize("cap", ["0", "64", "64tp"], ids=["shipping", "staged-latency-route", "staged-throughput-flavour"])
-def test_rew_end_model_and_actor_critic_vs_goldens_on_the_interpreter(models, monkeypatch, cap):
+def test_rew_end_model_and_actor_critic_vs_goldens_on_the_interpreter(models):
     """reward / end model (32-channel AdaGN encoder, fused 8x8 tail, LSTM, head) and the actor-critic (forward + every gradient)
-    against the reference-generated goldens; with the cap, their eligible 32- and 64-channel 3x3s run on conv_lat_kernel"""
+    against the reference-generated goldens"""
     M, counter = models
-    monkeypatch.setenv("DIAMOND_CONV_LATENCY_TP", "1" if cap.endswith("tp") else "0")
-    cap = cap.rstrip("tp")
-    monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", cap)
     ag = M.make_agent()
     M.test_rew_end_model_vs_golden(ag)
     M.test_actor_critic_vs_golden(ag)
-    lat = sum(v for k, v in counter.n.items() if k.startswith("conv_lat_"))
-    assert (lat >= 30) if cap != "0" else (lat == 0), counter.n
     assert counter.n.get("dmd_lowres_chain32", 0) >= 2 and counter.n.get("dmd_lstm_pointwise_bwd", 0) >= 1, counter.n
 
 
 @pytest.mark.skipif(os.environ.get("DIAMOND_SLOW_CPU_TESTS") != "1", reason="2-4 minutes on 8 cores: DIAMOND_SLOW_CPU_TESTS=1 runs it")
-@pytest.mark.parametrize("cap", ["0", "64"], ids=["shipping", "staged-latency-route"])
-def test_full_window_vs_reference_golden_on_the_interpreter(models, monkeypatch, cap):
+def test_full_window_vs_reference_golden_on_the_interpreter(models):
     """The whole north-star path on the CPU: two BPTT windows of ActorCritic.forward() + backward through WorldModelEnv /
     env_loop / DiffusionSampler / reward-end model with resets and burn-in, the reference's RNG order -- sampled actions,
     rewards, ends and truncations BIT-exact against the reference-generated golden, frames on its uint8 levels."""
     M, counter = models
-    monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", cap)  # batch 4: every level of the U-Net is within 64 tiles
     M.test_full_window_vs_reference_golden()
     assert counter.n.get("dmd_categorical_sample", 0) >= 12 and counter.n.get("lowres_chain_kernel", 0) >= 36, counter.n

@@ -235,23 +235,17 @@ WGRAD_CASES = [
 ]
 
 
-# what the launcher reads per call: DIAMOND_WGRAD_MODE (the staged 32-pixel / prefetching kernels, split precision only) and
-# DIAMOND_WGRAD_MAX_WG (fewer workgroups, each walking several tiles with its accumulators in registers)
-WGRAD_PLANS = [dict(), dict(mode=2), dict(mode=3), dict(mode=2, max_wg=1), dict(mode=3, max_wg=3), dict(max_wg=2)]
-# (DIAMOND_WGRAD_SINGLE_REDUCE: test_conv2d_wgrad_many_partials below)
+# the launcher's plan: at most DIAMOND_WGRAD_MAX_WG workgroups (default 256), each walking a contiguous range of tiles with its
+# accumulators in registers and the next tile's loads in flight under the current tile's MFMAs
+WGRAD_PLANS = [dict(), dict(max_wg=1), dict(max_wg=3), dict(max_wg=1024)]
 
 
 @pytest.mark.parametrize("schedule", SCHEDULES)
 @pytest.mark.parametrize("plan", WGRAD_PLANS, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()) or "default")
 @pytest.mark.parametrize("case", WGRAD_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
-def test_conv2d_wgrad(case, plan, schedule, monkeypatch, request):
+def test_conv2d_wgrad(case, plan, schedule, monkeypatch, request, dmd_env):
     monkeypatch.setenv("SIMT_SCHEDULE", str(schedule))
-    if "mode" in plan and not case.get("precision"):
-        pytest.skip("the staged modes are split-precision kernels")
-    if "mode" in plan:
-        monkeypatch.setenv("DIAMOND_WGRAD_MODE", str(plan["mode"]))
-    if "max_wg" in plan:
-        monkeypatch.setenv("DIAMOND_WGRAD_MAX_WG", str(plan["max_wg"]))
+    dmd_env(DIAMOND_WGRAD_MAX_WG=plan.get("max_wg"))
     rng = np.random.default_rng(11)
     L = S.lib()
     n, h, w, cin, cout, k = case["n"], case["h"], case["w"], case["cin"], case["cout"], case["k"]
@@ -294,8 +288,8 @@ def test_conv2d_wgrad(case, plan, schedule, monkeypatch, request):
         np.testing.assert_allclose(db, g.sum(axis=0), rtol=0, atol=2e-5 * np.abs(g.sum(axis=0)).max() + 1e-5)
 
 
-def test_conv2d_wgrad_many_partials(monkeypatch):
-    """more partials than the single-pass reduction takes by default (64): both reduction forms, and the staged threshold"""
+def test_conv2d_wgrad_many_partials(dmd_env):
+    """more partials than the single-pass reduction takes (64): the two-pass reduction, against the single pass of a small plan"""
     rng = np.random.default_rng(12)
     L = S.lib()
     n, h, w, c = 20, 16, 16, 32  # 80 8x8 blocks = 40 tiles... times 4 images more: 100 workgroups
@@ -310,7 +304,7 @@ def test_conv2d_wgrad_many_partials(monkeypatch):
             want[:, :, ky, kx] = g.T @ ap[:, ky:ky + h, kx:kx + w].reshape(-1, c)
     got = {}
     for single in ("0", "256"):
-        monkeypatch.setenv("DIAMOND_WGRAD_SINGLE_REDUCE", single)
+        dmd_env(DIAMOND_WGRAD_MAX_WG=1024 if single == "0" else 32)  # 200 tiles: 200 partials (two passes) / 32 (one pass)
         p = nv.WgradParams()
         p.N, p.H, p.W, p.Cout, p.taps, p.cin_real, p.precision = n, h, w, c, 9, c, 1
         p.src.x, p.src.C, p.src.prologue, p.dy = S.ptr(x), c, 0, S.ptr(dy)
@@ -400,8 +394,8 @@ def test_linear(m, n, k, acc, silu):
 @pytest.mark.parametrize("fold", [0, 1], ids=["three-launches", "staged-fold"])
 @pytest.mark.parametrize("n,hw,c,identity,skip", [(2, 64, 64, 0, True), (1, 300, 32, 0, False), (2, 256, 128, 1, True), (1, 64, 16, 0, False),
                                                   (3, 1024, 64, 0, True)])
-def test_gn_silu_bwd(n, hw, c, identity, skip, fold, monkeypatch):
-    monkeypatch.setenv("DIAMOND_GN_BWD_FOLD", str(fold))
+def test_gn_silu_bwd(n, hw, c, identity, skip, fold, dmd_env):
+    dmd_env(DIAMOND_GN_BWD_FOLD=fold)
     rng = np.random.default_rng(hw + c)
     L = S.lib()
     x = (rng.standard_normal((n, hw, 1, c)) * 1.4 + 0.3).astype(np.float32)
@@ -745,144 +739,6 @@ def test_lowres_chain(c, schedule, monkeypatch, request):
     assert err <= 2e-5, err
 
 
-# ---- conv_lat_kernel: the few-tile split-fp16 3x3 (STAGED; dmd_conv2d routes to it under DIAMOND_CONV_LATENCY_TILES) ---------------
-LAT_CASES = [
-    dict(n=1, h=8, w=16, cin=[64]),
-    dict(n=2, h=16, w=32, cin=[64], prologue=[1], film=True, stats=True, residual=True),
-    dict(n=1, h=16, w=16, cin=[64, 64], prologue=[1, 1], film=True, stats=True),             # ResBlock conv1 on cat(x, skip)
-    dict(n=1, h=8, w=32, cin=[64, 64], prologue=[1, 0]),
-    dict(n=2, h=16, w=16, cin=[64], upsample=1, stats=True),                                  # Upsample's conv
-    dict(n=1, h=16, w=16, cin=[64], upsample=1, prologue=[1]),
-    dict(n=2, h=16, w=16, cin=[64], prologue=[1], film=True, stats=True, proj=True),          # conv2 + fused skip projection
-    dict(n=1, h=8, w=16, cin=[128], prologue=[2]),
-    dict(n=2, h=16, w=16, cin=[32], cout=32, prologue=[1], film=True, stats=True, residual=True),   # reward / end encoder ResBlock convs
-    dict(n=1, h=16, w=32, cin=[32], cout=64, prologue=[1], stats=True),                              # actor-critic encoder 32 -> 64
-    dict(n=1, h=8, w=16, cin=[64], cout=32, prologue=[1]),
-    dict(n=2, h=16, w=16, cin=[16], stats=True),                                                      # conv_in: one chunk, nothing to normalise
-    dict(n=2, h=16, w=32, cin=[64], cout=3, prologue=[1], film=True, nchw=True),                      # conv_out: few-channel NCHW head
-    dict(n=2, h=16, w=16, cin=[64], stride=2, stats=True),                                            # Downsample: two staging rounds
-    dict(n=1, h=8, w=32, cin=[32], cout=32, stride=2, stats=True),
-    dict(n=3, h=8, w=8, cin=[64], prologue=[1], film=True, stats=True, residual=True),                # 8 x 8 blocks: images 0 | 1 in one workgroup, image 2 alone
-    dict(n=2, h=8, w=8, cin=[64, 64], prologue=[1, 1], film=True, stats=True),
-    dict(n=1, h=16, w=24, cin=[64], prologue=[1], stats=True),                                        # 2 x 3 blocks per image
-    dict(n=5, h=8, w=8, cin=[32], cout=32, prologue=[1], stats=True, residual=True),
-    dict(n=2, h=16, w=16, cin=[32], cout=32, prologue=[1], film=True, stats=True, residual=True, tp=1),  # the throughput flavour
-    dict(n=1, h=8, w=32, cin=[32], cout=32, tp=1),
-]
-
-
-@pytest.mark.parametrize("schedule", SCHEDULES)
-@pytest.mark.parametrize("case", LAT_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()).replace(" ", ""))
-def test_conv_latency_kernel(case, schedule, monkeypatch, request):
-    monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", "64")
-    monkeypatch.setenv("DIAMOND_CONV_LATENCY_TP", str(case.get("tp", 0)))
-    monkeypatch.setenv("SIMT_SCHEDULE", str(schedule))
-    rng = np.random.default_rng(17)
-    L = S.lib()
-    n, h, w, cins = case["n"], case["h"], case["w"], case["cin"]
-    up, prol, stride = case.get("upsample", 0), case.get("prologue", [0] * len(cins)), case.get("stride", 1)
-    hs, ws = (h // 2, w // 2) if up else (h * stride, w * stride)
-    cin, cout = sum(cins), case.get("cout", 64)
-    nchw = bool(case.get("nchw"))
-    cout_pad = 32 if nchw else cout
-    p = nv.ConvParams()
-    p.N, p.H, p.W, p.Cout, p.CoutPad, p.taps, p.stride, p.upsample, p.nsrc, p.precision = n, h, w, cout, cout_pad, 9, stride, up, len(cins), 1
-    keep, xs_ref = [], []
-    for i, c in enumerate(cins):
-        x = G((rng.standard_normal((n, hs, ws, c)) * 1.5 + 0.3).astype(np.float32), tight="start" if (n + hs + c) % 2 else "end")
-        p.src[i].x, p.src[i].C, p.src[i].prologue = S.ptr(x), c, prol[i]
-        if prol[i]:
-            tiles = 70 if i == 0 else 3  # more partial sums than lanes: the finalising wave strides over them
-            st = _partial_stats(x, hs, ws, tiles, rng)
-            film = case.get("film") or prol[i] == 2
-            mul = (rng.standard_normal((n, c)) * 0.3).astype(np.float32) if film else None
-            add = (rng.standard_normal((n, c)) * 0.3).astype(np.float32) if film else None
-            p.src[i].norm = _norm(st, tiles, mul, add, bool(case.get("film")))
-            xs_ref.append(_apply_norm(x, hs, ws, mul, add, bool(case.get("film")), silu=prol[i] == 1))
-            keep += [st, mul, add]
-        else:
-            xs_ref.append(x.astype(np.float64))
-        keep.append(x)
-    wt = np.zeros((cout_pad, cin, 3, 3), dtype=np.float32)
-    wt[:cout] = rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)
-    bias = np.zeros(cout_pad, dtype=np.float32)
-    bias[:cout] = rng.standard_normal(cout)
-    packed = np.zeros((cin // 16) * 9 * cout_pad * 16, dtype=np.float32)
-    S.check(L.dmd_pack_conv_weight(S.ptr(wt), S.ptr(packed), cout_pad, cin, 3, cout_pad, cin, None), "pack")
-    w16 = _pack16(wt)
-    p.w, p.bias, p.w_f16 = S.ptr(packed), S.ptr(bias), S.ptr(w16)
-    ref = _ref_conv(xs_ref, wt[:cout], bias[:cout], 3, stride, up, h, w)
-    if case.get("residual"):
-        r = G(rng.standard_normal((n, h, w, cout)).astype(np.float32))
-        p.residual = S.ptr(r)
-        ref = ref + r
-    if case.get("proj"):
-        j0, j1 = (G(rng.standard_normal((n, h, w, 64)).astype(np.float32)) for _ in range(2))
-        wpj = (rng.standard_normal((cout, 128, 1, 1)) / np.sqrt(128)).astype(np.float32)
-        bpj = rng.standard_normal(cout).astype(np.float32)
-        wpj16 = _pack16(wpj)
-        p.proj_nsrc, p.proj_C[0], p.proj_C[1] = 2, 64, 64
-        p.proj_x[0], p.proj_x[1], p.proj_w_f16, p.proj_bias = S.ptr(j0), S.ptr(j1), S.ptr(wpj16), S.ptr(bpj)
-        ref = ref + _ref_conv([j0.astype(np.float64), j1.astype(np.float64)], wpj, bpj, 1, 1, 0, h, w)
-    out = G(np.full((n, cout, h, w) if nchw else (n, h, w, cout), np.nan, dtype=np.float32))
-    p.out_nchw = int(nchw)
-    tiles = L.dmd_conv_stat_tiles(h, w)
-    stats = G(np.full((n, cout // 32, tiles, 2), np.nan)) if case.get("stats") else None
-    p.out, p.out_stats = S.ptr(out), S.ptr(stats)
-
-    assert L.dmd_conv2d_latency_eligible(p) == 1
-    name = bytes(96)
-    buf = (nv.C.c_char * 96)()
-    S.check(L.dmd_conv2d_kernel_name(p, buf, 96), "kernel_name")
-    name = buf.value.decode()
-    if w % 16:
-        assert name == f"conv_lat_b8_kernel<{cin // 4}, {cout}>"
-    elif stride == 2:
-        assert name == f"conv_lat_s2_kernel<{cin // 4}, {cout}>"
-    elif nchw:
-        assert name == "conv_lat_kernel<false, 16, 32, true>"
-    else:
-        assert name == f"conv_lat_kernel<{'true' if case.get('proj') else 'false'}, {cin // 4}, {cout}, false>"
-    S.check(L.dmd_conv2d(p, None), "dmd_conv2d")
-    got = out.transpose(0, 2, 3, 1) if nchw else out
-    err = np.abs(got - ref).max()
-    assert err <= 2e-5 * max(1.0, np.abs(ref).max()), err
-    _same_bits_as_schedule_0(request, schedule, out, stats)
-    if stats is not None:
-        # one partial per 8 x 16 tile and 32-channel group, in dmd_conv_stat_tiles order
-        tw = 16 if w % 16 == 0 else 8
-        t8 = out.reshape(n, h // 8, 8, w // tw, tw, cout // 32, 32).astype(np.float64)
-        want = np.stack([t8.sum(axis=(2, 4, 6)), (t8 * t8).sum(axis=(2, 4, 6))], axis=-1)  # (n, ty, tx, g, 2)
-        np.testing.assert_allclose(stats, want.transpose(0, 3, 1, 2, 4).reshape(n, cout // 32, tiles, 2), rtol=1e-9, atol=1e-6)
-
-    # the route is by tile count: above the cap the same parameters run on conv_f16ws_kernel (8 x 16 images: conv_mfma)
-    monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", "0")
-    S.check(L.dmd_conv2d_kernel_name(p, buf, 96), "kernel_name")
-    assert buf.value.decode().startswith("conv_f16ws_kernel<" if (h % 16 == 0 or w % 16 != 0) and stride == 1 else "conv_mfma_kernel<")
-    other = np.full_like(out, np.nan)
-    p.out, p.out_stats = S.ptr(other), None
-    S.check(L.dmd_conv2d(p, None), "dmd_conv2d")
-    d = np.abs(other - out).max() / np.abs(out).max()
-    assert d < 1e-5, d  # two kernels, the same split arithmetic (bitwise equal here when even the summation order coincides)
-
-
-def test_conv_latency_eligibility():
-    L = S.lib()
-    x = np.zeros((1, 8, 16, 64), dtype=np.float32)
-    p = nv.ConvParams()
-    p.N, p.H, p.W, p.Cout, p.CoutPad, p.taps, p.stride, p.nsrc, p.precision = 1, 8, 16, 64, 64, 9, 1, 1, 1
-    p.src[0].x, p.src[0].C = S.ptr(x), 64
-    p.w_f16 = S.ptr(x)
-    assert L.dmd_conv2d_latency_eligible(p) == 1
-    for field, bad in (("precision", 0), ("taps", 1), ("Cout", 48), ("W", 12), ("valid_h", 4), ("out_nchw", 1), ("stride", 3)):
-        good = getattr(p, field)
-        setattr(p, field, bad)
-        assert L.dmd_conv2d_latency_eligible(p) == 0, field
-        setattr(p, field, good)
-    p.src[0].C = 48
-    assert L.dmd_conv2d_latency_eligible(p) == 0
-
-
 # ---- conv_f16ws_kernel: the dominant, wave-specialised persistent kernel (its inline assembly spelled in C++ for this build) --------
 WS_CASES = [
     dict(n=2, h=16, w=16, cin=[64], cout=64, k=3, prologue=[1], film=True, stats=True, residual="raw"),     # WsGeom<false, 2, 9>
@@ -976,105 +832,6 @@ def test_conv_f16ws(case, schedule, monkeypatch, request):
     if stats is not None:
         want = _group_sums(np.ascontiguousarray(got.astype(np.float32)), hv, wv)
         np.testing.assert_allclose(stats.sum(axis=2), want, rtol=2e-6, atol=1e-4)  # (fp32 sums of a lane's 16 values inside)
-
-
-def test_conv_latency_route_caps(monkeypatch):
-    """the general cap and the one for the 32-output-channel layers (tile count of the launch: N * H * W / 256)"""
-    L = S.lib()
-    x = np.zeros((4, 16, 16, 64), dtype=np.float32)
-    buf = (nv.C.c_char * 96)()
-
-    def route(cout, cin):
-        p = nv.ConvParams()
-        p.N, p.H, p.W, p.Cout, p.CoutPad, p.taps, p.stride, p.nsrc, p.precision = 4, 16, 16, cout, cout, 9, 1, 1, 1
-        p.src[0].x, p.src[0].C, p.w, p.w_f16, p.out = S.ptr(x), cin, S.ptr(x), S.ptr(x), S.ptr(x)
-        S.check(L.dmd_conv2d_kernel_name(p, buf, 96), "kernel_name")
-        return buf.value.decode().startswith("conv_lat_")
-
-    monkeypatch.delenv("DIAMOND_CONV_LATENCY_TILES", raising=False)
-    monkeypatch.delenv("DIAMOND_CONV_LATENCY_TILES_C32", raising=False)
-    assert not route(64, 64) and not route(32, 32)              # staged: off by default
-    monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", "3")        # this launch is 4 tiles of 256 pixels
-    assert not route(64, 64) and not route(32, 32)
-    monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", "4")
-    assert route(64, 64) and route(32, 32) and route(64, 32)
-    monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES_C32", "0")
-    assert route(64, 64) and not route(32, 32)
-    monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", "0")
-    monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES_C32", "1000000000")
-    assert not route(64, 64) and route(32, 32) and route(32, 64)
-
-
-def test_conv_routes_agree_on_random_shapes(monkeypatch):
-    """Randomised cross-check of the three 3x3 families behind dmd_conv2d (seeded): whatever conv_lat_kernel is eligible for must
-    come out as on the route the launch takes without it (conv_f16ws / conv_mfma), outputs to split-fp16 rounding and statistics
-    alike -- odd block counts, non-square images, every source / prologue / residual combination the eligibility admits."""
-    rng = np.random.default_rng(2024)
-    L = S.lib()
-    tried = routed = 0
-    buf = (nv.C.c_char * 96)()
-    for _ in range(160):
-        n = int(rng.integers(1, 4))
-        h = int(rng.choice([8, 16, 24]))
-        w = int(rng.choice([8, 16, 24, 32]))
-        stride = int(rng.choice([1, 1, 1, 2]))
-        up = int(stride == 1 and w % 16 == 0 and h % 2 == 0 and rng.random() < 0.2)
-        cins = [[32], [64], [64, 64], [32, 32], [128]][int(rng.integers(0, 5))]
-        cout = int(rng.choice([32, 64]))
-        prol = [int(rng.choice([0, 1, 2])) for _ in cins]
-        if stride == 2:
-            cins, prol, cout = [cout], [0], cout
-        residual = bool(rng.random() < 0.5)
-        want_stats = bool(rng.random() < 0.7)
-        cin = sum(cins)
-        hs, ws = (h // 2, w // 2) if up else (h * stride, w * stride)
-        p = nv.ConvParams()
-        p.N, p.H, p.W, p.Cout, p.CoutPad, p.taps, p.stride, p.upsample, p.nsrc, p.precision = n, h, w, cout, cout, 9, stride, up, len(cins), 1
-        keep = []
-        for i, c in enumerate(cins):
-            x = G((rng.standard_normal((n, hs, ws, c)) * 1.3).astype(np.float32), tight="start" if (n + hs) % 2 else "end")
-            p.src[i].x, p.src[i].C, p.src[i].prologue = S.ptr(x), c, prol[i]
-            if prol[i]:
-                st = _partial_stats(x, hs, ws, 2, rng)
-                mul = (rng.standard_normal((n, c)) * 0.3).astype(np.float32)
-                add = (rng.standard_normal((n, c)) * 0.3).astype(np.float32)
-                p.src[i].norm = _norm(st, 2, mul, add, plus_one=prol[i] == 1)
-                keep += [st, mul, add]
-            keep.append(x)
-        wt = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
-        bias = rng.standard_normal(cout).astype(np.float32)
-        packed = np.zeros((cin // 16) * 9 * cout * 16, dtype=np.float32)
-        S.check(L.dmd_pack_conv_weight(S.ptr(wt), S.ptr(packed), cout, cin, 3, cout, cin, None), "pack")
-        w16 = _pack16(wt)
-        p.w, p.bias, p.w_f16 = S.ptr(packed), S.ptr(bias), S.ptr(w16)
-        if residual:
-            r = G(rng.standard_normal((n, h, w, cout)).astype(np.float32))
-            p.residual = S.ptr(r)
-        tried += 1
-        if not L.dmd_conv2d_latency_eligible(p):
-            continue
-        routed += 1
-        tiles = L.dmd_conv_stat_tiles(h, w)
-        res = {}
-        for cap in ("0", "1000000"):
-            monkeypatch.setenv("DIAMOND_CONV_LATENCY_TILES", cap)
-            out = G(np.full((n, h, w, cout), np.nan, dtype=np.float32))
-            stats = G(np.full((n, cout // 32, tiles, 2), np.nan)) if want_stats else None
-            p.out, p.out_stats = S.ptr(out), S.ptr(stats)
-            S.check(L.dmd_conv2d_kernel_name(p, buf, 96), "kernel_name")
-            assert buf.value.decode().startswith("conv_lat_") == (cap != "0")
-            S.check(L.dmd_conv2d(p, None), "dmd_conv2d")
-            res[cap] = (out, stats)
-        a, b = res["0"], res["1000000"]
-        what = (n, h, w, stride, up, cins, cout, prol, residual)
-        assert np.isfinite(b[0]).all(), what
-        assert np.abs(a[0] - b[0]).max() <= 1e-5 * max(1.0, np.abs(a[0]).max()), what
-        if want_stats:
-            np.testing.assert_allclose(a[1].sum(axis=2), b[1].sum(axis=2), rtol=1e-5, atol=1e-3, err_msg=str(what))
-            if w % 16 == 0 or stride == 1:  # same partial layout on both routes: compare tile by tile
-                np.testing.assert_allclose(a[1], b[1], rtol=1e-4, atol=1e-3, err_msg=str(what))
-    print(f"{routed} of {tried} random launches were eligible for the few-tile kernels")
-    assert routed >= 70, (tried, routed)
 
 
 def test_zz_schedule_comparisons_took_place():

@@ -1,8 +1,9 @@
 """Timeline of one workgroup of conv_f16ws_kernel (s_memtime stamps of a DMD_LAB -DWS_TRACE build): who waits for whom
 in a chunk step.
    bash tools/build_ws_ablations.sh trace   (WS_EXTRA=-DWS_TRACE)
-   DIAMOND_LIB=diamond_amd/ablate/libdiamond_hip_wstrace.so python tools/ws_trace.py [cin] [res]
-   res = 2: the fused skip projection (WsGeomProj) instead of a residual"""
+   DIAMOND_LIB=diamond_amd/ablate/libdiamond_hip_wstrace.so python tools/ws_trace.py [cin] [res] [cout] [h]
+   res = 2: the fused skip projection (WsGeomProj) instead of a residual; cout = 32: the 512-pixel-tile instance
+   (WsGeom<false, 1, 9>: reward / end model, actor-critic); h: image size (64)"""
 import collections
 import ctypes as C
 import os
@@ -15,22 +16,23 @@ from diamond_amd import engine as E, native as nv
 
 cin = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 res = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+cout = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 dev = "cuda"
-n, h = 256, 64
+n, h = 256, (int(sys.argv[4]) if len(sys.argv) > 4 else 64)
 srcs = []
-for c in [64] * (cin // 64):
+for c in ([64] * (cin // 64) if cin >= 64 else [cin]):
     a = E.gn_stats(torch.randn(n, h, h, c, device=dev))
     spec = E.NormSpec(mul=torch.randn(n, c, device=dev) * 0.1, add=torch.randn(n, c, device=dev) * 0.1, mul_stride=c, add_stride=c, plus_one=True)
     srcs.append((a, 1, spec))
-w = torch.randn(64, cin, 3, 3, device=dev) / (cin * 9) ** 0.5
+w = torch.randn(cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5
 wp, w16 = nv.pack_conv_weight(w), nv.pack_conv_weight_f16x2(w)
-b = torch.zeros(64, device=dev)
-r = E.Act(torch.randn(n, h, h, 64, device=dev)) if res == 1 else None
+b = torch.zeros(cout, device=dev)
+r = E.Act(torch.randn(n, h, h, cout, device=dev)) if res == 1 else None
 proj = None
 if res == 2:
     wpj = torch.randn(64, 128, 1, 1, device=dev) / 128 ** 0.5
     proj = ([E.Act(torch.randn(n, h, h, 64, device=dev)), E.Act(torch.randn(n, h, h, 64, device=dev))], nv.pack_conv_weight_f16x2(wpj), b)
-run = lambda: E.conv2d(srcs, wp, b, 64, residual=r, w_f16=w16, proj=proj)
+run = lambda: E.conv2d(srcs, wp, b, cout, residual=r, w_f16=w16, proj=proj)
 L = nv.lib()
 L.dmd_ws_trace_dump.argtypes = [C.c_void_p, C.c_void_p]
 NMAX = 4096
