@@ -58,7 +58,7 @@ def _wgrad(x: Act, prologue: int, spec: Optional[NormSpec], dy: Tensor, taps: in
     if prologue != nv.PROLOGUE_NONE:
         p.src.norm = spec.to_native(x)
     p.dy = nv.ptr(dy)
-    p.precision = nv.PRECISION_F16X2 if (split and not WGRAD_EXACT) else nv.PRECISION_F32
+    p.precision = nv.PRECISION_F16X2 if split else nv.PRECISION_F32
     ws = torch.empty(int(nv.lib().dmd_wgrad_workspace_floats(C.byref(p))), device=dy.device, dtype=torch.float32)
     dw = torch.empty(cout, cin_real, k, k, device=dy.device, dtype=torch.float32)
     db = torch.empty(cout, device=dy.device, dtype=torch.float32) if want_bias else None
@@ -87,10 +87,8 @@ def _gn_silu_bwd(x: Act, spec: NormSpec, da: Tensor, dskip: Optional[Tensor]) ->
 # Arithmetic of the encoder's forward and dgrad convolutions: "f16x2" = split-fp32 on the f16 matrix cores where the
 # shape is covered (fp32-class accuracy, see dmd_conv_f16ws.hip), "f32" = exact fp32 MFMA.  The weight gradient
 # (contraction over pixels) runs on the split-fp16 instance of the wgrad kernel as well (its operands are pre-scaled to
-# O(1) by the 2^k scaling of the backward), on the exact fp32 instance with "f32" or DIAMOND_WGRAD_EXACT=1.
+# O(1) by the 2^k scaling of the backward), on the exact fp32 instance with "f32".
 AC_PRECISION = os.environ.get("DIAMOND_AC_PRECISION", "f16x2")
-# DIAMOND_WGRAD_EXACT=1: weight gradients on the exact-fp32 instance of the wgrad kernel even where forward / dgrad run split
-WGRAD_EXACT = os.environ.get("DIAMOND_WGRAD_EXACT", "0") == "1"
 
 
 def _transposed(w: Tensor) -> Tensor:

@@ -316,9 +316,7 @@ extern "C" int dmd_attention(const float* qkv, float* out, int N, int T, int C, 
   DMD_CHECK_ARG(qkv && out, "attention: null");
   DMD_CHECK_ARG(head_dim == 8, "attention: head_dim must be 8 (ATTN_HEAD_DIM), got %d", head_dim);
   DMD_CHECK_ARG(C % 8 == 0 && T % 64 == 0 && N > 0, "attention: need C %% 8 == 0, T %% 64 == 0 (T=%d C=%d)", T, C);
-  static DmdEnvInt f16x2_env{"DIAMOND_ATTENTION_F16X2", 1};
-  const int use_f16x2 = f16x2_env.get();
-  if (use_f16x2 && T % 256 == 0) {
+  if (T % 256 == 0) {
     // long sequences (1024 / 4096 tokens of the 256x256 configuration): split-fp16 two-pass kernel
     hipLaunchKernelGGL(attention_f16x2_kernel, dim3(T / 256, C / 8, N), dim3(256), 0, (hipStream_t)stream, qkv, out, T, C,
                        1.4426950408889634f / sqrtf((float)head_dim));

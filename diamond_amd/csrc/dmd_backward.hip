@@ -158,27 +158,24 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const dmd_gn_bwd_par
   }
 }
 
-// FOLD (STAGED, DIAMOND_GN_BWD_FOLD=1): workgroup (0, n) also sums the T per-tile channel partials of image n into dmul / dadd,
-// in gn_bwd_chan_kernel's order (bitwise the same sums, one launch less per normalisation)
-template <bool FOLD>
+// Workgroup (0, n) also sums the T per-tile channel partials of image n into dmul / dadd, in tile order (round 4: a separate
+// launch until then; bitwise the same sums, one launch less per normalisation: 12.05 -> 11.90 ms per denoiser training step)
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const dmd_gn_bwd_params p, int T, const double* __restrict__ group_partial,
                                                            const float* __restrict__ chan_partial) {
   __shared__ float g_mean[GN_BWD_MAXG], g_rstd[GN_BWD_MAXG], g_m1[GN_BWD_MAXG], g_m2[GN_BWD_MAXG];
   const int t = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
   const int C = p.C, CQ = C / 4, G = C / DMD_GN_GROUP > 0 ? C / DMD_GN_GROUP : 1;
   const int gsz = C / G;
-  if constexpr (FOLD) {
-    if (t == 0) {
-      for (int c = tid; c < C; c += 256) {
-        float a = 0.f, b = 0.f;
-        for (int tt = 0; tt < T; ++tt) {
-          const float* o = chan_partial + (((size_t)n * T + tt) * C + c) * 2;
-          a += o[0];
-          b += o[1];
-        }
-        p.dmul[(size_t)n * C + c] = a;
-        p.dadd[(size_t)n * C + c] = b;
+  if (t == 0) {
+    for (int c = tid; c < C; c += 256) {
+      float a = 0.f, b = 0.f;
+      for (int tt = 0; tt < T; ++tt) {
+        const float* o = chan_partial + (((size_t)n * T + tt) * C + c) * 2;
+        a += o[0];
+        b += o[1];
       }
+      p.dmul[(size_t)n * C + c] = a;
+      p.dadd[(size_t)n * C + c] = b;
     }
   }
   if (tid < G) {
@@ -225,21 +222,6 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const dmd_gn_bwd_para
   }
 }
 
-__global__ void gn_bwd_chan_kernel(const float* __restrict__ chan_partial, float* __restrict__ dmul, float* __restrict__ dadd,
-                                   int N, int T, int C) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= N * C) return;
-  const int n = idx / C, c = idx - n * C;
-  float a = 0.f, b = 0.f;
-  for (int t = 0; t < T; ++t) {
-    const float* o = chan_partial + (((size_t)n * T + t) * C + c) * 2;
-    a += o[0];
-    b += o[1];
-  }
-  dmul[idx] = a;
-  dadd[idx] = b;
-}
-
 static inline int gn_bwd_tiles(int HW) { return (HW + GN_BWD_PIX - 1) / GN_BWD_PIX; }
 
 extern "C" int64_t dmd_gn_bwd_workspace_bytes(int N, int HW, int C) {
@@ -260,15 +242,7 @@ extern "C" int dmd_gn_silu_bwd(const dmd_gn_bwd_params* pp, dmd_stream_t stream)
   float* chan_partial = (float*)((char*)p.workspace + (size_t)p.N * G * T * 2 * 8);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(T, p.N), dim3(256), 0, st, p, T, group_partial, chan_partial);
-  static DmdEnvInt fold_env{"DIAMOND_GN_BWD_FOLD", 0};
-  const int fold = fold_env.get() == 1;
-  if (fold) {
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(T, p.N), dim3(256), 0, st, p, T, (const double*)group_partial, (const float*)chan_partial);
-  } else {
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(T, p.N), dim3(256), 0, st, p, T, (const double*)group_partial, (const float*)chan_partial);
-    hipLaunchKernelGGL(gn_bwd_chan_kernel, dim3((p.N * p.C + 255) / 256), dim3(256), 0, st, (const float*)chan_partial, p.dmul,
-                       p.dadd, p.N, T, p.C);
-  }
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(T, p.N), dim3(256), 0, st, p, T, (const double*)group_partial, (const float*)chan_partial);
   DMD_LAUNCH_CHECK();
   return 0;
 }
@@ -323,8 +297,6 @@ __device__ __forceinline__ SubTile wgrad_subtile(int N, int H, int W, int gs) {
   return t;
 }
 
-typedef _Float16 wg_h4 __attribute__((ext_vector_type(4)));
-
 // fp32 -> its split-fp16 pieces packed into the same 4 bytes: h = fp16(x) in the low half, l = fp16(x - h) in the high half
 __device__ __forceinline__ float wg_pack_hl(float x) {
   const _Float16 h = (_Float16)x;
@@ -332,16 +304,6 @@ __device__ __forceinline__ float wg_pack_hl(float x) {
   const unsigned u = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
   return __builtin_bit_cast(float, u);
 }
-// four packed values (k = 0..3) -> the h and the l operand of v_mfma_f32_16x16x16_f16
-__device__ __forceinline__ void wg_unpack4(const float (&r)[4], wg_h4& h, wg_h4& l) {
-  const unsigned r0 = __builtin_bit_cast(unsigned, r[0]), r1 = __builtin_bit_cast(unsigned, r[1]);
-  const unsigned r2 = __builtin_bit_cast(unsigned, r[2]), r3 = __builtin_bit_cast(unsigned, r[3]);
-  const uint2 hh = {__builtin_amdgcn_perm(r1, r0, 0x05040100u), __builtin_amdgcn_perm(r3, r2, 0x05040100u)};
-  const uint2 ll = {__builtin_amdgcn_perm(r1, r0, 0x07060302u), __builtin_amdgcn_perm(r3, r2, 0x07060302u)};
-  h = __builtin_bit_cast(wg_h4, hh);
-  l = __builtin_bit_cast(wg_h4, ll);
-}
-
 typedef _Float16 wg_h8 __attribute__((ext_vector_type(8)));
 // eight packed values (k = 0..7) -> the h and the l operand of v_mfma_f32_16x16x32_f16
 __device__ __forceinline__ void wg_unpack8(const float (&r)[8], wg_h8& h, wg_h8& l) {
@@ -356,22 +318,18 @@ __device__ __forceinline__ void wg_unpack8(const float (&r)[8], wg_h8& h, wg_h8&
   l = __builtin_bit_cast(wg_h8, ll);
 }
 
-// MODE (template parameter of wgrad_kernel):
-//   0  exact: v_mfma_f32_16x16x4_f32, an fp32 fma chain over the pixels
-//   1  SPLIT, 16 pixels per v_mfma_f32_16x16x16_f16 x 3 (what dmd_wgrad_params.precision == DMD_PRECISION_F16X2 runs)
-//   2  SPLIT, 32 pixels per v_mfma_f32_16x16x32_f16 x 3: the gfx950 instruction with twice the K per matrix-pipe cycle; same
-//      LDS layout and the same ds_read_b32 pattern, lane (i, kg) supplies pixels (row r, column kg + 4 h), r < 4, h < 2
-//   3  mode 2 with the NEXT tile's global loads issued before the MFMA phase of the current one and held in registers
-//      (the kernel runs one workgroup per CU, 512 registers per lane: ~84 of them carry the tile in flight)
-// Modes 2 and 3 are STAGED: selected only by DIAMOND_WGRAD_MODE, checked on the SIMT interpreter (tests/test_simt_kernels.py)
-// and by tests/test_gpu_staged.py, not yet measured on the GPU -- the default stays mode 1 until they are.
-//
-// SPLIT (dmd_wgrad_params.precision == DMD_PRECISION_F16X2): the staged activations and dy are kept as packed split-fp16
-// pairs (same 4 bytes per value, same LDS layout) and 16 pixels are contracted per MFMA -- three
-// v_mfma_f32_16x16x16_f16 per (cout block, column block) instead of four v_mfma_f32_16x16x4_f32 per 4 pixels: 24 instead
-// of 128 matrix-pipe cycles per 16 pixels.  Lane (i, kg) supplies pixels {kg, kg + 4, kg + 8, kg + 12} of a 2 x 8 pixel
-// group (the same two-lanes-per-bank ds_read_b32 pattern as the exact path).  The bias gradient sums the raw dy.
-// the 32-pixel contraction of modes 2 / 3 over the staged tile
+// SPLIT (template parameter of wgrad_kernel; dmd_wgrad_params.precision == DMD_PRECISION_F16X2):
+//   false  exact: v_mfma_f32_16x16x4_f32, an fp32 fma chain over the pixels, each tile strictly load -> LDS -> barrier -> MFMA
+//   true   the staged activations and dy are kept as packed split-fp16 pairs (same 4 bytes per value, same LDS layout, the same
+//          two-lanes-per-bank ds_read_b32 pattern: lane (i, kg) supplies pixels (row r, column kg + 4 h), r < 4, h < 2) and 32
+//          pixels are contracted per v_mfma_f32_16x16x32_f16 x 3 -- 12 instead of 128 matrix-pipe cycles per 16 pixels -- with
+//          the NEXT tile's global loads issued before the MFMA phase of the current one and held in registers (one workgroup
+//          per CU, 512 registers per lane: ~84 of them carry the tile in flight).  The bias gradient sums the raw dy.
+// Round 4, measured (profiles/r04_staged_wgrad_ab.txt, r04_ab_train.txt; denoiser training step at batch 32, one hipGraph):
+// 16-pixel MFMAs without prefetch on up to 1024 workgroups 13.99 ms -> 32-pixel MFMAs 13.53 -> + prefetch 13.11 -> at most 256
+// workgroups (each writes one 147 KB partial of the whole gradient: a quarter of the reduction traffic) 12.01; a one-pass
+// reduction of up to 256 partials instead of the two-pass one was slower (14.1) and is gone.
+// the 32-pixel contraction over the staged tile
 template <class G>
 __device__ __forceinline__ void wgrad_mfma_k32(f32x4 (&acc)[G::NCO][G::CB], const float* dyt, const float* patch, const int (&boff)[G::CB],
                                                int aoff) {
@@ -406,9 +364,8 @@ __device__ __forceinline__ void wgrad_mfma_k32(f32x4 (&acc)[G::NCO][G::CB], cons
   }
 }
 
-template <class G, int MODE>
+template <class G, bool SPLIT>
 __global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, int tiles_total, int tiles_per_wg) {
-  constexpr bool SPLIT = MODE != 0;
   DMD_DYNAMIC_LDS(float, smem);
   float* patch = smem;                        // [2][PP][SB]
   float* dyt = smem + G::PATCH_FLOATS;        // [128][SA]
@@ -441,7 +398,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, in
   const int tile_end = min(tiles_total, tile_begin + tiles_per_wg);
   int tab_n0 = -1, tab_n1 = -1;
 
-  if constexpr (MODE == 3) {
+  if constexpr (SPLIT) {
     // ---- software-pipelined tile loop: raw loads of tile t + 1 fly under the MFMA phase of tile t ----
     constexpr int NPQ = 2 * G::PP * CQI;           // patch quads of a tile
     constexpr int NP = (NPQ + 255) / 256;          // ... per thread
@@ -571,10 +528,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, in
           }
         }
       }
-      if (SPLIT) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = wg_pack_hl(v[e]);
-      }
       *(f32x4*)(patch + (size_t)pp2 * G::SB + 4 * q) = v;
     }
     // ---- stage dy (zero for a missing second subtile) ----
@@ -587,44 +540,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, in
       f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (t.valid) v = *(const f32x4*)(p.dy + (((size_t)t.n * p.H + t.y0 + (r >> 3)) * p.W + t.x0 + (r & 7)) * G::COUT + 4 * q);
       bsum += v;
-      if (SPLIT) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = wg_pack_hl(v[e]);
-      }
       *(f32x4*)(dyt + (size_t)pix * G::SA + 4 * q) = v;
     }
     __syncthreads();
-    if (SPLIT) {
-      // ---- 8 k-groups of 16 pixels (2 rows x 8 columns of a subtile) ----
-      // boff[] carries + kg * SB and aoff + kg * SA (pixel kg of the group); the other three pixels of this lane are
-      // 4 columns / one row further
-#pragma unroll 1
-      for (int kq = 0; kq < 8; ++kq) {
-        const int s = kq >> 2, j = kq & 3;
-        const float* ap = dyt + (size_t)(s * 64 + j * 16) * G::SA + aoff;
-        const float* bp = patch + (size_t)(s * G::PP + 2 * j * G::PW) * G::SB;
-        wg_h4 ah[G::NCO], al[G::NCO];
-#pragma unroll
-        for (int a = 0; a < G::NCO; ++a) {
-          const float r[4] = {ap[a * 16], ap[a * 16 + 4 * G::SA], ap[a * 16 + 8 * G::SA], ap[a * 16 + 12 * G::SA]};
-          wg_unpack4(r, ah[a], al[a]);
-        }
-#pragma unroll
-        for (int b = 0; b < G::CB; ++b) {
-          const float* q0 = bp + boff[b];
-          const float r[4] = {q0[0], q0[4 * G::SB], q0[G::PW * G::SB], q0[(G::PW + 4) * G::SB]};
-          wg_h4 bh, bl;
-          wg_unpack4(r, bh, bl);
-#pragma unroll
-          for (int a = 0; a < G::NCO; ++a) {
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[a], bl, acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x16f16(al[a], bh, acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[a], bh, acc[a][b], 0, 0, 0);
-          }
-        }
-      }
-      continue;
-    }
     // ---- 32 k-groups of 4 pixels ----
 #pragma unroll 2
     for (int kq = 0; kq < 32; ++kq) {
@@ -707,8 +625,8 @@ static int wgrad_plan(const dmd_wgrad_params* p, int* tiles, int* num_wg, int* t
   const int sub = p->N * (p->H / 8) * (p->W / 8);
   *tiles = (sub + 1) / 2;
   // at most `cap` workgroups, each walking a contiguous range of tiles with its accumulators in registers: every workgroup
-  // writes one partial of the whole gradient, so fewer of them is less reduction traffic.  DIAMOND_WGRAD_MAX_WG (STAGED, like
-  // the kernel modes above) lowers the cap from 1024; the workspace is always sized for 1024.
+  // writes one partial of the whole gradient, so fewer of them is less reduction traffic.  DIAMOND_WGRAD_MAX_WG (1..1024; a
+  // test hook for the multi-tile paths) changes the cap of 256 = one workgroup per CU; the workspace is always sized for 1024.
   static DmdEnvInt cap_env{"DIAMOND_WGRAD_MAX_WG", 256};
   const int cap = cap_env.get() >= 1 && cap_env.get() <= 1024 ? cap_env.get() : 256;
   int n = *tiles < cap ? *tiles : cap;
@@ -735,25 +653,17 @@ static int launch_wgrad(const dmd_wgrad_params& p, hipStream_t st) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DMD_MAX_DEVICES) dev = 0;
   if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<G, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<G, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        G::SMEM_BYTES);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<G, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM_BYTES);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<G, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM_BYTES);
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM_BYTES);
     DMD_CHECK_ARG(e == hipSuccess, "wgrad: hipFuncSetAttribute(%d bytes): %s", G::SMEM_BYTES, hipGetErrorString(e));
     attr_set[dev] = true;
   }
-  if ((p.precision & 0xff) == DMD_PRECISION_F16X2) {
-    static DmdEnvInt mode_env{"DIAMOND_WGRAD_MODE", 3};
-    const int mode = mode_env.get();
-    if (mode == 1)
-      hipLaunchKernelGGL((wgrad_kernel<G, 1>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
-    else
-      hipLaunchKernelGGL((wgrad_kernel<G, 3>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
-  } else {
-    hipLaunchKernelGGL((wgrad_kernel<G, 0>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
-  }
+  if ((p.precision & 0xff) == DMD_PRECISION_F16X2)
+    hipLaunchKernelGGL((wgrad_kernel<G, true>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
+  else
+    hipLaunchKernelGGL((wgrad_kernel<G, false>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
   const int per_total = G::NB * NCO * 256 + NCO * 16;
   float* ws2 = p.workspace + (size_t)num_wg * per_total;
   const int single = 4 * WGRAD_SLICES;

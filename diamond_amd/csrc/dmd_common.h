@@ -21,7 +21,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 void dmd_set_error(const char* fmt, ...);
 
 // An integer switch from the environment, read ONCE (and again after dmd_reload_env(), the tests' hook): the launchers do
-// not call getenv per launch.     static DmdEnvInt mode{"DIAMOND_WGRAD_MODE", 3};  ...  mode.get()
+// not call getenv per launch.     static DmdEnvInt cap{"DIAMOND_WGRAD_MAX_WG", 256};  ...  cap.get()
 int dmd_env_generation();
 struct DmdEnvInt {
   const char* name;

@@ -547,15 +547,9 @@ static int validate_conv(const dmd_conv_params* p) {
   return 0;
 }
 
-static int conv1x1_stream_on() {
-  static DmdEnvInt on{"DIAMOND_CONV1X1_STREAM", 1};
-  return on.get();
-}
-
-static int conv_mfma_split(const dmd_conv_params& p) {
-  static DmdEnvInt on{"DIAMOND_CONV_MFMA_SPLIT", 1};
-  return on.get() && (p.precision & 0xff) == DMD_PRECISION_F16X2;
-}
+// an "f16x2" launch that conv_f16ws does not cover (stride 2, qkv / out_proj, odd shapes, the data gradients of the training
+// steps) runs the SPLIT instance of the generic kernel
+static int conv_mfma_split(const dmd_conv_params& p) { return (p.precision & 0xff) == DMD_PRECISION_F16X2; }
 
 template <int WN, bool CFGB, int TAPS, int STRIDE>
 static void launch_conv(const dmd_conv_params& p, int groups, hipStream_t st) {
@@ -589,8 +583,7 @@ extern "C" int dmd_conv1x1_stream_eligible(const dmd_conv_params* p);
 extern "C" int dmd_conv2d(const dmd_conv_params* p, dmd_stream_t stream) {
   if (int e = validate_conv(p)) return e;
   hipStream_t st = (hipStream_t)stream;
-  const int use_1x1 = conv1x1_stream_on();
-  if (use_1x1 && dmd_conv1x1_stream_eligible(p)) {
+  if (dmd_conv1x1_stream_eligible(p)) {
     dmd_launch_conv1x1_stream(*p, st);
   } else if (dmd_conv2d_f16x2_eligible(p)) {
     if (int e = dmd_launch_conv_f16ws(*p, st)) return e;
@@ -610,9 +603,8 @@ extern "C" int dmd_conv2d(const dmd_conv_params* p, dmd_stream_t stream) {
 extern "C" int dmd_conv2d_kernel_name(const dmd_conv_params* p, char* buf, int buf_len) {
   if (int e = validate_conv(p)) return e;
   DMD_CHECK_ARG(buf && buf_len > 0, "kernel_name: buffer");
-  const int use_1x1 = conv1x1_stream_on();
   const bool b8 = p->W % 16 != 0;
-  if (use_1x1 && dmd_conv1x1_stream_eligible(p)) {
+  if (dmd_conv1x1_stream_eligible(p)) {
     int cin = 0;
     for (int i = 0; i < p->nsrc; ++i) cin += p->src[i].C;
     snprintf(buf, buf_len, "conv1x1_stream_kernel<%d, %d, %s>", cin / 16, cin == 128 ? 2 : 4,

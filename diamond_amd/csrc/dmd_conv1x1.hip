@@ -18,6 +18,14 @@
 // 187 / 189 us; timing proxies with fully coalesced 1 KiB-per-instruction loads 189 us, loads and stores 177 us.  The
 // practical ceiling of this 2 : 1 read : write mix on the chip is 5.0 TB/s = 160 us (tools/probe/read_bw_probe.hip:
 // 6.0 TB/s read-only, the same through registers and through LDS-DMA), so the kernel sits at 85 % of it.
+// (the C1X1_* knobs below are compile-time lab settings: only a -DDMD_LAB build may change them)
+#ifndef DMD_LAB
+#undef C1X1_NT_LOAD
+#undef C1X1_ABL_LINEAR
+#undef C1X1_NT_STORE
+#undef C1X1_PB128
+#undef C1X1_NWG
+#endif
 #ifndef C1X1_NT_LOAD
 #define C1X1_NT_LOAD 0
 #endif

@@ -30,11 +30,17 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define LR_H 4
 #define LR_P_UNITS (2 * 100 * 4 * 4)  // 16-byte units: [source][patch pixel][16-channel chunk][rotated position]
 #define LR_QS 196                   // floats per pixel row of the q | k | v overlay
+// DMD_LAB builds only (tools/chain_bench.py; never the shipped library): LR_ABL = timing proxies with WRONG results (1 = no weight
+// loads, 2 = no attention core, 4 = no statistics pass, 8 = no FiLM table loads), LR_TRACE = s_memtime stamps of workgroup 0
+#ifndef DMD_LAB
+#undef LR_ABL
+#undef LR_TRACE
+#endif
 #ifndef LR_ABL
-#define LR_ABL 0  // development only (WRONG results): 1 = no weight loads, 2 = no attention core, 4 = no statistics pass, 8 = no FiLM table loads
+#define LR_ABL 0
 #endif
 #ifndef LR_TRACE
-#define LR_TRACE 0  // development: s_memtime stamps of workgroup 0 at the phase boundaries (tools/chain_bench.py --trace)
+#define LR_TRACE 0
 #endif
 #if LR_TRACE
 __device__ unsigned long long lr_trace_buf[512];

@@ -21,7 +21,7 @@ _USE_NAIVE = os.environ.get("DIAMOND_CONV_IMPL", "mfma") == "naive"  # debugging
 #   "f16x2": split-fp32 operands on the f16 matrix cores where dmd_conv2d_f16x2_eligible (default);
 #   "f32"  : exact fp32 MFMA everywhere.
 # The actor-critic encoder has its own switch (ac_native.AC_PRECISION, DIAMOND_AC_PRECISION, default "f16x2" for its
-# forward and dgrad convolutions; its weight gradients run on the split instance of the wgrad kernel too; DIAMOND_WGRAD_EXACT=1: on the exact one).
+# forward and dgrad convolutions; its weight gradients run on the split instance of the wgrad kernel too).
 WORLD_MODEL_PRECISION = os.environ.get("DIAMOND_CONV_PRECISION", "f16x2")
 
 
@@ -402,7 +402,7 @@ def conv2d(
     return result
 
 
-FUSE_PROJ = os.environ.get("DIAMOND_FUSE_PROJ", "1") != "0"  # skip projections inside conv2's launch (dmd_conv_f16ws.hip: PROJECTION)
+FUSE_PROJ = True  # skip projections inside conv2's launch (dmd_conv_f16ws.hip: PROJECTION); a module attribute for the tests
 
 
 def proj_fusable(xs: Sequence[Act], cout: int, precision: str, naive: Optional[bool]) -> bool:

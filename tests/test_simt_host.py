@@ -53,10 +53,10 @@ def test_denoiser_vs_reference_golden_on_the_interpreter(models, monkeypatch):
     assert "conv_f16ws_kernel<WsGeom<false, 2, 9>>" in keys and "conv_f16ws_kernel<WsGeomProj>" in keys, keys
 
 
-@pytest.mark.parametrize("env", [{}, {"DIAMOND_WGRAD_MAX_WG": "7", "DIAMOND_GN_BWD_FOLD": "1"}], ids=["shipping", "few-workgroups+gn-fold"])
+@pytest.mark.parametrize("env", [{}, {"DIAMOND_WGRAD_MAX_WG": "7"}], ids=["shipping", "few-workgroups"])
 def test_denoiser_training_step_vs_reference_golden_on_the_interpreter(models, dmd_env, env):
     """loss and all 236 gradient tensors of Denoiser.forward + backward (split-fp16 arithmetic): the shipping plan, and 7
-    workgroups walking many tiles each with GroupNorm backward's channel sums folded into the apply pass"""
+    workgroups walking many tiles each"""
     if env and os.environ.get("DIAMOND_SLOW_CPU_TESTS") != "1":
         pytest.skip("a second 55 s end-to-end run: DIAMOND_SLOW_CPU_TESTS=1 runs it; the kernels' plans are in test_simt_kernels.py")
     M, counter = models

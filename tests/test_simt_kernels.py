@@ -391,11 +391,9 @@ def test_linear(m, n, k, acc, silu):
 
 
 # ---- dmd_gn_silu_bwd: fp64 finite-difference-free truth from the closed form in the header --------------------------------------
-@pytest.mark.parametrize("fold", [0, 1], ids=["three-launches", "staged-fold"])
 @pytest.mark.parametrize("n,hw,c,identity,skip", [(2, 64, 64, 0, True), (1, 300, 32, 0, False), (2, 256, 128, 1, True), (1, 64, 16, 0, False),
                                                   (3, 1024, 64, 0, True)])
-def test_gn_silu_bwd(n, hw, c, identity, skip, fold, dmd_env):
-    dmd_env(DIAMOND_GN_BWD_FOLD=fold)
+def test_gn_silu_bwd(n, hw, c, identity, skip):
     rng = np.random.default_rng(hw + c)
     L = S.lib()
     x = (rng.standard_normal((n, hw, 1, c)) * 1.4 + 0.3).astype(np.float32)

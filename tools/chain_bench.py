@@ -29,7 +29,7 @@ with torch.no_grad():
     torch.cuda.synchronize()
 print(f"lowres chain N={n}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per call", flush=True)
 
-if "--trace" in sys.argv:  # needs a -DLR_TRACE=1 build (DIAMOND_LIB=...)
+if "--trace" in sys.argv:  # needs a -DDMD_LAB -DLR_TRACE=1 build (DIAMOND_LIB=...)
     import ctypes as C
     from diamond_amd import native as nv
     buf = (C.c_ulonglong * 512)()

@@ -1,5 +1,5 @@
 """One conv_f16ws launch shape in a loop for a given time (development aid for tools/gpu/clock_table.sh: something for the
-clock / power sensors to look at).    python tools/conv_loop.py <seconds> [zero] [cin] [cout] [res]"""
+clock / power sensors to look at).    python tools/conv_loop.py <seconds> [zero] [cin] [cout] [res] [n]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,7 +11,7 @@ zero = len(sys.argv) > 2 and sys.argv[2] == "1"
 cin = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 cout = int(sys.argv[4]) if len(sys.argv) > 4 else 64
 res = len(sys.argv) > 5 and sys.argv[5] == "1"
-dev, n, h = "cuda", 256, 64
+dev, n, h = "cuda", (int(sys.argv[6]) if len(sys.argv) > 6 else 256), 64
 mk = (lambda *s: torch.zeros(*s, device=dev)) if zero else (lambda *s: torch.randn(*s, device=dev))
 srcs = []
 for c in ([64] * (cin // 64) if cin >= 64 else [cin]):
@@ -38,5 +38,5 @@ while time.perf_counter() - t0 < secs:
     per.append(e0.elapsed_time(e1) / 50 * 1e3)
 per.sort()
 flops = 2.0 * n * h * h * cout * cin * 9
-print(f"conv {cin}->{cout} 64x64 B256 res{int(res)} zero{int(zero)}: median {per[len(per) // 2]:.1f} us per launch (min {per[0]:.1f}, max {per[-1]:.1f}, "
+print(f"conv {cin}->{cout} 64x64 B{n} res{int(res)} zero{int(zero)}: median {per[len(per) // 2]:.1f} us per launch (min {per[0]:.1f}, max {per[-1]:.1f}, "
       f"{len(per) * 50} launches), {flops / per[len(per) // 2] / 1e6:.0f} TFLOP/s algorithmic")

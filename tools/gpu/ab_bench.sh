@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-box A/B of bench.py (configs[1]) under two settings of one environment variable, alternating, e.g.
-#   gpurun --timeout 1500 -- 'bash tools/gpu/ab_bench.sh DIAMOND_FUSE_PROJ 0 1'
+#   gpurun --timeout 1500 -- 'bash tools/gpu/ab_bench.sh DIAMOND_LOWRES_CHAIN 0 3'
 #   gpurun --timeout 1500 -- 'bash tools/gpu/ab_bench.sh DIAMOND_LIB diamond_amd/ablate/libdiamond_hip_r02.so diamond_amd/libdiamond_hip.so'
 # Boxes of the pool differ by several per cent at identical code: only numbers of one call are comparable.
 set -u
