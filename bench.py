@@ -15,8 +15,13 @@ Default workload = BASELINE.json configs[1]: Breakout-shaped 64x64x3 frames, bat
 
 Extra objects on the JSON line: `roofline` for the dominant kernel (found by measured time over EVERY C-ABI launch:
 HIP events around each one in a dedicated instrumented window after the timed region), `exact_fp32` = the same window
-with every convolution on the exact-fp32 MFMA kernels (configs[1] only), and `cpu_baseline` = the CPU oracle
-timed on this box's host cores on one whole window of configs[0] (rank 0, N=1 only).
+with every convolution on the exact-fp32 MFMA kernels (configs[1] only), `also` = what else fits one GPU, measured after the
+timed region (configs[3], configs[4], the B = 1 latency mode, the denoiser training step, and configs[1] WITHOUT the end-logit
+bias, i.e. with mid-window resets: `--no-also` skips them), and `cpu_baseline` = the REFERENCE ITSELF (its bytecode in
+oracle/_ref, see oracle/make_ref.py) and the CPU oracle port, both timed on this box's host cores on one whole window of
+configs[0] at the same thread count (rank 0, N=1 only).  The roofline prices the kernel against the dense f16 MFMA peak of the
+guide (2.5 PFLOP/s) as the contract asks; `roofline.power_limited_peak` is what an MFMA-only stream sustains on this chip
+with random operands (profiles/r04_clock.json: 1,661 TFLOP/s at the 1.58 GHz the power management allows it).
 """
 import argparse
 import json
@@ -33,6 +38,7 @@ if ROOT not in sys.path:
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_* = fp32 vector peak
 F16_MFMA_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak (same guide); the split kernels execute 3 f16 MACs per fp32 MAC
+F16_MFMA_SUSTAINED_TFLOPS = 1661.0  # measured: back-to-back v_mfma_f32_32x32x16_f16 on random operands, all SIMDs (profiles/r04_clock.json)
 HBM_PEAK_GBS = 8000.0
 
 # BASELINE.json configs -> (img_size, batch per GPU, horizon, denoise steps, sampler order, denoiser attn_depths)
@@ -94,12 +100,14 @@ END_LOGIT_BIAS_NOTE = ("end-logits of the synthetic reward/end model are biased 
                        "+ burn in together at the window boundary, no mid-window resets; same kernels and FLOPs per frame")
 
 
-def build_agent(device, img_size, rank, attn_depths=(0, 0, 0, 0)):
+def build_agent(device, img_size, rank, attn_depths=(0, 0, 0, 0), bias_end_logits=True):
     import diamond_amd as D
     from diamond_amd.testing import fill_module_
 
     agent = D.Agent(D.default_agent_config(num_actions=4, img_size=img_size, denoiser_attn_depths=tuple(attn_depths)))
     fill_module_(agent, 0)
+    if not bias_end_logits:
+        return agent.to(device)
     with torch.no_grad():
         # Synthetic weights would terminate ~half of the imagined episodes at every step; bias
         # the end logits (through one saturated hidden unit) so episodes end by horizon
@@ -159,31 +167,55 @@ def cpu_baseline_worker(img_size, threads):
     return {"value": b * t / dt, "unit": "imagined frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"configs[0]: one whole window, B={b}, reset + {t} imagined steps (3 Euler denoise + rew/end + actor-critic) "
                       f"+ AC backward, {img_size}x{img_size}, fp32 torch-CPU oracle (unbiased synthetic end-logits: includes "
-                      f"mid-window resets / burn-in), {dt:.1f}s",
-            "reference_measured": REFERENCE_MEASURED}
+                      f"mid-window resets / burn-in), {dt:.1f}s"}
 
 
-def cpu_baseline(img_size, timeout_s=240):
-    """Time the CPU oracle in a child process (own thread pool, hard timeout: the bench line must
-    never hang on the baseline)."""
+def _child_json(cmd, threads, timeout_s):
+    """stdout's last line of a child process as JSON (own thread pool, hard timeout: the bench line must never hang on a baseline)"""
     import subprocess
 
-    threads = usable_cores()
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(threads), "--img-size", str(img_size)]
-    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", PYTHONDONTWRITEBYTECODE="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, cwd=ROOT)
-    fail = {"value": None, "unit": "imagined frames/s", "cores": threads, "kind": "port", "reference_measured": REFERENCE_MEASURED}
     try:
         out, _ = proc.communicate(timeout=timeout_s)
         return json.loads(out.decode().strip().splitlines()[-1])
     except subprocess.TimeoutExpired:
         proc.kill()  # exactly the PID we started
         proc.communicate()
-        return dict(fail, sample=f"timed out after {timeout_s}s")
+        return {"value": None, "sample": f"timed out after {timeout_s}s"}
     except Exception as e:  # noqa: BLE001
-        return dict(fail, sample=f"failed: {e!r}")
+        return {"value": None, "sample": f"failed: {e!r}"}
+
+
+def cpu_baseline(img_size, timeout_s=240):
+    """The CPU path beside the GPU number, on this box's host cores, each in a child process: the REFERENCE ITSELF where its
+    bytecode travelled with the snapshot (oracle/_ref, built by oracle/make_ref.py in the build container: kind "reference") and
+    the oracle port (oracle/diamond_oracle.py: kind "port") on the same window at the same thread count."""
+    threads = usable_cores()
+    port = _child_json([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(threads), "--img-size", str(img_size)],
+                       threads, timeout_s)
+    port.setdefault("unit", "imagined frames/s"), port.setdefault("cores", threads), port.setdefault("kind", "port")
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    try:
+        import reference_window as RW  # test infrastructure: the locator only -- the run itself happens in the child
+
+        where, what = RW.reference_location()
+    except Exception as e:  # noqa: BLE001
+        where, what = None, repr(e)
+    finally:
+        sys.path.pop(0)
+    if where is None:
+        return dict(port, reference_unavailable=what, reference_measured=REFERENCE_MEASURED)
+    ref = _child_json([sys.executable, os.path.join(ROOT, "oracle", "reference_window.py"), "--threads", str(threads), "--img-size",
+                       str(img_size)], threads, timeout_s)
+    if ref.get("value") is None:
+        return dict(port, reference_unavailable=ref.get("sample"), reference_measured=REFERENCE_MEASURED)
+    ref["port"] = {k: port.get(k) for k in ("value", "unit", "cores", "kind", "sample")}
+    if port.get("value"):
+        ref["port_over_reference_at_equal_cores"] = port["value"] / ref["value"]
+    return ref
 
 
 def precision_label(E, ac_native):
@@ -228,9 +260,9 @@ def latency_run(graph: bool, frames: int, warmup: int = 12):
     return 1e3 * (time.perf_counter() - t0) / frames, 1e3 * t_s / frames
 
 
-def latency_line(args):
+def latency_line(args, eager=True):
     frames = args.steps or 200
-    eager, eager_s = latency_run(False, frames, args.warmup)
+    eager, eager_s = latency_run(False, frames, args.warmup) if eager else (None, None)
     graph, graph_s = latency_run(True, frames, args.warmup)
     return {"metric": "ms per imagined frame, B=1 interactive world-model env (64x64, 3 Euler denoise steps)", "value": graph,
             "unit": "ms/frame", "n_gpus": 1, "steps": frames, "warmup": max(args.warmup, 12), "ms_per_step": graph,
@@ -241,7 +273,7 @@ def latency_line(args):
             "sampler_only_eager_ms": eager_s}
 
 
-def train_line(args):
+def train_line(args, eager=True):
     """Denoiser training step (reference trainer.py:349-388, denoiser.py:93-122): forward over a segment of
     4 conditioning + 1 predicted frame, backward, gradient clipping, AdamW -- at the reference batch of 32 (--batch)."""
     from types import SimpleNamespace
@@ -269,14 +301,16 @@ def train_line(args):
         opt.zero_grad(set_to_none=True)
         return loss.detach()  # (no reference to the autograd graph survives the step: train_graph.py)
 
-    for _ in range(max(args.warmup, 3)):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
-    torch.cuda.synchronize()
-    dt_eager = (time.perf_counter() - t0) / steps
+    dt_eager = None
+    if eager:
+        for _ in range(max(args.warmup, 3)):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        dt_eager = (time.perf_counter() - t0) / steps
     # the same step captured into one hipGraph and replayed on static input buffers (diamond_amd/train_graph.py)
     from diamond_amd.train_graph import GraphedTrainStep
 
@@ -295,8 +329,103 @@ def train_line(args):
             "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f32 via split-f16 MFMA", "data": "synthetic",
             "config": {"workload": "SURVEY §8 (f2): Denoiser.forward(batch) + loss.backward() + clip_grad_norm_ + AdamW, the whole step "
                                    "replayed as one hipGraph (GraphedTrainStep)", "global_batch": b},
-            "frames_per_s": b / dt, "eager_ms_per_step": 1e3 * dt_eager, "loss": float(loss.detach()),
+            "frames_per_s": b / dt, "eager_ms_per_step": None if dt_eager is None else 1e3 * dt_eager, "loss": float(loss.detach()),
             "algorithmic_tflops": 3 * 6.0909e9 * b / dt / 1e12}
+
+
+def rollout_setup(device, rank, img_size, batch, horizon, denoise_steps, order, attn, use_dist=False, bias_end_logits=True):
+    """Agent + imagination env + optimizer of one configuration; returns (agent, actor_critic, window) with window() = one
+    optimiser step of `Trainer.train_component("actor_critic")` (reference trainer.py:363-382)."""
+    import diamond_amd as D
+    from diamond_amd.dist import GradAllReducer, broadcast_parameters
+
+    agent = build_agent(device, img_size, rank, attn, bias_end_logits)
+    if use_dist:
+        broadcast_parameters(agent, src=0)  # what the DDP constructor does in the reference (utils.py:106)
+    env = D.WorldModelEnv(agent.denoiser, agent.rew_end_model, _Loader(batch, 100 + rank, img_size),
+                          D.WorldModelEnvConfig(horizon=horizon, num_batches_to_preload=2,
+                                                diffusion_sampler=D.DiffusionSamplerConfig(num_steps_denoising=denoise_steps, order=order)))
+    agent.setup_training(D.SigmaDistributionConfig(-0.4, 1.2, 2e-3, 20),
+                         D.ActorCriticLossConfig(backup_every=horizon, gamma=0.985, lambda_=0.95,
+                                                 weight_value_loss=1.0, weight_entropy_loss=0.001), env)
+    ac = agent.actor_critic
+    opt = torch.optim.AdamW(ac.parameters(), lr=1e-4, eps=1e-8, weight_decay=0.0)
+    reducer = GradAllReducer(list(ac.parameters())) if use_dist else None
+
+    def window():
+        loss, metrics = ac()
+        loss.backward()
+        if reducer is not None:
+            reducer.all_reduce_mean()
+        torch.nn.utils.clip_grad_norm_(ac.parameters(), 100.0)
+        opt.step()
+        opt.zero_grad(set_to_none=False)
+        return loss
+
+    return agent, ac, window
+
+
+def timed_windows(window, steps, warmup):
+    for _ in range(warmup):
+        window()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        window()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def also_lines(device, args):
+    """What the default line carries besides configs[1] (single GPU, after the timed region; none of it is part of `value`):
+    the other BASELINE configs that fit one GPU, the SURVEY §8(f) rows, and configs[1] without the end-logit bias."""
+    from types import SimpleNamespace
+
+    out = {}
+    t_all = time.perf_counter()
+
+    def guarded(key, fn):  # an extra must never cost the line its headline value
+        try:
+            out[key] = fn()
+        except Exception as e:  # noqa: BLE001
+            out[key] = {"value": None, "error": repr(e)[:300]}
+        torch.cuda.empty_cache()
+
+    def unbiased():
+        # configs[1] with the UNBIASED synthetic reward/end model: ~half of the envs end at every step -> resets + reward/end
+        # burn-in (reference world_model_env.py:77-89, env_loop.py:45-56) inside the timed window
+        _, _, w = rollout_setup(device, 0, 64, 256, 15, 3, 1, (0, 0, 0, 0), bias_end_logits=False)
+        dt = timed_windows(w, 1, 1)
+        return {"value": 256 * 15 / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt, "steps": 1,
+                "workload": "configs[1] without the end-logit bias: mid-window resets and burn-in passes in the timed window"}
+
+    def config(idx, steps):
+        c = CONFIGS[idx]
+        attn = tuple(int(v) for v in c["attn_depths"].split(","))
+        _, _, w = rollout_setup(device, 0, c["img_size"], c["batch"], c["horizon"], c["denoise_steps"], c["order"], attn)
+        dt = timed_windows(w, steps, 1)
+        flop_pf, _, _ = algorithmic_work(c["img_size"], c["denoise_steps"], c["order"], attn)
+        fps = c["batch"] * c["horizon"] / dt
+        return {"value": fps, "unit": "frames/s", "ms_per_step": 1e3 * dt, "steps": steps, "warmup": 1, "global_batch": c["batch"],
+                "algorithmic_tflops": fps * flop_pf / 1e12,
+                "workload": f"{c['img_size']}x{c['img_size']}, batch {c['batch']}, {c['denoise_steps']} denoise steps order {c['order']}, "
+                            f"attention {c['attn_depths']}"}
+
+    def latency():
+        lat = latency_line(SimpleNamespace(steps=200, warmup=12), eager=False)
+        return dict({k: lat[k] for k in ("value", "unit", "steps", "frames_per_s", "sampler_only_graph_ms")}, workload=lat["config"]["workload"])
+
+    def train():
+        tr = train_line(SimpleNamespace(batch=32, steps=20, warmup=3), eager=False)
+        return dict({k: tr[k] for k in ("value", "unit", "steps", "frames_per_s", "loss")}, workload=tr["config"]["workload"] + ", batch 32")
+
+    guarded("unbiased_end_logits", unbiased)
+    guarded("configs[3]", lambda: config(3, 1))
+    guarded("configs[4]", lambda: config(4, 2))
+    guarded("latency", latency)
+    guarded("train", train)
+    out["seconds"] = time.perf_counter() - t_all
+    return out
 
 
 def main():
@@ -320,6 +449,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-exact-fp32", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra measurements the default configs[1] line carries (`also`)")
     ap.add_argument("--pmc-calibrate", action="store_true",
                     help="two Heun updates over 256 MiB arrays before the window (tools/pmc_collect.sh: a known byte count for the FETCH_SIZE / "
                          "WRITE_SIZE unit corrections in the same rocprofv3 pass)")
@@ -361,7 +491,7 @@ def main():
     from diamond_amd import ac_native
     from diamond_amd import engine as E
     from diamond_amd import native as nv
-    from diamond_amd.dist import GradAllReducer, broadcast_parameters, parameter_checksum
+    from diamond_amd.dist import parameter_checksum
 
     if args.pmc_calibrate:
         # a kernel the window itself never launches (configs[1] is Euler-only), with a known byte count: 2 launches x
@@ -373,29 +503,7 @@ def main():
         del cal
     torch.manual_seed(1234 + rank)
     attn = tuple(int(v) for v in args.attn_depths.split(","))
-    agent = build_agent(device, args.img_size, rank, attn)
-    if use_dist:
-        broadcast_parameters(agent, src=0)  # what the DDP constructor does in the reference (utils.py:106)
-    env = D.WorldModelEnv(agent.denoiser, agent.rew_end_model, _Loader(args.batch, 100 + rank, args.img_size),
-                          D.WorldModelEnvConfig(horizon=args.horizon, num_batches_to_preload=2,
-                                                diffusion_sampler=D.DiffusionSamplerConfig(
-                                                    num_steps_denoising=args.denoise_steps, order=args.order)))
-    agent.setup_training(D.SigmaDistributionConfig(-0.4, 1.2, 2e-3, 20),
-                         D.ActorCriticLossConfig(backup_every=args.horizon, gamma=0.985, lambda_=0.95,
-                                                 weight_value_loss=1.0, weight_entropy_loss=0.001), env)
-    ac = agent.actor_critic
-    opt = torch.optim.AdamW(ac.parameters(), lr=1e-4, eps=1e-8, weight_decay=0.0)
-    reducer = GradAllReducer(list(ac.parameters())) if use_dist else None
-
-    def window():
-        loss, metrics = ac()
-        loss.backward()
-        if reducer is not None:
-            reducer.all_reduce_mean()
-        torch.nn.utils.clip_grad_norm_(ac.parameters(), 100.0)
-        opt.step()
-        opt.zero_grad(set_to_none=False)
-        return loss
+    agent, ac, window = rollout_setup(device, rank, args.img_size, args.batch, args.horizon, args.denoise_steps, args.order, attn, use_dist)
 
     def fence():
         torch.cuda.synchronize()
@@ -500,6 +608,9 @@ def main():
                      "accuracy), so the matrix pipe executes 3x the algorithmic rate: executed_mfma_frac below."
                      if split else "exact-fp32 kernel: peak = fp32 MFMA/vector peak"),
             "executed_mfma_frac": (3.0 if split else 1.0) * achieved / peak,
+            # the chip is power-managed: an MFMA-only stream on random operands is held to 1.58 GHz (tools/probe/clock_probe.hip)
+            "power_limited_peak": F16_MFMA_SUSTAINED_TFLOPS if split else None,
+            "executed_frac_of_power_limited_peak": (3.0 * achieved / F16_MFMA_SUSTAINED_TFLOPS) if split else None,
             "frac_of_fp32_direct_conv_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
             "kernel_share_of_launch_time": d["ms"] / total_ms,
             # every C-ABI entry point / kernel instantiation of the window, by measured time (the dominant one is chosen over ALL)
@@ -526,6 +637,12 @@ def main():
                               "dtype": "f32 (every convolution on v_mfma_f32_16x16x4_f32: DIAMOND_CONV_PRECISION=f32 "
                                        "DIAMOND_AC_PRECISION=f32)"}
         progress("exact-fp32 window done")
+
+    if args.config == 1 and world == 1 and not custom and not args.no_also:
+        del agent, ac, window
+        torch.cuda.empty_cache()
+        line["also"] = also_lines(device, args)
+        progress(f"also: {line['also']['seconds']:.1f}s")
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(64)
