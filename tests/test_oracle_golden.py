@@ -1,5 +1,8 @@
 """Pin the CPU oracle (oracle/diamond_oracle.py) against fixtures produced by executing the
 reference itself (tests/golden/make_golden.py).  CPU only; runs everywhere."""
+import os
+
+import pytest
 import torch
 
 from oracle import diamond_oracle as O
@@ -196,3 +199,28 @@ def test_full_window_rollout_and_loss():
         loss.backward()
         for k, n in w["grad_norms"].items():
             assert abs(float(a.actor_critic[k].grad.norm()) - float(n)) <= 2e-2 * float(n) + 1e-6, k
+
+
+def test_reference_bytecode_runs_a_window():
+    """oracle/_ref (the reference's own modules as bytecode, oracle/make_ref.py) -- bench.py's `cpu_baseline.kind == "reference"`
+    leg: one tiny window of ActorCritic.forward() + backward through the reference's WorldModelEnv / env_loop, in a child process
+    (the stubs it installs must not leak into this one)."""
+    import json
+    import subprocess
+    import sys
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    try:
+        import reference_window as RW
+    finally:
+        sys.path.pop(0)
+    where, what = RW.reference_location()
+    if where is None:
+        pytest.skip(what)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "reference_window.py"), "--threads", "4", "--batch", "1"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd="/tmp", timeout=600,
+                         env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1", HIP_VISIBLE_DEVICES=""))
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    d = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    assert d["kind"] == "reference" and d["value"] > 0 and d["cores"] == 4 and "15 imagined steps" in d["sample"]
