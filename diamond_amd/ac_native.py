@@ -27,12 +27,18 @@ from . import native as nv
 from .engine import Act, NormSpec
 
 
-def _maxpool(y: Tensor) -> Tuple[Act, Tensor]:
+def _maxpool(y: Tensor, valid: Optional[Tuple[int, int]] = None) -> Tuple[Act, Tensor]:
+    """MaxPool2d(2) (floor: an odd valid extent loses its last row / column, like F.max_pool2d).  valid: the part of the
+    buffer that exists; the pooled tensor is the (vh // 2, vw // 2) part of a buffer half the size, and its GroupNorm
+    statistics count that part only."""
     n, h, w, c = y.shape
     out = torch.empty(n, h // 2, w // 2, c, device=y.device, dtype=torch.float32)
     arg = torch.empty(n, h // 2, w // 2, c, device=y.device, dtype=torch.uint8)
-    stats = E.new_stats(n, c, 1, y.device) if c % nv.GN_GROUP == 0 else None
+    stats = E.new_stats(n, c, 1, y.device) if (c % nv.GN_GROUP == 0 and valid is None) else None
     nv.check(nv.lib().dmd_maxpool2(nv.fptr(y), nv.fptr(out), nv.ptr(arg), nv.ptr(stats), n, h, w, c, nv.stream()), "dmd_maxpool2")
+    if valid is not None:
+        v2 = (valid[0] // 2, valid[1] // 2)
+        return (E.gn_stats(out, v2) if c % nv.GN_GROUP == 0 else Act(out, valid=v2)), arg
     return Act(out, stats, 1 if stats is not None else 0), arg
 
 
@@ -57,6 +63,8 @@ def _wgrad(x: Act, prologue: int, spec: Optional[NormSpec], dy: Tensor, taps: in
     p.src.prologue = prologue
     if prologue != nv.PROLOGUE_NONE:
         p.src.norm = spec.to_native(x)
+    if x.valid is not None:
+        p.valid_h, p.valid_w = x.valid
     p.dy = nv.ptr(dy)
     p.precision = nv.PRECISION_F16X2 if split else nv.PRECISION_F32
     ws = torch.empty(int(nv.lib().dmd_wgrad_workspace_floats(C.byref(p))), device=dy.device, dtype=torch.float32)
@@ -71,6 +79,8 @@ def _gn_silu_bwd(x: Act, spec: NormSpec, da: Tensor, dskip: Optional[Tensor]) ->
     n, h, w, c = x.shape
     p = nv.GnBwdParams()
     p.N, p.HW, p.C = n, h * w, c
+    if x.valid is not None:  # sums and the count over the valid extent, dx zero outside it
+        p.W, p.valid_h, p.valid_w = w, x.valid[0], x.valid[1]
     p.x = nv.ptr(x.t)
     p.norm = spec.to_native(x)
     p.da = nv.fptr(da)
@@ -143,10 +153,18 @@ class _Plan:
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan: _Plan, cache: E.PackCache, obs: Tensor, *params: Tensor) -> Tensor:
-        n, cimg = obs.shape[:2]
-        x16 = E.nchw_to_nhwc(obs.detach().float(), 16)
+        n, cimg, h, w = obs.shape
+        # Image sizes off the kernels' 8-pixel grid at some level (the reference runs any size, MaxPool2d floors:
+        # actor_critic.py:45, 72 -> 36 -> 18 -> 9 -> 4) live as the VALID EXTENT of a zero-padded buffer whose levels are all
+        # multiples of 8 (include/diamond_hip.h; the denoiser does the same, engine.padded_extent)
+        m = 8 * 2 ** sum(1 for _, pool in plan.blocks if pool)
+        valid = None if (h % m == 0 and w % m == 0) else (h, w)
+        obs_f = obs.detach().float()
+        if valid is not None:
+            obs_f = torch.nn.functional.pad(obs_f, (0, (w + m - 1) // m * m - w, 0, (h + m - 1) // m * m - h))
+        x16 = E.nchw_to_nhwc(obs_f, 16)
         ci = plan.conv_in
-        x = E.conv2d([(Act(x16), nv.PROLOGUE_NONE, None)], cache.conv_weight(ci), cache.conv_bias(ci), ci.out_channels,
+        x = E.conv2d([(Act(x16, valid=valid), nv.PROLOGUE_NONE, None)], cache.conv_weight(ci), cache.conv_bias(ci), ci.out_channels,
                      w_f16=_w16(cache, ci))
         saved = []
         for blk, pool in plan.blocks:
@@ -163,22 +181,26 @@ class _EncoderFn(torch.autograd.Function):
             arg = None
             nxt = y
             if pool:
-                nxt, arg = _maxpool(y.t)
+                nxt, arg = _maxpool(y.t, y.valid)
             saved.append((x, arg))
             x = nxt
-        ctx.plan, ctx.cache, ctx.x16, ctx.saved = plan, cache, x16, saved
+        ctx.plan, ctx.cache, ctx.x16, ctx.saved = plan, cache, Act(x16, valid=valid), saved
         ctx.cimg = cimg
+        ctx.out_valid, ctx.out_buf = x.valid, tuple(x.shape[1:3])
         # flatten in the reference's (c, h, w) order (actor_critic.py:71)
-        return E.nhwc_to_nchw(x.t).flatten(1)
+        feat = E.nhwc_to_nchw(x.t)
+        if x.valid is not None:
+            feat = feat[:, :, :x.valid[0], :x.valid[1]].contiguous()
+        return feat.flatten(1)
 
     @staticmethod
     def backward(ctx, dfeat: Tensor):
         plan, cache = ctx.plan, ctx.cache
         split = AC_PRECISION == "f16x2"  # weight gradients in the split-fp16 form too (exact fp32 with DIAMOND_AC_PRECISION=f32)
-        last_x, _ = ctx.saved[-1]
-        blk_last, pool_last = plan.blocks[-1]
+        blk_last, _ = plan.blocks[-1]
         cl = blk_last.f[2].out_channels
-        hl = last_x.shape[1] // (2 if pool_last else 1)
+        hb, wb = ctx.out_buf
+        hl, wl = ctx.out_valid if ctx.out_valid is not None else (hb, wb)
         n = dfeat.shape[0]
         # The whole backward is linear in dfeat, so it runs on dfeat * 2^k (k chosen on the device so that the largest
         # entry is O(1)) and the parameter gradients are scaled back by 2^-k: exact in fp32, and it keeps the split-fp16
@@ -188,14 +210,18 @@ class _EncoderFn(torch.autograd.Function):
         amax = dfeat.abs().amax()
         k = torch.where(amax > 0, torch.floor(-torch.log2(amax.clamp_min(1e-37))), torch.zeros_like(amax)).clamp(-120, 120)
         inv_scale = torch.exp2(-k)
-        dcur = E.nchw_to_nhwc((dfeat * torch.exp2(k)).reshape(n, cl, hl, hl).contiguous())
+        dfeat = (dfeat * torch.exp2(k)).reshape(n, cl, hl, wl)
+        if ctx.out_valid is not None:  # zero gradient outside the valid extent of the last buffer
+            dfeat = torch.nn.functional.pad(dfeat, (0, wb - wl, 0, hb - hl))
+        dcur = E.nchw_to_nhwc(dfeat.contiguous())
         grads_rev: List[Optional[Tensor]] = []
         for (blk, pool), (x, arg) in zip(reversed(plan.blocks), reversed(ctx.saved)):
             gn, conv = blk.f[0].norm, blk.f[2]
             spec = NormSpec(mul=cache.f32(gn.weight), add=cache.f32(gn.bias))
             dy = _maxpool_bwd(dcur, arg) if pool else dcur
             dw, db = _wgrad(x, nv.PROLOGUE_NORM_SILU, spec, dy, 9, conv.in_channels, split=split)
-            da = E.conv2d([(Act(dy), nv.PROLOGUE_NONE, None)], _dgrad_weight(cache, conv), None, conv.in_channels,
+            vy = x.valid  # (a stride-1 block: its output exists where its input does; dy is zero elsewhere, and is treated so)
+            da = E.conv2d([(Act(dy, valid=vy), nv.PROLOGUE_NONE, None)], _dgrad_weight(cache, conv), None, conv.in_channels,
                           want_stats=False, w_f16=_dgrad_w16(cache, conv)).t
             sp = blk.skip_projection
             g_skip: List[Optional[Tensor]] = []
@@ -203,7 +229,7 @@ class _EncoderFn(torch.autograd.Function):
                 dskip = dy
             else:
                 dws, dbs = _wgrad(x, nv.PROLOGUE_NONE, None, dy, 1, sp.in_channels, split=split)
-                dskip = E.conv2d([(Act(dy), nv.PROLOGUE_NONE, None)], _dgrad_weight(cache, sp), None, sp.in_channels, taps=1,
+                dskip = E.conv2d([(Act(dy, valid=vy), nv.PROLOGUE_NONE, None)], _dgrad_weight(cache, sp), None, sp.in_channels, taps=1,
                                  want_stats=False).t
                 g_skip = [dws, dbs]
             dx, dmul, dadd = _gn_silu_bwd(x, spec, da, dskip)
@@ -211,7 +237,7 @@ class _EncoderFn(torch.autograd.Function):
             grads_rev += list(reversed([dmul.sum(0), dadd.sum(0), dw, db] + g_skip))
             dcur = dx
         ci = plan.conv_in
-        dw_in, db_in = _wgrad(Act(ctx.x16), nv.PROLOGUE_NONE, None, dcur, 9, ctx.cimg, split=split)
+        dw_in, db_in = _wgrad(ctx.x16, nv.PROLOGUE_NONE, None, dcur, 9, ctx.cimg, split=split)
         grads = [g * inv_scale for g in [dw_in, db_in] + list(reversed(grads_rev))]
         return (None, None, None, *grads)
 

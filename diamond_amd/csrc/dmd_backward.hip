@@ -73,6 +73,14 @@ __device__ __forceinline__ GnBwdElem gn_bwd_elem(float x, float da, float mean, 
   return r;
 }
 
+// valid extent (dmd_gn_bwd_params.W / valid_h / valid_w; W == 0: everything exists)
+__device__ __forceinline__ bool gn_bwd_exists(const dmd_gn_bwd_params& p, int pix) {
+  if (p.W == 0) return true;
+  const int y = pix / p.W;
+  return y < p.valid_h && pix - y * p.W < p.valid_w;
+}
+__device__ __forceinline__ double gn_bwd_count(const dmd_gn_bwd_params& p) { return p.W == 0 ? (double)p.HW : (double)p.valid_h * p.valid_w; }
+
 #define GN_BWD_PIX 256  // pixels per workgroup in passes A and B
 #define GN_BWD_MAXG 8   // C <= 256
 
@@ -87,7 +95,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const dmd_gn_bwd_par
   if (tid < G) {
     float m, r;
     dmd_finalize_stats(p.norm.stats + ((size_t)(n * G + tid) * p.norm.stat_tiles) * 2, p.norm.stat_tiles,
-                       (double)gsz * p.HW, &m, &r);
+                       (double)gsz * gn_bwd_count(p), &m, &r);
     g_mean[tid] = m;
     g_rstd[tid] = r;
   }
@@ -108,6 +116,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const dmd_gn_bwd_par
   float dm[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
   const int pix_end = min(p.HW, (t + 1) * GN_BWD_PIX);
   for (int pix = t * GN_BWD_PIX + tid / CQ; pix < pix_end; pix += 256 / CQ) {
+    if (!gn_bwd_exists(p, pix)) continue;  // outside the valid extent: not part of any sum
     const size_t off = ((size_t)n * p.HW + pix) * C + c0;
     const f32x4 xv = *(const f32x4*)(p.x + off);
     const f32x4 dv = *(const f32x4*)(p.da + off);
@@ -180,7 +189,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const dmd_gn_bwd_para
   }
   if (tid < G) {
     float m, r;
-    const double cnt = (double)gsz * p.HW;
+    const double cnt = (double)gsz * gn_bwd_count(p);
     dmd_finalize_stats(p.norm.stats + ((size_t)(n * G + tid) * p.norm.stat_tiles) * 2, p.norm.stat_tiles, cnt, &m, &r);
     g_mean[tid] = m;
     g_rstd[tid] = r;
@@ -209,6 +218,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const dmd_gn_bwd_para
   const int pix_end = min(p.HW, (t + 1) * GN_BWD_PIX);
   for (int pix = t * GN_BWD_PIX + tid / CQ; pix < pix_end; pix += 256 / CQ) {
     const size_t off = ((size_t)n * p.HW + pix) * C + c0;
+    if (!gn_bwd_exists(p, pix)) {  // outside the valid extent: a zero gradient
+      *(f32x4*)(p.dx + off) = (f32x4){0.f, 0.f, 0.f, 0.f};
+      continue;
+    }
     const f32x4 xv = *(const f32x4*)(p.x + off);
     const f32x4 dv = *(const f32x4*)(p.da + off);
     f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -233,6 +246,9 @@ extern "C" int64_t dmd_gn_bwd_workspace_bytes(int N, int HW, int C) {
 extern "C" int dmd_gn_silu_bwd(const dmd_gn_bwd_params* pp, dmd_stream_t stream) {
   DMD_CHECK_ARG(pp && pp->x && pp->da && pp->dx && pp->workspace && pp->dmul && pp->dadd, "gn_silu_bwd: null");
   DMD_CHECK_ARG(pp->norm.stats && pp->norm.stat_tiles > 0, "gn_silu_bwd: statistics missing");
+  DMD_CHECK_ARG((pp->W == 0 && pp->valid_h == 0 && pp->valid_w == 0) ||
+                (pp->W > 0 && pp->HW % pp->W == 0 && pp->valid_h > 0 && pp->valid_h <= pp->HW / pp->W && pp->valid_w > 0 && pp->valid_w <= pp->W),
+                "gn_silu_bwd: valid extent %d x %d of a (%d / %d) x %d tensor", pp->valid_h, pp->valid_w, pp->HW, pp->W, pp->W);
   DMD_CHECK_ARG(pp->C % 4 == 0 && pp->C <= 256 && 256 % (pp->C / 4) == 0 && (pp->C % DMD_GN_GROUP == 0 || pp->C < DMD_GN_GROUP),
                 "gn_silu_bwd: unsupported C %d", pp->C);
   dmd_gn_bwd_params p = *pp;
@@ -394,6 +410,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, in
   constexpr int CQI = G::CIN / 4;
   f32x4 bsum = (f32x4){0.f, 0.f, 0.f, 0.f};  // bias gradient of channel quad (tid % CQO)
   const int Cx = p.src.C;                    // == CIN (checked on the host)
+  const int Hv = p.valid_h ? p.valid_h : p.H, Wv = p.valid_w ? p.valid_w : p.W;  // valid extent (include/diamond_hip.h)
   const int tile_begin = blockIdx.x * tiles_per_wg;
   const int tile_end = min(tiles_total, tile_begin + tiles_per_wg);
   int tab_n0 = -1, tab_n1 = -1;
@@ -416,7 +433,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, in
         const SubTile t = s ? f1 : f0;
         const int iy = t.y0 - G::PAD + py, ix = t.x0 - G::PAD + pxx;
         px[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (id < NPQ && t.valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+        if (id < NPQ && t.valid && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv)
           px[it] = *(const f32x4*)(p.src.x + (((size_t)t.n * p.H + iy) * p.W + ix) * Cx + 4 * q);
       }
 #pragma unroll
@@ -426,7 +443,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, in
         const int s = pix >> 6, r = pix & 63;
         const SubTile t = s ? f1 : f0;
         pd[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (t.valid) pd[it] = *(const f32x4*)(p.dy + (((size_t)t.n * p.H + t.y0 + (r >> 3)) * p.W + t.x0 + (r & 7)) * G::COUT + 4 * q);
+        if (t.valid && t.y0 + (r >> 3) < Hv && t.x0 + (r & 7) < Wv)
+          pd[it] = *(const f32x4*)(p.dy + (((size_t)t.n * p.H + t.y0 + (r >> 3)) * p.W + t.x0 + (r & 7)) * G::COUT + 4 * q);
       }
     };
     if (tile_begin < tile_end) fetch(tile_begin);
@@ -439,7 +457,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, in
         for (int c = tid; c < 2 * G::CIN; c += 256) {
           const int s = c / G::CIN, cc = c - s * G::CIN;
           float m, a, ad;
-          norm_entry(p.src.norm, s ? st[1].n : st[0].n, cc, Cx, (double)(Cx < DMD_GN_GROUP ? Cx : DMD_GN_GROUP) * p.H * p.W, &m, &a, &ad);
+          norm_entry(p.src.norm, s ? st[1].n : st[0].n, cc, Cx, (double)(Cx < DMD_GN_GROUP ? Cx : DMD_GN_GROUP) * Hv * Wv, &m, &a, &ad);
           tab[(s * 3 + 0) * G::CIN + cc] = m;
           tab[(s * 3 + 1) * G::CIN + cc] = a;
           tab[(s * 3 + 2) * G::CIN + cc] = ad;
@@ -460,7 +478,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, in
         const SubTile t = s ? st[1] : st[0];
         const int iy = t.y0 - G::PAD + py, ix = t.x0 - G::PAD + pxx;
         f32x4 v = px[it];
-        if (p.src.prologue != DMD_PROLOGUE_NONE && t.valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+        if (p.src.prologue != DMD_PROLOGUE_NONE && t.valid && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int cc = 4 * q + e;
@@ -498,7 +516,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, in
         const int s = c / G::CIN, cc = c - s * G::CIN;
         float m, a, ad;
         norm_entry(p.src.norm, s ? st[1].n : st[0].n, cc, Cx,  // (select, not st[s]: a per-lane index would put st[] in scratch)
-                   (double)(Cx < DMD_GN_GROUP ? Cx : DMD_GN_GROUP) * p.H * p.W, &m, &a, &ad);
+                   (double)(Cx < DMD_GN_GROUP ? Cx : DMD_GN_GROUP) * Hv * Wv, &m, &a, &ad);
         tab[(s * 3 + 0) * G::CIN + cc] = m;
         tab[(s * 3 + 1) * G::CIN + cc] = a;
         tab[(s * 3 + 2) * G::CIN + cc] = ad;
@@ -516,7 +534,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, in
       const SubTile t = s ? st[1] : st[0];
       const int iy = t.y0 - G::PAD + py, ix = t.x0 - G::PAD + px;
       f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (t.valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+      if (t.valid && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) {
         v = *(const f32x4*)(p.src.x + (((size_t)t.n * p.H + iy) * p.W + ix) * Cx + 4 * q);
         if (p.src.prologue != DMD_PROLOGUE_NONE) {
 #pragma unroll
@@ -538,7 +556,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, in
       const int s = pix >> 6, r = pix & 63;
       const SubTile t = s ? st[1] : st[0];
       f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (t.valid) v = *(const f32x4*)(p.dy + (((size_t)t.n * p.H + t.y0 + (r >> 3)) * p.W + t.x0 + (r & 7)) * G::COUT + 4 * q);
+      if (t.valid && t.y0 + (r >> 3) < Hv && t.x0 + (r & 7) < Wv)
+        v = *(const f32x4*)(p.dy + (((size_t)t.n * p.H + t.y0 + (r >> 3)) * p.W + t.x0 + (r & 7)) * G::COUT + 4 * q);
       bsum += v;
       *(f32x4*)(dyt + (size_t)pix * G::SA + 4 * q) = v;
     }
@@ -685,6 +704,8 @@ extern "C" int dmd_conv2d_wgrad(const dmd_wgrad_params* p, dmd_stream_t stream) 
   DMD_CHECK_ARG(p && p->src.x && p->dy && p->workspace && p->dw, "wgrad: null");
   DMD_CHECK_ARG(p->N > 0 && p->H % 8 == 0 && p->W % 8 == 0, "wgrad: H, W must be multiples of 8 (%d x %d)", p->H, p->W);
   DMD_CHECK_ARG(p->taps == 9 || p->taps == 1, "wgrad: taps");
+  DMD_CHECK_ARG(p->valid_h >= 0 && p->valid_h <= p->H && p->valid_w >= 0 && p->valid_w <= p->W && (p->valid_h == 0) == (p->valid_w == 0),
+                "wgrad: valid extent %d x %d outside the %d x %d buffer", p->valid_h, p->valid_w, p->H, p->W);
   DMD_CHECK_ARG(p->cin_real > 0 && p->cin_real <= p->src.C, "wgrad: cin_real");
   if (p->src.prologue != DMD_PROLOGUE_NONE)
     DMD_CHECK_ARG(p->src.norm.stats && p->src.norm.stat_tiles > 0, "wgrad: prologue without statistics");

@@ -54,13 +54,14 @@ class LinearParams(C.Structure):
 class GnBwdParams(C.Structure):
     _fields_ = [("N", C.c_int32), ("HW", C.c_int32), ("C", C.c_int32), ("identity_activation", C.c_int32), ("x", C.c_void_p),
                 ("norm", Norm), ("da", C.c_void_p), ("dskip", C.c_void_p), ("dx", C.c_void_p), ("workspace", C.c_void_p),
-                ("dmul", C.c_void_p), ("dadd", C.c_void_p)]
+                ("dmul", C.c_void_p), ("dadd", C.c_void_p), ("W", C.c_int32), ("valid_h", C.c_int32), ("valid_w", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class WgradParams(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cout", C.c_int32), ("taps", C.c_int32),
                 ("cin_real", C.c_int32), ("src", ConvSrc), ("dy", C.c_void_p), ("workspace", C.c_void_p), ("dw", C.c_void_p),
-                ("dbias", C.c_void_p), ("precision", C.c_int32), ("reserved", C.c_int32)]
+                ("dbias", C.c_void_p), ("precision", C.c_int32), ("valid_h", C.c_int32), ("valid_w", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PackJob(C.Structure):

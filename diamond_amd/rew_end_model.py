@@ -59,8 +59,9 @@ class RewEndEncoder(nn.Module):
         self.blocks = nn.ModuleList(blocks)
         self.downsamples = nn.ModuleList([nn.Identity()] + [Downsample(c) for c in channels[:-1]] + [nn.Identity()])
 
-    def run(self, ctx: RunCtx, x_nhwc16: Tensor) -> E.Act:
-        x = E.conv2d([(E.Act(x_nhwc16, needs_grad=False), nv.PROLOGUE_NONE, None)], ctx.cache.conv_weight(self.conv_in),
+    def run(self, ctx: RunCtx, x_nhwc16: Tensor, valid: Optional[Tuple[int, int]] = None) -> E.Act:
+        """valid = (h, w): the image is that part of the zero-padded buffer (engine.padded_extent; inference only)"""
+        x = E.conv2d([(E.Act(x_nhwc16, needs_grad=False, valid=valid), nv.PROLOGUE_NONE, None)], ctx.cache.conv_weight(self.conv_in),
                      ctx.cache.conv_bias(self.conv_in), self.conv_in.out_channels, naive=ctx.naive, w_f16=ctx.w16(self.conv_in),
                      module=self.conv_in)
         tail = len(self.blocks) - 2  # the last level and the final attention group both run at the deepest resolution
@@ -80,7 +81,7 @@ class RewEndEncoder(nn.Module):
 
         if not (int(BL.LOWRES_CHAIN) & 2) or ctx.precision != "f16x2" or ctx.naive or E.TAPE is not None or E._USE_NAIVE:
             return False
-        if tuple(x.shape[1:]) != (8, 8, 32):
+        if tuple(x.shape[1:]) != (8, 8, 32) or x.valid is not None:
             return False
         blks = self._chain_blocks()
         return len(blks) <= nv.CHAIN_MAX_BLOCKS and all(
@@ -154,12 +155,22 @@ class RewEndModel(nn.Module):
         b, t, c, h, w = obs.shape
         dev = obs.device
         x = torch.cat((obs.reshape(b * t, c, h, w), next_obs.reshape(b * t, c, h, w)), dim=1)
+        # sizes whose levels leave the kernels' tile grid (the reference runs any size its three stride-2 convolutions halve
+        # evenly, rew_end_model.py:33: 72 -> 36 -> 18 -> 9): the VALID EXTENT of a zero-padded buffer, like the denoiser
+        nd = len(self.encoder.downsamples) - 2
+        hp, wp = E.padded_extent(h, w, nd)
+        valid = None if (hp, wp) == (h, w) else (h, w)
+        if valid is not None:
+            assert h % 2 ** nd == 0 and w % 2 ** nd == 0, f"RewEndModel: {h}x{w} is not a multiple of {2 ** nd} (the reference's own constraint)"
+            x = torch.nn.functional.pad(x, (0, wp - w, 0, hp - h))
         x16 = E.nchw_to_nhwc(x, 16)
         cond = self._cache.f32(self.act_emb.weight)[act.reshape(b * t)].contiguous()  # embedding gather (plumbing)
         if self._film is None:
             self._film = FilmTable(self.encoder)
         ctx = RunCtx(self._cache, self._film, self._film.compute(cond))
-        feat = self.encoder.run(ctx, x16).t.reshape(b, t, -1)  # NHWC flatten; weight columns permuted to match
+        fa = self.encoder.run(ctx, x16, valid)
+        ft = fa.t if fa.valid is None else fa.t[:, :fa.valid[0], :fa.valid[1]].contiguous()
+        feat = ft.reshape(b, t, -1)  # NHWC flatten; weight columns permuted to match
         hd = self.cfg.lstm_dim
         if hx_cx is None:
             hx = torch.zeros(b, hd, device=dev)

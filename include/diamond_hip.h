@@ -315,6 +315,10 @@ typedef struct dmd_gn_bwd_params {
   void* workspace;     /* dmd_gn_bwd_workspace_bytes(N, HW, C) bytes           */
   float* dmul;         /* (N, C) */
   float* dadd;         /* (N, C) */
+  /* VALID EXTENT (ABI v8; all 0: the whole tensor): x is (N, HW / W, W, C) of which rows < valid_h, columns < valid_w exist.
+   * Only those pixels enter the sums and the GroupNorm count; dx is written as ZERO outside (so that what consumes it --
+   * max-pool backward, the next weight gradient -- sees no contribution from there). */
+  int32_t W, valid_h, valid_w, reserved;
 } dmd_gn_bwd_params;
 int64_t dmd_gn_bwd_workspace_bytes(int N, int HW, int C);
 int dmd_gn_silu_bwd(const dmd_gn_bwd_params* p, dmd_stream_t stream);
@@ -333,7 +337,9 @@ typedef struct dmd_wgrad_params {
   float* dw;           /* OIHW (Cout, cin_real, k, k) */
   float* dbias;        /* (Cout) or NULL */
   int32_t precision;   /* DMD_PRECISION_F32 (exact fp32 fma chain) | DMD_PRECISION_F16X2 (split-fp16 operands, fp32 accumulate) */
-  int32_t reserved;
+  /* VALID EXTENT (ABI v8; both 0: the whole tensor): rows < valid_h, columns < valid_w of src and dy exist; positions outside are
+   * the convolution's zero padding (input, after the prologue) / contribute nothing (dy), GroupNorm counts the valid pixels. */
+  int32_t valid_h, valid_w, reserved;
 } dmd_wgrad_params;
 int64_t dmd_wgrad_workspace_floats(const dmd_wgrad_params* p);
 int dmd_conv2d_wgrad(const dmd_wgrad_params* p, dmd_stream_t stream);

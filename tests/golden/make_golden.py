@@ -108,25 +108,25 @@ def gen_sampler_heun5(agent):
                               "sigmas": sampler.sigmas.clone()})
 
 
-def gen_rew_end(agent):
+def gen_rew_end(agent, name="rew_end.pt", size=64):
     g = torch.Generator().manual_seed(13)
     b = 2
-    obs = synthetic_frames(g, b, 4, 3, 64, 64)
+    obs = synthetic_frames(g, b, 4, 3, size, size)
     act = synthetic_actions(g, 4, b, 4)
     m = agent.rew_end_model
     with torch.no_grad():
         lr, le, (hx, cx) = m.predict_rew_end(obs[:, :-1], act[:, :-1], obs[:, 1:])  # burn-in form, T=3
         lr2, le2, (hx2, cx2) = m.predict_rew_end(obs[:, -1:], act[:, -1:], obs[:, :1], (hx, cx))  # step form
-    save("rew_end.pt", {"seed": 13, "logits_rew": lr, "logits_end": le, "hx": hx, "cx": cx,
+    save(name, {"seed": 13, "logits_rew": lr, "logits_end": le, "hx": hx, "cx": cx,
                         "logits_rew_step": lr2, "logits_end_step": le2, "hx_step": hx2, "cx_step": cx2})
 
 
-def gen_actor_critic(agent):
+def gen_actor_critic(agent, name="actor_critic.pt", size=64):
     g = torch.Generator().manual_seed(14)
     b = 3
     ac = agent.actor_critic
-    obs = synthetic_frames(g, b, 3, 64, 64)
-    obs2 = synthetic_frames(g, b, 3, 64, 64)
+    obs = synthetic_frames(g, b, 3, size, size)
+    obs2 = synthetic_frames(g, b, 3, size, size)
     hx = torch.randn(b, 512, generator=g) * 0.3
     cx = torch.randn(b, 512, generator=g) * 0.3
     ac.zero_grad()
@@ -136,7 +136,7 @@ def gen_actor_critic(agent):
     loss = (o2.logits_act * w).sum() + o2.val.square().sum() + o1.val.sum() + 0.1 * o2.hx_cx[1].sum()
     loss.backward()
     grads = {k: p.grad.clone() for k, p in ac.named_parameters()}
-    save("actor_critic.pt", {
+    save(name, {
         "seed": 14, "logits1": o1.logits_act.detach(), "val1": o1.val.detach(), "logits2": o2.logits_act.detach(),
         "val2": o2.val.detach(), "hx2": o2.hx_cx[0].detach(), "cx2": o2.hx_cx[1].detach(), "loss": loss.detach(),
         # norms accumulated in fp64: an fp32 norm over the 2M-element LSTM matrices is itself only good to ~1e-4
@@ -152,27 +152,26 @@ class _FakeLoader:
         def __init__(self, b):
             self.batch_size = b
 
-    def __init__(self, batch, seed):
+    def __init__(self, batch, seed, size=64):
         self.batch_sampler = self._BS(batch)
-        self._batch, self._seed = batch, seed
+        self._batch, self._seed, self._size = batch, seed, size
 
     def __iter__(self):
         from data import Batch
 
-        for obs, act in initial_condition_batches(self._seed, self._batch, 4):
+        for obs, act in initial_condition_batches(self._seed, self._batch, 4, h=self._size, w=self._size):
             yield Batch(obs=obs, act=act, rew=None, end=None, trunc=None, mask_padding=None, info=None, segment_ids=None)
 
 
-def gen_window():
+def gen_window(name="window.pt", size=64, b=4, horizon=4, t=6):
     """Two BPTT windows of ActorCritic.forward()+backward through the reference's own
     WorldModelEnv and env_loop, default RNG seeded (draw order: SURVEY App. A.5)."""
     from envs import WorldModelEnv, WorldModelEnvConfig
     from models.actor_critic import ActorCriticLossConfig
     from models.diffusion import DiffusionSamplerConfig, SigmaDistributionConfig
 
-    agent = ref_agent()
-    b, horizon, t = 4, 4, 6
-    env = WorldModelEnv(agent.denoiser, agent.rew_end_model, _FakeLoader(b, seed=21),
+    agent = ref_agent(img_size=size)
+    env = WorldModelEnv(agent.denoiser, agent.rew_end_model, _FakeLoader(b, seed=21, size=size),
                         WorldModelEnvConfig(horizon=horizon, num_batches_to_preload=2,
                                             diffusion_sampler=DiffusionSamplerConfig(num_steps_denoising=3)))
     agent.setup_training(SigmaDistributionConfig(-0.4, 1.2, 2e-3, 20),
@@ -180,7 +179,7 @@ def gen_window():
                                                weight_entropy_loss=0.001), env)
     torch.manual_seed(1234)
     random.seed(0)
-    out = {"b": b, "horizon": horizon, "backup_every": t, "pool_seed": 21, "rng_seed": 1234, "preload": 2, "windows": []}
+    out = {"b": b, "horizon": horizon, "backup_every": t, "pool_seed": 21, "rng_seed": 1234, "preload": 2, "size": size, "windows": []}
     ac = agent.actor_critic
     for _ in range(2):
         ac.zero_grad()
@@ -206,7 +205,7 @@ def gen_window():
             "grad_norms": {k: p.grad.norm().clone() for k, p in ac.named_parameters()},
         })
         print("window: loss", float(loss), "ends", int(end.sum()), "truncs", int(trunc.sum()))
-    save("window.pt", out)
+    save(name, out)
 
 
 def gen_window_teacher_forced():
@@ -328,7 +327,19 @@ def gen_rew_end_train():
     print("rew/end training step: loss", float(loss), "cm_rew", logs["confusion_matrix"]["rew"].tolist())
 
 
+def gen_offgrid_72():
+    """RewEndModel / ActorCritic at 72x72 (levels 72/36/18/9 and 72/36/18/9/4: off the kernels' 8-pixel tile grid; the
+    reference runs any size its strides divide, rew_end_model.py:33 / actor_critic.py:45)"""
+    agent = ref_agent(img_size=72)
+    gen_rew_end(agent, "rew_end_72x72.pt", 72)
+    gen_actor_critic(agent, "actor_critic_72x72.pt", 72)
+    gen_window("window_72x72.pt", size=72, b=3, horizon=3, t=4)  # whole path: sampler, reward / end model, resets, AC fwd + bwd
+
+
 def main():
+    if "--offgrid" in sys.argv:
+        gen_offgrid_72()
+        return
     if "--rew-end-train" in sys.argv:
         gen_rew_end_train()
         return

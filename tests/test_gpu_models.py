@@ -33,11 +33,11 @@ def check_quantised(mine_u8, ref_u8, max_frac, what=""):
     assert frac <= max_frac, f"{frac:.2e} of pixels off by one level"
 
 
-def make_agent(attn_depths=(0, 0, 0, 0)):
+def make_agent(attn_depths=(0, 0, 0, 0), img_size=64):
     import diamond_amd as D
     from diamond_amd.testing import fill_module_
 
-    agent = D.Agent(D.default_agent_config(denoiser_attn_depths=attn_depths))
+    agent = D.Agent(D.default_agent_config(denoiser_attn_depths=attn_depths, img_size=img_size))
     fill_module_(agent, WEIGHT_SEED)
     return agent.to(DEV).eval()
 
@@ -228,12 +228,27 @@ def test_sampler_heun5_batch2_every_step_teacher_forced_vs_reference_golden(agen
         assert frac <= 5e-4, (i, frac)
 
 
-def test_rew_end_model_vs_golden(agent):
+@pytest.fixture(scope="module")
+def agent72():
+    """img_size 72: levels 72 / 36 / 18 / 9 (/ 4) are off the kernels' 8-pixel tile grid -- the reward / end model and the
+    actor-critic run them as the valid extent of zero-padded buffers (reference rew_end_model.py:33, actor_critic.py:45)"""
+    return make_agent(img_size=72)
+
+
+def test_rew_end_model_72x72_vs_reference_golden(agent72):
+    test_rew_end_model_vs_golden(agent72, "rew_end_72x72.pt", 72)
+
+
+def test_actor_critic_72x72_fwd_bwd_vs_reference_golden(agent72):
+    test_actor_critic_vs_golden(agent72, "actor_critic_72x72.pt", 72)
+
+
+def test_rew_end_model_vs_golden(agent, fixture="rew_end.pt", size=64):
     from diamond_amd.testing import synthetic_actions, synthetic_frames
 
-    gold = load_golden("rew_end.pt")
+    gold = load_golden(fixture)
     g = torch.Generator().manual_seed(gold["seed"])
-    obs = synthetic_frames(g, 2, 4, 3, 64, 64).to(DEV)
+    obs = synthetic_frames(g, 2, 4, 3, size, size).to(DEV)
     act = synthetic_actions(g, 4, 2, 4).to(DEV)
     m = agent.rew_end_model
     lr, le, (hx, cx) = m.predict_rew_end(obs[:, :-1], act[:, :-1], obs[:, 1:])
@@ -244,15 +259,15 @@ def test_rew_end_model_vs_golden(agent):
         assert rel_err(mine, gold[key]) < 1e-4, (key, rel_err(mine, gold[key]))
 
 
-def test_actor_critic_vs_golden(agent):
+def test_actor_critic_vs_golden(agent, fixture="actor_critic.pt", size=64):
     from diamond_amd.testing import synthetic_frames
 
-    gold = load_golden("actor_critic.pt")
+    gold = load_golden(fixture)
     ac = agent.actor_critic
     g = torch.Generator().manual_seed(gold["seed"])
     b = 3
-    obs = synthetic_frames(g, b, 3, 64, 64).to(DEV)
-    obs2 = synthetic_frames(g, b, 3, 64, 64).to(DEV)
+    obs = synthetic_frames(g, b, 3, size, size).to(DEV)
+    obs2 = synthetic_frames(g, b, 3, size, size).to(DEV)
     hx = (torch.randn(b, 512, generator=g) * 0.3).to(DEV)
     cx = (torch.randn(b, 512, generator=g) * 0.3).to(DEV)
     ac.zero_grad()
@@ -281,29 +296,35 @@ class _Loader:
         def __init__(self, b):
             self.batch_size = b
 
-    def __init__(self, b, seed):
+    def __init__(self, b, seed, size=64):
         self.batch_sampler = self._BS(b)
-        self._b, self._seed = b, seed
+        self._b, self._seed, self._size = b, seed, size
 
     def __iter__(self):
         from types import SimpleNamespace
         from diamond_amd.testing import initial_condition_batches
 
-        for obs, act in initial_condition_batches(self._seed, self._b, 4):
+        for obs, act in initial_condition_batches(self._seed, self._b, 4, h=self._size, w=self._size):
             yield SimpleNamespace(obs=obs, act=act)
 
 
-def test_full_window_vs_reference_golden():
+def test_full_window_72x72_vs_reference_golden():
+    """the same at 72 x 72 (every network off the kernels' tile grid at some level: valid extents end to end)"""
+    test_full_window_vs_reference_golden("window_72x72.pt")
+
+
+def test_full_window_vs_reference_golden(fixture="window.pt"):
     """ActorCritic.forward() + backward over two BPTT windows through WorldModelEnv /
     env_loop with host-injected draws (reference RNG order): integer
     trajectories bit-exact as long as the frames stay on the reference's uint8 levels."""
     import random
     import diamond_amd as D
 
-    gold = load_golden("window.pt")
-    ag = make_agent()
+    gold = load_golden(fixture)
+    size = gold.get("size", 64)
+    ag = make_agent(img_size=size)
     b, t = gold["b"], gold["backup_every"]
-    env = D.WorldModelEnv(ag.denoiser, ag.rew_end_model, _Loader(b, gold["pool_seed"]),
+    env = D.WorldModelEnv(ag.denoiser, ag.rew_end_model, _Loader(b, gold["pool_seed"], size),
                           D.WorldModelEnvConfig(horizon=gold["horizon"], num_batches_to_preload=gold["preload"],
                                                 diffusion_sampler=D.DiffusionSamplerConfig(num_steps_denoising=3)))
     ag.setup_training(D.SigmaDistributionConfig(-0.4, 1.2, 2e-3, 20),

@@ -119,3 +119,69 @@ def test_attention_and_gn_stats_valid_extent():
     x = torch.randn(n, c, vh, vw, generator=g)
     a = E.gn_stats(_embed(x, hp, wp), (vh, vw))
     assert float((_stats_total(a) - _ref_totals(x)).abs().max()) < 1e-6
+
+
+# ---- the backward kernels of the actor-critic encoder (ABI v8): dmd_conv2d_wgrad, dmd_gn_silu_bwd, max-pool --------------------
+@pytest.mark.parametrize("split", [False, True], ids=["exact", "f16x2"])
+@pytest.mark.parametrize("cin,cout,taps,valid,buf", [(32, 32, 9, (36, 36), (40, 40)), (32, 64, 9, (18, 18), (24, 24)),
+                                                     (32, 64, 1, (18, 18), (24, 24)), (64, 64, 9, (9, 9), (16, 16)), (16, 32, 9, (72, 72), (80, 80))])
+def test_wgrad_valid_extent(cin, cout, taps, valid, buf, split):
+    """dW / db of a convolution whose input and output exist on the valid extent only: margins of x AND of dy are garbage"""
+    from diamond_amd import ac_native as A, engine as E
+
+    g = torch.Generator().manual_seed(cin + cout + taps + valid[0])
+    n, (vh, vw), k = 3, valid, 3 if taps == 9 else 1
+    prologue = 1 if cin % 32 == 0 else 0
+    x = torch.randn(n, cin, vh, vw, generator=g, dtype=torch.float64) * 1.3 + 0.2
+    gamma = torch.randn(cin, generator=g, dtype=torch.float64) * 0.2 + 1
+    beta = torch.randn(cin, generator=g, dtype=torch.float64) * 0.2
+    dy = torch.randn(n, cout, vh, vw, generator=g, dtype=torch.float64)
+    wgt = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+    bias = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    a = x
+    if prologue:
+        a = gn_ref(x, cin // 32) * gamma[None, :, None, None] + beta[None, :, None, None]
+        a = a * torch.sigmoid(a)
+    F.conv2d(a, wgt, bias, padding=1 if k == 3 else 0).backward(dy)
+    xa = E.gn_stats(_embed(x.float(), *buf), valid) if prologue else E.Act(_embed(x.float(), *buf), valid=valid)
+    spec = E.NormSpec(mul=gamma.float().to(DEV), add=beta.float().to(DEV)) if prologue else None
+    dw, db = A._wgrad(xa, prologue, spec, _embed(dy.float(), *buf, fill=-53.0), taps, cin, split=split)
+    assert rel_err(dw, wgt.grad) < 2e-5 and rel_err(db, bias.grad) < 2e-5, (rel_err(dw, wgt.grad), rel_err(db, bias.grad))
+
+
+@pytest.mark.parametrize("c,valid,buf,skip", [(32, (36, 36), (40, 40), True), (64, (9, 9), (16, 16), False), (32, (18, 20), (24, 24), True)])
+def test_gn_silu_bwd_valid_extent(c, valid, buf, skip):
+    """sums, count and dx over the valid extent; dx is ZERO outside it (what the max-pool backward / next wgrad rely on)"""
+    from diamond_amd import ac_native as A, engine as E
+
+    g = torch.Generator().manual_seed(c + valid[0])
+    n, (vh, vw) = 2, valid
+    x = (torch.randn(n, c, vh, vw, generator=g, dtype=torch.float64) * 1.7 + 0.4).requires_grad_(True)
+    gamma = (torch.randn(c, generator=g, dtype=torch.float64) * 0.2 + 1).requires_grad_(True)
+    beta = (torch.randn(c, generator=g, dtype=torch.float64) * 0.2).requires_grad_(True)
+    da = torch.randn(n, c, vh, vw, generator=g, dtype=torch.float64)
+    dskip = torch.randn(n, c, vh, vw, generator=g, dtype=torch.float64) if skip else None
+    u = F.group_norm(x, c // 32, gamma, beta, eps=1e-5)
+    tot = ((u * torch.sigmoid(u)) * da).sum() + ((x * dskip).sum() if skip else 0)
+    tot.backward()
+    xa = E.gn_stats(_embed(x.detach().float(), *buf), valid)
+    spec = E.NormSpec(mul=gamma.detach().float().to(DEV), add=beta.detach().float().to(DEV))
+    dx, dmul, dadd = A._gn_silu_bwd(xa, spec, _embed(da.float(), *buf, fill=91.0), _embed(dskip.float(), *buf, fill=-17.0) if skip else None)
+    assert rel_err(dx[:, :vh, :vw].permute(0, 3, 1, 2), x.grad) < 2e-5
+    assert rel_err(dmul.sum(0), gamma.grad) < 2e-5 and rel_err(dadd.sum(0), beta.grad) < 2e-5
+    outside = dx.clone()
+    outside[:, :vh, :vw] = 0
+    assert float(outside.abs().max()) == 0.0, "dx outside the valid extent must be exactly zero"
+
+
+def test_maxpool_valid_extent_floors_like_the_reference():
+    """MaxPool2d(2) of a 9x9 valid extent in a 16x16 buffer = F.max_pool2d's 4x4 (floor), statistics over those 16 pixels"""
+    from diamond_amd import ac_native as A
+
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 32, 9, 9, generator=g)
+    act, arg = A._maxpool(_embed(x, 16, 16, fill=1e4), (9, 9))
+    ref = F.max_pool2d(x, 2)
+    assert act.valid == (4, 4) and tuple(act.t.shape) == (2, 8, 8, 32)
+    assert torch.equal(act.t[:, :4, :4].cpu().permute(0, 3, 1, 2), ref)
+    assert torch.allclose(_stats_total(act), _ref_totals(ref), rtol=1e-12, atol=1e-9)
