@@ -142,6 +142,10 @@ class _Plan:
             pool = i + 1 < len(layers) and isinstance(layers[i + 1], nn.MaxPool2d)
             self.blocks.append((blk, pool))
             i += 2 if pool else 1
+        # Image sizes the kernels take as they are: every convolution's level a multiple of the 8-pixel tiles.  A block's
+        # convolution runs at the size left by the pools BEFORE it (the last pool's output only gets flattened): 64 for the
+        # default encoder (levels 64 / 32 / 16 / 8 -> 4).  Other sizes: the valid extent of a padded buffer (_EncoderFn.forward).
+        self.grid_multiple = 8 * 2 ** max(sum(1 for _, pool in self.blocks[:i] if pool) for i in range(len(self.blocks)))
         self.params: List[nn.Parameter] = [self.conv_in.weight, self.conv_in.bias]
         for blk, _ in self.blocks:
             gn, conv = blk.f[0].norm, blk.f[2]
@@ -157,7 +161,7 @@ class _EncoderFn(torch.autograd.Function):
         # Image sizes off the kernels' 8-pixel grid at some level (the reference runs any size, MaxPool2d floors:
         # actor_critic.py:45, 72 -> 36 -> 18 -> 9 -> 4) live as the VALID EXTENT of a zero-padded buffer whose levels are all
         # multiples of 8 (include/diamond_hip.h; the denoiser does the same, engine.padded_extent)
-        m = 8 * 2 ** sum(1 for _, pool in plan.blocks if pool)
+        m = plan.grid_multiple
         valid = None if (h % m == 0 and w % m == 0) else (h, w)
         obs_f = obs.detach().float()
         if valid is not None:
