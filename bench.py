@@ -449,6 +449,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-exact-fp32", action="store_true")
+    ap.add_argument("--no-end-logit-bias", action="store_true",
+                    help="the synthetic reward/end model unbiased: ~half of the envs end at every step (mid-window resets + burn-in in the timed region)")
     ap.add_argument("--no-also", action="store_true", help="skip the extra measurements the default configs[1] line carries (`also`)")
     ap.add_argument("--pmc-calibrate", action="store_true",
                     help="two Heun updates over 256 MiB arrays before the window (tools/pmc_collect.sh: a known byte count for the FETCH_SIZE / "
@@ -503,7 +505,8 @@ def main():
         del cal
     torch.manual_seed(1234 + rank)
     attn = tuple(int(v) for v in args.attn_depths.split(","))
-    agent, ac, window = rollout_setup(device, rank, args.img_size, args.batch, args.horizon, args.denoise_steps, args.order, attn, use_dist)
+    agent, ac, window = rollout_setup(device, rank, args.img_size, args.batch, args.horizon, args.denoise_steps, args.order, attn, use_dist,
+                                      bias_end_logits=not args.no_end_logit_bias)
 
     def fence():
         torch.cuda.synchronize()
@@ -540,7 +543,7 @@ def main():
     else:
         replicas_in_sync = None
     progress(f"timed region done: {elapsed:.2f}s for {args.steps} steps")
-    custom = any(getattr(args, k) != v for k, v in preset.items())
+    custom = any(getattr(args, k) != v for k, v in preset.items()) or args.no_end_logit_bias
     cfg_idx = args.config if world == 1 or args.config != 1 else 2
     cfg_name = f"configs[{cfg_idx}]" + (" (modified by flags)" if custom else "") + \
         (" (sharded over the GPUs)" if world > 1 else "")
@@ -561,7 +564,8 @@ def main():
         "config": {"workload": f"{cfg_name}: {sz}x3 frames, batch {args.batch}/GPU, horizon {args.horizon}, {sampler}"
                                f"{', denoiser attention at levels ' + args.attn_depths if any(attn) else ''}; step = "
                                f"ActorCritic.forward()+backward+all-reduce+clip+AdamW over one {args.horizon}-step imagined window; "
-                               + END_LOGIT_BIAS_NOTE,
+                               + ("UNBIASED synthetic end-logits: mid-window resets and burn-in inside the timed region" if args.no_end_logit_bias
+                                  else END_LOGIT_BIAS_NOTE),
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (batch-sharded envs, flat-bucket "
                    "RCCL all-reduce of actor-critic grads)", "actor_critic_backend": ac.backend,
                    "world_model_precision": E.WORLD_MODEL_PRECISION, "actor_critic_precision": ac_native.AC_PRECISION,

@@ -108,16 +108,18 @@ class DiffusionSampler:
         return x.clone(), [t.clone() for t in traj]
 
     @torch.no_grad()
-    def sample_ring(self, ctx_obs: Tensor, ctx_act: Tensor, obs_head: int, act_head: int) -> Tuple[Tensor, List[Tensor]]:
+    def sample_ring(self, ctx_obs: Tensor, ctx_act: Tensor, obs_head: int, act_head: int,
+                    noise: Optional[Tensor] = None) -> Tuple[Tensor, List[Tensor]]:
         """`sample` over ring-indexed context buffers (logical step t at slot (head + t) % T): what WorldModelEnv
-        calls every step, so its context is never rolled (world_model_env.py:74-75)."""
+        calls every step, so its context is never rolled (world_model_env.py:74-75).  noise: the initial draw (B, C, H, W),
+        made by the caller (WorldModelEnv keeps it to repeat a dropped speculative step with the same draw)."""
         device = ctx_obs.device
         b, t, c, h, w = ctx_obs.size()
         ctx_obs = ctx_obs.contiguous()
         ring = (obs_head, act_head)
         sig = self._host_sigmas
         gamma_ = min(self.cfg.s_churn / (len(sig) - 1), 2 ** 0.5 - 1)
-        x = self._randn((b, c, h, w), device)
+        x = noise if noise is not None else self._randn((b, c, h, w), device)
         trajectory = [x]
         for sigma, next_sigma in zip(sig[:-1], sig[1:]):  # 0-dim fp32 CPU tensors
             gamma = gamma_ if self.cfg.s_tmin <= sigma <= self.cfg.s_tmax else 0

@@ -58,6 +58,14 @@ def make_env_loop(env, model, epsilon: float = 0.0, expo_fn: Optional[Callable[[
     # small launches.  If an episode did end, the speculative result is dropped and the step is recomputed after the reset,
     # with the SAME exponential draws: every random stream is consumed in the reference's order either way.
     two_phase = hasattr(env, "step_begin") and os.environ.get("DIAMOND_SPECULATIVE_POLICY", "1") != "0"
+    # ... and, where the env can hand its synchronisation over (WorldModelEnv.step_end_issue / step_end_finish), the NEXT
+    # step's imagined frame as well: env.step_begin(act of step n + 1) is issued before the host asks whether an episode
+    # ended in step n.  The device then holds a whole sampler step of queued work while the host waits, instead of running
+    # dry until the host has issued the first launches of the next step (~1-2 ms per step on a 20 ms step).  A speculation an
+    # ended episode voids is dropped by the env, which keeps its draws for the repetition; after such a step the env
+    # declines to speculate for a while (may_speculate).  Not with epsilon-greedy actions (the override of step n + 1 is
+    # drawn at the top of that step: the speculated action could change).
+    three_phase = two_phase and epsilon == 0.0 and all(hasattr(env, a) for a in ("step_end_issue", "step_end_finish", "may_speculate"))
 
     def draw_expo(logits: Tensor) -> Tensor:
         if expo_fn is not None:
@@ -71,6 +79,7 @@ def make_env_loop(env, model, epsilon: float = 0.0, expo_fn: Optional[Callable[[
         any_dead = False
         spec = None        # (logits, val, (hx, cx), act) of this step, issued during the previous one
         saved_expo = None  # draws of a dropped speculative step, to be used by its recomputation
+        begun = None       # the imagined frame of this step if env.step_begin(act) was issued during the previous one
         for n in range(num_steps):
             if spec is not None:
                 logits_act, val, (hx, cx), act = spec
@@ -84,12 +93,18 @@ def make_env_loop(env, model, epsilon: float = 0.0, expo_fn: Optional[Callable[[
                 act = torch.randint(low=0, high=env.num_actions, size=(obs.size(0),), device=obs.device)
             cand = None
             if two_phase:
-                nxt = env.step_begin(act)
+                nxt, begun = (begun, None) if begun is not None else (env.step_begin(act), None)
                 if n + 1 < num_steps:
                     s_logits, s_val, s_hc = model.predict_act_value(nxt, (hx, cx))
                     s_expo = draw_expo(s_logits)
                     cand = (s_logits, s_val, s_hc, sample_categorical(s_logits, s_expo))
-                next_obs, rew, end, trunc, info = env.step_end()
+                if three_phase:
+                    env.step_end_issue()
+                    if cand is not None and env.may_speculate():
+                        begun = env.step_begin(cand[3], speculative=True)
+                    next_obs, rew, end, trunc, info = env.step_end_finish()
+                else:
+                    next_obs, rew, end, trunc, info = env.step_end()
             else:
                 next_obs, rew, end, trunc, info = env.step(act)
 
@@ -102,6 +117,7 @@ def make_env_loop(env, model, epsilon: float = 0.0, expo_fn: Optional[Callable[[
             dead = torch.logical_or(end, trunc)
             any_dead = info["any_dead"] if "any_dead" in info else bool(dead.any())
             if any_dead:
+                begun = None  # (the env dropped the speculative half-step itself and kept its draws)
                 if cand is not None:
                     saved_expo, cand = s_expo, None  # an episode ended: this step's policy output is recomputed after the reset
                 with torch.no_grad():

@@ -146,6 +146,16 @@ class WorldModelEnv:
         self._head = 0                      # physical slot of logical step 0 (both rings advance together)
         # test hook: injected exponential draws for the reward / end samples (host RNG parity)
         self.expo_fn: Optional[Callable[[Tensor], Tensor]] = None
+        # speculative step_begin (env_loop issues step n + 1's sampler before step n's host synchronisation, see
+        # step_end_issue): the draws of a dropped speculation, re-used by its repetition; how long not to speculate after a
+        # step in which an episode ended (doubles with every wasted speculation, back to 4 after 16 that were used)
+        self._pending = None
+        self._pending_speculative = False
+        self._saved_draws: Optional[Tuple[Optional[Tensor], Tensor, Tensor]] = None
+        self._issued = None
+        self._spec_cooldown, self._spec_penalty, self._spec_streak = 0, 4, 0
+        self._flag_host: Optional[Tensor] = None
+        self._flag_event = None
 
     @property
     def device(self) -> torch.device:
@@ -182,6 +192,8 @@ class WorldModelEnv:
             self._ctx = torch.empty(shape, dtype=torch.float32, device=dev)
             self._act = torch.empty(shape[:2], dtype=torch.long, device=dev)
         self._head = 0
+        self._pending, self._pending_speculative, self._saved_draws, self._issued = None, False, None, None
+        self._spec_cooldown = 0
         self.pool.scatter_frames(idx, None, self._ctx, 0)
         self._act.copy_(self.pool.act[idx])
         self.hx_rew_end = self.pool.hx[idx].unsqueeze(0).clone()
@@ -192,7 +204,8 @@ class WorldModelEnv:
     @torch.no_grad()
     def reset_dead(self, dead: Tensor) -> Tensor:
         """Replace the context / action ring / reward-end LSTM state of the dead envs by fresh pool rows;
-        returns the dead row indices."""
+        returns the dead row indices.  INVARIANT (env_loop's speculation relies on it): no draw from torch's random
+        generators happens here or in the pool's preload -- a reset consumes no random stream."""
         rows = dead.nonzero(as_tuple=True)[0]
         idx = self.pool.take(int(rows.numel()))
         self.pool.scatter_frames(idx, rows, self._ctx, self._head)
@@ -208,29 +221,55 @@ class WorldModelEnv:
         return self.step_end()
 
     @torch.no_grad()
-    def step_begin(self, act: Tensor) -> Tensor:
-        """First half of `step`: the imagined next frame.  Nothing here waits for the device.  The random draws of the second
-        half (reward / end samples) are made NOW, so that a caller may interleave its own draws between the two halves
-        without changing the order in which the streams are consumed (env_loop issues the policy's next step in between)."""
+    def step_begin(self, act: Tensor, speculative: bool = False) -> Tensor:
+        """First half of `step`: the imagined next frame.  Nothing here waits for the device.  The random draws of the step
+        (initial noise of the sampler, reward / end samples) are made NOW, in the reference's order, so that a caller may
+        interleave its own draws between the two halves without changing the order in which the streams are consumed
+        (env_loop issues the policy's next step in between).
+        speculative: issued BEFORE the previous step's host synchronisation (between step_end_issue and step_end_finish), on
+        the assumption that no episode ended there.  If one did, step_end_finish drops this half-step, keeps its draws, and
+        the caller's next step_begin -- with the action recomputed after the reset -- consumes them: every random stream is
+        consumed in the same order either way (no draw is made by a reset: `reset_dead` and the pool preload use none)."""
         newest = self._slot(-1)
         self._act[:, newest] = act
-        next_obs, denoising_trajectory = self.predict_next_obs()
-        b, dev = next_obs.shape[0], next_obs.device
-        if self.expo_fn is None:
-            e_rew = torch.empty(b, 3, device=dev).exponential_(1)
-            e_end = torch.empty(b, 2, device=dev).exponential_(1)
-        else:  # (test hook: draws injected in the reference's order -- the hook looks at the shape only)
-            e_rew = self.expo_fn(torch.empty(b, 1, 3, device=dev))
-            e_end = self.expo_fn(torch.empty(b, 1, 2, device=dev))
-        self._pending = (next_obs, denoising_trajectory, e_rew, e_end)
+        saved, self._saved_draws = self._saved_draws, None
+        own_noise = not self._use_graph()  # (a captured sampler graph draws inside the graph: never speculated, see may_speculate)
+        if saved is not None:
+            noise, e_rew, e_end = saved
+        else:
+            b, dev = self._ctx.shape[0], self._ctx.device
+            noise = self.sampler._randn((b,) + tuple(self._ctx.shape[2:]), dev) if own_noise else None
+            if self.expo_fn is None:
+                e_rew = torch.empty(b, 3, device=dev).exponential_(1)
+                e_end = torch.empty(b, 2, device=dev).exponential_(1)
+            else:  # (test hook: draws injected in the reference's order -- the hook looks at the shape only)
+                e_rew = self.expo_fn(torch.empty(b, 1, 3, device=dev))
+                e_end = self.expo_fn(torch.empty(b, 1, 2, device=dev))
+        next_obs, denoising_trajectory = self.predict_next_obs(noise)
+        self._pending = (next_obs, denoising_trajectory, e_rew, e_end, noise)
+        self._pending_speculative = speculative
         return next_obs
+
+    def may_speculate(self) -> bool:
+        """May the caller issue the NEXT step's step_begin before this step's step_end_finish?  Not while the cool-down after an
+        ended episode runs (a dropped speculation costs a whole sampler step), not with a captured sampler graph (its noise is
+        drawn inside the graph) or stochastic churn (more draws inside the sampler than this class keeps)."""
+        return self._spec_cooldown == 0 and not self._use_graph() and self.sampler.cfg.s_churn == 0
 
     @torch.no_grad()
     def step_end(self):
         """Second half of `step`: reward / termination, ring bookkeeping and -- the one host synchronisation of a step -- the
         check for finished episodes (`if dead.any()`, world_model_env.py:77-83)."""
-        next_obs, denoising_trajectory, e_rew, e_end = self._pending
-        self._pending = None
+        self.step_end_issue()
+        return self.step_end_finish()
+
+    @torch.no_grad()
+    def step_end_issue(self) -> None:
+        """Everything of step_end that the host can issue without knowing whether an episode ended; the answer travels to the
+        host asynchronously (pinned flag + event).  The caller may issue more work -- the policy's and the sampler's next step
+        -- before it asks for it with step_end_finish: the device then never runs dry while the host waits."""
+        next_obs, denoising_trajectory, e_rew, e_end, _ = self._pending
+        self._pending, self._pending_speculative = None, False
         rew, end = self.predict_rew_end(next_obs.unsqueeze(1), e_rew, e_end)
 
         self.ep_len += 1
@@ -245,10 +284,41 @@ class WorldModelEnv:
         info: Dict[str, Any] = {}
         if self.return_denoising_trajectory:
             info["denoising_trajectory"] = torch.stack(denoising_trajectory, dim=1)
+        flag = dead.any()
+        if flag.is_cuda:
+            if self._flag_host is None:
+                self._flag_host = torch.zeros((), dtype=torch.bool).pin_memory()
+                self._flag_event = torch.cuda.Event()
+            self._flag_host.copy_(flag, non_blocking=True)
+            self._flag_event.record()
+        self._issued = (next_obs, rew, end, trunc, dead, info, flag)
+
+    @torch.no_grad()
+    def step_end_finish(self):
+        """THE host synchronisation of a step: did an episode end?  If so: resets, and a speculative step_begin issued
+        meanwhile is dropped (its draws are kept for the repetition)."""
+        next_obs, rew, end, trunc, dead, info, flag = self._issued
+        self._issued = None
+        if flag.is_cuda:
+            self._flag_event.synchronize()
+            any_dead = bool(self._flag_host)
+        else:
+            any_dead = bool(flag)
         obs = next_obs  # a fresh tensor every step: never aliases the ring
-        any_dead = bool(dead.any())
         info["any_dead"] = any_dead  # (so that the caller does not have to synchronise again for the same answer)
+        if self._spec_cooldown > 0:
+            self._spec_cooldown -= 1
+        if self._pending is not None and self._pending_speculative:
+            if any_dead:  # wasted: remember the draws, back off for longer
+                self._saved_draws = (self._pending[4], self._pending[2], self._pending[3])
+                self._pending, self._pending_speculative = None, False
+                self._spec_penalty, self._spec_streak = min(64, 2 * self._spec_penalty), 0
+            else:
+                self._spec_streak += 1
+                if self._spec_streak >= 16:
+                    self._spec_penalty = 4
         if any_dead:
+            self._spec_cooldown = self._spec_penalty
             rows = self.reset_dead(dead)
             info["final_observation"] = next_obs[rows]
             cols = self._cols()
@@ -256,13 +326,16 @@ class WorldModelEnv:
             obs = self._ctx[:, self._slot(-1)].clone()  # dead envs now show the newest frame of their new episode
         return obs, rew, end, trunc, info
 
-    @torch.no_grad()
-    def predict_next_obs(self) -> Tuple[Tensor, List[Tensor]]:
+    def _use_graph(self) -> bool:
         # (no replay while a launch profiler is installed: a replayed graph issues no launches it could time, and a first
         #  capture inside the profiled window would record timing events into the graph)
-        if self.graph_sampler and self.sampler.noise_fn is None and nv.PROFILER is None:
+        return self.graph_sampler and self.sampler.noise_fn is None and nv.PROFILER is None
+
+    @torch.no_grad()
+    def predict_next_obs(self, noise: Optional[Tensor] = None) -> Tuple[Tensor, List[Tensor]]:
+        if self._use_graph():
             return self.sampler.sample_ring_graphed(self._ctx, self._act, self._head, self._head)
-        return self.sampler.sample_ring(self._ctx, self._act, self._head, self._head)
+        return self.sampler.sample_ring(self._ctx, self._act, self._head, self._head, noise)
 
     @torch.no_grad()
     def predict_rew_end(self, next_obs: Tensor, e_rew: Optional[Tensor] = None, e_end: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
