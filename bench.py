@@ -189,6 +189,16 @@ def _child_json(cmd, threads, timeout_s):
         return {"value": None, "sample": f"failed: {e!r}"}
 
 
+def cpu_baseline_config4(timeout_s=240):
+    """configs[4]'s frame on the reference itself (one env, a 2-step window at 256x256 with attention [0,0,1,1]): there is no
+    CPU-runnable BASELINE config at this size, so the sample is as small as the reference's loop allows."""
+    threads = usable_cores()
+    ref = _child_json([sys.executable, os.path.join(ROOT, "oracle", "reference_window.py"), "--threads", str(threads), "--img-size", "256",
+                       "--batch", "1", "--horizon", "2", "--attn-depths", "0,0,1,1"], threads, timeout_s)
+    ref.setdefault("unit", "imagined frames/s"), ref.setdefault("cores", threads), ref.setdefault("kind", "reference")
+    return ref
+
+
 def cpu_baseline(img_size, timeout_s=240):
     """The CPU path beside the GPU number, on this box's host cores, each in a child process: the REFERENCE ITSELF where its
     bytecode travelled with the snapshot (oracle/_ref, built by oracle/make_ref.py in the build container: kind "reference") and
@@ -544,6 +554,7 @@ def main():
         replicas_in_sync = None
     progress(f"timed region done: {elapsed:.2f}s for {args.steps} steps")
     custom = any(getattr(args, k) != v for k, v in preset.items()) or args.no_end_logit_bias
+    custom_flags = custom
     cfg_idx = args.config if world == 1 or args.config != 1 else 2
     cfg_name = f"configs[{cfg_idx}]" + (" (modified by flags)" if custom else "") + \
         (" (sharded over the GPUs)" if world > 1 else "")
@@ -593,8 +604,8 @@ def main():
                  or ((key.startswith("conv1x1_stream") or key.startswith("conv_mfma")) and key.endswith("true>")))
         peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
         pmc, pmc_set = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path) and args.config == 1 and world == 1:
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json" if args.config == 1 else f"pmc_traffic_cfg{args.config}.json")
+        if os.path.exists(pmc_path) and world == 1 and not custom_flags:
             pmc = json.load(open(pmc_path)).get(key)  # keyed by the rocprofv3 kernel name (tools/pmc_to_profile.py)
         total_ms = sum(v["ms"] for v in summ.values())
         line["roofline"] = {
@@ -602,7 +613,7 @@ def main():
             # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB units;
             # tools/pmc_collect.sh -> tools/pmc_to_profile.py -> profiles/<set>_pmc_traffic.json), next to the algorithmic bytes
             "traffic": None if pmc is None else pmc["hbm_bytes_per_launch"],
-            "traffic_source": None if pmc is None else f"profiles/pmc_traffic.json [{pmc.get('profile_set')}]: {pmc.get('workload')}",
+            "traffic_source": None if pmc is None else f"profiles/{os.path.basename(pmc_path)} [{pmc.get('profile_set')}]: {pmc.get('workload')}",
             "algorithmic_bytes_per_launch": d["bytes"] / d["launches"], "launches": d["launches"],
             "avg_launch_ms": d["ms"] / d["launches"], "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
             "algorithmic_hbm_gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9,
@@ -649,7 +660,7 @@ def main():
         progress(f"also: {line['also']['seconds']:.1f}s")
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(64)
+        line["cpu_baseline"] = cpu_baseline_config4() if args.config == 4 else cpu_baseline(64)
         progress("cpu baseline done")
 
     if rank == 0:

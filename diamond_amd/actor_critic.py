@@ -106,6 +106,14 @@ class ActorCritic(nn.Module):
         logits, val, hx, cx = lstm_heads(self._native_encoder.cache, x, hx, cx, self.lstm, self.actor_linear, self.critic_linear)
         return ActorCriticOutput(logits, val, (hx, cx))
 
+    def predict_from_features(self, x: Tensor, hx_cx: Tuple[Tensor, Tensor]) -> ActorCriticOutput:
+        """predict_act_value behind the encoder: LSTM cell + heads on features `encode` produced (env_loop encodes the burn-in
+        frames of a reset in ONE pass and steps the LSTM over them)."""
+        from .lstm_native import lstm_heads
+        hx, cx = hx_cx
+        logits, val, hx, cx = lstm_heads(self._native_encoder.cache, x, hx, cx, self.lstm, self.actor_linear, self.critic_linear)
+        return ActorCriticOutput(logits, val, (hx, cx))
+
     def forward(self):
         c = self.loss_cfg
         _, act, rew, end, trunc, logits_act, val, val_bootstrap, _ = self.env_loop.send(c.backup_every)

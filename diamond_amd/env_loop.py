@@ -57,7 +57,8 @@ def make_env_loop(env, model, epsilon: float = 0.0, expo_fn: Optional[Callable[[
     # denoiser can be launched at once; without this the GPU idles ~1 ms per step while the host issues the policy's ~40
     # small launches.  If an episode did end, the speculative result is dropped and the step is recomputed after the reset,
     # with the SAME exponential draws: every random stream is consumed in the reference's order either way.
-    two_phase = hasattr(env, "step_begin") and os.environ.get("DIAMOND_SPECULATIVE_POLICY", "1") != "0"
+    spec_mode = os.environ.get("DIAMOND_SPECULATIVE_POLICY", "1")  # "0": neither speculation, "policy": the policy step only
+    two_phase = hasattr(env, "step_begin") and spec_mode != "0"
     # ... and, where the env can hand its synchronisation over (WorldModelEnv.step_end_issue / step_end_finish), the NEXT
     # step's imagined frame as well: env.step_begin(act of step n + 1) is issued before the host asks whether an episode
     # ended in step n.  The device then holds a whole sampler step of queued work while the host waits, instead of running
@@ -65,7 +66,7 @@ def make_env_loop(env, model, epsilon: float = 0.0, expo_fn: Optional[Callable[[
     # ended episode voids is dropped by the env, which keeps its draws for the repetition; after such a step the env
     # declines to speculate for a while (may_speculate).  Not with epsilon-greedy actions (the override of step n + 1 is
     # drawn at the top of that step: the speculated action could change).
-    three_phase = two_phase and epsilon == 0.0 and all(hasattr(env, a) for a in ("step_end_issue", "step_end_finish", "may_speculate"))
+    three_phase = two_phase and spec_mode != "policy" and epsilon == 0.0 and all(hasattr(env, a) for a in ("step_end_issue", "step_end_finish", "may_speculate"))
 
     def draw_expo(logits: Tensor) -> Tensor:
         if expo_fn is not None:
@@ -75,7 +76,7 @@ def make_env_loop(env, model, epsilon: float = 0.0, expo_fn: Optional[Callable[[
     while True:
         hx, cx = hx.detach(), cx.detach()  # BPTT window boundary
         rows, infos = [], []
-        dead = val_final_obs = None
+        dead = val_final_obs = ridx = None
         any_dead = False
         spec = None        # (logits, val, (hx, cx), act) of this step, issued during the previous one
         saved_expo = None  # draws of a dropped speculative step, to be used by its recomputation
@@ -111,7 +112,7 @@ def make_env_loop(env, model, epsilon: float = 0.0, expo_fn: Optional[Callable[[
             if n > 0:  # the bootstrap value of step n-1 is this step's value (:39-43)
                 vb = val.detach().clone()
                 if any_dead:
-                    vb[dead] = val_final_obs
+                    vb = vb.index_copy(0, ridx, val_final_obs) if ridx is not None else vb.masked_scatter(dead, val_final_obs)
                 rows[-1][-1] = vb
 
             dead = torch.logical_or(end, trunc)
@@ -120,14 +121,31 @@ def make_env_loop(env, model, epsilon: float = 0.0, expo_fn: Optional[Callable[[
                 begun = None  # (the env dropped the speculative half-step itself and kept its draws)
                 if cand is not None:
                     saved_expo, cand = s_expo, None  # an episode ended: this step's policy output is recomputed after the reset
+                ridx = info.get("dead_rows")  # device index list of the dead rows (WorldModelEnv), else boolean masks
+                if ridx is not None:
+                    h_d, c_d = hx.index_select(0, ridx), cx.index_select(0, ridx)
+                else:
+                    h_d, c_d = hx[dead], cx[dead]
                 with torch.no_grad():
-                    _, val_final_obs, _ = model.predict_act_value(info["final_observation"], (hx[dead], cx[dead]))
+                    _, val_final_obs, _ = model.predict_act_value(info["final_observation"], (h_d, c_d))
                 gate = 1 - dead.float().unsqueeze(1)
                 hx, cx = hx * gate, cx * gate
                 if "burnin_obs" in info:  # burn-in of the policy LSTM on the new episode, WITH grad (:53-56)
                     burnin = info["burnin_obs"]
-                    for i in range(burnin.size(1)):
-                        _, _, (hx[dead], cx[dead]) = model.predict_act_value(burnin[:, i], (hx[dead], cx[dead]))
+                    if ridx is not None and hasattr(model, "predict_from_features"):
+                        # the encoder does not depend on the LSTM state: all burn-in frames in ONE pass (frame-major), then
+                        # the recurrence over their features -- per sample the same arithmetic as frame by frame (the
+                        # kernels are batch-invariant), a third of the launches forward and backward, no boolean-mask
+                        # gathers (each one a host synchronisation)
+                        nd, tb = burnin.shape[:2]
+                        feats = model.encode(burnin.transpose(0, 1).reshape(nd * tb, *burnin.shape[2:]))
+                        hz, cz = torch.zeros_like(h_d), torch.zeros_like(c_d)  # (the gated state of a dead row)
+                        for i in range(tb):
+                            _, _, (hz, cz) = model.predict_from_features(feats[i * nd:(i + 1) * nd], (hz, cz))
+                        hx, cx = hx.index_copy(0, ridx, hz), cx.index_copy(0, ridx, cz)
+                    else:
+                        for i in range(burnin.size(1)):
+                            _, _, (hx[dead], cx[dead]) = model.predict_act_value(burnin[:, i], (hx[dead], cx[dead]))
             spec = cand
 
             rows.append([obs, act, rew, end, trunc, logits_act, val, None])
@@ -137,7 +155,7 @@ def make_env_loop(env, model, epsilon: float = 0.0, expo_fn: Optional[Callable[[
         with torch.no_grad():
             _, vb, _ = model.predict_act_value(obs, (hx, cx))
         if any_dead:
-            vb[dead] = val_final_obs
+            vb = vb.index_copy(0, ridx, val_final_obs) if ridx is not None else vb.masked_scatter(dead, val_final_obs)
         rows[-1][-1] = vb
         stacked = tuple(torch.stack(col, dim=1) for col in zip(*rows))
         num_steps = yield (*stacked, infos)

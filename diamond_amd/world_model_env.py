@@ -320,6 +320,7 @@ class WorldModelEnv:
         if any_dead:
             self._spec_cooldown = self._spec_penalty
             rows = self.reset_dead(dead)
+            info["dead_rows"] = rows  # device index list: the caller gathers / scatters with it (no further synchronisation)
             info["final_observation"] = next_obs[rows]
             cols = self._cols()
             info["burnin_obs"] = self._ctx[rows[:, None], cols[None, :-1]]

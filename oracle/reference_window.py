@@ -65,7 +65,7 @@ class _Loader:
             yield Batch(obs=obs, act=act, rew=None, end=None, trunc=None, mask_padding=None, info=None, segment_ids=None)
 
 
-def run_window(img_size=64, threads=None, batch=16, horizon=15, windows=1):
+def run_window(img_size=64, threads=None, batch=16, horizon=15, windows=1, attn_depths=(0, 0, 0, 0)):
     """Builds the reference agent + imagination env and times `windows` complete windows, the first one including the reset
     (pool preload + reward/end burn-in), like bench.py's port baseline.  Returns a dict for the bench line."""
     import torch
@@ -83,7 +83,7 @@ def run_window(img_size=64, threads=None, batch=16, horizon=15, windows=1):
 
     from diamond_amd.testing import fill_module_
 
-    agent = Agent(R.default_agent_config(num_actions=4, img_size=img_size))
+    agent = Agent(R.default_agent_config(num_actions=4, img_size=img_size, denoiser_attn_depths=tuple(attn_depths)))
     fill_module_(agent, 0)
     torch.manual_seed(1)
     t0 = time.perf_counter()
@@ -103,7 +103,7 @@ def run_window(img_size=64, threads=None, batch=16, horizon=15, windows=1):
         per.append(time.perf_counter() - t1)
     dt = time.perf_counter() - t0
     return {"value": batch * horizon * windows / dt, "unit": "imagined frames/s", "cores": torch.get_num_threads(), "kind": "reference",
-            "sample": f"configs[0] on the reference's own code ({what}): {windows} whole window(s), B={batch}, reset + {horizon} imagined "
+            "sample": f"the reference's own code ({what}): {windows} whole window(s), B={batch}, reset + {horizon} imagined "
                       f"steps (3 Euler denoise + rew/end + actor-critic) + AC backward, {img_size}x{img_size}, torch-CPU fp32 "
                       f"(unbiased synthetic end-logits: includes mid-window resets / burn-in), {dt:.1f}s",
             "seconds_per_window": per, "loss": float(loss.detach())}
@@ -117,6 +117,8 @@ if __name__ == "__main__":
     ap.add_argument("--img-size", type=int, default=64)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--windows", type=int, default=1)
+    ap.add_argument("--horizon", type=int, default=15)
+    ap.add_argument("--attn-depths", type=str, default="0,0,0,0")
     a = ap.parse_args()
     sys.dont_write_bytecode = True
-    print(json.dumps(run_window(a.img_size, a.threads or None, a.batch, 15, a.windows)))
+    print(json.dumps(run_window(a.img_size, a.threads or None, a.batch, a.horizon, a.windows, tuple(int(v) for v in a.attn_depths.split(",")))))

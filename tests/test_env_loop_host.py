@@ -191,3 +191,71 @@ def test_epsilon_greedy_rollouts_do_not_speculate_the_sampler(monkeypatch):
     """the epsilon override of step n + 1 is drawn at the top of that step: the action a speculative step_begin used could change"""
     _, env, _ = _rollout(monkeypatch, 3, 0.0, epsilon=0.2)
     assert "begin-spec" not in env.log
+
+
+class SeparablePolicy(ToyPolicy):
+    """a policy whose encoder does not see the LSTM state (like ActorCritic): env_loop may encode all burn-in frames of a reset in
+    one pass (`encode` + `predict_from_features`) instead of frame by frame"""
+
+    def __init__(self, batched):
+        super().__init__()
+        self.encodes = 0
+        if not batched:
+            self.predict_from_features = None
+            del self.predict_from_features
+
+    def encode(self, obs):
+        self.encodes += 1
+        return obs.flatten(1)[:, :6] * 1.5 - 0.25
+
+    def predict_from_features(self, feat, hx_cx):
+        hx, cx = hx_cx
+        z = feat + hx[:, :1]
+        return z @ self.w.t(), z.sum(1), (torch.tanh(hx + z[:, :5]), cx + 1)
+
+    def predict_act_value(self, obs, hx_cx):
+        self.calls += 1
+        return SeparablePolicy.predict_from_features(self, self.encode(obs), hx_cx)
+
+
+class BurninEnv(ToyEnv3):
+    """ToyEnv3 + what WorldModelEnv hands over at a reset: burn-in frames of the new episodes and (optionally) the device index
+    list of the dead rows"""
+
+    def __init__(self, b, p_end, with_rows):
+        super().__init__(b, p_end)
+        self.with_rows = with_rows
+
+    def step_end_finish(self):
+        nxt, rew, end, trunc, dead = self._issued
+        out = super().step_end_finish()
+        info = out[4]
+        if info["any_dead"]:
+            rows = dead.nonzero(as_tuple=True)[0]
+            g = torch.Generator().manual_seed(int(rows.sum()) + 17 * len(self.log))
+            info["burnin_obs"] = torch.randn(rows.numel(), 3, 2, 3, generator=g)
+            if self.with_rows:
+                info["dead_rows"] = rows
+        return out
+
+
+@pytest.mark.parametrize("p_end", [0.12, 0.35])
+def test_batched_burn_in_is_bitwise_the_frame_by_frame_one(monkeypatch, p_end):
+    """resets: V(final observation) and the burn-in of the policy LSTM with index lists and ONE encoder pass over all burn-in frames
+    (env_loop's fast path for WorldModelEnv + ActorCritic) against boolean masks and one policy call per frame"""
+    monkeypatch.setattr(EL, "sample_categorical", lambda logits, expo: (torch.softmax(logits.detach(), -1) / expo).argmax(-1))
+    outs = []
+    for batched in (False, True):
+        torch.manual_seed(11)
+        random.seed(5)
+        env, pol = BurninEnv(5, p_end, with_rows=batched), SeparablePolicy(batched)
+        loop = EL.make_env_loop(env, pol, epsilon=0.0)
+        cols = []
+        for _ in range(3):
+            *c, infos = loop.send(6)
+            cols.append([x.clone() for x in c])
+        outs.append((cols, pol))
+    for wa, wb in zip(outs[0][0], outs[1][0]):
+        for a, b in zip(wa, wb):
+            assert torch.equal(a, b)
+    assert outs[1][1].encodes < outs[0][1].encodes, "the batched path did not save encoder passes"

@@ -37,7 +37,9 @@ def normalise(name: str) -> str:
 
 def main() -> None:
     tag = sys.argv[1] if len(sys.argv) > 1 else "latest"
-    src = os.path.join(ROOT, "gpurun_out", "pmc")
+    cfg = sys.argv[2] if len(sys.argv) > 2 else "1"  # BASELINE configs[] index the window was taken on (tools/pmc_collect.sh CFG=)
+    suffix = "" if cfg == "1" else f"_cfg{cfg}"
+    src = os.path.join(ROOT, "gpurun_out", "pmc" + suffix)
     f = json.load(open(os.path.join(src, "FETCH_SIZE.json")))
     w = json.load(open(os.path.join(src, "WRITE_SIZE.json")))
     out = {}
@@ -48,7 +50,8 @@ def main() -> None:
         out[normalise(name)] = {
             "launches": fv["launches"], "fetch_bytes_per_launch": fv["mean"] * 2 * 1024, "write_bytes_per_launch": wv["mean"] * 1024,
             "hbm_bytes_per_launch": fv["mean"] * 2 * 1024 + wv["mean"] * 1024,
-            "workload": "one bench window of configs[1] + its warm-up window (bench.py --steps 1 --warmup 1), separate --pmc passes", "profile_set": tag}
+            "workload": f"one bench window of configs[{cfg}] + its warm-up window (bench.py --config {cfg} --steps 1 --warmup 1), separate --pmc passes",
+            "profile_set": tag}
     cal = [k for k in f if "heun_step_kernel" in k and k in w]  # bench.py --pmc-calibrate: 2 x (4 x 256 MiB read, 256 MiB written)
     if cal:
         cp = cal[0]
@@ -56,11 +59,11 @@ def main() -> None:
                                "FETCH_SIZE_total_KiB": f[cp]["total"], "WRITE_SIZE_total_KiB": w[cp]["total"],
                                "fetch_factor": 2 * 2 ** 30 / (f[cp]["total"] * 1024),
                                "write_factor": 2 ** 29 / (w[cp]["total"] * 1024)}
-    dst = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
+    dst = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic{suffix}.json")
     json.dump(out, open(dst, "w"), indent=1)
-    shutil.copyfile(dst, os.path.join(ROOT, "profiles", "pmc_traffic.json"))
+    shutil.copyfile(dst, os.path.join(ROOT, "profiles", f"pmc_traffic{suffix}.json"))
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        shutil.copyfile(os.path.join(src, f"{c}.json"), os.path.join(ROOT, "profiles", f"{tag}_pmc_{c}.json"))
+        shutil.copyfile(os.path.join(src, f"{c}.json"), os.path.join(ROOT, "profiles", f"{tag}_pmc_{c}{suffix}.json"))
     print(json.dumps(out, indent=1))
 
 
