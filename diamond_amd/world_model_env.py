@@ -149,13 +149,16 @@ class WorldModelEnv:
         # speculative step_begin (env_loop issues step n + 1's sampler before step n's host synchronisation, see
         # step_end_issue): the draws of a dropped speculation, re-used by its repetition; how long not to speculate after a
         # step in which an episode ended (doubles with every wasted speculation, back to 4 after 16 that were used)
+        self._flag_host: Optional[Tensor] = None
+        self._flag_event = None
+        self._reset_speculation()
+
+    def _reset_speculation(self) -> None:
         self._pending = None
         self._pending_speculative = False
         self._saved_draws: Optional[Tuple[Optional[Tensor], Tensor, Tensor]] = None
         self._issued = None
         self._spec_cooldown, self._spec_penalty, self._spec_streak = 0, 4, 0
-        self._flag_host: Optional[Tensor] = None
-        self._flag_event = None
 
     @property
     def device(self) -> torch.device:
@@ -192,8 +195,7 @@ class WorldModelEnv:
             self._ctx = torch.empty(shape, dtype=torch.float32, device=dev)
             self._act = torch.empty(shape[:2], dtype=torch.long, device=dev)
         self._head = 0
-        self._pending, self._pending_speculative, self._saved_draws, self._issued = None, False, None, None
-        self._spec_cooldown = 0
+        self._reset_speculation()
         self.pool.scatter_frames(idx, None, self._ctx, 0)
         self._act.copy_(self.pool.act[idx])
         self.hx_rew_end = self.pool.hx[idx].unsqueeze(0).clone()
@@ -286,7 +288,7 @@ class WorldModelEnv:
             info["denoising_trajectory"] = torch.stack(denoising_trajectory, dim=1)
         flag = dead.any()
         if flag.is_cuda:
-            if self._flag_host is None:
+            if getattr(self, "_flag_host", None) is None:
                 self._flag_host = torch.zeros((), dtype=torch.bool).pin_memory()
                 self._flag_event = torch.cuda.Event()
             self._flag_host.copy_(flag, non_blocking=True)

@@ -194,7 +194,8 @@ def test_ring_env_bookkeeping_matches_roll_based_shadow_cpu():
     loader = SimpleNamespace(batch_sampler=SimpleNamespace(batch_size=b))
     fake_den = SimpleNamespace(device=torch.device("cpu"))
     env = D.WorldModelEnv.__new__(D.WorldModelEnv)
-    env.sampler = SimpleNamespace(denoiser=fake_den, noise_fn=None)
+    env.sampler = SimpleNamespace(denoiser=fake_den, noise_fn=None, cfg=SimpleNamespace(s_churn=0.0),
+                                  _randn=lambda shape, dev: torch.zeros(*shape))
     env.rew_end_model, env.horizon, env.return_denoising_trajectory, env.num_envs = None, 3, False, b
     env.graph_sampler, env.expo_fn = False, None
     env._ctx = env._act = None
@@ -218,7 +219,7 @@ def test_ring_env_bookkeeping_matches_roll_based_shadow_cpu():
     cursor, rnd = b, 0
     assert torch.equal(obs0, sh_obs[:, -1]) and torch.equal(env.obs_buffer, sh_obs)
     state = {}
-    env.predict_next_obs = lambda: (state["nxt"], [])
+    env.predict_next_obs = lambda noise=None: (state["nxt"], [])
     env.predict_rew_end = lambda next_obs, e_rew=None, e_end=None: (torch.zeros(b), state["end"])
     for step in range(14):
         act = torch.randint(0, 4, (b,), generator=g)
