@@ -247,7 +247,8 @@ class WorldModelEnv:
             else:  # (test hook: draws injected in the reference's order -- the hook looks at the shape only)
                 e_rew = self.expo_fn(torch.empty(b, 1, 3, device=dev))
                 e_end = self.expo_fn(torch.empty(b, 1, 2, device=dev))
-        next_obs, denoising_trajectory = self.predict_next_obs(noise)
+        self._next_noise = noise  # (handed over out of band: predict_next_obs keeps the reference's zero-argument signature,
+        next_obs, denoising_trajectory = self.predict_next_obs()  # trainer.py:182-184 re-assigns it with a wrapper)
         self._pending = (next_obs, denoising_trajectory, e_rew, e_end, noise)
         self._pending_speculative = speculative
         return next_obs
@@ -335,7 +336,10 @@ class WorldModelEnv:
         return self.graph_sampler and self.sampler.noise_fn is None and nv.PROFILER is None
 
     @torch.no_grad()
-    def predict_next_obs(self, noise: Optional[Tensor] = None) -> Tuple[Tensor, List[Tensor]]:
+    def predict_next_obs(self) -> Tuple[Tensor, List[Tensor]]:
+        """Reference signature (world_model_env.py:91-93).  The initial noise step_begin drew for this call, if any, waits in
+        `_next_noise`; a direct call draws its own."""
+        noise, self._next_noise = getattr(self, "_next_noise", None), None
         if self._use_graph():
             return self.sampler.sample_ring_graphed(self._ctx, self._act, self._head, self._head)
         return self.sampler.sample_ring(self._ctx, self._act, self._head, self._head, noise)

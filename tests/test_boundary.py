@@ -219,7 +219,7 @@ def test_ring_env_bookkeeping_matches_roll_based_shadow_cpu():
     cursor, rnd = b, 0
     assert torch.equal(obs0, sh_obs[:, -1]) and torch.equal(env.obs_buffer, sh_obs)
     state = {}
-    env.predict_next_obs = lambda noise=None: (state["nxt"], [])
+    env.predict_next_obs = lambda: (state["nxt"], [])
     env.predict_rew_end = lambda next_obs, e_rew=None, e_end=None: (torch.zeros(b), state["end"])
     for step in range(14):
         act = torch.randint(0, 4, (b,), generator=g)

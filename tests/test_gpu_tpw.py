@@ -251,8 +251,8 @@ def test_actor_critic_encoder_batch256_tpw_fwd_bwd_vs_oracle():
     choices = []
     orig_maxpool = ac_native._maxpool
 
-    def recording_maxpool(y):
-        out, arg = orig_maxpool(y)
+    def recording_maxpool(y, valid=None):
+        out, arg = orig_maxpool(y, valid)
         choices.append(arg.permute(0, 3, 1, 2).cpu())  # (N, Ho, Wo, C) element index 2 dy + dx -> (N, C, Ho, Wo)
         return out, arg
 

@@ -10,7 +10,7 @@ mkdir -p $O
 cd $R
 export TMPDIR=/tmp
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
-  timeout 1100 python -m pytest tests -m gpu -q -s -p no:cacheprovider ${PYTEST_ARGS:-} > $O/tests.log 2>&1
+  timeout 1100 python -m pytest tests -m gpu -q -s -p no:cacheprovider --durations=15 ${PYTEST_ARGS:-} > $O/tests.log 2>&1
   echo "pytest rc=$?" >> $O/tests.log
   tail -3 $O/tests.log
 fi
@@ -29,7 +29,7 @@ if [ "${SKIP_PROFILE:-0}" != "1" ]; then
   mkdir -p $O/pmc_cfg4 && cp gpurun_out/pmc_cfg4/*.json $O/pmc_cfg4/ 2>/dev/null
 fi
 if [ "${SKIP_CONFIGS:-0}" != "1" ]; then
-  timeout 300 python bench.py --config 4 --no-cpu-baseline > $O/bench_config4.json 2> $O/bench_config4.err; echo "cfg4 rc=$?"; tail -c 300 $O/bench_config4.json
+  timeout 500 python bench.py --config 4 > $O/bench_config4.json 2> $O/bench_config4.err; echo "cfg4 rc=$?"; tail -c 300 $O/bench_config4.json
   timeout 400 python bench.py --config 3 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_config3.json 2> $O/bench_config3.err; echo "cfg3 rc=$?"; tail -c 300 $O/bench_config3.json
   timeout 300 python bench.py --config latency > $O/bench_latency.json 2> $O/bench_latency.err; echo "latency rc=$?"; tail -c 400 $O/bench_latency.json
   timeout 300 python bench.py --config train > $O/bench_train.json 2> $O/bench_train.err; echo "train rc=$?"; tail -c 400 $O/bench_train.json
