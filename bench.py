@@ -533,11 +533,16 @@ def main():
         window()
     fence()
     progress("warmup done")
+    # per-step stamps WITHOUT synchronising: events on the current stream at the window boundaries, read after the fence
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         window()
+        marks[i + 1].record()
     fence()
     elapsed = time.perf_counter() - t0
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     if use_dist:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -570,6 +575,7 @@ def main():
     line = {
         "metric": metric, "value": fps, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "step_ms": [round(v, 2) for v in step_ms],  # (device time between window boundaries, this rank; diagnostic)
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": precision_label(E, ac_native), "data": "synthetic",
         "config": {"workload": f"{cfg_name}: {sz}x3 frames, batch {args.batch}/GPU, horizon {args.horizon}, {sampler}"
