@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 // attention_f16x2_kernel -- the same attention for long sequences (T a multiple of 256: 1024 / 4096 tokens at the 32x32 /
 // 64x64 levels of the 256x256 configuration) on the f16 matrix cores with SPLIT fp32 operands (x = h + l, fp16 pieces,
 // as in dmd_conv_f16ws.hip).  With head_dim 8 a (query, key) pair costs 16 MACs and one exponential: the kernel is bound by
-// the vector unit (v_exp_f32 is quarter rate), so everything else is taken off it:
+// the vector unit's issue port (v_exp_f32 takes two of its slots: 8 cycles per wave64 instruction, additive with plain VALU work,
+// tools/probe/trans_probe.hip / profiles/r04_trans_probe.txt), so everything else is taken off it:
 //   * TWO passes over the keys instead of an online softmax.  Pass 1: S^T = K Q^T blocks and a running per-lane maximum
 //     (one cross-lane reduction per query at its end).  Pass 2: the score MFMA starts from the accumulator -m_q + 13, so
 //     its output is directly the exponent: p = 2^(s - m + 13) -- no subtraction, no per-block maximum, no rescaling of O,
@@ -134,6 +135,19 @@ typedef _Float16 att_h2 __attribute__((ext_vector_type(2)));
       "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"           \
       : "=&v"(lw)                                                                   \
       : "v"(p0), "v"(p1), "v"(hw))
+#endif
+
+// max(a, b, c) as ONE v_max3_f32.  Pairwise fmaxf() trees made hipcc quiet every MFMA output first (v_max_f32 v, v, v: 72 of the
+// 92 vector instructions of pass 1's inner loop, which made that pass VALU-bound instead of MFMA-bound); the three-input form
+// needs no quieting.  (Not inline asm: the compiler has to see the MFMA -> VALU dependency to place the wait states.)
+__device__ __forceinline__ float af_max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+// lab builds only (tools/build_attention_ablations.sh; WRONG results): timing proxies, bits: 1 no pass 1, 2 no exponentials,
+// 4 no l-piece of P, 8 no row sums, 16 no PV MFMAs, 32 no score MFMAs in pass 2, 64 tiles staged once
+#if defined(DMD_LAB) && defined(AF_ABL)
+#define AF_LAB(bit) ((AF_ABL) & (bit))
+#else
+#define AF_LAB(bit) 0
 #endif
 
 #define AF_KT 256                   // keys per LDS tile
@@ -220,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16x2_kernel(const float* __
   stage_load(0, false);
   stage_store(tiles[0], false);
   __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
+  for (int t = 0; t < (AF_LAB(1) ? 1 : ntiles); ++t) {
     const AfTile& tl = tiles[t & 1];
     if (t + 1 < ntiles) stage_load(t + 1, false);
 #pragma unroll 2
@@ -230,8 +244,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16x2_kernel(const float* __
       for (int g = 0; g < AF_QG; ++g) {
         const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka0, bq[g], zero4, 0, 0, 0);
         const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka1, bq[g], zero4, 0, 0, 0);
-        const float a = fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), b = fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3]));
-        mx[g] = fmaxf(mx[g], fmaxf(a, b));
+        mx[g] = af_max3(af_max3(mx[g], s0[0], s0[1]), af_max3(s0[2], s0[3], s1[0]), af_max3(s1[1], s1[2], s1[3]));
       }
     }
     if (t + 1 < ntiles) stage_store(tiles[(t + 1) & 1], false);
@@ -259,8 +272,8 @@ __global__ __launch_bounds__(256, 2) void attention_f16x2_kernel(const float* __
   stage_store(tiles[0], true);
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
-    const AfTile& tl = tiles[t & 1];
-    if (t + 1 < ntiles) stage_load(t + 1, true);
+    const AfTile& tl = tiles[AF_LAB(64) ? 0 : (t & 1)];
+    if (t + 1 < ntiles && !AF_LAB(64)) stage_load(t + 1, true);
 #pragma unroll 2
     for (int k0 = 0; k0 < AF_KT; k0 += 32) {
       const att_h8 ka0 = k_frag(tl, k0), ka1 = k_frag(tl, k0 + 16);
@@ -269,30 +282,37 @@ __global__ __launch_bounds__(256, 2) void attention_f16x2_kernel(const float* __
       const att_h8 vf = (att_h8){va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
 #pragma unroll
       for (int g = 0; g < AF_QG; ++g) {
-        const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka0, bq[g], negm[g], 0, 0, 0);
-        const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka1, bq[g], negm[g], 0, 0, 0);
+        const f32x4 s0 = AF_LAB(32) ? negm[g] + oacc[g] : __builtin_amdgcn_mfma_f32_16x16x32_f16(ka0, bq[g], negm[g], 0, 0, 0);
+        const f32x4 s1 = AF_LAB(32) ? negm[g] - oacc[g] : __builtin_amdgcn_mfma_f32_16x16x32_f16(ka1, bq[g], negm[g], 0, 0, 0);
         float p[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          p[r] = __builtin_amdgcn_exp2f(s0[r]);
-          p[4 + r] = __builtin_amdgcn_exp2f(s1[r]);
+          p[r] = AF_LAB(2) ? s0[r] : __builtin_amdgcn_exp2f(s0[r]);
+          p[4 + r] = AF_LAB(2) ? s1[r] : __builtin_amdgcn_exp2f(s1[r]);
         }
-        lsum[g] += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+        if (!AF_LAB(8)) lsum[g] += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
         // split p = h + l: packed fp16 conversion for h, one mixed-precision fma per element for l = fp16(p - h)
         unsigned hw[4], lw[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           hw[r] = __builtin_bit_cast(unsigned, (att_h2){(_Float16)p[2 * r], (_Float16)p[2 * r + 1]});
-          ATT_SPLIT_LOW_PAIR(lw[r], p[2 * r], p[2 * r + 1], hw[r]);
+          if (AF_LAB(4))
+            lw[r] = hw[r];
+          else
+            ATT_SPLIT_LOW_PAIR(lw[r], p[2 * r], p[2 * r + 1], hw[r]);
         }
         typedef unsigned att_u4 __attribute__((ext_vector_type(4)));
         const att_h8 ph = __builtin_bit_cast(att_h8, (att_u4){hw[0], hw[1], hw[2], hw[3]});
         const att_h8 pl = __builtin_bit_cast(att_h8, (att_u4){lw[0], lw[1], lw[2], lw[3]});
-        oacc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, ph, oacc[g], 0, 0, 0);
-        oacc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pl, oacc[g], 0, 0, 0);
+        if (AF_LAB(16)) {
+          oacc[g] += __builtin_bit_cast(f32x4, ph) + __builtin_bit_cast(f32x4, pl);  // (keeps the operands alive: 8 plain adds)
+        } else {
+          oacc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, ph, oacc[g], 0, 0, 0);
+          oacc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pl, oacc[g], 0, 0, 0);
+        }
       }
     }
-    if (t + 1 < ntiles) stage_store(tiles[(t + 1) & 1], true);
+    if (t + 1 < ntiles && !AF_LAB(64)) stage_store(tiles[(t + 1) & 1], true);
     __syncthreads();
   }
   // rows dim (v_h) and 8 + dim (v_l) live in lanes kg and kg + 2; the row sum is spread over the 4 kg lanes of a query
