@@ -324,7 +324,9 @@ def train_line(args, eager=True):
     # the same step captured into one hipGraph and replayed on static input buffers (diamond_amd/train_graph.py)
     from diamond_amd.train_graph import GraphedTrainStep
 
-    opt_g = torch.optim.AdamW(den.parameters(), lr=1e-4, capturable=True)
+    # fused=True: the capturable FOREACH AdamW divides every tensor by its 0-dim bias corrections with one broadcast kernel each
+    # (2 x 236 launches of ~4 us per step: profiles/r04_train_kernel_stats.csv); torch's fused form is one multi-tensor kernel
+    opt_g = torch.optim.AdamW(den.parameters(), lr=1e-4, capturable=True, fused=None if getattr(args, "foreach_adamw", False) else True)
     gstep = GraphedTrainStep(den, opt_g, 1.0, batch, warmup_steps=max(args.warmup, 3))
     for _ in range(2):
         gstep(batch)
@@ -338,7 +340,8 @@ def train_line(args, eager=True):
             "value": 1e3 * dt, "unit": "ms/step", "n_gpus": 1, "steps": steps, "warmup": max(args.warmup, 3), "ms_per_step": 1e3 * dt,
             "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f32 via split-f16 MFMA", "data": "synthetic",
             "config": {"workload": "SURVEY §8 (f2): Denoiser.forward(batch) + loss.backward() + clip_grad_norm_ + AdamW, the whole step "
-                                   "replayed as one hipGraph (GraphedTrainStep)", "global_batch": b},
+                                   "replayed as one hipGraph (GraphedTrainStep; torch.optim.AdamW(capturable=True, "
+                                   f"fused={not getattr(args, 'foreach_adamw', False)}))", "global_batch": b},
             "frames_per_s": b / dt, "eager_ms_per_step": None if dt_eager is None else 1e3 * dt_eager, "loss": float(loss.detach()),
             "algorithmic_tflops": 3 * 6.0909e9 * b / dt / 1e12}
 
@@ -461,6 +464,7 @@ def main():
     ap.add_argument("--no-exact-fp32", action="store_true")
     ap.add_argument("--no-end-logit-bias", action="store_true",
                     help="the synthetic reward/end model unbiased: ~half of the envs end at every step (mid-window resets + burn-in in the timed region)")
+    ap.add_argument("--foreach-adamw", action="store_true", help="--config train: the capturable FOREACH AdamW instead of the fused one (A/B)")
     ap.add_argument("--no-also", action="store_true", help="skip the extra measurements the default configs[1] line carries (`also`)")
     ap.add_argument("--pmc-calibrate", action="store_true",
                     help="two Heun updates over 256 MiB arrays before the window (tools/pmc_collect.sh: a known byte count for the FETCH_SIZE / "

@@ -83,6 +83,10 @@ class FilmTable:
         self._packed: Optional[Tuple[Tuple[int, ...], Tensor, Tensor]] = None
         self.stale_epoch = 0  # (see engine.PackCache)
         self.frees_epoch = 0
+        E._WEIGHT_CACHES.add(self)  # optimizer steps that do not bump `_version` (fused AdamW) invalidate through engine's hook
+
+    def depends_on(self, param_ids) -> bool:
+        return any(id(m.linear.weight) in param_ids or id(m.linear.bias) in param_ids for m in self.norms)
 
     def weights(self) -> Tuple[Tensor, Tensor]:
         ver = tuple((m.linear.weight._version, m.linear.weight.data_ptr(), m.linear.bias._version, m.linear.bias.data_ptr())

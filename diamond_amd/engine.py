@@ -114,9 +114,30 @@ def _stamp(p: Tensor) -> Tuple:
     return (p._version, p.data_ptr(), p.device)
 
 
+# Every live cache of kernel-layout weight copies (PackCache below, blocks.FilmTable).  Staleness is normally read off
+# `Tensor._version`, which torch's in-place ops bump -- but not everything that updates a parameter does: the FUSED optimizers
+# (`torch.optim.AdamW(fused=True)`, Adam, SGD: `torch._fused_adamw_` writes through TensorLists) leave `_version` alone, and a
+# model trained with one would keep running on the weights of its first forward, silently.  So a process-wide optimizer
+# post-step hook marks stale every cache that holds a copy of a parameter of the optimizer that just stepped (a Python set
+# intersection per step; the copies are rebuilt in place by their next use, as after a version bump).
+_WEIGHT_CACHES: "weakref.WeakSet" = weakref.WeakSet()
+
+
+def _optimizer_stepped(optimizer, args, kwargs) -> None:
+    ids = {id(p) for group in optimizer.param_groups for p in group["params"]}
+    for cache in list(_WEIGHT_CACHES):
+        if cache.depends_on(ids):
+            cache.invalidate()
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_post_hook  # noqa: E402
+
+_register_step_post_hook(_optimizer_stepped)
+
+
 class PackCache:
     """Kernel-layout copies of nn.Module parameters, refreshed when a parameter changes
-    (optimizer steps bump `Tensor._version`).  Parameters keep the reference's OIHW / (out,in)
+    (optimizer steps bump `Tensor._version`, or are seen by the hook above).  Parameters keep the reference's OIHW / (out,in)
     layouts so checkpoints stay interchangeable (agent.py:48-62).
 
     The convolution copies (packed fp32, split-fp16 pieces, padded biases, and the transposed / sliced weights of the data
@@ -136,10 +157,15 @@ class PackCache:
         # in place changes neither: the graph reads the new values through the same pointer.)
         self.stale_epoch = 0
         self.frees_epoch = 0
+        _WEIGHT_CACHES.add(self)
+
+    def depends_on(self, param_ids) -> bool:
+        """Does this cache hold a copy of any of these parameters (ids)?"""
+        return any(k[0] in param_ids for k in self._jobs) or any(k[0] in param_ids for k in self._store)
 
     def invalidate(self) -> None:
         """Every packed copy is stale.  Needed after writes that do not bump `Tensor._version` (anything done through
-        `p.data`: `.data.copy_`, `.data.fill_`, collectives on `.data`).  Buffers and the job table are kept: the next use
+        `p.data`: `.data.copy_`, `.data.fill_`, collectives on `.data`; optimizer steps are covered by the hook above).  Buffers and the job table are kept: the next use
         rebuilds the copies IN PLACE (a captured graph that reads them keeps valid pointers; it is the weights EPOCH that
         tells its owner that what it captured may be out of date)."""
         for key, hit in list(self._store.items()):

@@ -7,7 +7,7 @@ torch's current stream, allocates nothing and synchronises nothing (include/diam
 of host synchronisations (Denoiser.forward masks the loss arithmetically instead of gathering), so forward, backward,
 clipping and the optimizer update record into one graph that is replayed per step on static input buffers:
 
-    step = GraphedTrainStep(agent.denoiser, opt, max_grad_norm, example_batch)     # opt: capturable=True
+    step = GraphedTrainStep(agent.denoiser, opt, max_grad_norm, example_batch)     # opt: capturable=True (+ fused=True)
     for batch in loader:
         loss, metrics = step(batch)          # == model(batch) ... opt.step(); opt.zero_grad() of the eager loop
 
@@ -15,8 +15,13 @@ Nothing of an earlier eager step's autograd graph may still be referenced when t
 tensor): its AccumulateGrad nodes belong to the stream they were created on, and autograd would synchronise the capturing
 stream with it (torch warns "AccumulateGrad node's stream does not match"; the capture then aborts).
 
+The optimizer: `torch.optim.AdamW(..., capturable=True, fused=True)`.  The capturable FOREACH form divides every tensor by its
+0-dim bias corrections with one broadcast kernel each -- 2 x 236 launches of ~4 us, 1.5 ms of an 11.9 ms step
+(profiles/r04_train_kernel_stats_foreach_adamw.csv); torch's fused form is one multi-tensor kernel: 10.35 ms.  It does not
+bump `Tensor._version`; engine's optimizer post-step hook marks the weight caches stale instead.
+
 What is captured is exactly the eager step's launch sequence.  Weight packing (engine.PackCache, blocks.FilmTable) is keyed
-on parameter versions: the warm-up steps' optimizer updates bump every version, so every pack / transpose kernel is recorded
+on parameter versions / that hook: the warm-up steps' optimizer updates make every copy stale, so every pack / transpose kernel is recorded
 too: the step ends with an explicit refresh of every cache behind the optimizer update (one dmd_pack_jobs launch per cache,
 in place), so after a replay the packed copies equal the parameters -- also for readers that never look a copy up again (the
 sampler's captured imagination graphs read the packed buffers directly).

@@ -149,3 +149,27 @@ def test_looked_up_copies_outside_the_job_table_are_rebuilt_in_place_too():
     # a view of the parameter itself stays a view (nothing to copy, the pointer follows the parameter)
     v = cache.f32(w)
     assert v.data_ptr() == w.data_ptr()
+
+
+def test_a_fused_optimizer_step_is_seen_although_it_bumps_no_version():
+    """torch's fused optimizers (`AdamW(fused=True)`: one multi-tensor kernel, what GraphedTrainStep's bench line uses) update the
+    parameters without touching `Tensor._version`; engine's optimizer post-step hook must mark the copies stale."""
+    from diamond_amd import engine as E, native as nv
+    from diamond_amd.blocks import AdaGroupNorm, FilmTable
+
+    torch.manual_seed(3)
+    net = nn.ModuleDict({"conv": nn.Conv2d(64, 64, 3, padding=1), "norm": AdaGroupNorm(64, 256)}).to(DEV)
+    other = nn.Conv2d(64, 64, 3, padding=1).to(DEV)
+    cache, film, cache_other = E.PackCache(), FilmTable(net), E.PackCache()
+    w0, f0 = cache.conv_weight_f16x2(net["conv"]).clone(), film.weights()[0].clone()
+    cache_other.conv_weight(other)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-2, fused=True)
+    for p in net.parameters():
+        p.grad = torch.randn_like(p)
+    epochs = (cache.stale_epoch, film.stale_epoch, cache_other.stale_epoch)
+    opt.step()
+    w1, f1 = cache.conv_weight_f16x2(net["conv"]), film.weights()[0]
+    assert torch.equal(w1, nv.pack_conv_weight_f16x2(net["conv"].weight)) and not torch.equal(w1, w0)
+    assert torch.equal(f1, net["norm"].linear.weight.detach()) and not torch.equal(f1, f0)
+    # a graph owner watching the epochs sees the step; a cache of parameters the optimizer does not hold is left alone
+    assert cache.stale_epoch == epochs[0] + 1 and film.stale_epoch == epochs[1] + 1 and cache_other.stale_epoch == epochs[2]
