@@ -87,8 +87,8 @@ def _gn_silu_bwd(x: Act, spec: NormSpec, da: Tensor, dskip: Optional[Tensor]) ->
     p.dskip = nv.fptr(dskip)
     dx = torch.empty_like(x.t)
     ws = torch.empty(int(nv.lib().dmd_gn_bwd_workspace_bytes(n, h * w, c)), device=da.device, dtype=torch.uint8)
-    dmul = torch.empty(n, c, device=da.device, dtype=torch.float32)
-    dadd = torch.empty(n, c, device=da.device, dtype=torch.float32)
+    dma = torch.empty(2, n, c, device=da.device, dtype=torch.float32)  # [dmul; dadd]: callers that only need the sums over the batch
+    dmul, dadd = dma[0], dma[1]                                        # reduce both with one launch (dmul.sum(0) and dadd.sum(0) = dma.sum(1))
     p.dx, p.workspace, p.dmul, p.dadd = nv.ptr(dx), nv.ptr(ws), nv.ptr(dmul), nv.ptr(dadd)
     nv.check(nv.lib().dmd_gn_silu_bwd(C.byref(p), nv.stream()), "dmd_gn_silu_bwd")
     return dx, dmul, dadd
@@ -238,11 +238,13 @@ class _EncoderFn(torch.autograd.Function):
                 g_skip = [dws, dbs]
             dx, dmul, dadd = _gn_silu_bwd(x, spec, da, dskip)
             # reversed order of [gn.weight, gn.bias, conv.weight, conv.bias, (skip.weight, skip.bias)]
-            grads_rev += list(reversed([dmul.sum(0), dadd.sum(0), dw, db] + g_skip))
+            dms = dmul._base.sum(1)  # (2, C): both batch sums with one reduction (same per-column order as two .sum(0))
+            grads_rev += list(reversed([dms[0], dms[1], dw, db] + g_skip))
             dcur = dx
         ci = plan.conv_in
         dw_in, db_in = _wgrad(ctx.x16, nv.PROLOGUE_NONE, None, dcur, 9, ctx.cimg, split=split)
-        grads = [g * inv_scale for g in [dw_in, db_in] + list(reversed(grads_rev))]
+        # (one multi-tensor launch instead of one broadcast multiplication per gradient: 18 per step, 270 per window)
+        grads = torch._foreach_mul([dw_in, db_in] + list(reversed(grads_rev)), inv_scale)
         return (None, None, None, *grads)
 
 
