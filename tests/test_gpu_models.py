@@ -737,3 +737,61 @@ def test_speculative_policy_step_is_bitwise_the_sequential_one(monkeypatch):
     for wa, wb in zip(*runs):
         for a, b_ in zip(wa, wb):
             assert torch.equal(a, b_)
+
+
+@pytest.mark.parametrize("num_actions", [6, 18])
+def test_other_action_set_sizes_against_the_oracle(num_actions):
+    """Every fixture uses Breakout's 4 actions; the reference takes the size of the game's action set (6, 9, 18 for other Atari
+    games: agent.py:15-25 copies `num_actions` into the three sub-configs).  The shapes it reaches -- the denoiser's and the
+    reward/end model's action embeddings, `actor_linear` (A, 512), the (B, A) categorical draw -- against the oracle (pinned by the
+    reference-generated fixtures at A = 4; the same restatement here) on seeded inputs: network outputs, and for the
+    actor-critic every gradient."""
+    import diamond_amd as D
+    from diamond_amd.env_loop import sample_categorical
+    from diamond_amd.testing import fill_module_, synthetic_actions, synthetic_frames
+    from oracle import diamond_oracle as O
+
+    agent = D.Agent(D.default_agent_config(num_actions=num_actions))
+    fill_module_(agent, WEIGHT_SEED)
+    sd = {k: v.detach().clone() for k, v in agent.state_dict().items()}
+    agent = agent.to(DEV).eval()
+
+    def sub(prefix):
+        return {k[len(prefix) + 1:]: v for k, v in sd.items() if k.startswith(prefix + ".")}
+
+    g = torch.Generator().manual_seed(40 + num_actions)
+    b = 3
+    obs = synthetic_frames(g, b, 4, 3, 64, 64)
+    act = synthetic_actions(g, num_actions, b, 4)
+    assert int(act.max()) >= 4, "the draw must reach actions beyond Breakout's"
+    noise = torch.randn(b, 3, 64, 64, generator=g)
+    # denoiser: one model output at the first sigma of the 3-step schedule
+    sig = O.build_sigmas(O.SamplerSpec())
+    f_ref = O.model_output(sub("denoiser"), O.DenoiserSpec(), noise, sig[0], obs.reshape(b, 12, 64, 64), act)
+    f_hip = agent.denoiser.compute_model_output(noise.to(DEV), obs.reshape(b, 12, 64, 64).to(DEV), act.to(DEV), sig[0])
+    assert rel_err(f_hip, f_ref) < 1e-4
+    # reward / end model over three transitions
+    lr_ref, le_ref, (h_ref, c_ref) = O.rew_end_predict(sub("rew_end_model"), O.RewEndSpec(), obs[:, :-1], act[:, :-1], obs[:, 1:])
+    lr, le, (h, c) = agent.rew_end_model.predict_rew_end(obs[:, :-1].to(DEV), act[:, :-1].to(DEV), obs[:, 1:].to(DEV))
+    for mine, ref in ((lr, lr_ref), (le, le_ref), (h, h_ref), (c, c_ref)):
+        assert tuple(mine.shape) == tuple(ref.shape) and rel_err(mine, ref) < 1e-4
+    # actor-critic: two recurrent steps, loss over logits of width A, every gradient
+    ac_sd = {k: v.clone().requires_grad_(True) for k, v in sub("actor_critic").items()}
+    hx, cx = torch.randn(b, 512, generator=g) * 0.3, torch.randn(b, 512, generator=g) * 0.3
+    w = torch.randn(b, num_actions, generator=g)
+    l1, v1, hc1 = O.ac_predict(ac_sd, O.ActorCriticSpec(), obs[:, 0], hx, cx)
+    l2, v2, hc2 = O.ac_predict(ac_sd, O.ActorCriticSpec(), obs[:, 1], *hc1)
+    ((l2 * w).sum() + v2.square().sum() + v1.sum()).backward()
+    ac = agent.actor_critic
+    ac.zero_grad()
+    o1 = ac.predict_act_value(obs[:, 0].to(DEV), (hx.to(DEV), cx.to(DEV)))
+    o2 = ac.predict_act_value(obs[:, 1].to(DEV), o1.hx_cx)
+    assert tuple(o2.logits_act.shape) == (b, num_actions)
+    ((o2.logits_act * w.to(DEV)).sum() + o2.val.square().sum() + o1.val.sum()).backward()
+    assert rel_err(o2.logits_act.detach(), l2.detach()) < 1e-4 and rel_err(o2.val.detach(), v2.detach()) < 1e-4
+    bad = {k: rel_err(p.grad, ac_sd[k].grad) for k, p in ac.named_parameters() if rel_err(p.grad, ac_sd[k].grad) >= 1e-4}
+    assert not bad, bad
+    # the categorical draw over A classes: argmax(softmax(logits) / E) of the host arithmetic
+    expo = torch.empty(b, num_actions).exponential_(1, generator=g)
+    mine = sample_categorical(o2.logits_act.detach(), expo.to(DEV))
+    assert torch.equal(mine.cpu(), O.categorical_sample(l2.detach(), expo))
