@@ -375,6 +375,7 @@ def rollout_setup(device, rank, img_size, batch, horizon, denoise_steps, order, 
         opt.zero_grad(set_to_none=False)
         return loss
 
+    window.reducer = reducer
     return agent, ac, window
 
 
@@ -441,6 +442,32 @@ def also_lines(device, args):
     return out
 
 
+def _free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n, argv, dry=False):
+    """Re-execute this script under torch.distributed.run with N ranks on this node (127.0.0.1 rendezvous: the container hostname
+    may not resolve).  Returns the launcher's exit code; the children inherit stdout, so rank 0's JSON line is this process's."""
+    import subprocess
+
+    argv = [a for a in argv if a != "--dry-launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    if dry:
+        print(json.dumps({"self_launch": cmd, "env": {k: env[k] for k in ("MASTER_ADDR", "HSA_ENABLE_IPC_MODE_LEGACY", "OMP_NUM_THREADS")},
+                          "nproc_per_node": n}))
+        return 0
+    print(f"[bench] --gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -470,7 +497,17 @@ def main():
                     help="two Heun updates over 256 MiB arrays before the window (tools/pmc_collect.sh: a known byte count for the FETCH_SIZE / "
                          "WRITE_SIZE unit corrections in the same rocprofv3 pass)")
     ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="with --gpus N > 1 and no launcher environment: print the command / environment the self-launch would run "
+                         "(one JSON line) instead of running it")
+    ap.add_argument("--self-launch", action="store_true",
+                    help="take the self-launch route at any N (tests/test_gpu_dist.py runs it at N = 1 on the one-GPU box; the ranks "
+                         "then run the distributed branch as with --force-dist)")
     args = ap.parse_args()
+    if (args.gpus > 1 or args.self_launch) and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher around it: start the N ranks ourselves, one process per GPU, like the
+        # reference's main.py:22-27 (mp.spawn over torch.cuda.device_count()).  Rank 0 of the children prints the JSON line.
+        sys.exit(self_launch(args.gpus, sys.argv[1:], args.dry_launch))
     if args.config in ("latency", "train"):
         assert args.gpus == 1, "--config latency / train are single-GPU measurements"
         torch.cuda.set_device(0)
@@ -495,7 +532,7 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    use_dist = world > 1 or args.force_dist
+    use_dist = world > 1 or args.force_dist or args.self_launch
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -537,6 +574,8 @@ def main():
         window()
     fence()
     progress("warmup done")
+    if use_dist:
+        window.reducer.timing = True
     # per-step stamps WITHOUT synchronising: events on the current stream at the window boundaries, read after the fence
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
@@ -556,11 +595,22 @@ def main():
         gathered = [torch.zeros_like(cs) for _ in range(world)]
         dist.all_gather(gathered, cs)
         replicas_in_sync = all(float(g) == float(gathered[0]) for g in gathered)
+        # self-description of the N > 1 run: what RCCL itself says the world is, every rank's own mean step time, and the device
+        # time of the one gradient all-reduce per step (events around it on this rank)
+        window.reducer.timing = False
+        ar_ms = window.reducer.elapsed_ms()
+        mine = torch.tensor([sum(step_ms) / len(step_ms), sum(ar_ms) / max(1, len(ar_ms))], device=device, dtype=torch.float64)
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+        dist_info = {"rccl_world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                     "per_rank_step_ms": [round(float(t[0]), 2) for t in per_rank],
+                     "allreduce_ms_per_step": [round(float(t[1]), 3) for t in per_rank],
+                     "grad_bucket_mb": window.reducer.bucket.numel() * 4 / 1e6}
         if not replicas_in_sync and rank == 0:
             print(f"[bench] WARNING: replicas diverged: checksums {[float(g) for g in gathered]}", file=sys.stderr, flush=True)
 
     else:
-        replicas_in_sync = None
+        replicas_in_sync, dist_info = None, None
     progress(f"timed region done: {elapsed:.2f}s for {args.steps} steps")
     custom = any(getattr(args, k) != v for k, v in preset.items()) or args.no_end_logit_bias
     custom_flags = custom
@@ -590,7 +640,7 @@ def main():
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (batch-sharded envs, flat-bucket "
                    "RCCL all-reduce of actor-critic grads)", "actor_critic_backend": ac.backend,
                    "world_model_precision": E.WORLD_MODEL_PRECISION, "actor_critic_precision": ac_native.AC_PRECISION,
-                   "replicas_in_sync": replicas_in_sync},
+                   "replicas_in_sync": replicas_in_sync, "distributed": dist_info},
         "whole_step_algorithmic": {"gflop_per_frame": flop_pf / 1e9, "mb_per_frame": bytes_pf / 1e6,
                                    "tflops": fps * flop_pf / 1e12 / world,
                                    "frac_fp32_peak": fps * flop_pf / 1e12 / world / FP32_MFMA_PEAK_TFLOPS,

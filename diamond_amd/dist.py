@@ -24,6 +24,11 @@ class GradAllReducer:
         total = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.bucket = torch.zeros(total, device=ref.device, dtype=ref.dtype)
+        # measurement hook (bench.py): with `timing` on, every all_reduce_mean is bracketed by two events on the current
+        # stream (the collective runs on RCCL's own stream, but a blocking dist.all_reduce makes the current stream wait
+        # for it, so the pair spans it); `elapsed_ms()` reads them after a synchronisation
+        self.timing = False
+        self._events: List = []
         off = 0
         for p in self.params:
             n = p.numel()
@@ -50,10 +55,23 @@ class GradAllReducer:
         # (also at world size 1: the same RCCL call on the same bucket, so that a 1-GPU run of the distributed path
         #  exercises everything an N-GPU run does)
         if dist.is_available() and dist.is_initialized():
+            timed = self.timing and self.bucket.is_cuda
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group)
             if dist.get_world_size(self.group) > 1:
                 self.bucket.div_(dist.get_world_size(self.group))
+            if timed:
+                e1.record()
+                self._events.append((e0, e1))
         return self.bucket
+
+    def elapsed_ms(self) -> List[float]:
+        """Device time of every timed all_reduce_mean since the last call (synchronise first); clears the list."""
+        out = [a.elapsed_time(b) for a, b in self._events]
+        self._events = []
+        return out
 
 
 def broadcast_parameters(module: nn.Module, src: int = 0, group=None) -> None:

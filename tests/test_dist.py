@@ -115,3 +115,28 @@ def test_grad_allreduce_gloo(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert err < 1e-5 and ok
+
+
+def test_bench_self_launch_command():
+    """`python bench.py --gpus N` without WORLD_SIZE in the environment must start its own N ranks (it used to assert): the
+    command it would run, and that `--gpus 1` does not take that route."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    cmd = d["self_launch"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "2" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    tail = cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:]
+    assert tail == ["--gpus", "2", "--steps", "2", "--warmup", "1"]  # the ranks get the caller's flags (minus --dry-launch)
+    assert d["env"]["MASTER_ADDR"] == "127.0.0.1" and d["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # under a launcher (WORLD_SIZE set) nothing is re-launched: the rank path is taken (and fails here for want of a GPU, not on an assert
+    # about the launcher)
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                        capture_output=True, text=True, timeout=300)
+    assert "self_launch" not in r2.stdout

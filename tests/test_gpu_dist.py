@@ -42,3 +42,21 @@ def test_bench_distributed_branch_world1():
                       "--horizon", "3", "--no-roofline", "--no-exact-fp32", "--no-cpu-baseline"], 29612)
     assert line["n_gpus"] == 1 and line["value"] > 0
     assert line["config"]["replicas_in_sync"] is True
+
+
+def test_bench_self_launch_world1():
+    """`python bench.py --gpus N` with no launcher around it starts its own ranks (the reference launches itself: main.py:22-27);
+    here the same route at N = 1 (--self-launch), i.e. bench.py -> torch.distributed.run -> one rank on RCCL -> the JSON line on
+    the parent's stdout."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--self-launch", "--steps", "1", "--warmup", "0",
+                        "--batch", "16", "--horizon", "3", "--no-roofline", "--no-exact-fp32", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    d = line["config"]["distributed"]
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["replicas_in_sync"] is True
+    assert d["rccl_world_size"] == 1 and d["backend"] == "nccl" and len(d["per_rank_step_ms"]) == 1
+    assert d["allreduce_ms_per_step"][0] > 0 and d["grad_bucket_mb"] > 10
