@@ -100,7 +100,29 @@ END_LOGIT_BIAS_NOTE = ("end-logits of the synthetic reward/end model are biased 
                        "+ burn in together at the window boundary, no mid-window resets; same kernels and FLOPs per frame")
 
 
-def build_agent(device, img_size, rank, attn_depths=(0, 0, 0, 0), bias_end_logits=True):
+def set_end_rate(agent, p=None):
+    """The synthetic reward/end model's end probability per env-step, through ONE saturated hidden unit of its head (in place: the
+    packed weight copies notice the version bump).  None: the round-1..4 bias (logit difference 20 +- 0.4: nobody ever ends);
+    0 < p < 1: hidden unit 0 is pinned to silu(50) = 50 exactly and the two end logits are -+ log(p / (1 - p)) / 2, i.e. every env
+    ends with probability p at every step, independently of the frame."""
+    import math
+
+    with torch.no_grad():
+        head = agent.rew_end_model.head
+        head[0].bias[0] = 50.0
+        head[2].weight[3].zero_()
+        head[2].weight[4].zero_()
+        if p is None:
+            head[2].weight[3, 0] = 0.2
+            head[2].weight[4, 0] = -0.2
+        else:
+            head[0].weight[0].zero_()
+            d = math.log(p / (1.0 - p))
+            head[2].weight[3, 0] = -d / 100.0
+            head[2].weight[4, 0] = d / 100.0
+
+
+def build_agent(device, img_size, rank, attn_depths=(0, 0, 0, 0), bias_end_logits=True, end_rate=None):
     import diamond_amd as D
     from diamond_amd.testing import fill_module_
 
@@ -108,16 +130,10 @@ def build_agent(device, img_size, rank, attn_depths=(0, 0, 0, 0), bias_end_logit
     fill_module_(agent, 0)
     if not bias_end_logits:
         return agent.to(device)
-    with torch.no_grad():
-        # Synthetic weights would terminate ~half of the imagined episodes at every step; bias
-        # the end logits (through one saturated hidden unit) so episodes end by horizon
-        # truncation like a trained world model's do.  Disclosed in config.workload (END_LOGIT_BIAS_NOTE).
-        head = agent.rew_end_model.head
-        head[0].bias[0] = 50.0
-        head[2].weight[3].zero_()
-        head[2].weight[4].zero_()
-        head[2].weight[3, 0] = 0.2
-        head[2].weight[4, 0] = -0.2
+    # Synthetic weights would terminate ~half of the imagined episodes at every step; bias the end logits (through one
+    # saturated hidden unit) so episodes end by horizon truncation like a trained world model's do -- or at a stated rate.
+    # Disclosed in config.workload (END_LOGIT_BIAS_NOTE).
+    set_end_rate(agent, end_rate)
     return agent.to(device)
 
 
@@ -346,13 +362,13 @@ def train_line(args, eager=True):
             "algorithmic_tflops": 3 * 6.0909e9 * b / dt / 1e12}
 
 
-def rollout_setup(device, rank, img_size, batch, horizon, denoise_steps, order, attn, use_dist=False, bias_end_logits=True):
+def rollout_setup(device, rank, img_size, batch, horizon, denoise_steps, order, attn, use_dist=False, bias_end_logits=True, end_rate=None):
     """Agent + imagination env + optimizer of one configuration; returns (agent, actor_critic, window) with window() = one
     optimiser step of `Trainer.train_component("actor_critic")` (reference trainer.py:363-382)."""
     import diamond_amd as D
     from diamond_amd.dist import GradAllReducer, broadcast_parameters
 
-    agent = build_agent(device, img_size, rank, attn, bias_end_logits)
+    agent = build_agent(device, img_size, rank, attn, bias_end_logits, end_rate)
     if use_dist:
         broadcast_parameters(agent, src=0)  # what the DDP constructor does in the reference (utils.py:106)
     env = D.WorldModelEnv(agent.denoiser, agent.rew_end_model, _Loader(batch, 100 + rank, img_size),
@@ -375,7 +391,7 @@ def rollout_setup(device, rank, img_size, batch, horizon, denoise_steps, order, 
         opt.zero_grad(set_to_none=False)
         return loss
 
-    window.reducer = reducer
+    window.reducer, window.env = reducer, env
     return agent, ac, window
 
 
@@ -390,10 +406,82 @@ def timed_windows(window, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
+def measured_windows(window, steps=3, warmup=2):
+    """(mean seconds per window, [device ms of every timed window]): `warmup` untimed windows first (the first window of a fresh
+    configuration builds caches and is up to 50 % slow), then `steps` windows between two synchronisations, stamped by events."""
+    for _ in range(warmup):
+        window()
+    torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(steps):
+        window()
+        marks[i + 1].record()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return dt, [round(marks[i].elapsed_time(marks[i + 1]), 2) for i in range(steps)]
+
+
+def stagger_episodes(env, horizon):
+    """The steady state of the reference's training loop: every `end` desynchronises its env for good (its truncation then falls
+    mid-window, world_model_env.py:71-72), so after a few thousand steps the episode lengths of a batch are spread over the
+    horizon and B / horizon envs truncate at EVERY step.  Set that state directly: ep_len[r] = r mod horizon."""
+    env.set_episode_lengths(torch.arange(env.num_envs) % horizon)
+
+
+def dominant_kernel_roofline(window, nv, config_idx, world=1, custom=False):
+    """One instrumented window (HIP events around every C-ABI launch) -> the `roofline` object of the dominant kernel."""
+    nv.PROFILER = nv.LaunchProfiler()
+    try:
+        window()
+        summ = nv.PROFILER.summary()
+    finally:
+        nv.PROFILER = None
+    key = max(summ, key=lambda k: summ[k]["ms"])
+    d = summ[key]
+    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    # kernels that run split-fp16 arithmetic (3 f16 MFMAs per algorithmic MAC) are priced against the f16 peak
+    split = (key.startswith("conv_f16ws") or key.startswith("attention_f16x2") or key.startswith("lowres_chain")
+             or ((key.startswith("conv1x1_stream") or key.startswith("conv_mfma")) and key.endswith("true>")))
+    peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+    pmc = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json" if config_idx == 1 else f"pmc_traffic_cfg{config_idx}.json")
+    if os.path.exists(pmc_path) and world == 1 and not custom:
+        pmc = json.load(open(pmc_path)).get(key)  # keyed by the rocprofv3 kernel name (tools/pmc_to_profile.py)
+    total_ms = sum(v["ms"] for v in summ.values())
+    return {
+        "kernel": key, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+        # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB units;
+        # tools/pmc_collect.sh -> tools/pmc_to_profile.py -> profiles/<set>_pmc_traffic.json), next to the algorithmic bytes
+        "traffic": None if pmc is None else pmc["hbm_bytes_per_launch"],
+        "traffic_source": None if pmc is None else f"profiles/{os.path.basename(pmc_path)} [{pmc.get('profile_set')}]: {pmc.get('workload')}",
+        "algorithmic_bytes_per_launch": d["bytes"] / d["launches"], "launches": d["launches"],
+        "avg_launch_ms": d["ms"] / d["launches"], "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
+        "algorithmic_hbm_gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9,
+        "frac_hbm_peak": d["bytes"] / (d["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "note": ("achieved = ALGORITHMIC fp32 FLOPs (2 per MAC) / measured kernel time; peak = dense f16 MFMA. The kernel "
+                 "splits each fp32 operand into two fp16 pieces and issues 3 f16 MFMAs per algorithmic MAC (fp32-class "
+                 "accuracy), so the matrix pipe executes 3x the algorithmic rate: executed_mfma_frac below."
+                 if split else "exact-fp32 kernel: peak = fp32 MFMA/vector peak"),
+        "executed_mfma_frac": (3.0 if split else 1.0) * achieved / peak,
+        # the chip is power-managed: an MFMA-only stream on random operands is held to 1.58 GHz (tools/probe/clock_probe.hip)
+        "power_limited_peak": F16_MFMA_SUSTAINED_TFLOPS if split else None,
+        "executed_frac_of_power_limited_peak": (3.0 * achieved / F16_MFMA_SUSTAINED_TFLOPS) if split else None,
+        "frac_of_fp32_direct_conv_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
+        "kernel_share_of_launch_time": d["ms"] / total_ms,
+        # every C-ABI entry point / kernel instantiation of the window, by measured time (the dominant one is chosen over ALL)
+        "launch_time_ms": {k: round(v["ms"], 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])},
+    }
+
+
 def also_lines(device, args):
     """What the default line carries besides configs[1] (single GPU, after the timed region; none of it is part of `value`):
-    the other BASELINE configs that fit one GPU, the SURVEY §8(f) rows, and configs[1] without the end-logit bias."""
+    configs[1] under the conditions the reference trains in (episodes that end), the other BASELINE configs that fit one GPU and
+    the SURVEY §8(f) rows.  Every window-based line: 2 untimed windows, then 3 timed ones (`step_ms` = each of them)."""
     from types import SimpleNamespace
+
+    from diamond_amd import native as nv
 
     out = {}
     t_all = time.perf_counter()
@@ -405,25 +493,61 @@ def also_lines(device, args):
             out[key] = {"value": None, "error": repr(e)[:300]}
         torch.cuda.empty_cache()
 
+    def env_stats(env, before):
+        return {k: env.stats[k] - before.get(k, 0) for k in env.stats}
+
+    def regimes():
+        """configs[1] with episodes that END (reference world_model_env.py:77-82, env_loop.py:45-56: resets, V(final observation),
+        burn-in inside the window): the synthetic reward/end model ends every env with probability p per step; `lockstep` starts
+        from synchronised episodes (what 3 windows after a fresh start look like), `steady_state` from episode lengths spread over
+        the horizon (what the reference's training loop converges to: B / horizon truncations at every step)."""
+        agent, _, w = rollout_setup(device, 0, 64, 256, 15, 3, 1, (0, 0, 0, 0))
+        env, res = w.env, {}
+        base_dt, base_ms = measured_windows(w, 3, 2)
+        res["no_ends"] = {"value": 256 * 15 / base_dt, "step_ms": base_ms}
+        for name, p, stagger in (("p=0.003", 0.003, False), ("p=0.01", 0.01, False), ("p=0.5", 0.5, False),
+                                 ("steady_state p=0", 1e-9, True), ("steady_state p=0.003", 0.003, True), ("steady_state p=0.01", 0.01, True)):
+            set_end_rate(agent, p)
+            if stagger:
+                stagger_episodes(env, 15)
+            else:
+                env.set_episode_lengths(torch.zeros(256, dtype=torch.long))
+            w()  # (the regime's own warm-up: the running averages of the speculation decision settle)
+            before = dict(env.stats)
+            dt, ms = measured_windows(w, 3, 1)
+            st = env_stats(env, before)
+            res[name] = {"value": 256 * 15 / dt, "step_ms": ms, "vs_no_ends": base_dt / dt,
+                         "steps_with_deaths": st["steps_with_deaths"] / max(1, st["steps"]),
+                         "dead_rows_per_step": (st["planned_rows"] + st["void_rows"]) / max(1, st["steps"]),
+                         "planned_share_of_resets": st["planned_rows"] / max(1, st["planned_rows"] + st["void_rows"]),
+                         "speculated_sampler_steps": st["speculated"] / max(1, st["steps"]), "repairs": st["repairs"]}
+        res["unit"] = "frames/s"
+        res["workload"] = ("configs[1], end probability p per env-step through the synthetic reward/end head, 2 + 1 warm-up and 3 timed "
+                           "windows per line; vs_no_ends = this line / the no-ends line measured by the same agent in the same process")
+        return res
+
     def unbiased():
         # configs[1] with the UNBIASED synthetic reward/end model: ~half of the envs end at every step -> resets + reward/end
         # burn-in (reference world_model_env.py:77-89, env_loop.py:45-56) inside the timed window
         _, _, w = rollout_setup(device, 0, 64, 256, 15, 3, 1, (0, 0, 0, 0), bias_end_logits=False)
-        dt = timed_windows(w, 1, 1)
-        return {"value": 256 * 15 / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt, "steps": 1,
+        dt, ms = measured_windows(w, 3, 2)
+        return {"value": 256 * 15 / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt, "steps": 3, "warmup": 2, "step_ms": ms,
                 "workload": "configs[1] without the end-logit bias: mid-window resets and burn-in passes in the timed window"}
 
-    def config(idx, steps):
+    def config(idx, steps, warmup, roofline=False):
         c = CONFIGS[idx]
         attn = tuple(int(v) for v in c["attn_depths"].split(","))
         _, _, w = rollout_setup(device, 0, c["img_size"], c["batch"], c["horizon"], c["denoise_steps"], c["order"], attn)
-        dt = timed_windows(w, steps, 1)
+        dt, ms = measured_windows(w, steps, warmup)
         flop_pf, _, _ = algorithmic_work(c["img_size"], c["denoise_steps"], c["order"], attn)
         fps = c["batch"] * c["horizon"] / dt
-        return {"value": fps, "unit": "frames/s", "ms_per_step": 1e3 * dt, "steps": steps, "warmup": 1, "global_batch": c["batch"],
-                "algorithmic_tflops": fps * flop_pf / 1e12,
-                "workload": f"{c['img_size']}x{c['img_size']}, batch {c['batch']}, {c['denoise_steps']} denoise steps order {c['order']}, "
-                            f"attention {c['attn_depths']}"}
+        res = {"value": fps, "unit": "frames/s", "ms_per_step": 1e3 * dt, "steps": steps, "warmup": warmup, "step_ms": ms,
+               "global_batch": c["batch"], "algorithmic_tflops": fps * flop_pf / 1e12,
+               "workload": f"{c['img_size']}x{c['img_size']}, batch {c['batch']}, {c['denoise_steps']} denoise steps order {c['order']}, "
+                           f"attention {c['attn_depths']}"}
+        if roofline:
+            res["roofline"] = dominant_kernel_roofline(w, nv, idx)
+        return res
 
     def latency():
         lat = latency_line(SimpleNamespace(steps=200, warmup=12), eager=False)
@@ -433,9 +557,10 @@ def also_lines(device, args):
         tr = train_line(SimpleNamespace(batch=32, steps=20, warmup=3), eager=False)
         return dict({k: tr[k] for k in ("value", "unit", "steps", "frames_per_s", "loss")}, workload=tr["config"]["workload"] + ", batch 32")
 
+    guarded("end_rate", regimes)
     guarded("unbiased_end_logits", unbiased)
-    guarded("configs[3]", lambda: config(3, 1))
-    guarded("configs[4]", lambda: config(4, 2))
+    guarded("configs[3]", lambda: config(3, 3, 1))
+    guarded("configs[4]", lambda: config(4, 3, 2, roofline=True))
     guarded("latency", latency)
     guarded("train", train)
     out["seconds"] = time.perf_counter() - t_all
@@ -491,6 +616,11 @@ def main():
     ap.add_argument("--no-exact-fp32", action="store_true")
     ap.add_argument("--no-end-logit-bias", action="store_true",
                     help="the synthetic reward/end model unbiased: ~half of the envs end at every step (mid-window resets + burn-in in the timed region)")
+    ap.add_argument("--end-rate", type=float, default=None,
+                    help="every env ends with this probability per step (through the synthetic reward/end head): mid-window resets at a stated rate")
+    ap.add_argument("--stagger", action="store_true",
+                    help="start the timed windows from episode lengths spread over the horizon (the steady state of the reference's "
+                         "training loop: batch / horizon truncations at every step)")
     ap.add_argument("--foreach-adamw", action="store_true", help="--config train: the capturable FOREACH AdamW instead of the fused one (A/B)")
     ap.add_argument("--no-also", action="store_true", help="skip the extra measurements the default configs[1] line carries (`also`)")
     ap.add_argument("--pmc-calibrate", action="store_true",
@@ -557,7 +687,7 @@ def main():
     torch.manual_seed(1234 + rank)
     attn = tuple(int(v) for v in args.attn_depths.split(","))
     agent, ac, window = rollout_setup(device, rank, args.img_size, args.batch, args.horizon, args.denoise_steps, args.order, attn, use_dist,
-                                      bias_end_logits=not args.no_end_logit_bias)
+                                      bias_end_logits=not args.no_end_logit_bias, end_rate=args.end_rate)
 
     def fence():
         torch.cuda.synchronize()
@@ -570,8 +700,10 @@ def main():
             print(f"[bench +{time.perf_counter() - t_start:.1f}s] {msg}", file=sys.stderr, flush=True)
 
     progress("setup done")
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         window()
+        if args.stagger and i == 0:
+            stagger_episodes(window.env, args.horizon)
     fence()
     progress("warmup done")
     if use_dist:
@@ -612,7 +744,7 @@ def main():
     else:
         replicas_in_sync, dist_info = None, None
     progress(f"timed region done: {elapsed:.2f}s for {args.steps} steps")
-    custom = any(getattr(args, k) != v for k, v in preset.items()) or args.no_end_logit_bias
+    custom = any(getattr(args, k) != v for k, v in preset.items()) or args.no_end_logit_bias or args.end_rate is not None or args.stagger
     custom_flags = custom
     cfg_idx = args.config if world == 1 or args.config != 1 else 2
     cfg_name = f"configs[{cfg_idx}]" + (" (modified by flags)" if custom else "") + \
@@ -636,7 +768,10 @@ def main():
                                f"{', denoiser attention at levels ' + args.attn_depths if any(attn) else ''}; step = "
                                f"ActorCritic.forward()+backward+all-reduce+clip+AdamW over one {args.horizon}-step imagined window; "
                                + ("UNBIASED synthetic end-logits: mid-window resets and burn-in inside the timed region" if args.no_end_logit_bias
-                                  else END_LOGIT_BIAS_NOTE),
+                                  else f"every env ends with probability {args.end_rate} per step (synthetic reward/end head)" if args.end_rate is not None
+                                  else END_LOGIT_BIAS_NOTE)
+                               + ("; episode lengths staggered over the horizon" if args.stagger else ""),
+                   "env_stats": dict(window.env.stats),
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (batch-sharded envs, flat-bucket "
                    "RCCL all-reduce of actor-critic grads)", "actor_critic_backend": ac.backend,
                    "world_model_precision": E.WORLD_MODEL_PRECISION, "actor_critic_precision": ac_native.AC_PRECISION,
@@ -645,52 +780,18 @@ def main():
                                    "tflops": fps * flop_pf / 1e12 / world,
                                    "frac_fp32_peak": fps * flop_pf / 1e12 / world / FP32_MFMA_PEAK_TFLOPS,
                                    "hbm_gbs": fps * bytes_pf / 1e9 / world,
-                                   "frac_hbm_peak": fps * bytes_pf / 1e9 / world / HBM_PEAK_GBS},
+                                   "frac_hbm_peak": fps * bytes_pf / 1e9 / world / HBM_PEAK_GBS,
+                                   "note": "north_star asks for >= 10k frames/s at >= 50 % of the HBM roofline; the path's arithmetic intensity is "
+                                           "118 FLOP/B (SURVEY 8d), so 50 % of 8 TB/s would be 23.7k frames/s = 452 TFLOP/s of fp32 convolution, "
+                                           "2.9x the exact-fp32 peak: the two targets are not self-consistent; the path is matrix-pipe / power "
+                                           "bound (roofline), its HBM share is what these FLOPs need"},
     }
 
     if not args.no_roofline:
         # instrumented window (not part of `value`): HIP events around EVERY C-ABI launch (convolutions, attention, linears,
         # fused low-resolution levels, pointwise) on the stream they are launched on; the env replays no captured graph
         # while a profiler is installed (a replay would hide its kernels from the events)
-        nv.PROFILER = nv.LaunchProfiler()
-        window()
-        summ = nv.PROFILER.summary()
-        nv.PROFILER = None
-        key = max(summ, key=lambda k: summ[k]["ms"])
-        d = summ[key]
-        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        # kernels that run split-fp16 arithmetic (3 f16 MFMAs per algorithmic MAC) are priced against the f16 peak
-        split = (key.startswith("conv_f16ws") or key.startswith("attention_f16x2") or key.startswith("lowres_chain")
-                 or ((key.startswith("conv1x1_stream") or key.startswith("conv_mfma")) and key.endswith("true>")))
-        peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
-        pmc, pmc_set = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json" if args.config == 1 else f"pmc_traffic_cfg{args.config}.json")
-        if os.path.exists(pmc_path) and world == 1 and not custom_flags:
-            pmc = json.load(open(pmc_path)).get(key)  # keyed by the rocprofv3 kernel name (tools/pmc_to_profile.py)
-        total_ms = sum(v["ms"] for v in summ.values())
-        line["roofline"] = {
-            "kernel": key, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB units;
-            # tools/pmc_collect.sh -> tools/pmc_to_profile.py -> profiles/<set>_pmc_traffic.json), next to the algorithmic bytes
-            "traffic": None if pmc is None else pmc["hbm_bytes_per_launch"],
-            "traffic_source": None if pmc is None else f"profiles/{os.path.basename(pmc_path)} [{pmc.get('profile_set')}]: {pmc.get('workload')}",
-            "algorithmic_bytes_per_launch": d["bytes"] / d["launches"], "launches": d["launches"],
-            "avg_launch_ms": d["ms"] / d["launches"], "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
-            "algorithmic_hbm_gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9,
-            "frac_hbm_peak": d["bytes"] / (d["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "note": ("achieved = ALGORITHMIC fp32 FLOPs (2 per MAC) / measured kernel time; peak = dense f16 MFMA. The kernel "
-                     "splits each fp32 operand into two fp16 pieces and issues 3 f16 MFMAs per algorithmic MAC (fp32-class "
-                     "accuracy), so the matrix pipe executes 3x the algorithmic rate: executed_mfma_frac below."
-                     if split else "exact-fp32 kernel: peak = fp32 MFMA/vector peak"),
-            "executed_mfma_frac": (3.0 if split else 1.0) * achieved / peak,
-            # the chip is power-managed: an MFMA-only stream on random operands is held to 1.58 GHz (tools/probe/clock_probe.hip)
-            "power_limited_peak": F16_MFMA_SUSTAINED_TFLOPS if split else None,
-            "executed_frac_of_power_limited_peak": (3.0 * achieved / F16_MFMA_SUSTAINED_TFLOPS) if split else None,
-            "frac_of_fp32_direct_conv_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
-            "kernel_share_of_launch_time": d["ms"] / total_ms,
-            # every C-ABI entry point / kernel instantiation of the window, by measured time (the dominant one is chosen over ALL)
-            "launch_time_ms": {k: round(v["ms"], 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])},
-        }
+        line["roofline"] = dominant_kernel_roofline(window, nv, args.config, world, custom_flags)
         progress("roofline window done")
 
     if args.config == 1 and not args.no_exact_fp32 and not custom:

@@ -1,5 +1,6 @@
 // Shared helpers for libdiamond_hip (gfx950 only).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -23,18 +24,21 @@ void dmd_set_error(const char* fmt, ...);
 // An integer switch from the environment, read ONCE (and again after dmd_reload_env(), the tests' hook): the launchers do
 // not call getenv per launch.     static DmdEnvInt cap{"DIAMOND_WGRAD_MAX_WG", 256};  ...  cap.get()
 int dmd_env_generation();
+// (launchers may be called from several host threads: generation and value travel together in one atomic word)
 struct DmdEnvInt {
   const char* name;
   int def;
-  int gen = -1, val = 0;
+  std::atomic<long long> gen_val{-1};  // (generation << 32) | (unsigned) value; -1: never read
   int get() {
     const int g = dmd_env_generation();
-    if (g != gen) {
+    long long gv = gen_val.load(std::memory_order_acquire);
+    if (gv < 0 || (int)(gv >> 32) != g) {
       const char* e = getenv(name);
-      val = e ? atoi(e) : def;
-      gen = g;
+      const int v = e ? atoi(e) : def;
+      gv = ((long long)g << 32) | (unsigned int)v;
+      gen_val.store(gv, std::memory_order_release);
     }
-    return val;
+    return (int)(unsigned int)(gv & 0xffffffffll);
   }
 };
 

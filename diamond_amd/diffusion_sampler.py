@@ -100,6 +100,11 @@ class DiffusionSampler:
             if len(self._graphs) > 64:
                 self._graphs.clear()
             cap = _CapturedSample(self, ctx_obs, ctx_act, obs_head, act_head)
+            # the capture's warm-up may have CREATED caches (the lazy FilmTable, packed copies on a new device): they belong in
+            # the lists `versions` and `stamp` are derived from, from this call on
+            self._stamp_params = list(self.denoiser.parameters())
+            self._stamp_caches = list(_weight_caches(self.denoiser))
+            self._graph_versions = (tuple((p._version, p.data_ptr()) for p in self._stamp_params), sum(c.stale_epoch for c in self._stamp_caches))
             if stamp() != self._graph_stamp:  # the warm-up replaced a buffer (e.g. copies built on another device before)
                 self._graphs.clear()
                 self._graph_stamp = stamp()

@@ -188,6 +188,8 @@ class PackCache:
                 and old.shape == new.shape and old.dtype == new.dtype and old.device == new.device and old.is_contiguous():
             old.copy_(new)  # same buffer: whoever holds its pointer (a captured graph, a device-side table) sees the update
             new = old
+        elif isinstance(old, Tensor) and isinstance(new, Tensor) and old.data_ptr() == new.data_ptr():
+            pass  # a "copy" that IS the parameter's storage (f32() of a contiguous fp32 parameter): nothing was replaced
         elif hit is not None:
             self.frees_epoch += 1
         hit = (_stamp(p), weakref.ref(p), new, fn)

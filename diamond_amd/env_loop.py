@@ -42,9 +42,141 @@ def sample_categorical(logits: Tensor, expo: Optional[Tensor] = None) -> Tensor:
     return out.reshape(shape)
 
 
+PIPELINE_PROTOCOL = ("step_begin", "step_begin_repair", "step_end_issue", "step_end_finish", "may_speculate", "plan_resets")
+
+
+def _reset_chain(model, final_obs: Tensor, burnin: Tensor, new_obs: Optional[Tensor], h_d: Tensor, c_d: Tensor):
+    """What a reset asks of the policy, for the k rows it concerns (reference env_loop.py:45-56 + the next step's :31):
+    V(final observation) without grad on the state the episode ended with; the burn-in of the LSTM over the new episode's context
+    frames WITH grad from a zero state; and -- if `new_obs` is given -- the policy's step on the new episode's newest frame.
+    The encoder does not see the LSTM state, so all (1 + T-1 + 1) k frames go through it in ONE pass (`encode` +
+    `predict_from_features`); per sample the arithmetic is that of separate calls (batch-invariant kernels).
+    Returns (val_final, (h, c) after the burn-in, None | (logits, val, (h, c)) of the step on new_obs)."""
+    k, tb = burnin.shape[:2]
+    if hasattr(model, "predict_from_features"):
+        parts = [final_obs, burnin.transpose(0, 1).reshape(k * tb, *burnin.shape[2:])] + ([new_obs] if new_obs is not None else [])
+        feats = model.encode(torch.cat(parts))
+        with torch.no_grad():
+            _, val_final, _ = model.predict_from_features(feats[:k], (h_d, c_d))
+        hz, cz = torch.zeros_like(h_d), torch.zeros_like(c_d)  # (the gated state of a dead row)
+        for i in range(tb):
+            _, _, (hz, cz) = model.predict_from_features(feats[(1 + i) * k:(2 + i) * k], (hz, cz))
+        step = model.predict_from_features(feats[(1 + tb) * k:], (hz, cz)) if new_obs is not None else None
+    else:
+        with torch.no_grad():
+            _, val_final, _ = model.predict_act_value(final_obs, (h_d, c_d))
+        hz, cz = torch.zeros_like(h_d), torch.zeros_like(c_d)
+        for i in range(tb):
+            _, _, (hz, cz) = model.predict_act_value(burnin[:, i], (hz, cz))
+        step = model.predict_act_value(new_obs, (hz, cz)) if new_obs is not None else None
+    return val_final, (hz, cz), step
+
+
+def _pipelined_env_loop(env, model, expo_fn: Optional[Callable[[Tensor], Tensor]], num_steps: int):
+    """make_env_loop for an env that implements WorldModelEnv's pipelining protocol (PIPELINE_PROTOCOL), epsilon = 0.
+
+    Per imagined step the reference has ONE data-dependent branch (`if dead.any()`, world_model_env.py:77, env_loop.py:45): a
+    host wait for the device.  Here the work of step n + 1 is issued BEFORE the wait of step n:
+      * the policy's step n + 1 on the imagined frame (between env.step_begin and env.step_end_issue);
+      * the sampler's step n + 1 (env.step_begin(..., speculative=True) between step_end_issue and step_end_finish), when the
+        env says it pays (may_speculate);
+      * resets the host can foresee -- truncations: env.plan_resets() -- are part of that pipeline: V(final observation), the
+        burn-in and the policy's step on the new episodes are computed for those rows ahead of the wait, the env resets them
+        right behind the reward / end model, and the speculative sampler step already runs on the new episodes.
+    Deaths nobody planned (`end` sampled by the reward / end model) void ONLY their own rows (info["void_rows"]): the policy is
+    recomputed for them after the reset with the exponential draws the speculation made, the env repeats their sampler step
+    (step_begin_repair), and every other row keeps its speculated result -- per row the same arithmetic in the same order on
+    batch-invariant kernels, every random stream consumed in the reference's order: bitwise the sequential rollout
+    (tests/test_env_loop_host.py on a toy env; the window goldens and the sequential A/B on the GPU)."""
+    dev = model.device
+    hx = torch.zeros(env.num_envs, model.lstm_dim, device=dev)
+    cx = torch.zeros(env.num_envs, model.lstm_dim, device=dev)
+    seed = random.randint(0, 2 ** 31 - 1)
+    obs, _ = env.reset(seed=[seed + i for i in range(env.num_envs)])
+
+    def draw_expo(logits: Tensor) -> Tensor:
+        e = expo_fn(logits) if expo_fn is not None else None
+        return e if e is not None else torch.empty(logits.shape, device=logits.device, dtype=torch.float32).exponential_(1)
+
+    def merge(cand, rows: Tensor, step, expo: Tensor):
+        """rows of the candidate policy output <- the step recomputed for them after their reset (their own exponential draws)"""
+        logits, val, (h, c) = step
+        act = sample_categorical(logits, expo.index_select(0, rows))
+        return [cand[0].index_copy(0, rows, logits), cand[1].index_copy(0, rows, val),
+                (cand[2][0].index_copy(0, rows, h), cand[2][1].index_copy(0, rows, c)), cand[3].index_copy(0, rows, act)]
+
+    while True:
+        hx, cx = hx.detach(), cx.detach()  # BPTT window boundary
+        rows_out, infos = [], []
+        pol = None    # (logits, val, (hx, cx), act) of this step when it was issued during the previous one
+        begun = None  # the imagined frame of this step when env.step_begin was issued during the previous one
+        prev_dead = prev_vfinal = None
+        for n in range(num_steps):
+            if pol is None:
+                logits_act, val, (hx, cx) = model.predict_act_value(obs, (hx, cx))
+                act = sample_categorical(logits_act, draw_expo(logits_act))
+            else:
+                logits_act, val, (hx, cx), act = pol
+                pol = None
+            if n > 0:  # the bootstrap value of step n-1 is this step's value, V(final observation) where the episode ended (:39-43)
+                vb = val.detach().clone()
+                rows_out[-1][-1] = vb if prev_dead is None else torch.where(prev_dead, prev_vfinal, vb)
+            nxt = begun if begun is not None else env.step_begin(act)
+            begun = None
+            cand = s_expo = vfinal = None
+            if n + 1 < num_steps:
+                plan = env.plan_resets()
+                cand = list(model.predict_act_value(nxt, (hx, cx)))
+                s_expo = draw_expo(cand[0])
+                cand.append(sample_categorical(cand[0], s_expo))
+                if plan is not None:
+                    r = plan["rows"]
+                    v, _, step = _reset_chain(model, nxt.index_select(0, r), plan["burnin_obs"], plan["obs"], hx.index_select(0, r), cx.index_select(0, r))
+                    cand = merge(cand, r, step, s_expo)
+                    vfinal = torch.zeros_like(val.detach()).index_copy(0, r, v)
+            env.step_end_issue()
+            if cand is not None and env.may_speculate():
+                begun = env.step_begin(cand[3], speculative=True)
+            next_obs, rew, end, trunc, info = env.step_end_finish()
+
+            prev_dead = prev_vfinal = None
+            if info["any_dead"]:
+                prev_dead = torch.logical_or(end, trunc)
+                ridx, void = info["dead_rows"], info.get("void_rows")
+                if void is not None:  # deaths no plan covered: their part of the reset chain now, on the rows concerned only
+                    pos = info.get("void_pos")
+                    fin, burn = info["final_observation"], info["burnin_obs"]
+                    if pos is not None:
+                        fin, burn = fin.index_select(0, pos), burn.index_select(0, pos)
+                    new_obs = next_obs.index_select(0, void) if cand is not None else None
+                    v, (hz, cz), step = _reset_chain(model, fin, burn, new_obs, hx.index_select(0, void), cx.index_select(0, void))
+                    vfinal = (torch.zeros_like(val.detach()) if vfinal is None else vfinal).index_copy(0, void, v)
+                    if cand is not None:
+                        cand = merge(cand, void, step, s_expo)
+                        if info.get("repair_pending"):
+                            begun = env.step_begin_repair(cand[3])
+                    else:  # last step of the window: the state the next window starts from
+                        gate = 1 - prev_dead.float().unsqueeze(1)
+                        hx, cx = (hx * gate).index_copy(0, void, hz), (cx * gate).index_copy(0, void, cz)
+                prev_vfinal = vfinal
+            pol = cand
+            rows_out.append([obs, act, rew, end, trunc, logits_act, val, None])
+            infos.append(info)
+            obs = next_obs
+
+        with torch.no_grad():
+            _, vb, _ = model.predict_act_value(obs, (hx, cx))
+        rows_out[-1][-1] = vb if prev_dead is None else torch.where(prev_dead, prev_vfinal, vb)
+        stacked = tuple(torch.stack(col, dim=1) for col in zip(*rows_out))
+        num_steps = yield (*stacked, infos)
+
+
 @coroutine
 def make_env_loop(env, model, epsilon: float = 0.0, expo_fn: Optional[Callable[[Tensor], Tensor]] = None):
     num_steps = yield
+    if epsilon == 0.0 and os.environ.get("DIAMOND_SPECULATIVE_POLICY", "1") == "1" and all(hasattr(env, a) for a in PIPELINE_PROTOCOL):
+        yield from _pipelined_env_loop(env, model, expo_fn, num_steps)
+        return
     dev = model.device
     hx = torch.zeros(env.num_envs, model.lstm_dim, device=dev)
     cx = torch.zeros(env.num_envs, model.lstm_dim, device=dev)

@@ -23,12 +23,43 @@ import os
 from dataclasses import dataclass
 from typing import Any, Callable, Dict, Iterator, List, Optional, Tuple
 
+import numpy as np
 import torch
 from torch import Tensor
 
 from . import native as nv
 from .diffusion_sampler import DiffusionSampler, DiffusionSamplerConfig
 from .env_loop import sample_categorical
+
+
+class _no_random_draws:
+    """Guard of the invariant the pipelined env loop relies on: a reset (pool preload included) draws from NO torch generator,
+    so planning / repeating / reordering resets cannot change the order in which the random streams are consumed.  With
+    DIAMOND_CHECK_RESET_RNG=1 (the test suites set it) the CPU and the device generator states are compared around the guarded
+    block -- a loader or pool that draws from them fails loudly instead of silently reordering the streams."""
+
+    def __init__(self, dev: torch.device, what: str, cpu: bool = True) -> None:
+        # cpu=False: only the device generator is watched (a DataLoader seeds its workers from the CPU default generator; that
+        # is harmless where the env's own draws come from the device generator, i.e. everywhere but in the hook-driven tests)
+        self.dev, self.what, self.cpu = dev, what, cpu or dev.type != "cuda"
+        self.on = os.environ.get("DIAMOND_CHECK_RESET_RNG") == "1"
+
+    def _state(self):
+        st = [torch.get_rng_state()] if self.cpu else []
+        if self.dev.type == "cuda":
+            st.append(torch.cuda.get_rng_state(self.dev))
+        return st
+
+    def __enter__(self):
+        if self.on:
+            self.before = self._state()
+
+    def __exit__(self, *exc):
+        if self.on and exc[0] is None:
+            assert all(torch.equal(a, b) for a, b in zip(self.before, self._state())), \
+                f"{self.what} drew from a torch random generator: the env loop's pipelining (env_loop.py) requires resets to be RNG-free " \
+                "(DIAMOND_SPECULATIVE_POLICY=0 runs the sequential order)"
+        return False
 
 
 GRAPH_SAMPLER_MAX_ENVS = 8  # below this the sampler is launch-latency-bound and runs as a replayed hipGraph
@@ -62,6 +93,8 @@ class InitialConditionPool:
         self.hx: Optional[Tensor] = None          # (P, lstm_dim)
         self.cx: Optional[Tensor] = None
         self._cursor = 0
+        self._watch_cpu_rng = False  # (WorldModelEnv sets it while draws are injected from the CPU generator: tests)
+        self._generation = 0  # counts preload rounds (a peeked plan is void once the pool it pointed into was replaced)
 
     @property
     def size(self) -> int:
@@ -75,7 +108,8 @@ class InitialConditionPool:
         q_, f_, act_, hx_, cx_ = [], [], [], [], []
         off_grid = torch.zeros(1, dtype=torch.int32, device=dev)
         for _ in range(self._num_batches):
-            batch = next(self._iter)
+            with _no_random_draws(dev, "the initial-condition loader", cpu=self._watch_cpu_rng):
+                batch = next(self._iter)
             obs = batch.obs.to(dev, non_blocking=True).float().contiguous()  # async when the loader pins its batches
             act = batch.act.to(dev, non_blocking=True)
             *_, (hx, cx) = self._model.predict_rew_end(obs[:, :-1], act[:, :-1], obs[:, 1:])
@@ -100,18 +134,36 @@ class InitialConditionPool:
             self.frames_u8, self.frames_f32 = None, torch.cat(f_)
         self.act, self.hx, self.cx = torch.cat(act_), torch.cat(hx_), torch.cat(cx_)
         self._cursor = 0
+        self._generation += 1
 
-    def take(self, count: int) -> Tensor:
-        """Device index vector of the next `count` pool rows (preloading when the pool runs short)."""
+    def peek(self, count: int) -> Tuple[Tensor, Tuple[int, int]]:
+        """Device index vector of the next `count` pool rows WITHOUT serving them (preloading when the pool runs short, exactly
+        as `take` would for this count), and a token (pool generation, cursor) for `commit` / `still_valid`.  A planned reset
+        (WorldModelEnv.plan_resets) peeks; the rows are served once the host has confirmed the plan."""
         if self.size == 0:
             self._preload()
         while self._cursor + count > self.size:
             assert count <= self._num_batches * self._loader.batch_sampler.batch_size, \
                 "more simultaneous resets than one preload round holds"
             self._preload()
-        idx = torch.arange(self._cursor, self._cursor + count, device=self.act.device)
+        return torch.arange(self._cursor, self._cursor + count, device=self.act.device), (self._generation, self._cursor)
+
+    def commit(self, token: Tuple[int, int], count: int) -> None:
+        assert token == (self._generation, self._cursor), "pool rows were served between peek and commit"
         self._cursor += count
+
+    def take(self, count: int) -> Tensor:
+        """Device index vector of the next `count` pool rows (preloading when the pool runs short)."""
+        idx, token = self.peek(count)
+        self.commit(token, count)
         return idx
+
+    def gather_frames(self, idx: Tensor) -> Tensor:
+        """(len(idx), T, C, H, W) fp32 copies of pool rows in logical order."""
+        src = self.frames_u8 if self.frames_u8 is not None else self.frames_f32
+        out = torch.empty((idx.numel(),) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+        self.scatter_frames(idx, None, out, 0)
+        return out
 
     def scatter_frames(self, idx: Tensor, rows: Optional[Tensor], ring: Tensor, head: int) -> None:
         """ring[rows[i]] <- pool frames idx[i] in logical order (slot (head + t) % T); rows None = all rows."""
@@ -124,6 +176,13 @@ class InitialConditionPool:
             cols = (head + torch.arange(t, device=ring.device)) % t
             r = rows if rows is not None else torch.arange(b, device=ring.device)
             ring[r[:, None], cols[None, :]] = self.frames_f32[idx]
+
+
+# Sampler speculation (env_loop issues step n + 1's sampler before step n's host synchronisation): what an UNPLANNED death costs
+# with it -- the void rows' sampler step again on a small batch, latency-bound (~3 ms) plus their share of a full step (~19 ms
+# at batch 256) -- against the hole the device sits through without it (~2 ms per step while the host issues the first launches
+# of the sampler).  may_speculate() compares running averages of both; DIAMOND_SPEC_SAMPLER=0/1 pins the answer (A/B).
+SPEC_REPAIR_MS, SPEC_FULL_STEP_MS, SPEC_HOLE_MS = 3.0, 19.0, 2.0
 
 
 class WorldModelEnv:
@@ -146,19 +205,20 @@ class WorldModelEnv:
         self._head = 0                      # physical slot of logical step 0 (both rings advance together)
         # test hook: injected exponential draws for the reward / end samples (host RNG parity)
         self.expo_fn: Optional[Callable[[Tensor], Tensor]] = None
-        # speculative step_begin (env_loop issues step n + 1's sampler before step n's host synchronisation, see
-        # step_end_issue): the draws of a dropped speculation, re-used by its repetition; how long not to speculate after a
-        # step in which an episode ended (doubles with every wasted speculation, back to 4 after 16 that were used)
-        self._flag_host: Optional[Tensor] = None
+        self._dead_host: Optional[Tensor] = None  # pinned (B,) copy of a step's `dead` mask: THE host synchronisation of a step
         self._flag_event = None
+        self._rows_pinned: Optional[Tensor] = None
+        self._ep_len_host: Optional[np.ndarray] = None  # host mirror of ep_len (truncations are predictable: plan_resets)
         self._reset_speculation()
 
     def _reset_speculation(self) -> None:
         self._pending = None
         self._pending_speculative = False
-        self._saved_draws: Optional[Tuple[Optional[Tensor], Tensor, Tensor]] = None
         self._issued = None
-        self._spec_cooldown, self._spec_penalty, self._spec_streak = 0, 4, 0
+        self._plan: Optional[Dict[str, Any]] = None       # a planned reset (predicted truncations of the current step)
+        self._repair_rows: Optional[Tensor] = None        # rows of the pending speculative half-step an unplanned death voided
+        self._void_events, self._void_frac = 0.0, 0.0     # running averages: steps with unplanned deaths, their share of the rows
+        self.stats = {"steps": 0, "steps_with_deaths": 0, "planned_rows": 0, "void_rows": 0, "repairs": 0, "speculated": 0}
 
     @property
     def device(self) -> torch.device:
@@ -183,6 +243,28 @@ class WorldModelEnv:
     def act_buffer(self) -> Tensor:
         return self._act[:, self._cols()]
 
+    def _rows_to_device(self, rows_host) -> Tensor:
+        """Host row list -> device index vector through a pinned staging buffer (no synchronisation)."""
+        k = len(rows_host)
+        dev = self._ctx.device
+        if dev.type != "cuda":
+            return torch.as_tensor(np.asarray(rows_host, dtype=np.int64), device=dev)
+        # (a fresh pinned buffer per call would synchronise in the allocator; the staging buffer is reused only after the copy
+        #  that read it was issued on the same stream as everything else, and H2D copies from pinned memory read at execution
+        #  time: so each call gets its own slice of a ring of slices)
+        if self._rows_pinned is None:
+            self._rows_pinned = torch.empty(64, self.num_envs, dtype=torch.int64).pin_memory()
+            self._rows_slot = 0
+        self._rows_slot = (self._rows_slot + 1) % self._rows_pinned.shape[0]
+        buf = self._rows_pinned[self._rows_slot]
+        buf[:k] = torch.as_tensor(np.asarray(rows_host, dtype=np.int64))
+        return buf[:k].to(dev, non_blocking=True)
+
+    def set_episode_lengths(self, ep_len: Tensor) -> None:
+        """Overwrite ep_len (device counter AND the host mirror the planned resets are derived from)."""
+        self.ep_len = ep_len.to(device=self._ctx.device, dtype=torch.long).clone()
+        self._ep_len_host = self.ep_len.cpu().numpy().copy()
+
     # -- gym-style API ---------------------------------------------------------------------------
     @torch.no_grad()
     def reset(self, **kwargs) -> Tuple[Tensor, Dict[str, Any]]:
@@ -201,26 +283,47 @@ class WorldModelEnv:
         self.hx_rew_end = self.pool.hx[idx].unsqueeze(0).clone()
         self.cx_rew_end = self.pool.cx[idx].unsqueeze(0).clone()
         self.ep_len = torch.zeros(self.num_envs, dtype=torch.long, device=dev)
+        self._ep_len_host = np.zeros(self.num_envs, dtype=np.int64)
         return self._ctx[:, self._slot(-1)].clone(), {}  # a copy: ring slots are overwritten T steps later
 
     @torch.no_grad()
+    def _reset_rows(self, rows: Tensor, idx: Tensor) -> None:
+        """Context / action ring / reward-end LSTM state / episode length of `rows` <- pool rows `idx` (reference reset_dead,
+        world_model_env.py:56-62).  INVARIANT (env_loop's speculation relies on it): no draw from torch's random generators
+        happens here or in the pool's preload -- a reset consumes no random stream."""
+        with _no_random_draws(self._ctx.device, "WorldModelEnv._reset_rows"):
+            self.pool.scatter_frames(idx, rows, self._ctx, self._head)
+            self._act[rows[:, None], self._cols()[None, :]] = self.pool.act[idx]
+            self.hx_rew_end[0, rows] = self.pool.hx[idx]
+            self.cx_rew_end[0, rows] = self.pool.cx[idx]
+            self.ep_len[rows] = 0
+
+    @torch.no_grad()
     def reset_dead(self, dead: Tensor) -> Tensor:
-        """Replace the context / action ring / reward-end LSTM state of the dead envs by fresh pool rows;
-        returns the dead row indices.  INVARIANT (env_loop's speculation relies on it): no draw from torch's random
-        generators happens here or in the pool's preload -- a reset consumes no random stream."""
+        """Replace the state of the dead envs by fresh pool rows; returns the dead row indices (synchronises: prefer the
+        step_end_finish path, which knows the rows on the host)."""
         rows = dead.nonzero(as_tuple=True)[0]
-        idx = self.pool.take(int(rows.numel()))
-        self.pool.scatter_frames(idx, rows, self._ctx, self._head)
-        self._act[rows[:, None], self._cols()[None, :]] = self.pool.act[idx]
-        self.hx_rew_end[0, rows] = self.pool.hx[idx]
-        self.cx_rew_end[0, rows] = self.pool.cx[idx]
-        self.ep_len[rows] = 0
+        self._reset_rows(rows, self.pool.take(int(rows.numel())))
+        if self._ep_len_host is not None:
+            self._ep_len_host[rows.cpu().numpy()] = 0
         return rows
 
     @torch.no_grad()
     def step(self, act: Tensor):
         self.step_begin(act)
         return self.step_end()
+
+    def _draw_step(self, own_noise: bool):
+        b, dev = self._ctx.shape[0], self._ctx.device
+        self.pool._watch_cpu_rng = self.expo_fn is not None or self.sampler.noise_fn is not None
+        noise = self.sampler._randn((b,) + tuple(self._ctx.shape[2:]), dev) if own_noise else None
+        if self.expo_fn is None:
+            e_rew = torch.empty(b, 3, device=dev).exponential_(1)
+            e_end = torch.empty(b, 2, device=dev).exponential_(1)
+        else:  # (test hook: draws injected in the reference's order -- the hook looks at the shape only)
+            e_rew = self.expo_fn(torch.empty(b, 1, 3, device=dev))
+            e_end = self.expo_fn(torch.empty(b, 1, 2, device=dev))
+        return noise, e_rew, e_end
 
     @torch.no_grad()
     def step_begin(self, act: Tensor, speculative: bool = False) -> Tensor:
@@ -229,35 +332,77 @@ class WorldModelEnv:
         interleave its own draws between the two halves without changing the order in which the streams are consumed
         (env_loop issues the policy's next step in between).
         speculative: issued BEFORE the previous step's host synchronisation (between step_end_issue and step_end_finish), on
-        the assumption that no episode ended there.  If one did, step_end_finish drops this half-step, keeps its draws, and
-        the caller's next step_begin -- with the action recomputed after the reset -- consumes them: every random stream is
-        consumed in the same order either way (no draw is made by a reset: `reset_dead` and the pool preload use none)."""
+        the assumption that no episode ends there that was not planned for (plan_resets).  If one did, step_end_finish keeps
+        this half-step and marks the rows it voided; the caller's step_begin_repair -- with the actions recomputed after the
+        reset -- redoes exactly those rows with the draws made here: every random stream is consumed in the same order either
+        way (no draw is made by a reset: `_reset_rows` and the pool preload use none)."""
+        assert self._pending is None, "step_begin twice without step_end (a speculative half-step is repaired, not repeated)"
         newest = self._slot(-1)
         self._act[:, newest] = act
-        saved, self._saved_draws = self._saved_draws, None
         own_noise = not self._use_graph()  # (a captured sampler graph draws inside the graph: never speculated, see may_speculate)
-        if saved is not None:
-            noise, e_rew, e_end = saved
-        else:
-            b, dev = self._ctx.shape[0], self._ctx.device
-            noise = self.sampler._randn((b,) + tuple(self._ctx.shape[2:]), dev) if own_noise else None
-            if self.expo_fn is None:
-                e_rew = torch.empty(b, 3, device=dev).exponential_(1)
-                e_end = torch.empty(b, 2, device=dev).exponential_(1)
-            else:  # (test hook: draws injected in the reference's order -- the hook looks at the shape only)
-                e_rew = self.expo_fn(torch.empty(b, 1, 3, device=dev))
-                e_end = self.expo_fn(torch.empty(b, 1, 2, device=dev))
+        noise, e_rew, e_end = self._draw_step(own_noise)
         self._next_noise = noise  # (handed over out of band: predict_next_obs keeps the reference's zero-argument signature,
         next_obs, denoising_trajectory = self.predict_next_obs()  # trainer.py:182-184 re-assigns it with a wrapper)
         self._pending = (next_obs, denoising_trajectory, e_rew, e_end, noise)
         self._pending_speculative = speculative
+        if speculative:
+            self.stats["speculated"] += 1
+        return next_obs
+
+    @torch.no_grad()
+    def step_begin_repair(self, act: Tensor) -> Tensor:
+        """After a step_end_finish that reported `void_rows` while a speculative step_begin was pending: the imagined frame of
+        exactly those rows again -- their context is the new episode's now, `act` carries their recomputed actions -- on a
+        small batch with the rows' own initial noise; every other row keeps what the speculation computed.  The kernels are
+        batch-invariant (a sample's result does not depend on what else is in the launch:
+        tests/test_gpu_models.py::test_batch_shard_invariance_at_full_batch), so the patched frame is bitwise the one a full
+        repetition of the step would have produced."""
+        rows, self._repair_rows = self._repair_rows, None
+        assert rows is not None and self._pending is not None
+        next_obs, trajectory, _, _, noise = self._pending
+        newest = self._slot(-1)
+        self._act[rows, newest] = act.index_select(0, rows)
+        x, tr = self.sampler.sample_ring(self._ctx.index_select(0, rows), self._act.index_select(0, rows), self._head, self._head,
+                                         noise.index_select(0, rows))
+        next_obs.index_copy_(0, rows, x)
+        for full, part in zip(trajectory[1:], tr[1:]):  # (trajectory[0] is the noise itself)
+            if full is not next_obs:
+                full.index_copy_(0, rows, part)
+        self.stats["repairs"] += 1
         return next_obs
 
     def may_speculate(self) -> bool:
-        """May the caller issue the NEXT step's step_begin before this step's step_end_finish?  Not while the cool-down after an
-        ended episode runs (a dropped speculation costs a whole sampler step), not with a captured sampler graph (its noise is
-        drawn inside the graph) or stochastic churn (more draws inside the sampler than this class keeps)."""
-        return self._spec_cooldown == 0 and not self._use_graph() and self.sampler.cfg.s_churn == 0
+        """May the caller issue the NEXT step's step_begin before this step's step_end_finish?  Not with a captured sampler graph
+        (its noise is drawn inside the graph) or stochastic churn (more draws inside the sampler than this class keeps); and not
+        while unplanned deaths are frequent enough that repairing the speculation costs more than the hole it fills."""
+        if self._use_graph() or self.sampler.cfg.s_churn != 0:
+            return False
+        pin = os.environ.get("DIAMOND_SPEC_SAMPLER")
+        if pin in ("0", "1"):
+            return pin == "1"
+        return self._void_events * SPEC_REPAIR_MS + self._void_frac * SPEC_FULL_STEP_MS < SPEC_HOLE_MS
+
+    @torch.no_grad()
+    def plan_resets(self) -> Optional[Dict[str, Any]]:
+        """Truncations are predictable: the envs whose episode reaches the horizon IN THE STEP THAT IS PENDING (between step_begin
+        and step_end_issue) are known on the host.  For them the reset is planned ahead: their pool rows are peeked (assuming no
+        other env dies in this step: pool rows are served in row order, world_model_env.py:56-57,133-139), and the caller gets
+        what it needs to run the policy's burn-in and next step on the new episodes BEFORE the step's host synchronisation:
+        {"rows": device index vector, "burnin_obs": (k, T-1, C, H, W), "obs": (k, C, H, W) newest frame of the new episodes}.
+        step_end_issue then performs the planned reset right after the ring advance -- so a speculative step_begin issued
+        behind it already sees the new episodes -- and step_end_finish checks the plan against what really died: rows an
+        unplanned death (`end`) mis-ordered get their proper pool rows and are reported as `void_rows`."""
+        assert self._pending is not None and self._plan is None
+        if self._ep_len_host is None or self._use_graph():
+            return None
+        rows_host = np.flatnonzero(self._ep_len_host + 1 >= self.horizon)
+        if rows_host.size == 0:
+            return None
+        idx, token = self.pool.peek(int(rows_host.size))
+        rows = self._rows_to_device(rows_host)
+        frames = self.pool.gather_frames(idx)
+        self._plan = {"rows_host": rows_host, "rows": rows, "idx": idx, "token": token, "frames": frames}
+        return {"rows": rows, "burnin_obs": frames[:, :-1], "obs": frames[:, -1]}
 
     @torch.no_grad()
     def step_end(self):
@@ -268,9 +413,10 @@ class WorldModelEnv:
 
     @torch.no_grad()
     def step_end_issue(self) -> None:
-        """Everything of step_end that the host can issue without knowing whether an episode ended; the answer travels to the
-        host asynchronously (pinned flag + event).  The caller may issue more work -- the policy's and the sampler's next step
-        -- before it asks for it with step_end_finish: the device then never runs dry while the host waits."""
+        """Everything of step_end that the host can issue without knowing whether an episode ended; the answer -- the step's
+        `dead` mask -- travels to the host asynchronously (pinned buffer + event).  The caller may issue more work -- the policy's
+        and the sampler's next step -- before it asks for it with step_end_finish: the device then never runs dry while the
+        host waits."""
         next_obs, denoising_trajectory, e_rew, e_end, _ = self._pending
         self._pending, self._pending_speculative = None, False
         rew, end = self.predict_rew_end(next_obs.unsqueeze(1), e_rew, e_end)
@@ -287,47 +433,87 @@ class WorldModelEnv:
         info: Dict[str, Any] = {}
         if self.return_denoising_trajectory:
             info["denoising_trajectory"] = torch.stack(denoising_trajectory, dim=1)
-        flag = dead.any()
-        if flag.is_cuda:
-            if getattr(self, "_flag_host", None) is None:
-                self._flag_host = torch.zeros((), dtype=torch.bool).pin_memory()
+        if dead.is_cuda:
+            if self._dead_host is None or self._dead_host.numel() != dead.numel():
+                self._dead_host = torch.zeros(dead.numel(), dtype=torch.bool).pin_memory()
                 self._flag_event = torch.cuda.Event()
-            self._flag_host.copy_(flag, non_blocking=True)
+            self._dead_host.copy_(dead, non_blocking=True)
             self._flag_event.record()
-        self._issued = (next_obs, rew, end, trunc, dead, info, flag)
+        if self._plan is not None:  # the planned reset: behind the ring advance, in front of whatever the caller issues next
+            self._reset_rows(self._plan["rows"], self._plan["idx"])
+        self._issued = (next_obs, rew, end, trunc, dead, info)
 
     @torch.no_grad()
     def step_end_finish(self):
-        """THE host synchronisation of a step: did an episode end?  If so: resets, and a speculative step_begin issued
-        meanwhile is dropped (its draws are kept for the repetition)."""
-        next_obs, rew, end, trunc, dead, info, flag = self._issued
+        """THE host synchronisation of a step: which episodes ended?  Resets of the rows no plan covered (or covered with the
+        wrong pool rows); a speculative step_begin issued meanwhile stays pending, with those rows marked for
+        step_begin_repair.  info: any_dead, dead_rows (device index vector, ascending), final_observation, burnin_obs (both in
+        dead_rows order, as the reference's boolean-mask forms are), and -- only when some of the dead rows were not reset as
+        planned -- void_rows (device index vector) / void_pos (their positions within dead_rows)."""
+        next_obs, rew, end, trunc, dead, info = self._issued
         self._issued = None
-        if flag.is_cuda:
+        if dead.is_cuda:
             self._flag_event.synchronize()
-            any_dead = bool(self._flag_host)
+            rows_host = np.flatnonzero(self._dead_host.numpy())
         else:
-            any_dead = bool(flag)
+            rows_host = np.flatnonzero(dead.numpy())
+        any_dead = rows_host.size > 0
+        if self._ep_len_host is not None:
+            self._ep_len_host += 1
+            self._ep_len_host[rows_host] = 0
+        plan, self._plan = self._plan, None
         obs = next_obs  # a fresh tensor every step: never aliases the ring
         info["any_dead"] = any_dead  # (so that the caller does not have to synchronise again for the same answer)
-        if self._spec_cooldown > 0:
-            self._spec_cooldown -= 1
-        if self._pending is not None and self._pending_speculative:
-            if any_dead:  # wasted: remember the draws, back off for longer
-                self._saved_draws = (self._pending[4], self._pending[2], self._pending[3])
-                self._pending, self._pending_speculative = None, False
-                self._spec_penalty, self._spec_streak = min(64, 2 * self._spec_penalty), 0
-            else:
-                self._spec_streak += 1
-                if self._spec_streak >= 16:
-                    self._spec_penalty = 4
+        self.stats["steps"] += 1
+        void_host = rows_host
         if any_dead:
-            self._spec_cooldown = self._spec_penalty
-            rows = self.reset_dead(dead)
+            self.stats["steps_with_deaths"] += 1
+            total = int(rows_host.size)
+            rows = None
+            if plan is not None:
+                planned = plan["rows_host"]
+                assert np.isin(planned, rows_host).all(), "a predicted truncation did not happen: ep_len was changed behind the env's back (use set_episode_lengths)"
+                if total == planned.size:  # exactly the plan
+                    self.pool.commit(plan["token"], total)
+                    rows, void_host = plan["rows"], rows_host[:0]
+                else:
+                    # more deaths than planned: the reference serves ONE request for all of them in row order.  Planned rows in
+                    # front of the first unplanned death keep their pool rows (if the larger request still fits the pool that
+                    # was peeked into); everybody else is (re-)reset with the proper ones.
+                    idx_all, token = self.pool.peek(total)
+                    keep = 0
+                    if token == plan["token"]:
+                        first_unplanned = rows_host[~np.isin(rows_host, planned)][0]
+                        keep = int(np.searchsorted(planned, first_unplanned))
+                    self.pool.commit(token, total)
+                    void_host = rows_host[keep:] if keep else rows_host
+                    if keep:  # (rows_host[:keep] == planned[:keep]: both ascending, and nothing unplanned precedes them)
+                        self._reset_rows(self._rows_to_device(void_host), idx_all[keep:])
+                    else:
+                        self._reset_rows(self._rows_to_device(rows_host), idx_all)
+            else:
+                self._reset_rows(self._rows_to_device(rows_host), self.pool.take(total))
+            if rows is None:
+                rows = self._rows_to_device(rows_host)
             info["dead_rows"] = rows  # device index list: the caller gathers / scatters with it (no further synchronisation)
-            info["final_observation"] = next_obs[rows]
+            info["final_observation"] = next_obs.index_select(0, rows)
             cols = self._cols()
             info["burnin_obs"] = self._ctx[rows[:, None], cols[None, :-1]]
             obs = self._ctx[:, self._slot(-1)].clone()  # dead envs now show the newest frame of their new episode
+            self.stats["planned_rows"] += total - int(void_host.size)
+            self.stats["void_rows"] += int(void_host.size)
+            if void_host.size:
+                if void_host.size == total:
+                    info["void_rows"], info["void_pos"] = rows, None  # (None: all of dead_rows)
+                else:
+                    info["void_rows"] = self._rows_to_device(void_host)
+                    info["void_pos"] = self._rows_to_device(np.arange(total - void_host.size, total))
+        n_void = int(void_host.size) if any_dead else 0
+        self._void_events = 0.9 * self._void_events + 0.1 * (1.0 if n_void else 0.0)
+        self._void_frac = 0.9 * self._void_frac + 0.1 * (n_void / self.num_envs)
+        if self._pending is not None and self._pending_speculative and n_void:
+            self._repair_rows = info["void_rows"]
+            info["repair_pending"] = True
         return obs, rew, end, trunc, info
 
     def _use_graph(self) -> bool:

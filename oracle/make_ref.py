@@ -27,7 +27,11 @@ def build(verbose: bool = True) -> bool:
     """Returns False (and does nothing) where the reference is absent."""
     if not os.path.isdir(REF_SRC):
         return False
-    shutil.rmtree(os.path.join(HERE, "_ref"), ignore_errors=True)
+    # built beside the old copy and swapped in on success: a reference file that does not compile leaves the last good
+    # oracle/_ref in place (and raises: the caller decides what that means -- __graft_entry__.build() only logs it)
+    tmp = os.path.join(HERE, "_ref.tmp")
+    shutil.rmtree(tmp, ignore_errors=True)
+    out = os.path.join(tmp, "src")
     n = 0
     for root, dirs, files in os.walk(REF_SRC):
         dirs[:] = [d for d in dirs if d != "__pycache__"]
@@ -36,14 +40,16 @@ def build(verbose: bool = True) -> bool:
                 continue
             src = os.path.join(root, f)
             rel = os.path.relpath(src, REF_SRC)
-            dst = os.path.join(OUT, rel + "c")  # legacy (sourceless) location: foo.pyc where foo.py would be
+            dst = os.path.join(out, rel + "c")  # legacy (sourceless) location: foo.pyc where foo.py would be
             os.makedirs(os.path.dirname(dst), exist_ok=True)
             py_compile.compile(src, cfile=dst, dfile=os.path.join("reference/src", rel), doraise=True,
                                invalidation_mode=py_compile.PycInvalidationMode.UNCHECKED_HASH)
             n += 1
-    with open(os.path.join(HERE, "_ref", "MANIFEST.json"), "w") as fh:
+    with open(os.path.join(tmp, "MANIFEST.json"), "w") as fh:
         json.dump({"what": "CPython bytecode of /root/reference/src (py_compile, no sources), see oracle/make_ref.py",
                    "files": n, "python": sys.version.split()[0], "magic": importlib.util.MAGIC_NUMBER.hex()}, fh, indent=1)
+    shutil.rmtree(os.path.join(HERE, "_ref"), ignore_errors=True)
+    os.replace(tmp, os.path.join(HERE, "_ref"))
     if verbose:
         print(f"oracle/_ref: {n} modules of {REF_SRC} compiled to bytecode")
     return True

@@ -15,11 +15,62 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def trainer_body(dev):
+    """The loop body of the reference's Trainer.train_component("actor_critic") (trainer.py:363-382) for two optimiser steps, model =
+    DDP(agent.actor_critic) as utils.py:105-106 wraps it, grad_acc_steps = 1, max_grad_norm = 100 (config/trainer.yaml)."""
+    import diamond_amd as D
+    from bench import _Loader, build_agent
+
+    agent = build_agent(dev, 64, 0)
+    env = D.WorldModelEnv(agent.denoiser, agent.rew_end_model, _Loader(8, 100, 64),
+                          D.WorldModelEnvConfig(horizon=5, num_batches_to_preload=2,
+                                                diffusion_sampler=D.DiffusionSamplerConfig(num_steps_denoising=3)))
+    agent.setup_training(D.SigmaDistributionConfig(-0.4, 1.2, 2e-3, 20),
+                         D.ActorCriticLossConfig(backup_every=5, gamma=0.985, lambda_=0.95, weight_value_loss=1.0, weight_entropy_loss=0.001), env)
+    model = torch.nn.parallel.DistributedDataParallel(agent.actor_critic)
+    try:  # the reference's own optimizer factory (utils.py:129-165), from its bytecode where that travelled
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import reference_window as RW
+
+        path, _ = RW.reference_location()
+        RW._install(path)
+        from utils import configure_opt
+
+        opt, opt_from = configure_opt(agent.actor_critic, lr=1e-4, weight_decay=0.0, eps=1e-8), "reference configure_opt"
+    except Exception as e:  # noqa: BLE001
+        opt, opt_from = torch.optim.AdamW(agent.actor_critic.parameters(), lr=1e-4, eps=1e-8, weight_decay=0.0), f"torch AdamW ({e!r})"
+    before = torch.cat([p.detach().reshape(-1) for p in agent.actor_critic.parameters()]).clone()
+    model.train()
+    opt.zero_grad()
+    losses, norms, nkeys = [], [], 0
+    for i in range(2):
+        loss, metrics = model()
+        loss.backward()
+        grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), 100.0)
+        metrics["grad_norm_before_clip"] = grad_norm
+        opt.step()
+        opt.zero_grad()
+        losses.append(float(loss))
+        norms.append(float(grad_norm))
+        nkeys = len(metrics)
+    torch.cuda.synchronize()
+    after = torch.cat([p.detach().reshape(-1) for p in agent.actor_critic.parameters()])
+    return {"steps": 2, "losses": losses, "losses_finite": all(l == l and abs(l) < 1e30 for l in losses), "grad_norms": norms,
+            "params_moved": bool((after != before).any()), "optimizer": opt_from, "metrics_keys": nkeys,
+            "grads_zeroed": all(p.grad is None or not bool(p.grad.any()) for p in agent.actor_critic.parameters())}
+
+
 def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist.init_process_group("nccl", device_id=dev)
+    if "--trainer-body" in sys.argv:
+        out = trainer_body(dev)
+        dist.barrier()
+        dist.destroy_process_group()
+        print(json.dumps(out))
+        return
     import diamond_amd as D
     from bench import _Loader, build_agent
     from diamond_amd.dist import GradAllReducer, broadcast_parameters, parameter_checksum

@@ -71,6 +71,30 @@ def gen_denoiser(agent, tag, h=64, w=64, b=2, only=None):
     save(f"denoiser_{tag}.pt", out)
 
 
+def gen_denoiser_pixels(agent, tag, h=64, w=64, b=17, sampled=3):
+    """The quantised-frame budget (<= 1e-4 of the pixels on another uint8 level than the reference's) needs enough pixels to be
+    resolved: b * 3 * h * w >= 200k, where 1e-4 is >= 20 pixels instead of 1-3.  Denoiser.denoise at the sampler's sigmas (the
+    first `sampled` of them) and at a per-sample (B,) sigma; only the uint8 levels are stored (and one fp32 model output)."""
+    from models.diffusion import DiffusionSampler, DiffusionSamplerConfig
+
+    g = torch.Generator().manual_seed(31)
+    obs = synthetic_frames(g, b, 12, h, w)
+    act = synthetic_actions(g, 4, b, 4)
+    noise = torch.randn(b, 3, h, w, generator=g)
+    den = agent.denoiser
+    sampler = DiffusionSampler(den, DiffusionSamplerConfig(num_steps_denoising=3))
+    per_sample = torch.linspace(0.05, 4.0, b)
+    out = {"sigmas": sampler.sigmas.clone(), "seed": 31, "b": b, "h": h, "w": w, "per_sample_sigma": per_sample, "pixels": b * 3 * h * w}
+    with torch.no_grad():
+        for i, sigma in enumerate(list(sampler.sigmas[:sampled]) + [per_sample]):
+            x = noise * sigma.reshape(-1, 1, 1, 1) + obs[:, -3:] * 0.5
+            d = den.denoise(x, sigma, obs, act)
+            out[f"denoised_u8_{i}"] = d.add(1).div(2).mul(255).round().to(torch.uint8)
+            if i == 0:
+                out["model_output_0_sample0"] = den.compute_model_output(x, obs, act, den.compute_conditioners(sigma))[:1].clone()
+    save(f"denoiser_pixels_{tag}.pt", out)
+
+
 def gen_sampler(agent):
     from models.diffusion import DiffusionSampler, DiffusionSamplerConfig
 
@@ -339,6 +363,11 @@ def gen_offgrid_72():
 def main():
     if "--offgrid" in sys.argv:
         gen_offgrid_72()
+        return
+    if "--pixels" in sys.argv:  # >= 200k pixels per quantised-frame check
+        gen_denoiser_pixels(ref_agent(), "default")
+        gen_denoiser_pixels(ref_agent(), "72x72", h=72, w=72, b=14, sampled=1)
+        gen_denoiser_pixels(ref_agent(denoiser_attn_depths=(0, 0, 1, 1)), "attn0011", b=17, sampled=1)
         return
     if "--rew-end-train" in sys.argv:
         gen_rew_end_train()

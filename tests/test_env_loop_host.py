@@ -24,7 +24,7 @@ class ToyPolicy:
         self.calls += 1
         hx, cx = hx_cx
         feat = obs.flatten(1)[:, :6] + hx[:, :1]
-        logits = feat @ self.w.t()
+        logits = (feat[:, None, :] * self.w[None]).sum(-1)  # (per-row reduction: a GEMM's blocking depends on the batch)
         val = feat.sum(1)
         return logits, val, (torch.tanh(hx + feat[:, :5]), cx + 1)
 
@@ -211,7 +211,7 @@ class SeparablePolicy(ToyPolicy):
     def predict_from_features(self, feat, hx_cx):
         hx, cx = hx_cx
         z = feat + hx[:, :1]
-        return z @ self.w.t(), z.sum(1), (torch.tanh(hx + z[:, :5]), cx + 1)
+        return (z[:, None, :] * self.w[None]).sum(-1), z.sum(1), (torch.tanh(hx + z[:, :5]), cx + 1)
 
     def predict_act_value(self, obs, hx_cx):
         self.calls += 1
@@ -259,3 +259,225 @@ def test_batched_burn_in_is_bitwise_the_frame_by_frame_one(monkeypatch, p_end):
         for a, b in zip(wa, wb):
             assert torch.equal(a, b)
     assert outs[1][1].encodes < outs[0][1].encodes, "the batched path did not save encoder passes"
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The pipelined loop (env_loop._pipelined_env_loop) against the sequential one, on toy envs whose resets are served from a POOL
+# in row order (so that a wrong pool order, a wrong row, a stale frame or a draw out of order changes the result).
+
+
+def _pool_row(k, t=4):
+    """the k-th initial condition the pool serves: (t, 2, 3) frames"""
+    g = torch.Generator().manual_seed(1000 + k)
+    return torch.randn(t, 2, 3, generator=g)
+
+
+class PoolEnv:
+    """Reference semantics (world_model_env.py:64-89) with plain `step`: next frame from (state, act, noise), reward / end draws,
+    truncation at `horizon`, dead rows re-initialised from the pool in row order, info = final_observation / burnin_obs."""
+    num_actions = 4
+
+    def __init__(self, b, p_end, horizon, stagger=False):
+        self.num_envs, self.p_end, self.horizon, self.stagger = b, p_end, horizon, stagger
+        self.cursor = 0
+        self.log = []
+
+    def _serve(self, k):
+        rows = [_pool_row(self.cursor + i) for i in range(k)]
+        self.cursor += k
+        return torch.stack(rows)
+
+    def reset(self, **kw):
+        self.ctx = self._serve(self.num_envs)  # (B, 4, 2, 3): the newest frame is ctx[:, -1]
+        self.t = torch.arange(self.num_envs) % self.horizon if self.stagger else torch.zeros(self.num_envs, dtype=torch.long)
+        return self.ctx[:, -1].clone(), {}
+
+    def _dynamics(self, ctx, act, noise):
+        return ctx[:, -1] * 0.5 + ctx[:, 0] * 0.1 + act.float().view(-1, 1, 1) * 0.1 + noise
+
+    def _rew_end(self, nxt, e_rew, e_end):
+        rew = ((nxt.flatten(1)[:, :3]).softmax(-1) / e_rew).argmax(1).float() - 1
+        end = (torch.tensor([1 - self.p_end, self.p_end]).expand(nxt.shape[0], 2) / e_end).argmax(1)
+        return rew, end
+
+    def _draw(self):
+        b = self.num_envs
+        return torch.randn(b, 2, 3), torch.empty(b, 3).exponential_(1), torch.empty(b, 2).exponential_(1)
+
+    def step(self, act):
+        self.log.append("step")
+        noise, e_rew, e_end = self._draw()
+        nxt = self._dynamics(self.ctx, act, noise)
+        rew, end = self._rew_end(nxt, e_rew, e_end)
+        self.t += 1
+        trunc = (self.t >= self.horizon).long()
+        self.ctx = torch.cat([self.ctx[:, 1:], nxt[:, None]], 1)
+        dead = torch.logical_or(end, trunc)
+        info = {}
+        if dead.any():
+            self.ctx[dead] = self._serve(int(dead.sum()))
+            self.t[dead] = 0
+            info["final_observation"] = nxt[dead]
+            info["burnin_obs"] = self.ctx[dead, :-1]
+        return self.ctx[:, -1].clone(), rew, end, trunc, info
+
+
+class PipeEnv(PoolEnv):
+    """The same env behind WorldModelEnv's pipelining protocol (env_loop.PIPELINE_PROTOCOL): planned resets for the truncations
+    the host can foresee, speculative step_begin, per-row repair after unplanned deaths."""
+
+    def __init__(self, b, p_end, horizon, stagger=False, speculate=True):
+        super().__init__(b, p_end, horizon, stagger)
+        self.speculate = speculate
+        self._pending = self._plan = self._issued = self._repair = None
+        self.counts = {"planned": 0, "void": 0, "repairs": 0, "spec": 0, "mixed": 0}
+
+    def step(self, act):
+        self.step_begin(act)
+        self.step_end_issue()
+        return self.step_end_finish()
+
+    def step_begin(self, act, speculative=False):
+        assert self._pending is None
+        self.log.append("begin-spec" if speculative else "begin")
+        self.counts["spec"] += int(speculative)
+        noise, e_rew, e_end = self._draw()
+        self._acts = act.clone()
+        nxt = self._dynamics(self.ctx, act, noise)
+        self._pending, self._spec = (nxt, e_rew, e_end, noise), speculative
+        return nxt
+
+    def step_begin_repair(self, act):
+        rows, self._repair = self._repair, None
+        nxt, _, _, noise = self._pending
+        self.counts["repairs"] += 1
+        nxt[rows] = self._dynamics(self.ctx[rows], act[rows], noise[rows])
+        return nxt
+
+    def may_speculate(self):
+        return self.speculate
+
+    def plan_resets(self):
+        assert self._pending is not None and self._plan is None
+        rows = (self.t + 1 >= self.horizon).nonzero().flatten()
+        if rows.numel() == 0:
+            return None
+        frames = torch.stack([_pool_row(self.cursor + i) for i in range(rows.numel())])  # (peek)
+        self._plan = {"rows": rows, "frames": frames, "cursor": self.cursor}
+        return {"rows": rows, "burnin_obs": frames[:, :-1], "obs": frames[:, -1]}
+
+    def step_end_issue(self):
+        nxt, e_rew, e_end, _ = self._pending
+        self._pending, self._spec = None, False
+        rew, end = self._rew_end(nxt, e_rew, e_end)
+        self.t += 1
+        trunc = (self.t >= self.horizon).long()
+        self.ctx = torch.cat([self.ctx[:, 1:], nxt[:, None]], 1)
+        if self._plan is not None:
+            self.ctx[self._plan["rows"]] = self._plan["frames"]
+            self.t[self._plan["rows"]] = 0
+        self._issued = (nxt, rew, end, trunc, torch.logical_or(end, trunc))
+
+    def step_end_finish(self):
+        self.log.append("end")
+        nxt, rew, end, trunc, dead = self._issued
+        plan, self._plan = self._plan, None
+        rows = dead.nonzero().flatten()
+        info = {"any_dead": rows.numel() > 0}
+        obs = nxt
+        if info["any_dead"]:
+            total = rows.numel()
+            void = rows
+            if plan is not None:
+                planned = plan["rows"]
+                assert all(int(r) in rows.tolist() for r in planned)
+                if planned.numel() == total:
+                    self.cursor += total
+                    void = rows[:0]
+                else:
+                    self.counts["mixed"] += 1
+                    first = min(set(rows.tolist()) - set(planned.tolist()))
+                    keep = int((planned < first).sum())
+                    fresh = torch.stack([_pool_row(self.cursor + i) for i in range(total)])
+                    self.cursor += total
+                    void = rows[keep:]
+                    self.ctx[void] = fresh[keep:]
+                    self.t[void] = 0
+            else:
+                self.ctx[rows] = self._serve(total)
+                self.t[rows] = 0
+            self.counts["planned"] += total - void.numel()
+            self.counts["void"] += void.numel()
+            info["dead_rows"] = rows
+            info["final_observation"] = nxt[rows]
+            info["burnin_obs"] = self.ctx[rows, :-1]
+            obs = self.ctx[:, -1].clone()
+            if void.numel():
+                info["void_rows"] = void
+                info["void_pos"] = None if void.numel() == total else torch.arange(total - void.numel(), total)
+                if self._pending is not None and self._spec:
+                    self._repair = void
+                    info["repair_pending"] = True
+        return obs, rew, end, trunc, info
+
+
+def _windows(env, pol, windows, t, monkeypatch, mode):
+    monkeypatch.setattr(EL, "sample_categorical", lambda logits, expo: (torch.softmax(logits.detach(), -1) / expo).argmax(-1))
+    monkeypatch.setenv("DIAMOND_SPECULATIVE_POLICY", mode)
+    torch.manual_seed(11)
+    random.seed(5)
+    loop = EL.make_env_loop(env, pol, epsilon=0.0)
+    outs = []
+    for _ in range(windows):
+        *cols, infos = loop.send(t)
+        outs.append([c.clone() for c in cols])
+    return outs
+
+
+@pytest.mark.parametrize("separable", [True, False])
+@pytest.mark.parametrize("speculate", [True, False])
+@pytest.mark.parametrize("p_end,horizon,stagger", [(0.0, 6, False), (0.0, 7, True), (0.02, 7, True), (0.12, 7, True), (0.35, 5, False), (0.6, 9, True)])
+def test_pipelined_loop_is_bitwise_the_sequential_one(monkeypatch, p_end, horizon, stagger, speculate, separable):
+    """planned truncation resets inside the pipeline, speculative sampler steps, unplanned deaths repaired row by row, deaths at
+    the last step of a window, mixed steps (an `end` in front of planned truncations: pool order), all of it on ONE shared random
+    stream against the reference's order of operations"""
+    b, t, windows = 9, 6, 5
+    pol = lambda: SeparablePolicy(True) if separable else ToyPolicy()
+    seq = _windows(PoolEnv(b, p_end, horizon, stagger), pol(), windows, t, monkeypatch, "1")  # (no protocol: the generic loop)
+    env = PipeEnv(b, p_end, horizon, stagger, speculate)
+    pipe = _windows(env, pol(), windows, t, monkeypatch, "1")
+    names = ("obs", "act", "rew", "end", "trunc", "logits", "val", "val_bootstrap")
+    for w, (wa, wb) in enumerate(zip(seq, pipe)):
+        for name, a, b_ in zip(names, wa, wb):
+            assert torch.equal(a, b_), (w, name)
+    c = env.counts
+    if speculate:
+        assert c["spec"] > 0
+    if (stagger or horizon % t) and p_end < 0.5:  # (at p = 0.6 hardly an episode reaches the horizon)
+        assert c["planned"] > 0, "no truncation was planned"
+    if p_end > 0:
+        assert c["void"] > 0 and (c["repairs"] > 0) == speculate
+    if 0.12 <= p_end < 0.5 and stagger:
+        assert c["mixed"] > 0, "no step had an unplanned death next to planned truncations"
+    # the protocol-less path on the same env class gives the same thing (PipeEnv.step = begin + issue + finish without a plan)
+    again = _windows(PipeEnv(b, p_end, horizon, stagger), pol(), windows, t, monkeypatch, "0")
+    for wa, wb in zip(seq, again):
+        for a, b_ in zip(wa, wb):
+            assert torch.equal(a, b_)
+
+
+def test_pipelined_loop_gradients_match_the_sequential_ones(monkeypatch):
+    """index_copy merges of recomputed rows carry the same gradient as the sequential graph (up to summation order)"""
+    outs = []
+    for cls in (PoolEnv, PipeEnv):
+        pol = SeparablePolicy(True)
+        pol.w.requires_grad_(True)
+        cols = _windows(cls(9, 0.12, 7, True), pol, 1, 6, monkeypatch, "1")
+        monkeypatch.setattr(EL, "sample_categorical", lambda logits, expo: (torch.softmax(logits.detach(), -1) / expo).argmax(-1))
+        torch.manual_seed(11)
+        random.seed(5)
+        loop = EL.make_env_loop(cls(9, 0.12, 7, True), pol, epsilon=0.0)
+        *c, _ = loop.send(6)
+        (c[5].square().sum() + c[6].sum()).backward()
+        outs.append(pol.w.grad.clone())
+    assert torch.allclose(outs[0], outs[1], rtol=1e-5, atol=1e-6)

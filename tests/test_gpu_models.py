@@ -3,6 +3,8 @@ WorldModelEnv+ActorCritic window vs (a) the committed golden fixtures produced b
 the reference and (b) the CPU oracle on the same seeded inputs.  Tolerances (north_star):
 fp32 values within 1e-4 relative (max-abs-err / max-abs-ref), integer indices bit-exact,
 quantised frames on the same uint8 level except a <=1e-4 fraction one level off."""
+import os
+
 import pytest
 import torch
 
@@ -12,6 +14,9 @@ from tests.conftest import WEIGHT_SEED, load_golden, make_oracle_agent
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def rel_err(a, b):
@@ -108,6 +113,33 @@ def test_denoiser_sizes_off_the_tile_grid_vs_reference_golden(tag, attn, b, h, w
             frac = levels[flipped] - levels[flipped].floor()
             dist = torch.minimum(frac, 1 - frac)
             assert float(dist.max()) < 2e-3, f"a flipped pixel is {float(dist.max()):.2e} levels away from a truncation boundary"
+
+
+@pytest.mark.parametrize("tag,attn", [("default", (0, 0, 0, 0)), ("72x72", (0, 0, 0, 0)), ("attn0011", (0, 0, 1, 1))])
+def test_quantised_frame_budget_on_200k_pixels_vs_reference_golden(tag, attn):
+    """The contract's pixel bar where it can be RESOLVED: <= 1e-4 of the quantised denoiser output's pixels on another uint8 level
+    than the reference's, asserted on >= 200k pixels per check (1e-4 = 20+ pixels, not the 1-3 of the batch-2 fixtures, whose
+    counts are Poisson noise), teacher-forced at the sampler's sigmas and at per-sample sigmas; no relaxed variant -- 64x64, the
+    off-grid 72x72 (valid extents) and attention inside the U-Net (tests/golden/make_golden.py --pixels, from the reference)."""
+    from diamond_amd.testing import synthetic_actions, synthetic_frames
+
+    gold = load_golden(f"denoiser_pixels_{tag}.pt")
+    b, h, w = gold["b"], gold["h"], gold["w"]
+    assert gold["pixels"] == b * 3 * h * w >= 200_000
+    ag = make_agent(attn)
+    g = torch.Generator().manual_seed(gold["seed"])
+    obs = synthetic_frames(g, b, 12, h, w)
+    act = synthetic_actions(g, 4, b, 4)
+    noise = torch.randn(b, 3, h, w, generator=g)
+    n = sum(1 for k in gold if k.startswith("denoised_u8_"))
+    sigmas = list(gold["sigmas"][:n - 1]) + [gold["per_sample_sigma"]]
+    for i, sigma in enumerate(sigmas):
+        x = noise * sigma.reshape(-1, 1, 1, 1) + obs[:, -3:] * 0.5
+        if i == 0:
+            f = ag.denoiser.compute_model_output(x[:1].to(DEV), obs[:1].to(DEV), act[:1].to(DEV), sigma)
+            assert rel_err(f, gold["model_output_0_sample0"]) < 1e-4
+        d = ag.denoiser.denoise(x.to(DEV), sigma, obs.to(DEV), act.to(DEV))
+        check_quantised(u8(d), gold[f"denoised_u8_{i}"], max_frac=1e-4, what=f"{tag} teacher-forced sigma#{i} ({gold['pixels']} pixels)")
 
 
 def test_denoiser_not_further_from_fp64_than_cpu_fp32(agent):
@@ -737,6 +769,56 @@ def test_speculative_policy_step_is_bitwise_the_sequential_one(monkeypatch):
     for wa, wb in zip(*runs):
         for a, b_ in zip(wa, wb):
             assert torch.equal(a, b_)
+
+
+@pytest.mark.parametrize("spec", ["1", "0"])
+@pytest.mark.parametrize("b,horizon,p_end,stagger", [(24, 5, 0.03, True), (12, 7, 0.25, False), (16, 6, 0.0, True)])
+def test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon, p_end, stagger, spec):
+    """env_loop's pipelined form (planned truncation resets inside the speculated pipeline, unplanned deaths repaired row by row on
+    a small batch: env_loop._pipelined_env_loop, WorldModelEnv.plan_resets / step_begin_repair) against the reference's sequential
+    order of operations (DIAMOND_SPECULATIVE_POLICY=0), three windows on the DEVICE random generator at batches the graphed
+    sampler does not take: every output bitwise identical, and the paths in question were actually taken."""
+    import random
+    import sys
+    import diamond_amd as D
+
+    sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+    from bench import set_end_rate
+
+    t = 6
+    runs, stats = [], None
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DIAMOND_SPECULATIVE_POLICY", mode)
+        monkeypatch.setenv("DIAMOND_SPEC_SAMPLER", spec)
+        monkeypatch.setenv("DIAMOND_CHECK_RESET_RNG", "1")
+        ag = make_agent()
+        set_end_rate(ag, p_end if p_end > 0 else 1e-9)
+        env = D.WorldModelEnv(ag.denoiser, ag.rew_end_model, _Loader(b, 77),
+                              D.WorldModelEnvConfig(horizon=horizon, num_batches_to_preload=2,
+                                                    diffusion_sampler=D.DiffusionSamplerConfig(num_steps_denoising=2)))
+        ag.setup_training(D.SigmaDistributionConfig(-0.4, 1.2, 2e-3, 20),
+                          D.ActorCriticLossConfig(backup_every=t, gamma=0.985, lambda_=0.95, weight_value_loss=1.0,
+                                                  weight_entropy_loss=0.001), env)
+        torch.manual_seed(4321)
+        random.seed(0)
+        outs = []
+        for w in range(3):
+            all_obs, act, rew, end, trunc, logits_act, val, vb, _ = ag.actor_critic.env_loop.send(t)
+            outs.append([x.detach().cpu() for x in (all_obs, act, rew, end, trunc, logits_act, val, vb)])
+            if w == 0 and stagger:
+                env.set_episode_lengths(torch.arange(b) % horizon)
+        runs.append(outs)
+        if mode == "1":
+            stats = dict(env.stats)
+    print(stats)
+    names = ("obs", "act", "rew", "end", "trunc", "logits", "val", "val_bootstrap")
+    for w, (wa, wb) in enumerate(zip(*runs)):
+        for name, a, b_ in zip(names, wa, wb):
+            assert torch.equal(a, b_), (w, name)
+    assert stats["planned_rows"] > 0, stats
+    if p_end > 0:
+        assert stats["void_rows"] > 0 and (stats["repairs"] > 0) == (spec == "1"), stats
+    assert (stats["speculated"] > 0) == (spec == "1"), stats
 
 
 @pytest.mark.parametrize("num_actions", [6, 18])

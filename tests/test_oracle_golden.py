@@ -62,6 +62,24 @@ def test_denoiser_sizes_off_the_tile_grid():
     _denoiser_case("attn0011_68x76", (0, 0, 1, 1), 1, 68, 76)
 
 
+@pytest.mark.parametrize("tag,attn", [("default", (0, 0, 0, 0)), ("72x72", (0, 0, 0, 0))])
+def test_quantised_frame_budget_on_200k_pixels(tag, attn):
+    """the oracle against the >= 200k-pixel fixtures (make_golden.py --pixels): the fraction of pixels on another uint8 level than
+    the reference's, where 1e-4 is 20+ pixels (first sampler sigma and the per-sample sigmas; the GPU test does all of them)"""
+    gold = load_golden(f"denoiser_pixels_{tag}.pt")
+    b, h, w = gold["b"], gold["h"], gold["w"]
+    a = make_oracle_agent(attn_depths=attn)
+    g = torch.Generator().manual_seed(gold["seed"])
+    obs = synthetic_frames(g, b, 12, h, w)
+    act = synthetic_actions(g, 4, b, 4)
+    noise = torch.randn(b, 3, h, w, generator=g)
+    n = sum(1 for k in gold if k.startswith("denoised_u8_"))
+    for i, sigma in ((0, gold["sigmas"][0]), (n - 1, gold["per_sample_sigma"])):
+        x = noise * sigma.reshape(-1, 1, 1, 1) + obs[:, -3:] * 0.5
+        d = O.denoise(a.denoiser, a.dspec, x, sigma, obs, act)
+        check_quantised(u8(d), gold[f"denoised_u8_{i}"], max_frac=1e-4)
+
+
 def test_sampler_euler_and_heun():
     gold = load_golden("sampler.pt")
     a = make_oracle_agent()

@@ -85,3 +85,11 @@ def test_full_window_vs_reference_golden_on_the_interpreter(models):
     M, counter = models
     M.test_full_window_vs_reference_golden()
     assert counter.n.get("dmd_categorical_sample", 0) >= 12 and counter.n.get("lowres_chain_kernel", 0) >= 36, counter.n
+
+
+@pytest.mark.skipif(os.environ.get("DIAMOND_SLOW_CPU_TESTS") != "1", reason="several minutes: DIAMOND_SLOW_CPU_TESTS=1 runs it")
+def test_pipelined_window_is_bitwise_the_sequential_one_on_the_interpreter(models, monkeypatch):
+    """env_loop's pipelined form through the REAL WorldModelEnv (planned resets, pool peek / commit, per-row repair of a speculative
+    sampler step) against the sequential order, on the CPU: three windows of three envs with truncations and sampled ends"""
+    M, counter = models
+    M.test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, 3, 4, 0.15, True, "1")
