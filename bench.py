@@ -427,7 +427,10 @@ def stagger_episodes(env, horizon):
     """The steady state of the reference's training loop: every `end` desynchronises its env for good (its truncation then falls
     mid-window, world_model_env.py:71-72), so after a few thousand steps the episode lengths of a batch are spread over the
     horizon and B / horizon envs truncate at EVERY step.  Set that state directly: ep_len[r] = r mod horizon."""
-    env.set_episode_lengths(torch.arange(env.num_envs) % horizon)
+    if hasattr(env, "set_episode_lengths"):
+        env.set_episode_lengths(torch.arange(env.num_envs) % horizon)
+    else:  # (an env without the host mirror: tools/ab_env_loop.sh runs the round-4 classes through this file)
+        env.ep_len = (torch.arange(env.num_envs) % horizon).to(env.ep_len.device)
 
 
 def dominant_kernel_roofline(window, nv, config_idx, world=1, custom=False):
@@ -771,7 +774,7 @@ def main():
                                   else f"every env ends with probability {args.end_rate} per step (synthetic reward/end head)" if args.end_rate is not None
                                   else END_LOGIT_BIAS_NOTE)
                                + ("; episode lengths staggered over the horizon" if args.stagger else ""),
-                   "env_stats": dict(window.env.stats),
+                   "env_stats": dict(getattr(window.env, "stats", {})),
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (batch-sharded envs, flat-bucket "
                    "RCCL all-reduce of actor-critic grads)", "actor_critic_backend": ac.backend,
                    "world_model_precision": E.WORLD_MODEL_PRECISION, "actor_critic_precision": ac_native.AC_PRECISION,

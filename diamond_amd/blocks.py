@@ -83,10 +83,14 @@ class FilmTable:
         self._packed: Optional[Tuple[Tuple[int, ...], Tensor, Tensor]] = None
         self.stale_epoch = 0  # (see engine.PackCache)
         self.frees_epoch = 0
+        self._audit = E.WeightAudit("FilmTable: the concatenated AdaGroupNorm linears")
         E._WEIGHT_CACHES.add(self)  # optimizer steps that do not bump `_version` (fused AdamW) invalidate through engine's hook
 
     def depends_on(self, param_ids) -> bool:
         return any(id(m.linear.weight) in param_ids or id(m.linear.bias) in param_ids for m in self.norms)
+
+    def audits(self):
+        return (self._audit,)
 
     def weights(self) -> Tuple[Tensor, Tensor]:
         ver = tuple((m.linear.weight._version, m.linear.weight.data_ptr(), m.linear.bias._version, m.linear.bias.data_ptr())
@@ -103,6 +107,10 @@ class FilmTable:
                 w, b = torch.cat(ws, dim=0).contiguous(), torch.cat(bs, dim=0).contiguous()
                 self.frees_epoch += 1 if self._packed is not None else 0
             self._packed = (ver, w, b)
+            srcs = [t for m in self.norms for t in (m.linear.weight, m.linear.bias)]
+            if all(t.dtype == torch.float32 and t.is_contiguous() for t in srcs):
+                self._audit.record(srcs)  # what the table was concatenated from (engine.WeightAudit)
+        self._audit.tick()
         return self._packed[1], self._packed[2]
 
     def invalidate(self) -> None:
@@ -110,6 +118,7 @@ class FilmTable:
         if self._packed is not None:
             self._packed = (None, self._packed[1], self._packed[2])
         self.stale_epoch += 1
+        self._audit.forget()
 
     def refresh(self) -> None:
         self.weights()

@@ -58,3 +58,32 @@ extern "C" int dmd_pack_jobs(const dmd_pack_job* jobs_device, int njobs, int64_t
   DMD_LAUNCH_CHECK();
   return 0;
 }
+
+
+// dmd_checksums -- the audit of the packed copies (ABI v9).  A copy is rebuilt when its parameter's `Tensor._version` / storage
+// pointer changes or an optimizer hook says so; a write that shows in neither (`p.data.copy_`, a collective on `.data`) would
+// leave the kernels running on the old weights, silently.  So the host records, right behind every (re)build, an exact
+// fingerprint of the SOURCE it was built from, and every so often compares it with the live parameter: one launch over all
+// sources.  Fingerprint of a source = DMD_CHECKSUM_PARTS 64-bit sums of its 32-bit words taken as signed integers, part b over the
+// words w with (w / 256) % PARTS == b: exact, no atomics, the same value for the same bits whatever the launch looks like.
+__global__ __launch_bounds__(256) void checksums_kernel(const dmd_checksum_job* __restrict__ jobs, long long* __restrict__ out) {
+  __shared__ long long red[256];
+  const dmd_checksum_job j = jobs[blockIdx.y];
+  const int32_t* w = (const int32_t*)j.src;
+  long long s = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < j.words; i += (int64_t)DMD_CHECKSUM_PARTS * 256) s += (long long)w[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[(size_t)blockIdx.y * DMD_CHECKSUM_PARTS + blockIdx.x] = red[0];
+}
+
+extern "C" int dmd_checksums(const dmd_checksum_job* jobs_device, int njobs, long long* out_device, dmd_stream_t stream) {
+  DMD_CHECK_ARG(jobs_device && out_device && njobs > 0 && njobs <= 65535, "checksums: %d jobs", njobs);
+  hipLaunchKernelGGL(checksums_kernel, dim3(DMD_CHECKSUM_PARTS, (unsigned)njobs), dim3(256), 0, (hipStream_t)stream, jobs_device, out_device);
+  DMD_LAUNCH_CHECK();
+  return 0;
+}

@@ -135,6 +135,158 @@ from torch.optim.optimizer import register_optimizer_step_post_hook as _register
 _register_step_post_hook(_optimizer_stepped)
 
 
+
+class WeightAudit:
+    """Always-on guard of the packed weight copies of ONE cache group (ABI v9, `dmd_checksums`).
+
+    A copy is rebuilt when its parameter's (`_version`, storage pointer) stamp changes, or when the optimizer hook above says
+    so.  A write that shows in neither -- `p.data.copy_(...)`, `p.data.fill_`, a collective on `.data` -- used to be a
+    documented hole: the kernels would go on computing with the old weights.  Now every (re)build is followed by a launch that
+    records an exact fingerprint of the SOURCE values the copy was built from (device-resident, next to the copy), and every
+    AUDIT_EVERY lookups one launch fingerprints the live parameters and compares: a mismatch on a row whose stamp still says
+    "unchanged" is a silent write.  The comparison's answer travels to a pinned buffer asynchronously and is looked at by the
+    next tick / by `check_weight_audits()` (WorldModelEnv calls it right after its per-step host synchronisation): the culprit
+    RAISES instead of training on stale weights.  Cost: one small launch per rebuild, one per few thousand lookups.
+    Capturable: a replayed training step (GraphedTrainStep) rebuilds copies and re-records fingerprints inside the graph."""
+
+    AUDIT_EVERY = 4096
+    CAPACITY = 4096
+
+    def __init__(self, what: str) -> None:
+        self.what = what
+        self._refs: List["weakref.ref"] = []
+        self._row: Dict[int, int] = {}
+        self._ptr: List[int] = []
+        self._stamps: List[Optional[Tuple]] = []
+        self._table: Optional[Tensor] = None
+        self._rec: Optional[Tensor] = None
+        self._live: Optional[Tensor] = None
+        self._pending = None
+        self.ticks = 0
+        self.audits = 0
+
+    @staticmethod
+    def _capturing() -> bool:
+        return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+    def _ensure_row(self, p: Tensor) -> int:
+        i = self._row.get(id(p))
+        if i is not None and self._refs[i]() is p and self._ptr[i] == p.data_ptr() and self._table is not None and self._table.device == p.device:
+            return i
+        assert not self._capturing(), f"WeightAudit({self.what}): a new parameter inside a hipGraph capture (warm the step up eagerly first)"
+        if self._table is None or self._table.device != p.device:
+            self._table = torch.zeros(self.CAPACITY * C.sizeof(nv.ChecksumJob), dtype=torch.uint8, device=p.device)
+            self._rec = torch.zeros(self.CAPACITY, nv.CHECKSUM_PARTS, dtype=torch.int64, device=p.device)
+            self._live = torch.zeros_like(self._rec)
+            self._refs, self._row, self._ptr, self._stamps, self._pending = [], {}, [], [], None
+            i = None
+        if i is None or self._refs[i]() is not p:
+            i = len(self._refs)
+            assert i < self.CAPACITY, f"WeightAudit({self.what}): more than {self.CAPACITY} parameters"
+            self._refs.append(weakref.ref(p))
+            self._ptr.append(0)
+            self._stamps.append(None)
+            self._row[id(p)] = i
+        assert p.element_size() == 4 and p.is_contiguous(), "audited parameters are contiguous 32-bit tensors"
+        job = nv.ChecksumJob()
+        job.src, job.words = p.data_ptr(), p.numel()
+        sz = C.sizeof(nv.ChecksumJob)
+        self._table[i * sz:(i + 1) * sz].copy_(torch.frombuffer(bytearray(bytes(job)), dtype=torch.uint8))
+        self._ptr[i] = p.data_ptr()
+        self._stamps[i] = None
+        return i
+
+    def _launch(self, first: int, count: int, out: Tensor) -> None:
+        sz = C.sizeof(nv.ChecksumJob)
+        nv.check(nv.lib().dmd_checksums(self._table.data_ptr() + first * sz, count, out.data_ptr() + first * nv.CHECKSUM_PARTS * 8,
+                                        nv.stream()), "dmd_checksums")
+
+    def record(self, params) -> None:
+        """The copies of these parameters were (re)built just now, on the current stream: record what they were built from."""
+        rows = sorted(self._ensure_row(p) for p in params)
+        if not rows:
+            return
+        # (contiguous runs: the jobs of a PackCache refresh are all of its rows -> one launch)
+        start = prev = rows[0]
+        for r in rows[1:] + [None]:
+            if r is None or r != prev + 1:
+                self._launch(start, prev - start + 1, self._rec)
+                start = r
+            prev = r
+        for p in params:
+            self._stamps[self._row[id(p)]] = _stamp(p)
+
+    def forget(self) -> None:
+        """The cache was invalidated by someone who knows the values changed (optimizer hook, PackCache.invalidate): nothing is
+        believed fresh until it is rebuilt and recorded again."""
+        self._stamps = [None] * len(self._stamps)
+        self._pending = None
+
+    def tick(self) -> None:
+        self.ticks += 1
+        if self.ticks % self.AUDIT_EVERY == 0:
+            self.run()
+
+    def run(self) -> None:
+        """Fingerprint the live parameters and compare with what the copies were built from (asynchronous; `check` reads it)."""
+        if self._table is None or not self._refs or self._capturing():
+            return
+        self.check()
+        n = len(self._refs)
+        believed = []
+        for i, ref in enumerate(self._refs):
+            p = ref()
+            believed.append(p is not None and self._stamps[i] is not None and self._stamps[i] == _stamp(p))
+        if not any(believed):
+            return
+        self._launch(0, n, self._live)
+        bad = (self._live[:n] != self._rec[:n]).any(dim=1)
+        self.audits += 1
+        if bad.is_cuda:
+            host = torch.empty(n, dtype=torch.bool).pin_memory()
+            host.copy_(bad, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            host, ev = bad.clone(), None
+        self._pending = (ev, host, believed)
+
+    def check(self, wait: bool = False) -> None:
+        if self._pending is None:
+            return
+        ev, host, believed = self._pending
+        if ev is not None:
+            if wait:
+                ev.synchronize()
+            elif not ev.query():
+                return
+        self._pending = None
+        rows = [i for i, (b, ok) in enumerate(zip(host.tolist(), believed)) if b and ok]
+        # (a row counts only if its stamp STILL says unchanged: a visible update between audit and check is not a silent one)
+        rows = [i for i in rows if self._refs[i]() is not None and self._stamps[i] is not None and self._stamps[i] == _stamp(self._refs[i]())]
+        if rows:
+            shapes = [tuple(self._refs[i]().shape) for i in rows[:4]]
+            self.forget()
+            raise RuntimeError(
+                f"stale packed weights ({self.what}): {len(rows)} parameter(s), e.g. of shape {shapes}, changed WITHOUT a version bump "
+                "(`p.data.copy_`, `p.data.fill_`, a collective on `.data`, ...) after their kernel-layout copies were built, and the kernels "
+                "have been reading the old values since.  Write through the parameter itself (`with torch.no_grad(): p.copy_(x)`) or call "
+                "`PackCache.invalidate()` / `FilmTable.invalidate()` after such a write.")
+
+
+def check_weight_audits(wait: bool = False) -> None:
+    """Raise if any cache's last audit found a silent parameter write (cheap: an event query per cache with an audit in flight)."""
+    for cache in list(_WEIGHT_CACHES):
+        for a in cache.audits():
+            a.check(wait)
+
+
+def run_weight_audits() -> None:
+    for cache in list(_WEIGHT_CACHES):
+        for a in cache.audits():
+            a.run()
+
+
 class PackCache:
     """Kernel-layout copies of nn.Module parameters, refreshed when a parameter changes
     (optimizer steps bump `Tensor._version`, or are seen by the hook above).  Parameters keep the reference's OIHW / (out,in)
@@ -157,7 +309,11 @@ class PackCache:
         # in place changes neither: the graph reads the new values through the same pointer.)
         self.stale_epoch = 0
         self.frees_epoch = 0
+        self._audit_jobs, self._audit_store = WeightAudit("PackCache: convolution copies"), WeightAudit("PackCache: other copies")
         _WEIGHT_CACHES.add(self)
+
+    def audits(self):
+        return (self._audit_jobs, self._audit_store)
 
     def depends_on(self, param_ids) -> bool:
         """Does this cache hold a copy of any of these parameters (ids)?"""
@@ -173,12 +329,15 @@ class PackCache:
         for ent in self._jobs.values():
             ent.stamp = None
         self.stale_epoch += 1
+        self._audit_jobs.forget()
+        self._audit_store.forget()
 
     def get(self, p: Tensor, kind: str, fn):
         key = (id(p), kind)
         hit = self._store.get(key)
         if hit is None or hit[0] != _stamp(p) or hit[1]() is not p:
             hit = self._rebuild(key, p, fn, hit)
+        self._audit_store.tick()
         return hit[2]
 
     def _rebuild(self, key, p: Tensor, fn, hit):
@@ -194,6 +353,8 @@ class PackCache:
             self.frees_epoch += 1
         hit = (_stamp(p), weakref.ref(p), new, fn)
         self._store[key] = hit
+        if isinstance(new, Tensor) and new.data_ptr() != p.data_ptr() and p.element_size() == 4 and p.is_contiguous():
+            self._audit_store.record([p])  # (a copy that IS the parameter cannot be stale)
         return hit
 
     def refresh(self) -> None:
@@ -215,6 +376,7 @@ class PackCache:
         key = (id(p), kind, cout_pad, transposed, c0, c1, cin_pad_to)
         ent = self._jobs.get(key)
         if ent is not None and ent.ref() is p and ent.stamp == _stamp(p):
+            self._audit_jobs.tick()
             return ent.out
         if ent is None or ent.ref() is not p or ent.out.device != p.device:
             assert p.dtype == torch.float32 and p.is_contiguous(), "convolution parameters are contiguous fp32"
@@ -253,6 +415,7 @@ class PackCache:
         table = torch.frombuffer(bytearray(bytes(e.job)), dtype=torch.uint8).to(e.out.device)
         nv.check(nv.lib().dmd_pack_jobs(nv.ptr(table), 1, e.elems, nv.stream()), "dmd_pack_jobs")
         e.stamp = _stamp(e.ref())
+        self._audit_jobs.record([e.ref()])
 
     def _refresh(self) -> None:
         """Rebuild every registered copy with one launch (all of them: whoever changed one parameter changed them all)."""
@@ -281,9 +444,13 @@ class PackCache:
             self._table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
             self._max_elems = max(e.elems for e in self._table_entries)
         nv.check(nv.lib().dmd_pack_jobs(nv.ptr(self._table), len(self._table_entries), self._max_elems, nv.stream()), "dmd_pack_jobs")
+        live = {}
         for e in self._table_entries:
             p = e.ref()
             e.stamp = None if p is None else _stamp(p)
+            if p is not None:
+                live[id(p)] = p
+        self._audit_jobs.record(list(live.values()))
 
     def conv_weight(self, conv: nn.Conv2d, cout_padded: Optional[int] = None) -> Tensor:
         return self._conv_job(conv.weight, nv.PACK_F32, cout_padded or nv.cout_pad(conv.out_channels))

@@ -42,7 +42,7 @@ def sample_categorical(logits: Tensor, expo: Optional[Tensor] = None) -> Tensor:
     return out.reshape(shape)
 
 
-PIPELINE_PROTOCOL = ("step_begin", "step_begin_repair", "step_end_issue", "step_end_finish", "may_speculate", "plan_resets")
+PIPELINE_PROTOCOL = ("step_begin", "step_begin_repair", "step_end_issue", "step_end_finish", "may_speculate", "plan_resets", "policy_speculation_pays")
 
 
 def _reset_chain(model, final_obs: Tensor, burnin: Tensor, new_obs: Optional[Tensor], h_d: Tensor, c_d: Tensor):
@@ -72,22 +72,57 @@ def _reset_chain(model, final_obs: Tensor, burnin: Tensor, new_obs: Optional[Ten
     return val_final, (hz, cz), step
 
 
+def _policy_step(model, obs: Tensor, hx: Tensor, cx: Tensor, resets=None):
+    """The policy's step on `obs` -- and, in the SAME encoder pass, what the resets in front of it ask for (reference
+    env_loop.py:45-56): resets = (rows, final_obs, burnin_obs) of the envs whose episode just ended (`obs` already shows their new
+    episode's newest frame): V(final observation) without grad on the state the episode ended with, the LSTM's burn-in over the new
+    episode's context frames WITH grad from a zero state (= the reference's gate-then-burn-in), then the step for everybody.
+    The encoder does not see the LSTM state, so obs + final + burn-in frames are ONE batch for it (`encode` /
+    `predict_from_features`; per sample the arithmetic of separate calls: batch-invariant kernels) -- no small-batch encoder pass,
+    forward or backward.  Returns (logits, val, (h, c) after the step, (h0, c0) the state the step started from, val_final | None)."""
+    if resets is None:
+        logits, val, hc = model.predict_act_value(obs, (hx, cx))
+        return logits, val, hc, (hx, cx), None
+    rows, fin, burn = resets
+    k, tb = burn.shape[:2]
+    b = obs.shape[0]
+    h_d, c_d = hx.index_select(0, rows), cx.index_select(0, rows)
+    if hasattr(model, "predict_from_features"):
+        feats = model.encode(torch.cat([obs, fin, burn.transpose(0, 1).reshape(k * tb, *burn.shape[2:])]))
+        run = lambda lo, hi, frames, hc: model.predict_from_features(feats[lo:hi], hc)
+    else:  # a model without a separable encoder: the reference's own sequence of calls
+        run = lambda lo, hi, frames, hc: model.predict_act_value(frames, hc)
+    with torch.no_grad():
+        _, val_final, _ = run(b, b + k, fin, (h_d, c_d))
+    hz, cz = torch.zeros_like(h_d), torch.zeros_like(c_d)  # (the gated state of a dead row)
+    for i in range(tb):
+        _, _, (hz, cz) = run(b + (1 + i) * k, b + (2 + i) * k, burn[:, i], (hz, cz))
+    h0, c0 = hx.index_copy(0, rows, hz), cx.index_copy(0, rows, cz)
+    logits, val, hc = run(0, b, obs, (h0, c0))
+    return logits, val, hc, (h0, c0), val_final
+
+
 def _pipelined_env_loop(env, model, expo_fn: Optional[Callable[[Tensor], Tensor]], num_steps: int):
     """make_env_loop for an env that implements WorldModelEnv's pipelining protocol (PIPELINE_PROTOCOL), epsilon = 0.
 
     Per imagined step the reference has ONE data-dependent branch (`if dead.any()`, world_model_env.py:77, env_loop.py:45): a
-    host wait for the device.  Here the work of step n + 1 is issued BEFORE the wait of step n:
-      * the policy's step n + 1 on the imagined frame (between env.step_begin and env.step_end_issue);
-      * the sampler's step n + 1 (env.step_begin(..., speculative=True) between step_end_issue and step_end_finish), when the
-        env says it pays (may_speculate);
-      * resets the host can foresee -- truncations: env.plan_resets() -- are part of that pipeline: V(final observation), the
-        burn-in and the policy's step on the new episodes are computed for those rows ahead of the wait, the env resets them
-        right behind the reward / end model, and the speculative sampler step already runs on the new episodes.
-    Deaths nobody planned (`end` sampled by the reward / end model) void ONLY their own rows (info["void_rows"]): the policy is
-    recomputed for them after the reset with the exponential draws the speculation made, the env repeats their sampler step
-    (step_begin_repair), and every other row keeps its speculated result -- per row the same arithmetic in the same order on
-    batch-invariant kernels, every random stream consumed in the reference's order: bitwise the sequential rollout
-    (tests/test_env_loop_host.py on a toy env; the window goldens and the sequential A/B on the GPU)."""
+    host wait for the device.  Two things are done about it, both exact:
+
+    (a) ONE encoder pass per step.  What a reset asks of the policy -- V(final observation), the burn-in frames of the new
+        episode -- rides in the batch of the policy's next step (_policy_step): no small-batch encoder pass forward or backward.
+    (b) While unforeseen deaths are rare (env.policy_speculation_pays()), the work of step n + 1 is issued BEFORE the wait of
+        step n: the policy's step n + 1 on the imagined frame (between env.step_begin and env.step_end_issue); the sampler's step
+        n + 1 (env.step_begin(..., speculative=True) between step_end_issue and step_end_finish) when the env says it pays
+        (may_speculate); and the resets the host can foresee -- truncations: env.plan_resets() -- are part of that pipeline:
+        their frames are in the speculated policy pass, the env resets those rows right behind the reward / end model, and the
+        speculative sampler step already runs on the new episodes.  Deaths nobody planned (`end` sampled by the reward / end
+        model) void ONLY their own rows (info["void_rows"]): the policy is recomputed for them after the reset with the
+        exponential draws the speculation made, the env repeats their sampler step (step_begin_repair), every other row keeps
+        its speculated result.  Where unforeseen deaths are frequent nothing is speculated: the reference's order, with (a).
+
+    Per row the same arithmetic in the same order on batch-invariant kernels, every random stream consumed in the reference's
+    order: bitwise the sequential rollout whatever the mode (tests/test_env_loop_host.py on a toy env; the window goldens and the
+    sequential A/B on the GPU)."""
     dev = model.device
     hx = torch.zeros(env.num_envs, model.lstm_dim, device=dev)
     cx = torch.zeros(env.num_envs, model.lstm_dim, device=dev)
@@ -96,7 +131,9 @@ def _pipelined_env_loop(env, model, expo_fn: Optional[Callable[[Tensor], Tensor]
 
     def draw_expo(logits: Tensor) -> Tensor:
         e = expo_fn(logits) if expo_fn is not None else None
-        return e if e is not None else torch.empty(logits.shape, device=logits.device, dtype=torch.float32).exponential_(1)
+        if e is None:
+            return torch.empty(logits.shape, device=logits.device, dtype=torch.float32).exponential_(1)
+        return e.to(device=logits.device, dtype=torch.float32)  # (hook-injected draws may come from the CPU generator)
 
     def merge(cand, rows: Tensor, step, expo: Tensor):
         """rows of the candidate policy output <- the step recomputed for them after their reset (their own exponential draws)"""
@@ -105,6 +142,10 @@ def _pipelined_env_loop(env, model, expo_fn: Optional[Callable[[Tensor], Tensor]
         return [cand[0].index_copy(0, rows, logits), cand[1].index_copy(0, rows, val),
                 (cand[2][0].index_copy(0, rows, h), cand[2][1].index_copy(0, rows, c)), cand[3].index_copy(0, rows, act)]
 
+    def full(rows: Tensor, v: Tensor, like: Tensor) -> Tensor:
+        return torch.zeros_like(like).index_copy(0, rows, v)
+
+    pending = None  # (rows, final_obs, burnin_obs): deaths whose policy-side reset rides in the next _policy_step
     while True:
         hx, cx = hx.detach(), cx.detach()  # BPTT window boundary
         rows_out, infos = [], []
@@ -113,7 +154,9 @@ def _pipelined_env_loop(env, model, expo_fn: Optional[Callable[[Tensor], Tensor]
         prev_dead = prev_vfinal = None
         for n in range(num_steps):
             if pol is None:
-                logits_act, val, (hx, cx) = model.predict_act_value(obs, (hx, cx))
+                logits_act, val, (hx, cx), _, vfin = _policy_step(model, obs, hx, cx, pending)
+                if pending is not None:
+                    prev_vfinal, pending = full(pending[0], vfin, val.detach()), None
                 act = sample_categorical(logits_act, draw_expo(logits_act))
             else:
                 logits_act, val, (hx, cx), act = pol
@@ -124,16 +167,17 @@ def _pipelined_env_loop(env, model, expo_fn: Optional[Callable[[Tensor], Tensor]
             nxt = begun if begun is not None else env.step_begin(act)
             begun = None
             cand = s_expo = vfinal = None
-            if n + 1 < num_steps:
+            if n + 1 < num_steps and env.policy_speculation_pays():
                 plan = env.plan_resets()
-                cand = list(model.predict_act_value(nxt, (hx, cx)))
-                s_expo = draw_expo(cand[0])
-                cand.append(sample_categorical(cand[0], s_expo))
-                if plan is not None:
+                if plan is None:
+                    c_logits, c_val, c_hc, _, _ = _policy_step(model, nxt, hx, cx, None)
+                else:
                     r = plan["rows"]
-                    v, _, step = _reset_chain(model, nxt.index_select(0, r), plan["burnin_obs"], plan["obs"], hx.index_select(0, r), cx.index_select(0, r))
-                    cand = merge(cand, r, step, s_expo)
-                    vfinal = torch.zeros_like(val.detach()).index_copy(0, r, v)
+                    c_logits, c_val, c_hc, _, v = _policy_step(model, nxt.index_copy(0, r, plan["obs"]), hx, cx,
+                                                               (r, nxt.index_select(0, r), plan["burnin_obs"]))
+                    vfinal = full(r, v, val.detach())
+                s_expo = draw_expo(c_logits)
+                cand = [c_logits, c_val, c_hc, sample_categorical(c_logits, s_expo)]
             env.step_end_issue()
             if cand is not None and env.may_speculate():
                 begun = env.step_begin(cand[3], speculative=True)
@@ -142,22 +186,19 @@ def _pipelined_env_loop(env, model, expo_fn: Optional[Callable[[Tensor], Tensor]
             prev_dead = prev_vfinal = None
             if info["any_dead"]:
                 prev_dead = torch.logical_or(end, trunc)
-                ridx, void = info["dead_rows"], info.get("void_rows")
-                if void is not None:  # deaths no plan covered: their part of the reset chain now, on the rows concerned only
+                void = info.get("void_rows")
+                if cand is None:  # nothing was speculated: the resets ride in the next policy step (all of them: no plan either)
+                    pending = (info["dead_rows"], info["final_observation"], info["burnin_obs"])
+                elif void is not None:  # deaths no plan covered: their part now, on the rows concerned only
                     pos = info.get("void_pos")
                     fin, burn = info["final_observation"], info["burnin_obs"]
                     if pos is not None:
                         fin, burn = fin.index_select(0, pos), burn.index_select(0, pos)
-                    new_obs = next_obs.index_select(0, void) if cand is not None else None
-                    v, (hz, cz), step = _reset_chain(model, fin, burn, new_obs, hx.index_select(0, void), cx.index_select(0, void))
+                    v, _, step = _reset_chain(model, fin, burn, next_obs.index_select(0, void), hx.index_select(0, void), cx.index_select(0, void))
                     vfinal = (torch.zeros_like(val.detach()) if vfinal is None else vfinal).index_copy(0, void, v)
-                    if cand is not None:
-                        cand = merge(cand, void, step, s_expo)
-                        if info.get("repair_pending"):
-                            begun = env.step_begin_repair(cand[3])
-                    else:  # last step of the window: the state the next window starts from
-                        gate = 1 - prev_dead.float().unsqueeze(1)
-                        hx, cx = (hx * gate).index_copy(0, void, hz), (cx * gate).index_copy(0, void, cz)
+                    cand = merge(cand, void, step, s_expo)
+                    if info.get("repair_pending"):
+                        begun = env.step_begin_repair(cand[3])
                 prev_vfinal = vfinal
             pol = cand
             rows_out.append([obs, act, rew, end, trunc, logits_act, val, None])
@@ -165,7 +206,10 @@ def _pipelined_env_loop(env, model, expo_fn: Optional[Callable[[Tensor], Tensor]
             obs = next_obs
 
         with torch.no_grad():
-            _, vb, _ = model.predict_act_value(obs, (hx, cx))
+            _, vb, _, (h0, c0), vfin = _policy_step(model, obs, hx, cx, pending)
+        if pending is not None:  # deaths at the window's last step: the state the next window starts from is the burnt-in one
+            prev_vfinal, pending = full(pending[0], vfin, vb), None
+            hx, cx = h0, c0
         rows_out[-1][-1] = vb if prev_dead is None else torch.where(prev_dead, prev_vfinal, vb)
         stacked = tuple(torch.stack(col, dim=1) for col in zip(*rows_out))
         num_steps = yield (*stacked, infos)

@@ -72,6 +72,13 @@ class PackJob(C.Structure):
 
 PACK_F32, PACK_F16X2, PACK_BIAS = 0, 1, 2
 
+
+class ChecksumJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("words", C.c_int64)]
+
+
+CHECKSUM_PARTS = 8
+
 CHAIN_MAX_BLOCKS = 8
 
 
@@ -91,7 +98,7 @@ class LowresChainParams(C.Structure):
 
 EXPORTS = (
     "dmd_conv2d", "dmd_conv2d_kernel_name", "dmd_conv2d_naive", "dmd_conv_stat_tiles", "dmd_pack_conv_weight", "dmd_conv2d_f16x2_eligible",
-    "dmd_conv1x1_stream_eligible", "dmd_conv2d_proj_eligible", "dmd_pack_jobs",
+    "dmd_conv1x1_stream_eligible", "dmd_conv2d_proj_eligible", "dmd_pack_jobs", "dmd_checksums",
     "dmd_pack_conv_weight_f16x2", "dmd_linear", "dmd_attention", "dmd_attention_valid", "dmd_attention_bwd", "dmd_attention_bwd_workspace_floats",
     "dmd_edm_pack_input", "dmd_cond_embed", "dmd_edm_denoised", "dmd_euler_step", "dmd_heun_step", "dmd_quantize_u8",
     "dmd_dequant_gather", "dmd_nchw_to_nhwc",
@@ -179,6 +186,7 @@ def declare_signatures(L: C.CDLL) -> None:
     L.dmd_conv1x1_stream_eligible.argtypes = [C.POINTER(ConvParams)]
     L.dmd_conv2d_proj_eligible.argtypes = [C.POINTER(ConvParams)]
     L.dmd_pack_jobs.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
+    L.dmd_checksums.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.dmd_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.dmd_attention_valid.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.dmd_attention_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

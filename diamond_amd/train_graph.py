@@ -108,6 +108,11 @@ class GraphedTrainStep:
                 f"batch.{k}: {tuple(src.shape)} {src.dtype}, captured with {tuple(buf.shape)} {buf.dtype} (static shapes)"
             buf.copy_(src, non_blocking=True)
         self.graph.replay()
+        self._replays = getattr(self, "_replays", 0) + 1
+        if self._replays % 64 == 0:  # the always-on audit of the packed copies (engine.WeightAudit): no lookup runs inside a replay
+            for c in _weight_caches(self.model):
+                for a in c.audits():
+                    a.run()
         # The replayed optimizer update changed every parameter without bumping its `_version`; the packed copies were
         # rebuilt from the new values by the replay itself, in place: the stamps of capture time still describe them, and
         # graphs captured elsewhere from the same weights (DiffusionSampler.sample_ring_graphed) read the new values through

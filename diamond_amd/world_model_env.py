@@ -28,6 +28,7 @@ import torch
 from torch import Tensor
 
 from . import native as nv
+from .engine import check_weight_audits
 from .diffusion_sampler import DiffusionSampler, DiffusionSamplerConfig
 from .env_loop import sample_categorical
 
@@ -182,7 +183,13 @@ class InitialConditionPool:
 # with it -- the void rows' sampler step again on a small batch, latency-bound (~3 ms) plus their share of a full step (~19 ms
 # at batch 256) -- against the hole the device sits through without it (~2 ms per step while the host issues the first launches
 # of the sampler).  may_speculate() compares running averages of both; DIAMOND_SPEC_SAMPLER=0/1 pins the answer (A/B).
-SPEC_REPAIR_MS, SPEC_FULL_STEP_MS, SPEC_HOLE_MS = 3.0, 19.0, 2.0
+SPEC_REPAIR_MS, SPEC_FULL_STEP_MS, SPEC_HOLE_MS = 3.0, 19.0, 0.5
+# Policy speculation (the policy's step n + 1 issued before step n's host synchronisation, planned resets included): an unforeseen
+# death costs a small-batch repetition of the reset chain for its rows (~2-3 ms, latency-bound, forward and backward) where the
+# unspeculated order would have carried those frames in the next step's encoder pass for free; a step without one saves the
+# ~2 ms the device waits while the host issues the policy's launches.  Worth it while fewer than this share of the steps has
+# an unforeseen death (DIAMOND_SPEC_POLICY=0/1 pins the answer).
+POLICY_SPEC_MAX_UNFORESEEN = 0.3
 
 
 class WorldModelEnv:
@@ -382,6 +389,14 @@ class WorldModelEnv:
             return pin == "1"
         return self._void_events * SPEC_REPAIR_MS + self._void_frac * SPEC_FULL_STEP_MS < SPEC_HOLE_MS
 
+    def policy_speculation_pays(self) -> bool:
+        """Should the caller issue the policy's NEXT step (with planned resets) before this step's host synchronisation?  Only
+        while deaths the host cannot foresee are rare: see POLICY_SPEC_MAX_UNFORESEEN."""
+        pin = os.environ.get("DIAMOND_SPEC_POLICY")
+        if pin in ("0", "1"):
+            return pin == "1"
+        return self._void_events < POLICY_SPEC_MAX_UNFORESEEN
+
     @torch.no_grad()
     def plan_resets(self) -> Optional[Dict[str, Any]]:
         """Truncations are predictable: the envs whose episode reaches the horizon IN THE STEP THAT IS PENDING (between step_begin
@@ -455,11 +470,14 @@ class WorldModelEnv:
         if dead.is_cuda:
             self._flag_event.synchronize()
             rows_host = np.flatnonzero(self._dead_host.numpy())
+            check_weight_audits()  # (the host is synchronised anyway: did an audit of the packed weight copies find a silent write?)
         else:
             rows_host = np.flatnonzero(dead.numpy())
         any_dead = rows_host.size > 0
+        unforeseen = int(rows_host.size)
         if self._ep_len_host is not None:
             self._ep_len_host += 1
+            unforeseen = int(np.count_nonzero(self._ep_len_host[rows_host] < self.horizon))  # (not a truncation: an `end`)
             self._ep_len_host[rows_host] = 0
         plan, self._plan = self._plan, None
         obs = next_obs  # a fresh tensor every step: never aliases the ring
@@ -509,8 +527,10 @@ class WorldModelEnv:
                     info["void_rows"] = self._rows_to_device(void_host)
                     info["void_pos"] = self._rows_to_device(np.arange(total - void_host.size, total))
         n_void = int(void_host.size) if any_dead else 0
-        self._void_events = 0.9 * self._void_events + 0.1 * (1.0 if n_void else 0.0)
-        self._void_frac = 0.9 * self._void_frac + 0.1 * (n_void / self.num_envs)
+        # running averages the speculation decisions are taken from: the share of steps with a death the host could not foresee
+        # (whatever was planned or speculated in THIS step), and the share of rows such steps void
+        self._void_events = 0.9 * self._void_events + 0.1 * (1.0 if unforeseen else 0.0)
+        self._void_frac = 0.9 * self._void_frac + 0.1 * ((n_void if plan is not None else unforeseen) / self.num_envs)
         if self._pending is not None and self._pending_speculative and n_void:
             self._repair_rows = info["void_rows"]
             info["repair_pending"] = True

@@ -135,6 +135,18 @@ typedef struct dmd_pack_job {
 } dmd_pack_job;
 int dmd_pack_jobs(const dmd_pack_job* jobs_device, int njobs, int64_t max_elems, dmd_stream_t stream);
 
+/* ABI v9: fingerprints of parameter storage, for the always-on audit of the packed copies (engine.WeightAudit): a copy is keyed on
+ * the parameter's version counter and storage pointer, and a write that changes neither (`p.data.copy_`, a collective on
+ * `.data`) must not go unnoticed.  out[j * DMD_CHECKSUM_PARTS + b] = the sum, in 64 bits, of the 32-bit words w of jobs[j].src
+ * (as signed integers) with (w / 256) % DMD_CHECKSUM_PARTS == b: exact and independent of the launch.  No reference
+ * counterpart (torch keeps no second copy of a parameter: F.conv2d reads the parameter itself, /root/reference/src/models/blocks.py:18-31). */
+#define DMD_CHECKSUM_PARTS 8
+typedef struct dmd_checksum_job {
+  const void* src;
+  int64_t words; /* 32-bit words */
+} dmd_checksum_job;
+int dmd_checksums(const dmd_checksum_job* jobs_device, int njobs, long long* out_device, dmd_stream_t stream);
+
 int dmd_conv2d(const dmd_conv_params* p, dmd_stream_t stream);
 /* name of the kernel instantiation dmd_conv2d launches for these parameters, spelled like rocprofv3's kernel trace
  * (e.g. "conv_f16ws_kernel<WsGeom<false, 2, 9>>"): measurement plumbing for bench.py / profiles */

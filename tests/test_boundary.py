@@ -109,7 +109,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     for sym in sorted(declared):
         assert hasattr(lib, sym), f"{sym} declared in include/diamond_hip.h but not exported"
     assert set(native.EXPORTS) == declared
-    assert lib.dmd_abi_version() == 8
+    assert lib.dmd_abi_version() == 9
     assert lib.dmd_conv_stat_tiles(64, 64) == 32 and lib.dmd_conv_stat_tiles(8, 8) == 1
 
 

@@ -326,9 +326,9 @@ class PipeEnv(PoolEnv):
     """The same env behind WorldModelEnv's pipelining protocol (env_loop.PIPELINE_PROTOCOL): planned resets for the truncations
     the host can foresee, speculative step_begin, per-row repair after unplanned deaths."""
 
-    def __init__(self, b, p_end, horizon, stagger=False, speculate=True):
+    def __init__(self, b, p_end, horizon, stagger=False, speculate=True, policy_spec=True):
         super().__init__(b, p_end, horizon, stagger)
-        self.speculate = speculate
+        self.speculate, self.policy_spec, self._asked = speculate, policy_spec, 0
         self._pending = self._plan = self._issued = self._repair = None
         self.counts = {"planned": 0, "void": 0, "repairs": 0, "spec": 0, "mixed": 0}
 
@@ -356,6 +356,10 @@ class PipeEnv(PoolEnv):
 
     def may_speculate(self):
         return self.speculate
+
+    def policy_speculation_pays(self):
+        self._asked += 1
+        return self._asked % 3 != 0 if self.policy_spec == "alternate" else self.policy_spec
 
     def plan_resets(self):
         assert self._pending is not None and self._plan is None
@@ -435,16 +439,16 @@ def _windows(env, pol, windows, t, monkeypatch, mode):
 
 
 @pytest.mark.parametrize("separable", [True, False])
-@pytest.mark.parametrize("speculate", [True, False])
+@pytest.mark.parametrize("speculate,policy_spec", [(True, True), (False, True), (False, False), (True, "alternate")])
 @pytest.mark.parametrize("p_end,horizon,stagger", [(0.0, 6, False), (0.0, 7, True), (0.02, 7, True), (0.12, 7, True), (0.35, 5, False), (0.6, 9, True)])
-def test_pipelined_loop_is_bitwise_the_sequential_one(monkeypatch, p_end, horizon, stagger, speculate, separable):
+def test_pipelined_loop_is_bitwise_the_sequential_one(monkeypatch, p_end, horizon, stagger, speculate, policy_spec, separable):
     """planned truncation resets inside the pipeline, speculative sampler steps, unplanned deaths repaired row by row, deaths at
     the last step of a window, mixed steps (an `end` in front of planned truncations: pool order), all of it on ONE shared random
     stream against the reference's order of operations"""
     b, t, windows = 9, 6, 5
     pol = lambda: SeparablePolicy(True) if separable else ToyPolicy()
     seq = _windows(PoolEnv(b, p_end, horizon, stagger), pol(), windows, t, monkeypatch, "1")  # (no protocol: the generic loop)
-    env = PipeEnv(b, p_end, horizon, stagger, speculate)
+    env = PipeEnv(b, p_end, horizon, stagger, speculate, policy_spec)
     pipe = _windows(env, pol(), windows, t, monkeypatch, "1")
     names = ("obs", "act", "rew", "end", "trunc", "logits", "val", "val_bootstrap")
     for w, (wa, wb) in enumerate(zip(seq, pipe)):
@@ -453,12 +457,15 @@ def test_pipelined_loop_is_bitwise_the_sequential_one(monkeypatch, p_end, horizo
     c = env.counts
     if speculate:
         assert c["spec"] > 0
-    if (stagger or horizon % t) and p_end < 0.5:  # (at p = 0.6 hardly an episode reaches the horizon)
-        assert c["planned"] > 0, "no truncation was planned"
-    if p_end > 0:
-        assert c["void"] > 0 and (c["repairs"] > 0) == speculate
-    if 0.12 <= p_end < 0.5 and stagger:
-        assert c["mixed"] > 0, "no step had an unplanned death next to planned truncations"
+    if policy_spec is False:  # the reference's order + one encoder pass per step: nothing planned, nothing speculated
+        assert c["planned"] == 0 and c["spec"] == 0 and c["repairs"] == 0
+    else:
+        if (stagger or horizon % t) and p_end < 0.5:  # (at p = 0.6 hardly an episode reaches the horizon)
+            assert c["planned"] > 0, "no truncation was planned"
+        if p_end > 0:
+            assert c["void"] > 0 and (c["repairs"] > 0) == speculate
+        if 0.12 <= p_end < 0.5 and stagger:
+            assert c["mixed"] > 0, "no step had an unplanned death next to planned truncations"
     # the protocol-less path on the same env class gives the same thing (PipeEnv.step = begin + issue + finish without a plan)
     again = _windows(PipeEnv(b, p_end, horizon, stagger), pol(), windows, t, monkeypatch, "0")
     for wa, wb in zip(seq, again):

@@ -771,9 +771,9 @@ def test_speculative_policy_step_is_bitwise_the_sequential_one(monkeypatch):
             assert torch.equal(a, b_)
 
 
-@pytest.mark.parametrize("spec", ["1", "0"])
+@pytest.mark.parametrize("spec,policy", [("1", "1"), ("0", "1"), ("0", "0"), ("auto", "auto")])
 @pytest.mark.parametrize("b,horizon,p_end,stagger", [(24, 5, 0.03, True), (12, 7, 0.25, False), (16, 6, 0.0, True)])
-def test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon, p_end, stagger, spec):
+def test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon, p_end, stagger, spec, policy="1"):
     """env_loop's pipelined form (planned truncation resets inside the speculated pipeline, unplanned deaths repaired row by row on
     a small batch: env_loop._pipelined_env_loop, WorldModelEnv.plan_resets / step_begin_repair) against the reference's sequential
     order of operations (DIAMOND_SPECULATIVE_POLICY=0), three windows on the DEVICE random generator at batches the graphed
@@ -789,7 +789,8 @@ def test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon,
     runs, stats = [], None
     for mode in ("1", "0"):
         monkeypatch.setenv("DIAMOND_SPECULATIVE_POLICY", mode)
-        monkeypatch.setenv("DIAMOND_SPEC_SAMPLER", spec)
+        for k, v in (("DIAMOND_SPEC_SAMPLER", spec), ("DIAMOND_SPEC_POLICY", policy)):  # pinned modes, or the env's own running averages
+            monkeypatch.delenv(k, raising=False) if v == "auto" else monkeypatch.setenv(k, v)
         monkeypatch.setenv("DIAMOND_CHECK_RESET_RNG", "1")
         ag = make_agent()
         set_end_rate(ag, p_end if p_end > 0 else 1e-9)
@@ -815,10 +816,13 @@ def test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon,
     for w, (wa, wb) in enumerate(zip(*runs)):
         for name, a, b_ in zip(names, wa, wb):
             assert torch.equal(a, b_), (w, name)
-    assert stats["planned_rows"] > 0, stats
-    if p_end > 0:
-        assert stats["void_rows"] > 0 and (stats["repairs"] > 0) == (spec == "1"), stats
-    assert (stats["speculated"] > 0) == (spec == "1"), stats
+    if policy == "1":
+        assert stats["planned_rows"] > 0, stats
+        if p_end > 0:
+            assert stats["void_rows"] > 0 and (stats["repairs"] > 0) == (spec == "1"), stats
+        assert (stats["speculated"] > 0) == (spec == "1"), stats
+    elif policy == "0":  # the reference's order with one encoder pass per step: nothing planned, nothing speculated
+        assert stats["planned_rows"] == 0 and stats["speculated"] == 0 and stats["repairs"] == 0, stats
 
 
 @pytest.mark.parametrize("num_actions", [6, 18])

@@ -173,3 +173,88 @@ def test_a_fused_optimizer_step_is_seen_although_it_bumps_no_version():
     assert torch.equal(f1, net["norm"].linear.weight.detach()) and not torch.equal(f1, f0)
     # a graph owner watching the epochs sees the step; a cache of parameters the optimizer does not hold is left alone
     assert cache.stale_epoch == epochs[0] + 1 and film.stale_epoch == epochs[1] + 1 and cache_other.stale_epoch == epochs[2]
+
+
+def _audited_setup():
+    from diamond_amd import engine as E
+    from diamond_amd.blocks import AdaGroupNorm, FilmTable
+
+    torch.manual_seed(5)
+    net = nn.ModuleDict({"conv": nn.Conv2d(64, 64, 3, padding=1), "conv2": nn.Conv2d(32, 32, 3, padding=1), "norm": AdaGroupNorm(64, 256),
+                         "lstm": nn.LSTMCell(128, 64)}).to(DEV)
+    cache, film = E.PackCache(), FilmTable(net)
+
+    def use():
+        cache.conv_weight_f16x2(net["conv"]), cache.conv_weight(net["conv2"]), cache.conv_bias(net["conv"], 128)
+        cache.get(net["lstm"].weight_ih, "T", lambda w: w.detach().t().contiguous())
+        cache.f32(net["lstm"].bias_ih)  # (aliases the parameter: never audited, never stale)
+        film.weights()
+
+    use()
+    return E, net, cache, film, use
+
+
+def _audit_all(E, wait=True):
+    E.run_weight_audits()
+    E.check_weight_audits(wait=wait)
+
+
+@pytest.mark.parametrize("victim", ["conv.weight", "conv.bias", "lstm.weight_ih", "norm.linear.weight"])
+@pytest.mark.parametrize("how", ["data.copy_", "data.mul_", "set_ under no_grad via .data view"])
+def test_a_silent_parameter_write_is_detected_by_the_audit(victim, how):
+    """`p.data.<op>_` changes a parameter without bumping `Tensor._version`, the stamp the packed copies are keyed on: it used to be
+    a documented hole (the kernels kept computing with the old weights).  The audit (engine.WeightAudit, `dmd_checksums`)
+    fingerprints what every copy was built from and compares with the live parameter: the write RAISES at the next check --
+    for a convolution copy of the job table, a padded bias, a looked-up transposed LSTM weight and the FiLM table alike."""
+    E, net, cache, film, use = _audited_setup()
+    _audit_all(E)  # clean: nothing to report
+    p = dict(net.named_parameters())[victim]
+    v0 = p._version
+    if how == "data.copy_":
+        p.data.copy_(torch.randn_like(p))
+    elif how == "data.mul_":
+        p.data.mul_(1.5)
+    else:
+        p.data.view(-1)[3] = 7.0
+    assert p._version == v0, "the write was visible after all"
+    use()  # still the stale copies: no stamp changed
+    with pytest.raises(RuntimeError, match="stale packed weights"):
+        _audit_all(E)
+    # after the documented remedy the copies are rebuilt and the audit is clean again
+    cache.invalidate(), film.invalidate()
+    use()
+    _audit_all(E)
+
+
+def test_the_audit_raises_no_false_alarm(monkeypatch):
+    """visible updates (in-place ops that bump the version, a fused optimizer step that bumps none but goes through the optimizer
+    hook, `p.data = other`) between the build of a copy and an audit, with and without a lookup in between: never flagged; and
+    the tick path -- an audit every AUDIT_EVERY lookups, its answer read by a later lookup -- catches a silent write on its own"""
+    E, net, cache, film, use = _audited_setup()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(1.25)
+    _audit_all(E)  # copies stale BY STAMP: not the audit's business
+    use()
+    _audit_all(E)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-2, fused=(DEV == "cuda"))
+    for p in net.parameters():
+        p.grad = torch.randn_like(p)
+    opt.step()
+    _audit_all(E)
+    use()
+    _audit_all(E)
+    net["conv"].weight.data = torch.randn_like(net["conv"].weight)  # new storage: the stamp's pointer changes
+    _audit_all(E)
+    use()
+    _audit_all(E)
+    monkeypatch.setattr(E.WeightAudit, "AUDIT_EVERY", 8)
+    for _ in range(20):
+        use()
+    E.check_weight_audits(wait=True)
+    net["conv2"].weight.data.add_(1.0)
+    with pytest.raises(RuntimeError, match="stale packed weights"):
+        for _ in range(40):
+            use()
+            if DEV == "cuda":
+                torch.cuda.synchronize()

@@ -92,4 +92,20 @@ def test_pipelined_window_is_bitwise_the_sequential_one_on_the_interpreter(model
     """env_loop's pipelined form through the REAL WorldModelEnv (planned resets, pool peek / commit, per-row repair of a speculative
     sampler step) against the sequential order, on the CPU: three windows of three envs with truncations and sampled ends"""
     M, counter = models
-    M.test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, 3, 4, 0.15, True, "1")
+    M.test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, 3, 4, 0.15, True, "1", "1")
+    if os.environ.get("DIAMOND_SLOW_CPU_TESTS_ALL") == "1":  # (another 7 minutes each)
+        M.test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, 3, 4, 0.15, True, "0", "0")
+        M.test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, 3, 4, 0.15, True, "auto", "auto")
+
+
+def test_weight_audit_on_the_interpreter(monkeypatch):
+    """engine.WeightAudit / dmd_checksums (the always-on guard against silent parameter writes) on the CPU: the GPU tests' own
+    functions with their device patched"""
+    from tests import test_gpu_pack_jobs as P
+
+    monkeypatch.setattr(P, "DEV", "cpu")
+    with engine_on_interpreter():
+        P.test_a_silent_parameter_write_is_detected_by_the_audit("conv.weight", "data.copy_")
+        P.test_a_silent_parameter_write_is_detected_by_the_audit("lstm.weight_ih", "data.mul_")
+        P.test_a_silent_parameter_write_is_detected_by_the_audit("norm.linear.weight", "set_ under no_grad via .data view")
+        P.test_the_audit_raises_no_false_alarm(monkeypatch)
