@@ -550,6 +550,11 @@ def also_lines(device, args):
                            f"attention {c['attn_depths']}"}
         if roofline:
             res["roofline"] = dominant_kernel_roofline(w, nv, idx)
+        if idx == 4 and not args.no_cpu_baseline:
+            # (north_star: "256x256x3 CSGO batches ... alongside the reference CPU path timed on the same box's host cores")
+            del w
+            torch.cuda.empty_cache()
+            res["cpu_baseline"] = cpu_baseline_config4()
         return res
 
     def latency():

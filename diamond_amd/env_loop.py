@@ -92,10 +92,17 @@ def _policy_step(model, obs: Tensor, hx: Tensor, cx: Tensor, resets=None):
         run = lambda lo, hi, frames, hc: model.predict_from_features(feats[lo:hi], hc)
     else:  # a model without a separable encoder: the reference's own sequence of calls
         run = lambda lo, hi, frames, hc: model.predict_act_value(frames, hc)
-    with torch.no_grad():
-        _, val_final, _ = run(b, b + k, fin, (h_d, c_d))
     hz, cz = torch.zeros_like(h_d), torch.zeros_like(c_d)  # (the gated state of a dead row)
-    for i in range(tb):
+    if tb > 0 and hasattr(model, "predict_from_features"):
+        # V(final observation) and the first burn-in step are both ONE LSTM step on k rows: one call on 2k rows (feats rows
+        # [b, b + 2k) are the final observations followed by the first burn-in frames); V is used without grad
+        _, v2, (h2, c2) = run(b, b + 2 * k, None, (torch.cat([h_d, hz]), torch.cat([c_d, cz])))
+        val_final, hz, cz, first = v2[:k].detach(), h2[k:], c2[k:], 1
+    else:
+        with torch.no_grad():
+            _, val_final, _ = run(b, b + k, fin, (h_d, c_d))
+        first = 0
+    for i in range(first, tb):
         _, _, (hz, cz) = run(b + (1 + i) * k, b + (2 + i) * k, burn[:, i], (hz, cz))
     h0, c0 = hx.index_copy(0, rows, hz), cx.index_copy(0, rows, cz)
     logits, val, hc = run(0, b, obs, (h0, c0))
@@ -151,13 +158,15 @@ def _pipelined_env_loop(env, model, expo_fn: Optional[Callable[[Tensor], Tensor]
         rows_out, infos = [], []
         pol = None    # (logits, val, (hx, cx), act) of this step when it was issued during the previous one
         begun = None  # the imagined frame of this step when env.step_begin was issued during the previous one
+        saved_expo = None  # the exponential draws of a speculated policy step that was dropped: its repetition uses them
         prev_dead = prev_vfinal = None
         for n in range(num_steps):
             if pol is None:
                 logits_act, val, (hx, cx), _, vfin = _policy_step(model, obs, hx, cx, pending)
                 if pending is not None:
                     prev_vfinal, pending = full(pending[0], vfin, val.detach()), None
-                act = sample_categorical(logits_act, draw_expo(logits_act))
+                act = sample_categorical(logits_act, saved_expo if saved_expo is not None else draw_expo(logits_act))
+                saved_expo = None
             else:
                 logits_act, val, (hx, cx), act = pol
                 pol = None
@@ -189,7 +198,12 @@ def _pipelined_env_loop(env, model, expo_fn: Optional[Callable[[Tensor], Tensor]
                 void = info.get("void_rows")
                 if cand is None:  # nothing was speculated: the resets ride in the next policy step (all of them: no plan either)
                     pending = (info["dead_rows"], info["final_observation"], info["burnin_obs"])
-                elif void is not None:  # deaths no plan covered: their part now, on the rows concerned only
+                elif void is not None and not info.get("repair_pending"):
+                    # deaths no plan covered, and no sampler step in flight that would keep the device busy meanwhile: drop the
+                    # speculated policy step (its draws are kept) -- ALL of this step's resets ride in its repetition's encoder
+                    # pass, which costs less than a small-batch chain for the void rows now plus its own backward later
+                    pending, cand, saved_expo, vfinal = (info["dead_rows"], info["final_observation"], info["burnin_obs"]), None, s_expo, None
+                elif void is not None:  # ... with the next sampler step already queued: their part now, on the rows concerned only
                     pos = info.get("void_pos")
                     fin, burn = info["final_observation"], info["burnin_obs"]
                     if pos is not None:
@@ -197,8 +211,7 @@ def _pipelined_env_loop(env, model, expo_fn: Optional[Callable[[Tensor], Tensor]
                     v, _, step = _reset_chain(model, fin, burn, next_obs.index_select(0, void), hx.index_select(0, void), cx.index_select(0, void))
                     vfinal = (torch.zeros_like(val.detach()) if vfinal is None else vfinal).index_copy(0, void, v)
                     cand = merge(cand, void, step, s_expo)
-                    if info.get("repair_pending"):
-                        begun = env.step_begin_repair(cand[3])
+                    begun = env.step_begin_repair(cand[3])
                 prev_vfinal = vfinal
             pol = cand
             rows_out.append([obs, act, rew, end, trunc, logits_act, val, None])

@@ -773,7 +773,7 @@ def test_speculative_policy_step_is_bitwise_the_sequential_one(monkeypatch):
 
 @pytest.mark.parametrize("spec,policy", [("1", "1"), ("0", "1"), ("0", "0"), ("auto", "auto")])
 @pytest.mark.parametrize("b,horizon,p_end,stagger", [(24, 5, 0.03, True), (12, 7, 0.25, False), (16, 6, 0.0, True)])
-def test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon, p_end, stagger, spec, policy="1"):
+def test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon, p_end, stagger, spec, policy):
     """env_loop's pipelined form (planned truncation resets inside the speculated pipeline, unplanned deaths repaired row by row on
     a small batch: env_loop._pipelined_env_loop, WorldModelEnv.plan_resets / step_begin_repair) against the reference's sequential
     order of operations (DIAMOND_SPECULATIVE_POLICY=0), three windows on the DEVICE random generator at batches the graphed
