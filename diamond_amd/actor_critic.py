@@ -114,6 +114,13 @@ class ActorCritic(nn.Module):
         logits, val, hx, cx = lstm_heads(self._native_encoder.cache, x, hx, cx, self.lstm, self.actor_linear, self.critic_linear)
         return ActorCriticOutput(logits, val, (hx, cx))
 
+    def burn_in_from_features(self, x: Tensor, num_frames: int) -> Tuple[Tensor, Tensor]:
+        """(hx, cx) of the LSTM stepped from the zero state over `num_frames` frames' features x (num_frames * k, F),
+        frame-major: the policy-side burn-in of a reset (reference env_loop.py:53-56) as one autograd node
+        (lstm_native.LstmBurnInFn); bitwise `num_frames` calls of predict_from_features."""
+        from .lstm_native import lstm_burn_in
+        return lstm_burn_in(self._native_encoder.cache, x, num_frames, self.lstm)
+
     def forward(self):
         c = self.loss_cfg
         _, act, rew, end, trunc, logits_act, val, val_bootstrap, _ = self.env_loop.send(c.backup_every)

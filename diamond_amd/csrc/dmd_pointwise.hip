@@ -403,6 +403,34 @@ extern "C" int dmd_dequant_gather(const uint8_t* pool, const int64_t* idx, const
   return 0;
 }
 
+// The small state of a reset in ONE launch (reference world_model_env.py:56-62 `reset_dead`: act_buffer[dead] = act,
+// hx_rew_end[:, dead] = hx, cx likewise, ep_len[dead] = 0 -- four indexed assignments, ~12 launches of torch glue on the step's
+// critical path, right behind its host synchronisation): block i handles env row rows[i] <- pool row idx[i].
+__global__ __launch_bounds__(256) void reset_state_kernel(const int64_t* __restrict__ idx, const int64_t* __restrict__ rows,
+                                                          const int64_t* __restrict__ pool_act, int64_t* __restrict__ act_ring, int T, int head,
+                                                          const float* __restrict__ pool_hx, const float* __restrict__ pool_cx,
+                                                          float* __restrict__ hx, float* __restrict__ cx, int hd, int64_t* __restrict__ ep_len) {
+  const int64_t q = idx[blockIdx.x], r = rows[blockIdx.x];
+  for (int j = threadIdx.x; j < hd; j += 256) {
+    hx[r * hd + j] = pool_hx[q * hd + j];
+    cx[r * hd + j] = pool_cx[q * hd + j];
+  }
+  if ((int)threadIdx.x < T) act_ring[r * T + (head + threadIdx.x) % T] = pool_act[q * T + threadIdx.x];
+  if (threadIdx.x == 0) ep_len[r] = 0;
+}
+
+extern "C" int dmd_reset_state(const int64_t* idx, const int64_t* rows, int count, const int64_t* pool_act, int64_t* act_ring, int T,
+                               int head, const float* pool_hx, const float* pool_cx, float* hx, float* cx, int hd, int64_t* ep_len,
+                               dmd_stream_t stream) {
+  DMD_CHECK_ARG(idx && rows && pool_act && act_ring && pool_hx && pool_cx && hx && cx && ep_len, "reset_state: null");
+  DMD_CHECK_ARG(T >= 1 && T <= 256 && head >= 0 && head < T && hd >= 1, "reset_state: T %d, head %d, hd %d", T, head, hd);
+  if (count == 0) return 0;
+  hipLaunchKernelGGL(reset_state_kernel, dim3((unsigned)count), dim3(256), 0, (hipStream_t)stream, idx, rows, pool_act, act_ring, T, head,
+                     pool_hx, pool_cx, hx, cx, hd, ep_len);
+  DMD_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int dmd_nchw_to_nhwc(const float* in, float* out, int N, int C, int H, int W, int CPad, dmd_stream_t stream) {
   DMD_CHECK_ARG(in && out && CPad % 4 == 0 && CPad >= C, "nchw_to_nhwc: args");
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(nblk((size_t)N * H * W * (CPad / 4), 256)), dim3(256), 0, (hipStream_t)stream, in,

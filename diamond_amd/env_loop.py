@@ -93,7 +93,13 @@ def _policy_step(model, obs: Tensor, hx: Tensor, cx: Tensor, resets=None):
     else:  # a model without a separable encoder: the reference's own sequence of calls
         run = lambda lo, hi, frames, hc: model.predict_act_value(frames, hc)
     hz, cz = torch.zeros_like(h_d), torch.zeros_like(c_d)  # (the gated state of a dead row)
-    if tb > 0 and hasattr(model, "predict_from_features"):
+    if tb > 0 and hasattr(model, "burn_in_from_features"):
+        # the burn-in as ONE autograd node (its weight gradients once, not once per frame)
+        with torch.no_grad():
+            _, val_final, _ = run(b, b + k, fin, (h_d, c_d))
+        hz, cz = model.burn_in_from_features(feats[b + k:b + (1 + tb) * k], tb)
+        first = tb
+    elif tb > 0 and hasattr(model, "predict_from_features"):
         # V(final observation) and the first burn-in step are both ONE LSTM step on k rows: one call on 2k rows (feats rows
         # [b, b + 2k) are the final observations followed by the first burn-in frames); V is used without grad
         _, v2, (h2, c2) = run(b, b + 2 * k, None, (torch.cat([h_d, hz]), torch.cat([c_d, cz])))

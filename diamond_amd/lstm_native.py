@@ -140,6 +140,64 @@ class LstmStepFn(torch.autograd.Function):
         return None, dgates, dhx, dc_prev if need[3] else None, dw_hh, dgates.sum(0)
 
 
+class LstmBurnInFn(torch.autograd.Function):
+    """The burn-in of the policy LSTM on the context frames of a NEW episode (reference env_loop.py:53-56: `tb` calls of
+    predict_act_value from a zeroed state, WITH grad; only (hx, cx) survive, the heads are not needed) as ONE autograd node:
+    x = the frames' encoder features, frame-major (tb * k, F).  Forward = the per-step arithmetic of LstmHeadsFn -- the input
+    projection of all tb * k rows in one GEMM (a row's summation order in dmd_linear does not depend on the batch), then per
+    frame the recurrent GEMM accumulated onto its rows and the gate kernel: bitwise the tb separate calls.  Backward = BPTT
+    inside the node with ONE set of weight gradients (three GEMMs over all tb * k rows) instead of tb sets that autograd
+    then adds up with one launch per parameter and call."""
+
+    @staticmethod
+    def forward(ctx, cache: E.PackCache, x: Tensor, tb: int, w_ih: Tensor, w_hh: Tensor, b_ih: Tensor, b_hh: Tensor):
+        x = x.detach().float().contiguous()
+        k, hd = x.shape[0] // tb, w_hh.shape[1]
+        gates = E.linear(x, w_ih.detach(), b_ih.detach())  # (tb * k, 4 hd)
+        hs = torch.zeros(tb + 1, k, hd, device=x.device, dtype=torch.float32)  # hs[i] = state before frame i (hs[0] = 0: the gated row)
+        cs = torch.zeros(tb + 1, k, hd, device=x.device, dtype=torch.float32)
+        whh, bhh = w_hh.detach(), b_hh.detach()
+        for i in range(tb):
+            g = gates[i * k:(i + 1) * k]
+            E.linear(hs[i], whh, bhh, out=g, accumulate=True)
+            nv.check(nv.lib().dmd_lstm_pointwise(nv.fptr(g), nv.fptr(cs[i]), nv.fptr(hs[i + 1]), nv.fptr(cs[i + 1]), k, hd, nv.stream()),
+                     "dmd_lstm_pointwise")
+        ctx.save_for_backward(x, gates, hs, cs)
+        ctx.tb = tb
+        ctx.w_ih_t = cache.get(w_ih, "T", lambda w: w.detach().t().contiguous()) if ctx.needs_input_grad[1] else None
+        ctx.w_hh_t = cache.get(w_hh, "T", lambda w: w.detach().t().contiguous())
+        return hs[tb].clone(), cs[tb].clone()
+
+    @staticmethod
+    def backward(ctx, dh: Optional[Tensor], dc: Optional[Tensor]):
+        x, gates, hs, cs = ctx.saved_tensors
+        tb = ctx.tb
+        k, hd = hs.shape[1], hs.shape[2]
+        dgates = torch.empty_like(gates)
+        dhc = torch.zeros(k, hd, device=x.device) if dh is None else dh.detach().float().contiguous()
+        dcc = torch.zeros(k, hd, device=x.device) if dc is None else dc.detach().float().contiguous()
+        for i in reversed(range(tb)):
+            dg, dc_prev = dgates[i * k:(i + 1) * k], torch.empty_like(dcc)
+            nv.check(nv.lib().dmd_lstm_pointwise_bwd(nv.fptr(gates[i * k:(i + 1) * k]), nv.fptr(cs[i]), nv.fptr(cs[i + 1]), nv.fptr(dhc), nv.fptr(dcc),
+                                                     nv.fptr(dg), nv.fptr(dc_prev), k, hd, nv.stream()), "dmd_lstm_pointwise_bwd")
+            dcc = dc_prev
+            if i > 0:
+                dhc = _mm_nt(dg, ctx.w_hh_t)
+        dx = _mm_nt(dgates, ctx.w_ih_t) if ctx.needs_input_grad[1] else None
+        dgt = dgates.t().contiguous()
+        dw_ih = _mm_nt(dgt, x.t())
+        # (frame 0 starts from the zero state: its rows contribute nothing to dW_hh)
+        dw_hh = _mm_nt(dgt[:, k:].contiguous(), hs[1:tb].reshape((tb - 1) * k, hd).t()) if tb > 1 else torch.zeros_like(ctx.w_hh_t.t())
+        db = dgates.sum(0)
+        return None, dx, None, dw_ih, dw_hh, db, db
+
+
+def lstm_burn_in(cache: E.PackCache, x: Tensor, tb: int, lstm) -> Tuple[Tensor, Tensor]:
+    """(hx, cx) after stepping `lstm` from the zero state over tb frames' features x (tb * k, F), frame-major."""
+    nv.require_gpu(x)
+    return LstmBurnInFn.apply(cache, x, tb, lstm.weight_ih, lstm.weight_hh, lstm.bias_ih, lstm.bias_hh)
+
+
 def lstm_heads(cache: E.PackCache, x: Tensor, hx: Tensor, cx: Tensor, lstm, actor_linear, critic_linear
                ) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """(logits_act, val, hx', cx') of reference actor_critic.py:72-73."""

@@ -300,10 +300,19 @@ class WorldModelEnv:
         happens here or in the pool's preload -- a reset consumes no random stream."""
         with _no_random_draws(self._ctx.device, "WorldModelEnv._reset_rows"):
             self.pool.scatter_frames(idx, rows, self._ctx, self._head)
-            self._act[rows[:, None], self._cols()[None, :]] = self.pool.act[idx]
-            self.hx_rew_end[0, rows] = self.pool.hx[idx]
-            self.cx_rew_end[0, rows] = self.pool.cx[idx]
-            self.ep_len[rows] = 0
+            hx, cx, pool = self.hx_rew_end, self.cx_rew_end, self.pool
+            if (hx.dtype == torch.float32 and hx.is_contiguous() and cx.is_contiguous() and pool.hx.is_contiguous() and pool.cx.is_contiguous()
+                    and self._act.is_contiguous() and pool.act.is_contiguous()):
+                # action ring, reward/end LSTM state and episode length of the rows in ONE launch (this sits on the step's
+                # critical path, right behind its host synchronisation: the four indexed assignments below are ~12 launches)
+                nv.check(nv.lib().dmd_reset_state(nv.ptr(idx), nv.ptr(rows), int(rows.numel()), nv.ptr(pool.act), nv.ptr(self._act),
+                                                  self._act.shape[1], self._head, nv.fptr(pool.hx), nv.fptr(pool.cx), nv.fptr(hx), nv.fptr(cx),
+                                                  hx.shape[-1], nv.ptr(self.ep_len), nv.stream()), "dmd_reset_state")
+            else:
+                self._act[rows[:, None], self._cols()[None, :]] = pool.act[idx]
+                hx[0, rows] = pool.hx[idx]
+                cx[0, rows] = pool.cx[idx]
+                self.ep_len[rows] = 0
 
     @torch.no_grad()
     def reset_dead(self, dead: Tensor) -> Tensor:
@@ -487,13 +496,13 @@ class WorldModelEnv:
         if any_dead:
             self.stats["steps_with_deaths"] += 1
             total = int(rows_host.size)
-            rows = None
+            rows = fresh = None  # fresh: (total, T, C, H, W) the new episodes' context frames in logical order, if at hand
             if plan is not None:
                 planned = plan["rows_host"]
                 assert np.isin(planned, rows_host).all(), "a predicted truncation did not happen: ep_len was changed behind the env's back (use set_episode_lengths)"
                 if total == planned.size:  # exactly the plan
                     self.pool.commit(plan["token"], total)
-                    rows, void_host = plan["rows"], rows_host[:0]
+                    rows, void_host, fresh = plan["rows"], rows_host[:0], plan["frames"]
                 else:
                     # more deaths than planned: the reference serves ONE request for all of them in row order.  Planned rows in
                     # front of the first unplanned death keep their pool rows (if the larger request still fits the pool that
@@ -509,15 +518,19 @@ class WorldModelEnv:
                         self._reset_rows(self._rows_to_device(void_host), idx_all[keep:])
                     else:
                         self._reset_rows(self._rows_to_device(rows_host), idx_all)
+                    fresh_idx = idx_all
             else:
-                self._reset_rows(self._rows_to_device(rows_host), self.pool.take(total))
+                fresh_idx = self.pool.take(total)
+                rows = self._rows_to_device(rows_host)
+                self._reset_rows(rows, fresh_idx)
             if rows is None:
                 rows = self._rows_to_device(rows_host)
+            if fresh is None:
+                fresh = self.pool.gather_frames(fresh_idx)  # (one launch; the same values the ring rows just received)
             info["dead_rows"] = rows  # device index list: the caller gathers / scatters with it (no further synchronisation)
             info["final_observation"] = next_obs.index_select(0, rows)
-            cols = self._cols()
-            info["burnin_obs"] = self._ctx[rows[:, None], cols[None, :-1]]
-            obs = self._ctx[:, self._slot(-1)].clone()  # dead envs now show the newest frame of their new episode
+            info["burnin_obs"] = fresh[:, :-1]
+            obs = next_obs.index_copy(0, rows, fresh[:, -1])  # dead envs now show the newest frame of their new episode
             self.stats["planned_rows"] += total - int(void_host.size)
             self.stats["void_rows"] += int(void_host.size)
             if void_host.size:

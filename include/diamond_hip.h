@@ -276,6 +276,11 @@ int dmd_quantize_u8(const float* x, uint8_t* q, int* off_grid, int64_t n, dmd_st
  * pool (P, T, per_frame) uint8, dst (B, T, per_frame) fp32, per_frame = C * H * W (multiple of 4). */
 int dmd_dequant_gather(const uint8_t* pool, const int64_t* idx, const int64_t* rows, float* dst, int M, int T,
                        int64_t per_frame, int head, dmd_stream_t stream);
+/* ABI v9: the rest of a reset (envs/world_model_env.py:56-62 `reset_dead`) in one launch, for i < count, r = rows[i], q = idx[i]:
+ * act_ring[r][(head + t) % T] = pool_act[q][t] (int64 (B, T) / (P, T)); hx[r] = pool_hx[q], cx[r] = pool_cx[q] ((B, hd) / (P, hd)
+ * fp32: the reward/end LSTM state); ep_len[r] = 0. */
+int dmd_reset_state(const int64_t* idx, const int64_t* rows, int count, const int64_t* pool_act, int64_t* act_ring, int T, int head,
+                    const float* pool_hx, const float* pool_cx, float* hx, float* cx, int hd, int64_t* ep_len, dmd_stream_t stream);
 
 /* NCHW (N, C, H, W) -> NHWC (N, H, W, CPad), zero padded channels */
 int dmd_nchw_to_nhwc(const float* in, float* out, int N, int C, int H, int W, int CPad, dmd_stream_t stream);

@@ -771,6 +771,34 @@ def test_speculative_policy_step_is_bitwise_the_sequential_one(monkeypatch):
             assert torch.equal(a, b_)
 
 
+def test_fused_burn_in_is_bitwise_the_frame_by_frame_one():
+    """ActorCritic.burn_in_from_features (lstm_native.LstmBurnInFn: the policy-side burn-in of a reset as ONE autograd node, one
+    set of weight gradients) against three chained predict_from_features calls from the zero state: states bitwise, gradients of
+    the features and of the four LSTM parameters to rounding"""
+    ag = make_agent()
+    ac = ag.actor_critic
+    g = torch.Generator().manual_seed(3)
+    k, tb = 5, 3
+    frames = torch.randn(tb * k, 3, 64, 64, generator=g).clamp(-1, 1).to(DEV)
+    w = (torch.randn(k, 512, generator=g).to(DEV), torch.randn(k, 512, generator=g).to(DEV))
+    out = []
+    for fused in (True, False):
+        ac.zero_grad()
+        feats = ac.encode(frames).detach().requires_grad_(True)
+        if fused:
+            h, c = ac.burn_in_from_features(feats, tb)
+        else:
+            h, c = torch.zeros(k, 512, device=DEV), torch.zeros(k, 512, device=DEV)
+            for i in range(tb):
+                _, _, (h, c) = ac.predict_from_features(feats[i * k:(i + 1) * k], (h, c))
+        ((h * w[0]).sum() + (c * w[1]).sum()).backward()
+        out.append((h.detach().clone(), c.detach().clone(), feats.grad.clone(), {n: p.grad.clone() for n, p in ac.lstm.named_parameters()}))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert rel_err(out[0][2], out[1][2]) < 1e-5
+    for n in out[0][3]:
+        assert rel_err(out[0][3][n], out[1][3][n]) < 1e-5, n
+
+
 @pytest.mark.parametrize("spec,policy", [("1", "1"), ("0", "1"), ("0", "0"), ("auto", "auto")])
 @pytest.mark.parametrize("b,horizon,p_end,stagger", [(24, 5, 0.03, True), (12, 7, 0.25, False), (16, 6, 0.0, True)])
 def test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon, p_end, stagger, spec, policy):
@@ -786,7 +814,7 @@ def test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon,
     from bench import set_end_rate
 
     t = 6
-    runs, stats = [], None
+    runs, stats, grads = [], None, []
     for mode in ("1", "0"):
         monkeypatch.setenv("DIAMOND_SPECULATIVE_POLICY", mode)
         for k, v in (("DIAMOND_SPEC_SAMPLER", spec), ("DIAMOND_SPEC_POLICY", policy)):  # pinned modes, or the env's own running averages
@@ -808,6 +836,13 @@ def test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon,
             outs.append([x.detach().cpu() for x in (all_obs, act, rew, end, trunc, logits_act, val, vb)])
             if w == 0 and stagger:
                 env.set_episode_lengths(torch.arange(b) % horizon)
+        # ... and the gradients of the last window's loss: the merged encoder pass, the index_copy merges of recomputed rows
+        # and the planned resets build a different autograd graph for the same function
+        from diamond_amd.actor_critic import actor_critic_loss
+        ag.actor_critic.zero_grad()
+        loss, _ = actor_critic_loss(logits_act, val, act, rew, end, trunc, vb, ag.actor_critic.loss_cfg)
+        loss.backward()
+        grads.append({k: p.grad.detach().double().cpu() for k, p in ag.actor_critic.named_parameters()})
         runs.append(outs)
         if mode == "1":
             stats = dict(env.stats)
@@ -816,6 +851,9 @@ def test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon,
     for w, (wa, wb) in enumerate(zip(*runs)):
         for name, a, b_ in zip(names, wa, wb):
             assert torch.equal(a, b_), (w, name)
+    gerr = {k: float((grads[0][k] - g).abs().max() / g.abs().max().clamp_min(1e-30)) for k, g in grads[1].items()}
+    print("pipelined vs sequential gradient rel diff:", f"{max(gerr.values()):.2e}")
+    assert max(gerr.values()) < 1e-4, {k: f"{v:.1e}" for k, v in gerr.items() if v >= 1e-4}
     if policy == "1":
         assert stats["planned_rows"] > 0, stats
         if p_end > 0:

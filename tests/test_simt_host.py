@@ -109,3 +109,9 @@ def test_weight_audit_on_the_interpreter(monkeypatch):
         P.test_a_silent_parameter_write_is_detected_by_the_audit("lstm.weight_ih", "data.mul_")
         P.test_a_silent_parameter_write_is_detected_by_the_audit("norm.linear.weight", "set_ under no_grad via .data view")
         P.test_the_audit_raises_no_false_alarm(monkeypatch)
+
+
+def test_fused_burn_in_on_the_interpreter(models):
+    """lstm_native.LstmBurnInFn (one autograd node for the policy-side burn-in of a reset) against chained per-frame calls"""
+    M, counter = models
+    M.test_fused_burn_in_is_bitwise_the_frame_by_frame_one()

@@ -592,6 +592,48 @@ def test_uint8_pool_round_trip():
     assert np.isnan(dst[2]).all()
 
 
+def test_reset_state_and_parameter_checksums():
+    """dmd_reset_state (the action ring, reward/end LSTM state and episode length of the reset rows in one launch: reference
+    world_model_env.py:56-62) against the indexed assignments it replaces; dmd_checksums (fingerprints of parameter storage for
+    the audit of the packed copies) against 64-bit sums of the 32-bit words, and its sensitivity to a single flipped bit"""
+    rng = np.random.default_rng(35)
+    L = S.lib()
+    b, p_, t, hd, head = 6, 9, 4, 40, 3
+    pool_act = rng.integers(0, 18, (p_, t)).astype(np.int64)
+    pool_hx, pool_cx = rng.standard_normal((p_, hd)).astype(f32), rng.standard_normal((p_, hd)).astype(f32)
+    act = rng.integers(0, 18, (b, t)).astype(np.int64)
+    hx, cx = rng.standard_normal((b, hd)).astype(f32), rng.standard_normal((b, hd)).astype(f32)
+    ep = rng.integers(1, 9, b).astype(np.int64)
+    idx, rows = np.array([7, 2, 8], dtype=np.int64), np.array([4, 0, 5], dtype=np.int64)
+    want = [a.copy() for a in (act, hx, cx, ep)]
+    cols = (head + np.arange(t)) % t
+    want[0][rows[:, None], cols[None, :]] = pool_act[idx]
+    want[1][rows], want[2][rows], want[3][rows] = pool_hx[idx], pool_cx[idx], 0
+    S.check(L.dmd_reset_state(S.ptr(idx), S.ptr(rows), 3, S.ptr(pool_act), S.ptr(act), t, head, S.ptr(pool_hx), S.ptr(pool_cx), S.ptr(hx),
+                              S.ptr(cx), hd, S.ptr(ep), None), "reset_state")
+    for got, w in zip((act, hx, cx, ep), want):
+        assert np.array_equal(got, w)
+
+    from diamond_amd import native as nv
+    import ctypes as C
+
+    tensors = [rng.standard_normal(n).astype(f32) for n in (1, 255, 256, 4097, 70000)]
+    jobs = (nv.ChecksumJob * len(tensors))()
+    for j, a in zip(jobs, tensors):
+        j.src, j.words = a.ctypes.data, a.size
+    table = np.frombuffer(bytes(jobs), dtype=np.uint8).copy()
+    out = np.full((len(tensors), nv.CHECKSUM_PARTS), -1, dtype=np.int64)
+    S.check(L.dmd_checksums(S.ptr(table), len(tensors), S.ptr(out), None), "checksums")
+    for a, o in zip(tensors, out):
+        w = a.view(np.int32).astype(np.int64)
+        part = (np.arange(a.size) // 256) % nv.CHECKSUM_PARTS
+        assert np.array_equal(o, np.array([w[part == k].sum() for k in range(nv.CHECKSUM_PARTS)]))
+    tensors[3].view(np.int32)[1234] ^= 1  # one bit
+    out2 = np.zeros_like(out)
+    S.check(L.dmd_checksums(S.ptr(table), len(tensors), S.ptr(out2), None), "checksums")
+    assert (out2 != out).any(axis=1).tolist() == [False, False, False, True, False]
+
+
 def test_maxpool_lstm_categorical():
     rng = np.random.default_rng(34)
     L = S.lib()

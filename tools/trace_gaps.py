@@ -1,5 +1,5 @@
 """GPU idle-gap analysis of a rocprofv3 kernel trace CSV (development aid).
-usage: python tools/trace_gaps.py kernel_trace.csv[.gz] [min_gap_us]
+usage: python tools/trace_gaps.py kernel_trace.csv[.gz] [min_gap_us] [last_ms]   (last_ms: look at the last N ms of the trace only)
 Prints the busy fraction, a gap histogram, the largest (previous kernel -> next kernel) gap classes and every individual gap
 above min_gap_us (default 500) with its time before the end of the trace -- for `bench.py --steps K --warmup W` the timed
 windows are the last K x ~330 ms."""
@@ -10,6 +10,9 @@ min_gap = float(sys.argv[2]) * 1e3 if len(sys.argv) > 2 else 5e5
 f = gzip.open(path, "rt") if path.endswith(".gz") else open(path)
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(f)]
 rows.sort()
+if len(sys.argv) > 3:  # the timed window(s) at the end of the trace only (warm-up windows build caches and idle more)
+    cut = rows[-1][1] - float(sys.argv[3]) * 1e6
+    rows = [r for r in rows if r[0] >= cut]
 end = rows[-1][1]
 span = rows[-1][1] - rows[0][0]
 busy = sum(e - s for s, e, _ in rows)
@@ -36,3 +39,26 @@ for (a, b), (c, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:12]:
 print(f"individual gaps >= {min_gap/1e3:.0f} us (ms before the end of the trace, gap ms, previous -> next):")
 for t, g, a, b in big[-80:]:
     print(f"  -{t:8.1f}  {g:7.2f}  {a}  ->  {b}")
+
+# the stretches between two LARGE kernels (>= 50 us): what the device does while the host is the critical path
+stretch, cur = [], None
+for s_, e_, n_ in rows:
+    if e_ - s_ >= 50_000:
+        if cur is not None and cur[2] >= 25:
+            stretch.append(cur)
+        cur = [e_, e_, 0, 0, []]  # start (end of a large kernel), last end, small kernels, their busy ns, their names
+    elif cur is not None:
+        cur[1], cur[2], cur[3] = max(cur[1], e_), cur[2] + 1, cur[3] + (e_ - s_)
+        cur[4].append((n_, e_ - s_, s_ - cur[0]))
+long_ = sorted(stretch, key=lambda c: -(c[1] - c[0]))[:40]
+tot = sum(c[1] - c[0] for c in stretch)
+print(f"stretches of >= 25 small kernels between two large ones: {len(stretch)}, {tot/1e6:.1f} ms in total; the longest (ms, kernels, their busy ms):")
+print("  " + "  ".join(f"{(c[1]-c[0])/1e6:.2f}/{c[2]}/{c[3]/1e6:.2f}" for c in long_))
+
+if stretch:  # the kernels of the MEDIAN stretch, in order: name, duration us, start offset us
+    import re
+    med = sorted(stretch, key=lambda c: c[1] - c[0])[len(stretch) // 2]
+    print(f"the median stretch ({(med[1]-med[0])/1e6:.2f} ms, {med[2]} kernels), in order (start us : name, us):")
+    short = lambda n: re.sub(r"at::native::|\(anonymous namespace\)::|void |std::array<char\*, \d+ul> ?|<unnamed>::", "", n)[:90]
+    for n_, d_, off in med[4]:
+        print(f"  {off/1e3:8.1f} : {short(n_)}  {d_/1e3:.1f}")
