@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 5: smoke(), the default bench line and the driver's own invocation on the final tree
+# smoke(), the default bench line and the driver's own invocation (python bench.py --gpus 1 --steps 20 --warmup 5)
 set -u
 TAG=${1:-r05e}
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R

@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 5, third GPU call: the whole -m gpu suite on the final env loop, idle-gap traces of three regimes, the default bench line
+# One GPU-box session: the whole -m gpu suite, idle-gap traces of three regimes (tools/gpu/gaps.sh) and the env-loop A/B (tools/ab_env_loop.py)
 set -u
 TAG=${1:-r05c}
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R

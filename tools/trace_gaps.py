@@ -55,6 +55,14 @@ tot = sum(c[1] - c[0] for c in stretch)
 print(f"stretches of >= 25 small kernels between two large ones: {len(stretch)}, {tot/1e6:.1f} ms in total; the longest (ms, kernels, their busy ms):")
 print("  " + "  ".join(f"{(c[1]-c[0])/1e6:.2f}/{c[2]}/{c[3]/1e6:.2f}" for c in long_))
 
+import os
+want = os.environ.get("TRACE_GAPS_STRETCH_WITH", "categorical_sample")  # the per-step FORWARD stretches contain the action sampling
+fwd = [c for c in stretch if any(want in n_ for n_, _, _ in c[4])]
+if fwd:
+    tot_f = sum(c[1] - c[0] for c in fwd)
+    print(f"stretches containing '{want}': {len(fwd)}, {tot_f/1e6:.1f} ms in total, {sum(c[3] for c in fwd)/1e6:.1f} ms of it busy, "
+          f"{sum(c[2] for c in fwd)/len(fwd):.0f} kernels each")
+    stretch = fwd
 if stretch:  # the kernels of the MEDIAN stretch, in order: name, duration us, start offset us
     import re
     med = sorted(stretch, key=lambda c: c[1] - c[0])[len(stretch) // 2]
