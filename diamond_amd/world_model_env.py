@@ -301,14 +301,14 @@ class WorldModelEnv:
         with _no_random_draws(self._ctx.device, "WorldModelEnv._reset_rows"):
             self.pool.scatter_frames(idx, rows, self._ctx, self._head)
             hx, cx, pool = self.hx_rew_end, self.cx_rew_end, self.pool
-            if (hx.dtype == torch.float32 and hx.is_contiguous() and cx.is_contiguous() and pool.hx.is_contiguous() and pool.cx.is_contiguous()
-                    and self._act.is_contiguous() and pool.act.is_contiguous()):
+            if (pool.frames_u8 is not None and hx.dtype == torch.float32 and hx.is_contiguous() and cx.is_contiguous()
+                    and pool.hx.is_contiguous() and pool.cx.is_contiguous() and self._act.is_contiguous() and pool.act.is_contiguous()):
                 # action ring, reward/end LSTM state and episode length of the rows in ONE launch (this sits on the step's
                 # critical path, right behind its host synchronisation: the four indexed assignments below are ~12 launches)
                 nv.check(nv.lib().dmd_reset_state(nv.ptr(idx), nv.ptr(rows), int(rows.numel()), nv.ptr(pool.act), nv.ptr(self._act),
                                                   self._act.shape[1], self._head, nv.fptr(pool.hx), nv.fptr(pool.cx), nv.fptr(hx), nv.fptr(cx),
                                                   hx.shape[-1], nv.ptr(self.ep_len), nv.stream()), "dmd_reset_state")
-            else:
+            else:  # (the fp32 pool of off-grid frames: plain indexed copies throughout, like its frames in scatter_frames)
                 self._act[rows[:, None], self._cols()[None, :]] = pool.act[idx]
                 hx[0, rows] = pool.hx[idx]
                 cx[0, rows] = pool.cx[idx]
