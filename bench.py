@@ -215,7 +215,7 @@ def cpu_baseline_config4(timeout_s=240):
     return ref
 
 
-def cpu_baseline(img_size, timeout_s=240):
+def cpu_baseline(img_size, timeout_s=240, allow_reference=True):
     """The CPU path beside the GPU number, on this box's host cores, each in a child process: the REFERENCE ITSELF where its
     bytecode travelled with the snapshot (oracle/_ref, built by oracle/make_ref.py in the build container: kind "reference") and
     the oracle port (oracle/diamond_oracle.py: kind "port") on the same window at the same thread count."""
@@ -223,6 +223,8 @@ def cpu_baseline(img_size, timeout_s=240):
     port = _child_json([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(threads), "--img-size", str(img_size)],
                        threads, timeout_s)
     port.setdefault("unit", "imagined frames/s"), port.setdefault("cores", threads), port.setdefault("kind", "port")
+    if not allow_reference:
+        return dict(port, reference_unavailable="--cpu-baseline-kind port", reference_measured=REFERENCE_MEASURED)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     try:
         import reference_window as RW  # test infrastructure: the locator only -- the run itself happens in the child
@@ -550,7 +552,7 @@ def also_lines(device, args):
                            f"attention {c['attn_depths']}"}
         if roofline:
             res["roofline"] = dominant_kernel_roofline(w, nv, idx)
-        if idx == 4 and not args.no_cpu_baseline:
+        if idx == 4 and not args.no_cpu_baseline and getattr(args, "cpu_baseline_kind", "reference") == "reference":
             # (north_star: "256x256x3 CSGO batches ... alongside the reference CPU path timed on the same box's host cores")
             del w
             torch.cuda.empty_cache()
@@ -620,6 +622,10 @@ def main():
                     help="run the distributed code path (RCCL process group, parameter broadcast, gradient all-reduce, replica "
                          "checksum) even at world size 1 (tests/test_gpu_dist.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-kind", choices=("reference", "port"), default="reference",
+                    help="reference (default): time the reference's own modules where their bytecode travelled with the snapshot "
+                         "(oracle/_ref, built by oracle/make_ref.py from /root/reference in the build container) beside the oracle port; "
+                         "port: never execute oracle/_ref, time the oracle port only and quote the recorded reference number")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-exact-fp32", action="store_true")
     ap.add_argument("--no-end-logit-bias", action="store_true",
@@ -829,7 +835,7 @@ def main():
         progress(f"also: {line['also']['seconds']:.1f}s")
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline_config4() if args.config == 4 else cpu_baseline(64)
+        line["cpu_baseline"] = cpu_baseline_config4() if args.config == 4 else cpu_baseline(64, allow_reference=args.cpu_baseline_kind == "reference")
         progress("cpu baseline done")
 
     if rank == 0:

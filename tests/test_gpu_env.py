@@ -160,6 +160,35 @@ def test_graph_captured_sampler_equals_eager_bitwise():
     assert torch.isfinite(a).all() and not torch.equal(a, b)
 
 
+def test_captured_sampler_graphs_survive_a_weight_update():
+    """An optimizer step / load changes every parameter: the packed copies are rebuilt IN PLACE, so the captured sampler graphs
+    stay valid (same graph objects, no recapture) and the next replay computes with the NEW weights -- also the copies that are
+    the parameter's own storage (cache.f32 of a contiguous fp32 parameter: a version change there is not a freed buffer)."""
+    import diamond_amd as D
+    from diamond_amd.testing import fill_module_, synthetic_actions, synthetic_frames
+
+    agent = D.Agent(D.default_agent_config())
+    fill_module_(agent, WEIGHT_SEED)
+    agent = agent.to(DEV).eval()
+    g = torch.Generator().manual_seed(10)
+    sampler = D.DiffusionSampler(agent.denoiser, D.DiffusionSamplerConfig(num_steps_denoising=3))
+    ctx = synthetic_frames(g, 1, 4, 3, 64, 64).to(DEV)
+    act = synthetic_actions(g, 4, 1, 4).to(DEV)
+    noise = torch.randn(1, 3, 64, 64, generator=g).to(DEV)
+    sampler.noise_fn = lambda shape, dev: noise
+    x0, _ = sampler.sample_ring_graphed(ctx, act, 0, 0)
+    x0b, _ = sampler.sample_ring_graphed(ctx, act, 0, 0)
+    caps = dict(sampler._graphs)
+    assert len(caps) == 1 and torch.equal(x0, x0b)
+    with torch.no_grad():
+        for p in agent.denoiser.parameters():
+            p.mul_(1.01)  # (an in-place update like an eager optimizer step: bumps every version)
+    x1, _ = sampler.sample_ring_graphed(ctx, act, 0, 0)
+    assert dict(sampler._graphs) == caps, "the weight update voided the captured graph"
+    xe, _ = sampler.sample_ring(ctx, act, 0, 0)
+    assert torch.equal(x1, xe) and not torch.equal(x1, x0)
+
+
 def test_batch_shard_invariance_at_full_batch():
     """§8e: imagined envs shard along the batch axis with no data-path exchange, so an env's trajectory must not depend
     on which other envs share its launch.  The 256 envs of configs[1] stepped as ONE batch vs as two shards of 128 with
