@@ -132,6 +132,25 @@ def gen_sampler_heun5(agent):
                               "sigmas": sampler.sigmas.clone()})
 
 
+def gen_sampler_heun_pixels(agent, b=17, steps=(1, 3)):
+    """configs[3]'s 2nd-order Heun step where the pixel budget can be resolved: b * 3 * 64 * 64 >= 200k values per step.  Of the
+    reference's 5-step Heun trajectory at batch b only the points around `steps` are kept (x_i -> x_{i+1}: two denoiser
+    evaluations each, teacher-forced by the test), fp32."""
+    from models.diffusion import DiffusionSampler, DiffusionSamplerConfig
+
+    g = torch.Generator().manual_seed(23)
+    prev_obs = synthetic_frames(g, b, 4, 3, 64, 64)
+    prev_act = synthetic_actions(g, 4, b, 4)
+    sampler = DiffusionSampler(agent.denoiser, DiffusionSamplerConfig(num_steps_denoising=5, order=2))
+    torch.manual_seed(123)
+    with torch.no_grad():
+        _, traj = sampler.sample(prev_obs, prev_act)
+    out = {"seed": 23, "noise_seed": 123, "b": b, "sigmas": sampler.sigmas.clone(), "steps": list(steps), "pixels": b * 3 * 64 * 64}
+    for i in steps:
+        out[f"x_{i}"], out[f"x_{i + 1}"] = traj[i].clone(), traj[i + 1].clone()
+    save("sampler_heun_pixels.pt", out)
+
+
 def gen_rew_end(agent, name="rew_end.pt", size=64):
     g = torch.Generator().manual_seed(13)
     b = 2
@@ -368,6 +387,10 @@ def main():
         gen_denoiser_pixels(ref_agent(), "default")
         gen_denoiser_pixels(ref_agent(), "72x72", h=72, w=72, b=14, sampled=1)
         gen_denoiser_pixels(ref_agent(denoiser_attn_depths=(0, 0, 1, 1)), "attn0011", b=17, sampled=1)
+        gen_sampler_heun_pixels(ref_agent())
+        return
+    if "--heun-pixels" in sys.argv:
+        gen_sampler_heun_pixels(ref_agent())
         return
     if "--rew-end-train" in sys.argv:
         gen_rew_end_train()

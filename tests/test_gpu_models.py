@@ -260,6 +260,37 @@ def test_sampler_heun5_batch2_every_step_teacher_forced_vs_reference_golden(agen
         assert frac <= 5e-4, (i, frac)
 
 
+def test_sampler_heun_step_budget_on_200k_pixels_vs_reference_golden(agent):
+    """BASELINE configs[3]'s 2nd-order Heun step (two denoiser evaluations + the fused dmd_heun_step) where the budget can be
+    resolved: 208,896 values per step, teacher-forced from the REFERENCE's own trajectory points (tests/golden/make_golden.py
+    --heun-pixels).  A quantised denoiser output on the neighbouring uint8 level moves the step's result by the flip amplitude
+    of that evaluation; budget: <= 1e-4 of the pixels per evaluation (2e-4 per step, no relaxation), every moved value within
+    the two evaluations' amplitudes."""
+    import diamond_amd as D
+    from diamond_amd.testing import synthetic_actions, synthetic_frames
+    from tests.test_oracle_golden import heun_step_budget
+
+    gold = load_golden("sampler_heun_pixels.pt")
+    b, sig = gold["b"], gold["sigmas"]
+    assert gold["pixels"] >= 200_000
+    g = torch.Generator().manual_seed(gold["seed"])
+    prev_obs = synthetic_frames(g, b, 4, 3, 64, 64).to(DEV)
+    prev_act = synthetic_actions(g, 4, b, 4).to(DEV)
+    sampler = D.DiffusionSampler(agent.denoiser, D.DiffusionSamplerConfig(num_steps_denoising=5, order=2))
+    assert torch.equal(sampler.sigmas.cpu(), sig)
+    for i in gold["steps"]:
+        sampler._host_sigmas = sig[i:i + 2].clone()
+        sampler.noise_fn = lambda shape, dev, i=i: gold[f"x_{i}"].to(dev)
+        x, traj = sampler.sample(prev_obs, prev_act)
+        assert len(traj) == 2
+        diff = (x.cpu() - gold[f"x_{i + 1}"]).abs()
+        frac = float((diff > 1e-4).float().mean())
+        print(f"heun step {i} on {diff.numel()} values: max diff {float(diff.max()):.2e} (flip amplitude {heun_step_budget(sig, i):.2e}), "
+              f"{frac:.2e} of the values moved (budget 2e-4)")
+        assert float(diff.max()) <= heun_step_budget(sig, i) * 2 + 1e-4
+        assert frac <= 2e-4, (i, frac)
+
+
 @pytest.fixture(scope="module")
 def agent72():
     """img_size 72: levels 72 / 36 / 18 / 9 (/ 4) are off the kernels' 8-pixel tile grid -- the reward / end model and the

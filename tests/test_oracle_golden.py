@@ -128,6 +128,22 @@ def test_sampler_heun5_every_step_teacher_forced():
         assert float((diff > 1e-4).float().mean()) <= 2e-4, (i, float((diff > 1e-4).float().mean()))
 
 
+def test_sampler_heun_step_budget_on_200k_pixels():
+    """the oracle's Heun step against the >= 200k-value fixture (make_golden.py --heun-pixels), one teacher-forced step"""
+    gold = load_golden("sampler_heun_pixels.pt")
+    b, sig = gold["b"], gold["sigmas"]
+    a = make_oracle_agent()
+    g = torch.Generator().manual_seed(gold["seed"])
+    prev_obs = synthetic_frames(g, b, 4, 3, 64, 64)
+    prev_act = synthetic_actions(g, 4, b, 4)
+    i = gold["steps"][-1]
+    spec = O.SamplerSpec(num_steps_denoising=5, order=2)
+    x, _ = O.sample(a.denoiser, a.dspec, spec, prev_obs, prev_act, gold[f"x_{i}"], sigmas=sig[i:i + 2])
+    diff = (x - gold[f"x_{i + 1}"]).abs()
+    assert float(diff.max()) <= heun_step_budget(sig, i) * 2 + 1e-4
+    assert float((diff > 1e-4).float().mean()) <= 2e-4
+
+
 def test_rew_end_model():
     gold = load_golden("rew_end.pt")
     a = make_oracle_agent()
