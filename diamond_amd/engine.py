@@ -149,7 +149,7 @@ class WeightAudit:
     RAISES instead of training on stale weights.  Cost: one small launch per rebuild, one per few thousand lookups.
     Capturable: a replayed training step (GraphedTrainStep) rebuilds copies and re-records fingerprints inside the graph."""
 
-    AUDIT_EVERY = 4096
+    AUDIT_EVERY = 16384  # (lookups of one cache group between audits: about one audit per imagined window; 14 us per launch)
     CAPACITY = 4096
 
     def __init__(self, what: str) -> None:
