@@ -196,11 +196,16 @@ def _pipelined_env_loop(env, model, expo_fn: Optional[Callable[[Tensor], Tensor]
             env.step_end_issue()
             if cand is not None and env.may_speculate():
                 begun = env.step_begin(cand[3], speculative=True)
+            elif cand is None and n + 1 < num_steps and hasattr(env, "predraw"):
+                # nothing of the next step is issued ahead -- but its random draws depend on nothing: the policy's exponentials,
+                # then the env's (the reference's order), in front of the host synchronisation instead of behind it
+                saved_expo = draw_expo(logits_act)
+                env.predraw()
             next_obs, rew, end, trunc, info = env.step_end_finish()
 
             prev_dead = prev_vfinal = None
             if info["any_dead"]:
-                prev_dead = torch.logical_or(end, trunc)
+                prev_dead = info["dead"] if "dead" in info else torch.logical_or(end, trunc)
                 void = info.get("void_rows")
                 if cand is None:  # nothing was speculated: the resets ride in the next policy step (all of them: no plan either)
                     pending = (info["dead_rows"], info["final_observation"], info["burnin_obs"])

@@ -221,6 +221,7 @@ class WorldModelEnv:
     def _reset_speculation(self) -> None:
         self._pending = None
         self._pending_speculative = False
+        self._predrawn = None
         self._issued = None
         self._plan: Optional[Dict[str, Any]] = None       # a planned reset (predicted truncations of the current step)
         self._repair_rows: Optional[Tensor] = None        # rows of the pending speculative half-step an unplanned death voided
@@ -356,7 +357,8 @@ class WorldModelEnv:
         newest = self._slot(-1)
         self._act[:, newest] = act
         own_noise = not self._use_graph()  # (a captured sampler graph draws inside the graph: never speculated, see may_speculate)
-        noise, e_rew, e_end = self._draw_step(own_noise)
+        drawn, self._predrawn = getattr(self, "_predrawn", None), None
+        noise, e_rew, e_end = drawn if drawn is not None else self._draw_step(own_noise)
         self._next_noise = noise  # (handed over out of band: predict_next_obs keeps the reference's zero-argument signature,
         next_obs, denoising_trajectory = self.predict_next_obs()  # trainer.py:182-184 re-assigns it with a wrapper)
         self._pending = (next_obs, denoising_trajectory, e_rew, e_end, noise)
@@ -386,6 +388,16 @@ class WorldModelEnv:
                 full.index_copy_(0, rows, part)
         self.stats["repairs"] += 1
         return next_obs
+
+    @torch.no_grad()
+    def predraw(self) -> None:
+        """Make the NEXT step_begin's random draws now (initial noise, reward / end samples).  They depend on nothing but their
+        shapes, so a caller that does not speculate may issue them in front of the step's host synchronisation -- behind its own
+        draws for the next action, i.e. in the reference's order -- instead of behind it, on the critical path."""
+        if self._use_graph():
+            return
+        assert getattr(self, "_predrawn", None) is None and self._pending is None
+        self._predrawn = self._draw_step(True)
 
     def may_speculate(self) -> bool:
         """May the caller issue the NEXT step's step_begin before this step's step_end_finish?  Not with a captured sampler graph
@@ -491,6 +503,7 @@ class WorldModelEnv:
         plan, self._plan = self._plan, None
         obs = next_obs  # a fresh tensor every step: never aliases the ring
         info["any_dead"] = any_dead  # (so that the caller does not have to synchronise again for the same answer)
+        info["dead"] = dead
         self.stats["steps"] += 1
         void_host = rows_host
         if any_dead:

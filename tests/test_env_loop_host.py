@@ -329,7 +329,7 @@ class PipeEnv(PoolEnv):
     def __init__(self, b, p_end, horizon, stagger=False, speculate=True, policy_spec=True):
         super().__init__(b, p_end, horizon, stagger)
         self.speculate, self.policy_spec, self._asked = speculate, policy_spec, 0
-        self._pending = self._plan = self._issued = self._repair = None
+        self._pending = self._plan = self._issued = self._repair = self._drawn = None
         self.counts = {"planned": 0, "void": 0, "repairs": 0, "spec": 0, "mixed": 0}
 
     def step(self, act):
@@ -337,11 +337,15 @@ class PipeEnv(PoolEnv):
         self.step_end_issue()
         return self.step_end_finish()
 
+    def predraw(self):
+        assert self._drawn is None
+        self._drawn = self._draw()
+
     def step_begin(self, act, speculative=False):
         assert self._pending is None
         self.log.append("begin-spec" if speculative else "begin")
         self.counts["spec"] += int(speculative)
-        noise, e_rew, e_end = self._draw()
+        (noise, e_rew, e_end), self._drawn = (self._drawn if self._drawn is not None else self._draw()), None
         self._acts = act.clone()
         nxt = self._dynamics(self.ctx, act, noise)
         self._pending, self._spec = (nxt, e_rew, e_end, noise), speculative
