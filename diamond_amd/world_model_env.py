@@ -141,13 +141,18 @@ class InitialConditionPool:
         """Device index vector of the next `count` pool rows WITHOUT serving them (preloading when the pool runs short, exactly
         as `take` would for this count), and a token (pool generation, cursor) for `commit` / `still_valid`.  A planned reset
         (WorldModelEnv.plan_resets) peeks; the rows are served once the host has confirmed the plan."""
+        start, token = self.peek_start(count)
+        return torch.arange(start, start + count, device=self.act.device), token
+
+    def peek_start(self, count: int) -> Tuple[int, Tuple[int, int]]:
+        """`peek` for a caller that builds the index vector itself (on the host, next to its row list: one upload for both)."""
         if self.size == 0:
             self._preload()
         while self._cursor + count > self.size:
             assert count <= self._num_batches * self._loader.batch_sampler.batch_size, \
                 "more simultaneous resets than one preload round holds"
             self._preload()
-        return torch.arange(self._cursor, self._cursor + count, device=self.act.device), (self._generation, self._cursor)
+        return self._cursor, (self._generation, self._cursor)
 
     def commit(self, token: Tuple[int, int], count: int) -> None:
         assert token == (self._generation, self._cursor), "pool rows were served between peek and commit"
@@ -261,7 +266,7 @@ class WorldModelEnv:
         #  that read it was issued on the same stream as everything else, and H2D copies from pinned memory read at execution
         #  time: so each call gets its own slice of a ring of slices)
         if self._rows_pinned is None:
-            self._rows_pinned = torch.empty(64, self.num_envs, dtype=torch.int64).pin_memory()
+            self._rows_pinned = torch.empty(64, 2 * self.num_envs, dtype=torch.int64).pin_memory()
             self._rows_slot = 0
         self._rows_slot = (self._rows_slot + 1) % self._rows_pinned.shape[0]
         buf = self._rows_pinned[self._rows_slot]
@@ -532,9 +537,11 @@ class WorldModelEnv:
                     else:
                         self._reset_rows(self._rows_to_device(rows_host), idx_all)
                     fresh_idx = idx_all
-            else:
-                fresh_idx = self.pool.take(total)
-                rows = self._rows_to_device(rows_host)
+            else:  # (the dead rows and their pool rows in ONE upload: this is the step's critical path)
+                start, token = self.pool.peek_start(total)
+                self.pool.commit(token, total)
+                both = self._rows_to_device(np.concatenate([rows_host, np.arange(start, start + total)]))
+                rows, fresh_idx = both[:total], both[total:]
                 self._reset_rows(rows, fresh_idx)
             if rows is None:
                 rows = self._rows_to_device(rows_host)
