@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}; cd $R
 VAR=$1; A=$2; B=$3
 for v in "$A" "$B" "$A" "$B"; do
   echo "== $VAR=$v"
-  env $VAR="$v" timeout 300 python bench.py --steps ${STEPS:-2} --warmup 1 --no-cpu-baseline --no-exact-fp32 2>/dev/null | python -c "
+  env $VAR="$v" timeout 300 python bench.py --steps ${STEPS:-2} --warmup 1 --no-cpu-baseline --no-exact-fp32 --no-also 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); r = d['roofline']
 print(round(d['value'], 1), 'frames/s;', r['kernel'], round(1e3 * r['avg_launch_ms'], 1), 'us;', {k: v for k, v in list(r['launch_time_ms'].items())[:5]})"
