@@ -580,19 +580,6 @@ int dmd_launch_conv_f16ws(const dmd_conv_params& p, hipStream_t st);  // dmd_con
 int dmd_launch_conv1x1_stream(const dmd_conv_params& p, hipStream_t st);  // dmd_conv1x1.hip (streaming 1x1, exact fp32)
 extern "C" int dmd_conv1x1_stream_eligible(const dmd_conv_params* p);
 
-int dmd_ws_w64();  // dmd_conv_f16ws.hip
-extern "C" int dmd_conv2d_f16x2_eligible(const dmd_conv_params* p);
-// GroupNorm partial-sum tiles per image that dmd_conv2d emits for THESE parameters (ABI v9): dmd_conv_stat_tiles(H, W), except
-// for launches that take the W64 geometry (one partial per 4 rows x 16 columns: a consumer wave covers 4 rows)
-extern "C" int dmd_conv2d_stat_tiles(const dmd_conv_params* p) {
-  if (!p) return -1;
-  if (dmd_ws_w64() && !p->proj_nsrc && p->taps == 9 && p->CoutPad == 64 && p->W % 16 == 0 && dmd_conv2d_f16x2_eligible(p) &&
-      !dmd_conv1x1_stream_eligible(p))
-    return (p->H / 4) * (p->W / 16);
-  return dmd_conv_stat_tiles(p->H, p->W);
-}
-
-
 extern "C" int dmd_conv2d(const dmd_conv_params* p, dmd_stream_t stream) {
   if (int e = validate_conv(p)) return e;
   hipStream_t st = (hipStream_t)stream;
@@ -624,8 +611,6 @@ extern "C" int dmd_conv2d_kernel_name(const dmd_conv_params* p, char* buf, int b
              (p->precision & 0xff) == DMD_PRECISION_F16X2 ? "true" : "false");
   } else if (p->proj_nsrc) {
     snprintf(buf, buf_len, "conv_f16ws_kernel<WsGeomProj>");
-  } else if (dmd_conv2d_f16x2_eligible(p) && dmd_ws_w64() && !b8 && p->taps == 9 && p->CoutPad == 64) {
-    snprintf(buf, buf_len, "conv_f16ws_kernel<WsGeomW64>");
   } else if (dmd_conv2d_f16x2_eligible(p)) {
     snprintf(buf, buf_len, "conv_f16ws_kernel<WsGeom<%s, %d, %d>>", b8 ? "true" : "false", p->CoutPad == 64 ? 2 : 1, p->taps);
   } else {

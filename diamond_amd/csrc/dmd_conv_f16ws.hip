@@ -117,18 +117,6 @@ struct WsGeom {
   static constexpr int blk_off(int blk) { return (B8_ ? (blk >> 1) * PPS + (blk & 1) * 4 * PW : blk * 2 * PW) * 64; }
   static constexpr bool PROJ = false;  // fused skip projection (WsGeomProj)
   static constexpr int PROJ_KS = 1;
-  static constexpr bool W64 = false;   // 64-cout x 64-pixel consumer wave tile (WsGeomW64)
-};
-
-// W64 (round 5, an A/B geometry behind DIAMOND_WS_W64=1): the 16x16-patch, 64-cout, 3x3 geometry with another consumer wave
-// tile.  A wave of WsGeom<false, 2, 9> owns 32 couts x 128 pixels (one cout block, four 32-pixel blocks): per tap it reads the
-// weight pieces once (2 reads) and the activation pieces of four pixel blocks (8 reads) for its 12 MFMAs.  Here a wave owns
-// BOTH cout blocks x 64 pixels (two pixel blocks): 4 weight + 4 activation reads per 12 MFMAs -- 20 % fewer LDS fragment reads,
-// the same registers (the weight pieces of the other cout block are fetched into the registers the previous half-tap's weights
-// just left), the same products in the same order per accumulator: BIT-IDENTICAL outputs.  The GroupNorm partial sums are
-// emitted per 4 image rows instead of 8 (a wave covers 4 rows: no exchange between waves): dmd_conv2d_stat_tiles().
-struct WsGeomW64 : WsGeom<false, 2, 9> {
-  static constexpr bool W64 = true;
 };
 
 // PROJECTION.  The up path's ResBlocks compute  proj(cat(x, skip)) + conv2(...)  (blocks.py:133,147) with a 128 -> 64
@@ -353,9 +341,9 @@ __device__ __forceinline__ h8 ws_read_b(const unsigned char* lds, const WsAddr& 
   using Wn = WsWin<G, TAP>;
   return *(const h8*)(lds + (LOW ? (G::PL_REGS ? ad.pl[Wn::dx] : (ad.ph[Wn::dx] ^ 32)) : ad.ph[Wn::dx]) + (Wn::off + G::blk_off(BLK)));
 }
-template <class G, int TAP, bool LOW, int CB = 0>
+template <class G, int TAP, bool LOW>
 __device__ __forceinline__ h8 ws_read_a(const unsigned char* lds, const WsAddr& ad) {
-  return *(const h8*)(lds + ad.w + ((TAP * 2 + (LOW ? 1 : 0)) * 2 * G::COUT + CB * 32) * 16);
+  return *(const h8*)(lds + ad.w + (TAP * 2 + (LOW ? 1 : 0)) * 2 * G::COUT * 16);
 }
 
 // One half-tap: 6 MFMAs on the accumulators of pixel blocks (P0, P0 + 1) with operands (a, b), and -- one per MFMA, in
@@ -413,68 +401,6 @@ __device__ __forceinline__ void ws_chunk_body(f32x16 (&acc)[4], WsA& a, WsB& b, 
     ws_halftap<G, 2 * H, NEXT, NT, 2 * NH>(acc, a, b, lds, ad, an, bn);
     b = bn;
     if (H == 1) a = an;  // the next half-tap starts a new tap
-  });
-}
-
-// ---- W64: a wave = both cout blocks x two pixel blocks.  acc[2 cb + pb]; a = {h0, l0 (cout block 0), h1, l1 (cout block 1)} ----
-struct WsA2 {
-  h8 h0, l0, h1, l1;
-};
-// One half-tap of tap T = the 6 MFMAs of cout block CBK on pixel blocks 0, 1 (per accumulator: w_h x_h, w_h x_l, w_l x_h, like
-// ws_halftap), with one fragment read per MFMA, in the order of first use:
-//   CBK == 0: the weight pieces of cout block 1 of THIS tap (into the registers block 1's previous pieces left with the last
-//             half-tap), then -- NEXT -- the h pieces of the next tap's activations;
-//   CBK == 1, NEXT == 1: the next tap's cout-block-0 weight pieces (block 0's are dead since the first half), then the l pieces
-//             of its activations;
-//   CBK == 1, NEXT == 3: the held-back last half-tap of a chunk, executed behind the barrier with `ad` already on the other
-//             buffer pair: the first tap's cout-block-0 weights and all four activation pieces of the NEXT chunk.
-template <class G, int CBK, int NEXT, int T>
-__device__ __forceinline__ void ws_halftap_w64(f32x16 (&acc)[4], WsA2& a, const WsB& b, const unsigned char* lds, const WsAddr& ad, WsB& bn) {
-#if WS_ABL & 16
-  return;
-#endif
-  constexpr int P0 = 2 * CBK, P1 = 2 * CBK + 1;
-  constexpr int NT = NEXT == 3 ? 0 : T + 1;
-  const h8 wh = CBK ? a.h1 : a.h0, wl = CBK ? a.l1 : a.l0;
-  acc[P0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b.h0, acc[P0], 0, 0, 0);
-  if constexpr (CBK == 0) a.h1 = ws_read_a<G, T, false, 1>(lds, ad);
-  if constexpr (CBK == 1 && NEXT != 0) a.h0 = ws_read_a<G, NT, false, 0>(lds, ad);
-  __builtin_amdgcn_sched_barrier(0);
-  acc[P1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b.h1, acc[P1], 0, 0, 0);
-  if constexpr (CBK == 0 && NEXT != 0) bn.h0 = ws_read_b<G, NT, 0, false>(lds, ad);
-  if constexpr (CBK == 1 && NEXT == 3) bn.h0 = ws_read_b<G, NT, 0, false>(lds, ad);
-  if constexpr (CBK == 1 && NEXT == 1) bn.l0 = ws_read_b<G, NT, 0, true>(lds, ad);
-  __builtin_amdgcn_sched_barrier(0);
-  acc[P0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b.l0, acc[P0], 0, 0, 0);
-  if constexpr (CBK == 0 && NEXT != 0) bn.h1 = ws_read_b<G, NT, 1, false>(lds, ad);
-  if constexpr (CBK == 1 && NEXT == 3) bn.h1 = ws_read_b<G, NT, 1, false>(lds, ad);
-  if constexpr (CBK == 1 && NEXT == 1) bn.l1 = ws_read_b<G, NT, 1, true>(lds, ad);
-  __builtin_amdgcn_sched_barrier(0);
-  acc[P1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, b.l1, acc[P1], 0, 0, 0);
-  if constexpr (CBK == 1 && NEXT == 3) bn.l0 = ws_read_b<G, NT, 0, true>(lds, ad);
-  __builtin_amdgcn_sched_barrier(0);
-  acc[P0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, b.h0, acc[P0], 0, 0, 0);
-  if constexpr (CBK == 0) a.l1 = ws_read_a<G, T, true, 1>(lds, ad);
-  if constexpr (CBK == 1 && NEXT == 3) bn.l1 = ws_read_b<G, NT, 1, true>(lds, ad);
-  __builtin_amdgcn_sched_barrier(0);
-  acc[P1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, b.h1, acc[P1], 0, 0, 0);
-  if constexpr (CBK == 1 && NEXT != 0) a.l0 = ws_read_a<G, NT, true, 0>(lds, ad);
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-// all of a chunk but its last half-tap: on entry (a.h0, a.l0, b) hold tap 0's cout-block-0 weights and activations; on exit
-// (a.h1, a.l1, b) hold the operands of the LAST half-tap (tap 8, cout block 1), which the caller executes behind the barrier
-template <class G>
-__device__ __forceinline__ void ws_chunk_body_w64(f32x16 (&acc)[4], WsA2& a, WsB& b, const unsigned char* lds, const WsAddr& ad) {
-  WsB bn = b;
-  ws_for<0, G::TAPS>([&](auto tc) {
-    constexpr int T = decltype(tc)::value;
-    constexpr bool more = T + 1 < G::TAPS;
-    ws_halftap_w64<G, 0, more ? 1 : 0, T>(acc, a, b, lds, ad, bn);
-    if constexpr (more) {
-      ws_halftap_w64<G, 1, 1, T>(acc, a, b, lds, ad, bn);
-      b = bn;
-    }
   });
 }
 
@@ -831,18 +757,15 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     // =================================== CONSUMER ===================================
     // static priority: the MFMA waves win issue arbitration against the co-resident staging wave of their SIMD
     __builtin_amdgcn_s_setprio(3);
-    // (W64: the wave owns BOTH cout blocks -- cb is 0 and the block's cout half is added where it matters -- and the four image
-    //  rows 4 wave .. 4 wave + 3 of the 16x16 tile, i.e. pixel blocks 0, 1 = rows {0, 1}, {2, 3} of them)
-    const int cb = G::W64 ? 0 : wave % G::NCB;  // 32-cout block == GroupNorm group
-    const int ph = G::W64 ? wave : wave / G::NCB;  // 128-pixel part of the tile (W64: 64-pixel part)
+    const int cb = wave % G::NCB;  // 32-cout block == GroupNorm group
+    const int ph = wave / G::NCB;  // 128-pixel part of the tile
     const int n31 = lane & 31, g = lane >> 5;
     WsAddr ad;
     {
       const int col = G::B8 ? (n31 & 7) : (n31 & 15);
       // block 0 of this wave: A16: rows (ph & 1) * 8 + {0, 1} of patch ph >> 1; B8: rows 0..3 of patch 2 ph
-      const int pixbase = G::W64 ? ((4 * wave + (n31 >> 4)) * G::PW + col)
-                          : G::B8 ? (ph * 2 * G::PPS + (n31 >> 3) * G::PW + col)
-                                  : ((ph >> 1) * G::PPS + ((ph & 1) * 8 + (n31 >> 4)) * G::PW + col);
+      const int pixbase = G::B8 ? (ph * 2 * G::PPS + (n31 >> 3) * G::PW + col)
+                                : ((ph >> 1) * G::PPS + ((ph & 1) * 8 + (n31 >> 4)) * G::PW + col);
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         ad.ph[dx] = (pixbase * 4 + ((g + ((col + dx) >> 1)) & 3)) * 16;
@@ -864,17 +787,17 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     int pixoff_[NPO];
     auto pixoff_of = [&](int blk) {
       const int base = pixoff_[G::B8 ? (blk >> 1) : 0];
-      const int rows = G::W64 ? (blk & 1) * 2 : (G::B8 ? (blk & 1) * 4 : blk * 2);
-      return base < 0 ? -1 : base + rows * p.W * (G::COUT / 4) + (G::W64 ? (blk >> 1) * 8 : 0);
+      const int rows = G::B8 ? (blk & 1) * 4 : blk * 2;
+      return base < 0 ? -1 : base + rows * p.W * (G::COUT / 4);
     };
     // bit blk: this lane's pixel of block blk lies outside the valid extent (its output is stored, but stays out of the
     // GroupNorm partial sums); always 0 without a valid extent.  (PROJ launches have none: eligibility.)
     int dead = 0;
-    constexpr int NSTAT = (G::B8 || G::W64) ? 2 : 1;  // statistics tiles of this wave's pixels (one per 8 rows x 8 | 16 columns; W64: per cout block, 4 rows x 16 columns)
+    constexpr int NSTAT = G::B8 ? 2 : 1;  // statistics tiles of this wave's 128 pixels (one per 8 rows x 8 | 16 columns)
     int stat_slot[NSTAT];  // out_stats slot per statistics tile of this wave, -1: none
     // per-lane partial sums of a statistics tile: fp64 across a 16x16 geometry's four blocks; the 8x8 geometries (two blocks
     // = 32 values per lane and tile, and short of registers) keep them in fp32 -- fp64 from the wave reduction on
-    using StatAcc = std::conditional_t<G::B8 || G::PROJ || G::W64, float, double>;  // (W64: two blocks per tile, like B8)  // (PROJ: at the register cap; 4 fp32 block sums per lane)
+    using StatAcc = std::conditional_t<G::B8 || G::PROJ, float, double>;  // (PROJ: at the register cap; 4 fp32 block sums per lane)
     StatAcc ssum[NSTAT], ssq[NSTAT];
     int pending = 4;   // next block of the finished tile to write (4 = nothing pending)
     // residual of the NEXT block to write, fetched a chunk step ahead (zeros without a residual): the write-out wave
@@ -933,7 +856,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
 #pragma unroll
       for (int s = 0; s < NPO; ++s) {
         // sub-tile (wave-uniform index; computed, not selected from a register array) and this lane's pixel of its block 0
-        const WsTile t = ws_subtile<G>(p, tile, G::B8 ? ph * 2 + s : (G::W64 ? 0 : (ph >> 1)));
+        const WsTile t = ws_subtile<G>(p, tile, G::B8 ? ph * 2 + s : (ph >> 1));
         int oy, ox;
         int n31e = n31;
         if constexpr (G::PROJ) {  // at the register cap: recomputed per tile from an OPAQUE copy of the thread index
@@ -944,9 +867,6 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         if (G::B8) {
           oy = t.y0 + (n31e >> 3);
           ox = t.x0 + (n31e & 7);
-        } else if (G::W64) {
-          oy = t.y0 + 4 * wave + (n31e >> 4);
-          ox = t.x0 + (n31e & 15);
         } else {
           oy = t.y0 + (ph & 1) * 8 + (n31e >> 4);
           ox = t.x0 + (n31e & 15);
@@ -957,29 +877,25 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
 #pragma unroll
           for (int b = 0; b < (G::B8 ? 2 : 4); ++b) {
             const int blk = G::B8 ? 2 * s + b : b;
-            const int row = oy + (G::W64 ? (b & 1) * 2 : (G::B8 ? b * 4 : b * 2));
+            const int row = oy + (G::B8 ? b * 4 : b * 2);
             dead |= (row >= Hv || ox >= Wv) ? (1 << blk) : 0;
           }
         }
       }
 #pragma unroll
       for (int kk = 0; kk < NSTAT; ++kk) {
-        const WsTile t = ws_subtile<G>(p, tile, G::B8 ? ph * 2 + kk : (G::W64 ? 0 : (ph >> 1)));
+        const WsTile t = ws_subtile<G>(p, tile, G::B8 ? ph * 2 + kk : (ph >> 1));
         int T, tt;
         if (G::B8) {
           const int tx8 = p.W / 8;
           T = tx8 * (p.H / 8);
           tt = (t.y0 / 8) * tx8 + t.x0 / 8;
-        } else if (G::W64) {  // one partial per 4 rows x 16 columns and cout block kk (dmd_conv2d_stat_tiles)
-          const int tx16 = p.W / 16;
-          T = tx16 * (p.H / 4);
-          tt = (t.y0 / 4 + wave) * tx16 + t.x0 / 16;
         } else {
           const int tx16 = p.W / 16;
           T = tx16 * (p.H / 8);
           tt = (t.y0 / 8 + (ph & 1)) * tx16 + t.x0 / 16;
         }
-        stat_slot[kk] = t.valid ? ((t.n * G::NCB + (G::W64 ? kk : cb)) * T + tt) : -1;
+        stat_slot[kk] = t.valid ? ((t.n * G::NCB + cb) * T + tt) : -1;
         ssum[kk] = 0;
         ssq[kk] = 0;
       }
@@ -1054,7 +970,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
             fq = 0.f;
           }
           if (RES_PREFETCH && blk + 1 < 4) res_prefetch(blk + 1);  // behind the stores: in flight across the barrier, used next step
-          const int slot = (G::B8 || G::W64) ? (blk >> 1) : 0;
+          const int slot = G::B8 ? (blk >> 1) : 0;
           ssum[slot] += (StatAcc)fs;
           ssq[slot] += (StatAcc)fq;
         }
@@ -1181,55 +1097,17 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       if (!G::PROJ && pending < 4) epi_blocks(4);
       {
         // lane owns couts cb*32 + 8 qd + 4 g + (0..3), qd = 0..3, of its pixel of each block
-        if constexpr (G::W64) {  // blocks 0, 1 = cout block 0, blocks 2, 3 = cout block 1
+        f32x4 bq[4];
 #pragma unroll
-          for (int cbk = 0; cbk < 2; ++cbk) {
-            f32x4 bq[4];
+        for (int qd = 0; qd < 4; ++qd) bq[qd] = *(const f32x4*)(bias_lds + cb * 32 + 8 * qd + 4 * g);
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) bq[qd] = *(const f32x4*)(bias_lds + cbk * 32 + 8 * qd + 4 * g);
+        for (int blk = 0; blk < 4; ++blk)
 #pragma unroll
-            for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) acc[2 * cbk + pb][r] = bq[r >> 2][r & 3];
-          }
-        } else {
-          f32x4 bq[4];
-#pragma unroll
-          for (int qd = 0; qd < 4; ++qd) bq[qd] = *(const f32x4*)(bias_lds + cb * 32 + 8 * qd + 4 * g);
-#pragma unroll
-          for (int blk = 0; blk < 4; ++blk)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[blk][r] = bq[r >> 2][r & 3];
-        }
+          for (int r = 0; r < 16; ++r) acc[blk][r] = bq[r >> 2][r & 3];
       }
       // operands of the tile's first half-tap (the one exposed LDS round trip per tile)
       ws_addr_move<G>(ad, (j & 1) - apar);
       apar = j & 1;
-      if constexpr (G::W64) {
-        WsA2 a;
-        WsB b, bn;
-        a.h0 = ws_read_a<G, 0, false, 0>(lds, ad);
-        b.h0 = ws_read_b<G, 0, 0, false>(lds, ad);
-        b.h1 = ws_read_b<G, 0, 1, false>(lds, ad);
-        b.l0 = ws_read_b<G, 0, 0, true>(lds, ad);
-        b.l1 = ws_read_b<G, 0, 1, true>(lds, ad);
-        a.l0 = ws_read_a<G, 0, true, 0>(lds, ad);
-        a.h1 = a.h0;
-        a.l1 = a.l0;
-        bn = b;
-        for (int ck = 0; ck < nchunks; ++ck, ++j) {
-          WS_STAMP(role, 4, j);
-          ws_chunk_body_w64<G>(acc, a, b, lds, ad);
-          WS_STAMP(role, 5, j);
-          ws_barrier();  // B(j + 1): every fragment of buffer j is in registers; buffer j + 1 is complete
-          WS_STAMP(role, 6, j);
-          // the held-back last half-tap (tap 8, cout block 1), under the first fragment reads of the next chunk (other pair)
-          ws_addr_move<G>(ad, 1 - 2 * apar);
-          apar ^= 1;
-          ws_halftap_w64<G, 1, 3, G::TAPS - 1>(acc, a, b, lds, ad, bn);
-          b = bn;
-        }
-      }
       WsA a, an;
       WsB b, bn;
       a.h = ws_read_a<G, 0, false>(lds, ad);
@@ -1241,7 +1119,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       an = a;
       bn = b;
       constexpr int LH = (G::HALVES - 1) % 2;
-      for (int ck = 0; ck < (G::W64 ? 0 : nchunks); ++ck, ++j) {  // (W64: the loop above did the tile; this one is compiled out)
+      for (int ck = 0; ck < nchunks; ++ck, ++j) {
         WS_STAMP(role, 4, j);
         ws_chunk_body<G>(acc, a, b, lds, ad);
         WS_STAMP(role, 5, j);
@@ -1256,7 +1134,6 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         a = an;
         b = bn;
       }
-
       epi_begin(k);  // written out while the other group computes the next tile
       if (k + 1 >= nmy) break;
       // ---- the other group's tile: write our finished tile out, a slice per chunk step, and move the weights ----
@@ -1324,11 +1201,6 @@ static int launch_f16ws(const dmd_conv_params& p, int ntiles, hipStream_t st) {
 }
 
 extern "C" int dmd_conv2d_proj_eligible(const dmd_conv_params* p);
-// DIAMOND_WS_W64=1: the 64-cout x 64-pixel consumer wave tile for the 3x3, 64-cout, 16x16-patch launches (WsGeomW64; A/B)
-int dmd_ws_w64() {
-  static DmdEnvInt w64{"DIAMOND_WS_W64", 0};
-  return w64.get() == 1;
-}
 int dmd_launch_conv_f16ws(const dmd_conv_params& p, hipStream_t st) {
   const bool b8 = p.W % 16 != 0;
   const int sub8 = p.N * (p.H / 8) * (p.W / 8), t16 = p.N * (p.H / 16) * (p.W / 16);
@@ -1338,7 +1210,6 @@ int dmd_launch_conv_f16ws(const dmd_conv_params& p, hipStream_t st) {
     return launch_f16ws<WsGeomProj>(p, t16, st);
   }
   if (p.taps == 9) {
-    if (p.CoutPad == 64 && !b8 && dmd_ws_w64()) return launch_f16ws<WsGeomW64>(p, t16, st);
     if (p.CoutPad == 64) return b8 ? launch_f16ws<WsGeom<true, 2, 9>>(p, (sub8 + 3) / 4, st) : launch_f16ws<WsGeom<false, 2, 9>>(p, t16, st);
     return b8 ? launch_f16ws<WsGeom<true, 1, 9>>(p, (sub8 + 7) / 8, st) : launch_f16ws<WsGeom<false, 1, 9>>(p, (t16 + 1) / 2, st);
   }

@@ -575,12 +575,11 @@ def conv2d(
         p.proj_w_f16 = nv.ptr(p_w16)
         p.proj_bias = nv.ptr(p_bias)
     stats, tiles = None, 0
-    use_naive = _USE_NAIVE if naive is None else naive
     if want_stats:
-        # (the tile count belongs to the kernel that will run: the W64 A/B geometry emits one partial per 4 rows)
-        tiles = nv.conv_stat_tiles(h, w) if use_naive else int(nv.lib().dmd_conv2d_stat_tiles(C.byref(p)))
+        tiles = nv.conv_stat_tiles(h, w)
         stats = new_stats(n, cout, tiles, dev)
         p.out_stats = nv.ptr(stats)
+    use_naive = _USE_NAIVE if naive is None else naive
     fn = nv.lib().dmd_conv2d_naive if use_naive else nv.lib().dmd_conv2d
     if nv.PROFILER is not None:
         cin = sum(a.C for a, _, _ in srcs)

@@ -97,7 +97,7 @@ class LowresChainParams(C.Structure):
 
 
 EXPORTS = (
-    "dmd_conv2d", "dmd_conv2d_kernel_name", "dmd_conv2d_naive", "dmd_conv_stat_tiles", "dmd_conv2d_stat_tiles", "dmd_pack_conv_weight", "dmd_conv2d_f16x2_eligible",
+    "dmd_conv2d", "dmd_conv2d_kernel_name", "dmd_conv2d_naive", "dmd_conv_stat_tiles", "dmd_pack_conv_weight", "dmd_conv2d_f16x2_eligible",
     "dmd_conv1x1_stream_eligible", "dmd_conv2d_proj_eligible", "dmd_pack_jobs", "dmd_checksums",
     "dmd_pack_conv_weight_f16x2", "dmd_linear", "dmd_attention", "dmd_attention_valid", "dmd_attention_bwd", "dmd_attention_bwd_workspace_floats",
     "dmd_edm_pack_input", "dmd_cond_embed", "dmd_edm_denoised", "dmd_euler_step", "dmd_heun_step", "dmd_quantize_u8", "dmd_reset_state",
@@ -109,7 +109,7 @@ EXPORTS = (
 
 # entry points that launch kernels (everything except queries / packing helpers that bench.py does not time)
 LAUNCHERS = frozenset(n for n in EXPORTS if n not in (
-    "dmd_conv2d_kernel_name", "dmd_conv_stat_tiles", "dmd_conv2d_stat_tiles", "dmd_conv2d_f16x2_eligible", "dmd_conv1x1_stream_eligible",
+    "dmd_conv2d_kernel_name", "dmd_conv_stat_tiles", "dmd_conv2d_f16x2_eligible", "dmd_conv1x1_stream_eligible",
     "dmd_conv2d_proj_eligible", "dmd_attention_bwd_workspace_floats", "dmd_gn_bwd_workspace_bytes", "dmd_wgrad_workspace_floats", "dmd_last_error", "dmd_abi_version", "dmd_reload_env"))
 
 
@@ -178,7 +178,6 @@ def declare_signatures(L: C.CDLL) -> None:
         getattr(L, name)  # AttributeError if the ABI is incomplete
     L.dmd_conv2d.argtypes = [C.POINTER(ConvParams), C.c_void_p]
     L.dmd_conv2d_naive.argtypes = [C.POINTER(ConvParams), C.c_void_p]
-    L.dmd_conv2d_stat_tiles.argtypes = [C.POINTER(ConvParams)]
     L.dmd_conv2d_kernel_name.argtypes = [C.POINTER(ConvParams), C.c_char_p, C.c_int]
     L.dmd_linear.argtypes = [C.POINTER(LinearParams), C.c_void_p]
     L.dmd_pack_conv_weight.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]

@@ -153,10 +153,6 @@ int dmd_conv2d(const dmd_conv_params* p, dmd_stream_t stream);
 int dmd_conv2d_kernel_name(const dmd_conv_params* p, char* buf, int buf_len);
 /* number of GroupNorm stat tiles per image a dmd_conv2d with output (H, W) emits */
 int dmd_conv_stat_tiles(int H, int W);
-/* ... for THESE parameters (ABI v9): the same, except for launches that take the 64-cout x 64-pixel wave-tile geometry of the
- * split-fp16 kernel (DIAMOND_WS_W64=1, an A/B switch: one partial per 4 rows x 16 columns).  out_stats must hold
- * N * (Cout / 32) * dmd_conv2d_stat_tiles(p) * 2 doubles; consumers take the tile count from dmd_norm.stat_tiles. */
-int dmd_conv2d_stat_tiles(const dmd_conv_params* p);
 /* OIHW (Cout, Cin, k, k) fp32 -> packed layout; Cin padded to 16, Cout padded to CoutPad. */
 int dmd_pack_conv_weight(const float* oihw, float* packed, int Cout, int Cin, int k, int CoutPad, int CinPad,
                          dmd_stream_t stream);

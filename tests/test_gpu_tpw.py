@@ -147,45 +147,6 @@ def test_conv2d_production_tiles_per_wg(case, precision):
             assert torch.equal(out.stats[pi], small.stats), f"{name}: statistics of images {pair} differ"
 
 
-W64_CASES = [c for c in TPW_CASES if c[5] == 64 and c[6] == 9 and ((2 * c[3]) if c[7] else c[3]) % 16 == 0 and not c[10]]
-
-
-@pytest.mark.parametrize("case", W64_CASES, ids=[c[0] for c in W64_CASES])
-def test_w64_wave_tile_is_bitwise_the_shipping_geometry(case, dmd_env):
-    """WsGeomW64 (DIAMOND_WS_W64=1, an A/B geometry: a consumer wave owns both cout blocks x 64 pixels -- 20 % fewer LDS fragment
-    reads, the same products in the same order per accumulator) at the production launch configurations: outputs BIT-identical
-    to the shipping geometry's, GroupNorm partial sums per 4 rows adding up to the same totals, and a ResBlock-style consumer
-    of those statistics agreeing to rounding."""
-    from diamond_amd import engine as E, native as nv
-
-    name, n, h, w, cins, cout, taps, up, prologue, use_res, head = case
-    cin = sum(cins)
-    ho, wo = (2 * h, 2 * w) if up else (h, w)
-    g = torch.Generator(device=DEV).manual_seed(sum(map(ord, name)))
-    xs = [torch.randn(n, h, w, c, device=DEV, generator=g) * 1.5 + 0.3 for c in cins]
-    wgt = torch.randn(cout, cin, 3, 3, device=DEV, generator=g) / math.sqrt(cin * 9)
-    bias = torch.randn(cout, device=DEV, generator=g) * 0.1
-    mul = torch.randn(n, cin, device=DEV, generator=g) * 0.3
-    add = torch.randn(n, cin, device=DEV, generator=g) * 0.3
-    res = torch.randn(n, ho, wo, cout, device=DEV, generator=g) if use_res else None
-    w2 = torch.randn(64, cout, 3, 3, device=DEV, generator=g) / math.sqrt(cout * 9)
-    outs = []
-    for w64 in (None, 1):
-        dmd_env(DIAMOND_WS_W64=w64)
-        out = _run(E, nv, xs, prologue, mul, add, cin, wgt, bias, cout, taps, up, res, head, True)
-        # a consumer of the statistics: GroupNorm + SiLU prologue of the next convolution
-        nxt = E.conv2d([(out, nv.PROLOGUE_NORM_SILU, E.NormSpec(mul=mul[:, :cout].contiguous(), add=add[:, :cout].contiguous(), mul_stride=cout,
-                                                                add_stride=cout, plus_one=True))],
-                       nv.pack_conv_weight(w2), nv.pad_vector(bias[:64].contiguous(), 64), 64, w_f16=nv.pack_conv_weight_f16x2(w2), fast_math=True)
-        torch.cuda.synchronize()
-        outs.append((out, nxt))
-    (a, an), (b, bn) = outs
-    assert torch.equal(a.t, b.t), name
-    assert b.tiles == 2 * a.tiles and b.stats.shape[2] == 2 * a.stats.shape[2]
-    assert rel_err(b.stats.sum(2), a.stats.sum(2)) < 1e-6  # (fp32 block sums per lane are grouped differently)
-    assert rel_err(bn.t, an.t) < 1e-6
-
-
 # ------------------------------------------------------------------------------------------------------------
 # model level, batch 256
 # ------------------------------------------------------------------------------------------------------------

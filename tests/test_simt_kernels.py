@@ -801,36 +801,6 @@ WS_CASES = [
 @pytest.mark.parametrize("schedule", SCHEDULES)
 @pytest.mark.parametrize("case", WS_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()).replace(" ", ""))
 def test_conv_f16ws(case, schedule, monkeypatch, request):
-    _run_ws_case(case, schedule, monkeypatch, request)
-
-
-W64_CASES = [c for c in WS_CASES if c["cout"] == 64 and c["k"] == 3 and c["w"] % 16 == 0 and not c.get("proj") and c.get("force_b8", True)]
-
-
-@pytest.mark.parametrize("schedule", SCHEDULES)
-@pytest.mark.parametrize("case", W64_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()).replace(" ", ""))
-def test_conv_f16ws_w64_wave_tile_is_bitwise_the_shipping_geometry(case, schedule, monkeypatch, request):
-    """WsGeomW64 (DIAMOND_WS_W64=1: a consumer wave owns both cout blocks x 64 pixels instead of one cout block x 128 pixels -- 20 %
-    fewer LDS fragment reads): the same products in the same order per accumulator, so the outputs are BIT-identical to the
-    shipping geometry's; its GroupNorm partial sums come per 4 image rows (dmd_conv2d_stat_tiles) and add up to the same totals."""
-    from tests.conftest import reload_dmd_env
-
-    base_out, base_stats, name0 = _run_ws_case(case, 0, monkeypatch, None)
-    monkeypatch.setenv("DIAMOND_WS_W64", "1")
-    reload_dmd_env()
-    try:
-        out, stats, name1 = _run_ws_case(case, schedule, monkeypatch, None)  # (any wave schedule: a missing barrier would show)
-    finally:
-        monkeypatch.delenv("DIAMOND_WS_W64")
-        reload_dmd_env()
-    assert name0 == "conv_f16ws_kernel<WsGeom<false, 2, 9>>" and name1 == "conv_f16ws_kernel<WsGeomW64>", (name0, name1)
-    assert np.array_equal(out, base_out)
-    if stats is not None:
-        assert stats.shape[2] == 2 * base_stats.shape[2]
-        np.testing.assert_allclose(stats.sum(axis=2), base_stats.sum(axis=2), rtol=1e-6, atol=1e-5)
-
-
-def _run_ws_case(case, schedule, monkeypatch, request):
     monkeypatch.delenv("DIAMOND_CONV_LATENCY_TILES", raising=False)
     monkeypatch.setenv("SIMT_SCHEDULE", str(schedule))
     rng = np.random.default_rng(23)
@@ -886,8 +856,7 @@ def _run_ws_case(case, schedule, monkeypatch, request):
     nchw = bool(case.get("nchw"))
     out = G(np.full((n, cout, h, w) if nchw else (n, h, w, cout), np.nan, dtype=np.float32))
     p.out, p.out_nchw = S.ptr(out), int(nchw)
-    tiles = L.dmd_conv2d_stat_tiles(p)  # (= dmd_conv_stat_tiles(h, w) for every shipping geometry)
-    assert tiles in (L.dmd_conv_stat_tiles(h, w), 2 * L.dmd_conv_stat_tiles(h, w))
+    tiles = L.dmd_conv_stat_tiles(h, w)
     stats = G(np.full((n, cout // 32, tiles, 2), np.nan)) if case.get("stats") else None
     p.out_stats = S.ptr(stats)
 
@@ -899,12 +868,10 @@ def _run_ws_case(case, schedule, monkeypatch, request):
     got = out.transpose(0, 2, 3, 1) if nchw else out
     err = np.abs(got[:, :hv, :wv] - ref[:, :hv, :wv]).max()
     assert err <= 2e-5 * max(1.0, np.abs(ref).max()), (buf.value, err)
-    if request is not None:
-        _same_bits_as_schedule_0(request, schedule, out[:, :hv, :wv] if not nchw else out[:, :, :hv, :wv], stats)
+    _same_bits_as_schedule_0(request, schedule, out[:, :hv, :wv] if not nchw else out[:, :, :hv, :wv], stats)
     if stats is not None:
         want = _group_sums(np.ascontiguousarray(got.astype(np.float32)), hv, wv)
         np.testing.assert_allclose(stats.sum(axis=2), want, rtol=2e-6, atol=1e-4)  # (fp32 sums of a lane's 16 values inside)
-    return np.array(out[:, :hv, :wv] if not nchw else out[:, :, :hv, :wv]), (None if stats is None else np.array(stats)), buf.value.decode()
 
 
 def test_zz_schedule_comparisons_took_place():
