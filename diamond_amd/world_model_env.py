@@ -63,7 +63,9 @@ class _no_random_draws:
         return False
 
 
-GRAPH_SAMPLER_MAX_ENVS = 8  # below this the sampler is launch-latency-bound and runs as a replayed hipGraph
+GRAPH_SAMPLER_MAX_ENVS = 8  # below this the sampler is launch-latency-bound and runs as a replayed hipGraph ...
+GRAPH_SAMPLER_MAX_PIXELS = 8 * 64 * 64  # ... if its launches are small: 8 envs at 256x256 are not (configs[4]: eager + speculation
+#                                         measured 367-370 frames/s against 364-365 replayed, same box, alternating)
 
 
 @dataclass
@@ -207,6 +209,7 @@ class WorldModelEnv:
         self.horizon = cfg.horizon
         self.return_denoising_trajectory = return_denoising_trajectory
         self.num_envs = data_loader.batch_sampler.batch_size
+        self._graph_forced = graph_sampler is not None or os.environ.get("DIAMOND_GRAPH_SAMPLER") is not None
         if graph_sampler is None:
             env = os.environ.get("DIAMOND_GRAPH_SAMPLER")
             graph_sampler = (self.num_envs <= GRAPH_SAMPLER_MAX_ENVS) if env is None else env == "1"
@@ -572,7 +575,12 @@ class WorldModelEnv:
     def _use_graph(self) -> bool:
         # (no replay while a launch profiler is installed: a replayed graph issues no launches it could time, and a first
         #  capture inside the profiled window would record timing events into the graph)
-        return self.graph_sampler and self.sampler.noise_fn is None and nv.PROFILER is None
+        if not (self.graph_sampler and self.sampler.noise_fn is None and nv.PROFILER is None):
+            return False
+        if self._graph_forced or self._ctx is None:
+            return True
+        b, _, _, h, w = self._ctx.shape
+        return b * h * w <= GRAPH_SAMPLER_MAX_PIXELS
 
     @torch.no_grad()
     def predict_next_obs(self) -> Tuple[Tensor, List[Tensor]]:

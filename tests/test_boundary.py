@@ -197,7 +197,7 @@ def test_ring_env_bookkeeping_matches_roll_based_shadow_cpu():
     env.sampler = SimpleNamespace(denoiser=fake_den, noise_fn=None, cfg=SimpleNamespace(s_churn=0.0),
                                   _randn=lambda shape, dev: torch.zeros(*shape))
     env.rew_end_model, env.horizon, env.return_denoising_trajectory, env.num_envs = None, 3, False, b
-    env.graph_sampler, env.expo_fn = False, None
+    env.graph_sampler, env.expo_fn, env._graph_forced = False, None, False
     env._ctx = env._act = None
     env._head = 0
     from diamond_amd.world_model_env import InitialConditionPool
@@ -262,7 +262,7 @@ def _fake_env(b, t, c, h, w, horizon, rounds):
     env.sampler = SimpleNamespace(denoiser=SimpleNamespace(device=torch.device("cpu")), noise_fn=None, cfg=SimpleNamespace(s_churn=0.0),
                                   _randn=lambda shape, dev: torch.randn(*shape), sample_ring=sample_ring)
     env.rew_end_model, env.horizon, env.return_denoising_trajectory, env.num_envs = None, horizon, False, b
-    env.graph_sampler, env.expo_fn = False, None
+    env.graph_sampler, env.expo_fn, env._graph_forced = False, None, False
     env._ctx = env._act = None
     env._head = 0
     env._dead_host = env._flag_event = env._rows_pinned = env._ep_len_host = None
