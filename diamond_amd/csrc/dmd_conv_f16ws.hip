@@ -640,12 +640,26 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
               }
             }
           }
+#if defined(DMD_LAB) && defined(WS_PK_MATH)
+          // (lab build, round 5: the two fmas as packed fp32 -- v_pk_fma_f32 handles two values per lane in one VALU slot; the same
+          //  IEEE fma per value: bit-identical.  Measured: profiles/r05x_pk_math_*.txt)
+          typedef float f2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+          for (int e2 = 0; e2 < 2; ++e2) {
+            const f2v x2 = {st[it][2 * e2], st[it][2 * e2 + 1]};
+            const f2v t2 = __builtin_elementwise_fma(x2, (f2v){ta[2 * e2], ta[2 * e2 + 1]}, (f2v){tb[2 * e2], tb[2 * e2 + 1]});
+            const f2v u2 = __builtin_elementwise_fma(x2, (f2v){tc[2 * e2], tc[2 * e2 + 1]}, (f2v){td[2 * e2], td[2 * e2 + 1]});
+            t[i][2 * e2] = t2[0], t[i][2 * e2 + 1] = t2[1];
+            u[i][2 * e2] = u2[0], u[i][2 * e2 + 1] = u2[1];
+          }
+#else
 #pragma unroll
           for (int el = 0; el < 4; ++el) {
             // y = a v + b (GroupNorm / FiLM; a = 1, b = 0 without a prologue); SiLU = y / (1 + 2^(c v + d))
             t[i][el] = __builtin_fmaf(st[it][el], ta[el], tb[el]);
             u[i][el] = __builtin_fmaf(st[it][el], tc[el], td[el]);
           }
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (BATCH == G::ITEMS) {
@@ -671,11 +685,21 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
           const bool zero = (zmask >> (I0 + i)) & 1;  // conv zero padding is applied AFTER the activation (blocks.py:143-144)
+#if defined(DMD_LAB) && defined(WS_PK_MATH)
+          typedef float f2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+          for (int e2 = 0; e2 < 2; ++e2) {
+            const f2v y2 = (f2v){t[i][2 * e2], t[i][2 * e2 + 1]} * (f2v){u[i][2 * e2], u[i][2 * e2 + 1]};  // v_pk_mul_f32
+            u[i][2 * e2] = zero ? 0.f : y2[0];
+            u[i][2 * e2 + 1] = zero ? 0.f : y2[1];
+          }
+#else
 #pragma unroll
           for (int el = 0; el < 4; ++el) {
             const float y = t[i][el] * u[i][el];
             u[i][el] = zero ? 0.f : y;  // no clamp: out-of-range operands turn into NaN outputs (header)
           }
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
 #endif
