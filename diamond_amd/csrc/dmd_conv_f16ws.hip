@@ -246,21 +246,6 @@ __device__ __forceinline__ unsigned ws_low_pair(float x0, float x1, unsigned h01
       : "v"(x0), "v"(x1), "v"(h01));
   return l01;
 }
-// fp32 additions the compiler must not pack (round 5): hipcc's SLP vectoriser turns neighbouring scalar adds into v_pk_add_f32
-// (plus the v_mov shuffles that line the pairs up).  On this SIMD packed fp32 arithmetic in a staging / write-out wave costs the
-// co-resident consumer wave more MFMA issue than the scalar instructions it replaces: the staging's fmas as v_pk_fma_f32 measured
-// 9-13 % SLOWER (profiles/r05x_pk_math_staging_ab.txt), and un-packing the adds the compiler had packed measured 1.6 % faster on the
-// dominant instance, +0.9 % on the window (profiles/r05y_scalar_adds_ab.txt).  Same IEEE addition: bit-identical results.
-__device__ __forceinline__ float ws_add(float a, float b) {
-  float r;
-  asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ float ws_add1(float a) {  // 1.0f + a (inline constant: no register for the 1)
-  float r;
-  asm("v_add_f32 %0, 1.0, %1" : "=v"(r) : "v"(a));
-  return r;
-}
 // `t` = an opaque copy of itself: the compiler may not reason about its value (no instruction)
 #define WS_OPAQUE(t) asm volatile("" : "+v"(t))
 // wait until at most n vector-memory operations of this wave are outstanding (a literal)
@@ -690,7 +675,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
 #pragma unroll
         for (int i = 0; i < NB; ++i)
 #pragma unroll
-          for (int el = 0; el < 4; ++el) u[i][el] = ws_add1(u[i][el]);  // (not v_pk_add_f32: see ws_add)
+          for (int el = 0; el < 4; ++el) u[i][el] = 1.0f + u[i][el];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < NB; ++i)
@@ -984,8 +969,14 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           for (int qd = 0; qd < 4; ++qd) {
             v[qd] = (f32x4){acc[blk][4 * qd], acc[blk][4 * qd + 1], acc[blk][4 * qd + 2], acc[blk][4 * qd + 3]};
             if (!G::PROJ) {
+              // element by element, and this file is compiled with -fno-slp-vectorize (build.sh): as ONE vector add -- or re-packed by
+              // the SLP vectoriser -- these become v_pk_add_f32 (+ v_mov shuffles), and packed fp32 arithmetic in a write-out / staging
+              // wave costs the co-resident consumer wave more MFMA issue than the scalar instructions (round 5: the staging's fmas
+              // as v_pk_fma_f32 measured 9-13 % SLOWER, profiles/r05x_*; these adds un-packed: profiles/r05y_*, r05z_*).  NOT inline
+              // assembly: the hazard recogniser does not look into it, and accumulators fresh out of the fused projection's MFMAs
+              // read that way gave batch-dependent frames (11 GPU tests caught the first version of this change).
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[qd][r] = ws_add(v[qd][r], rnext[qd][r]);  // (not v_pk_add_f32: see ws_add)
+              for (int r = 0; r < 4; ++r) v[qd][r] += rnext[qd][r];
             }
           }
           if (land) {  // (the waits hipcc emits for `rnext` leave the younger LDS-DMA in flight; this one does not)
@@ -996,7 +987,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
 #pragma unroll
           for (int qd = 0; qd < 4; ++qd) {
             if (!(WS_ABL & 128) || v[qd][0] == 1.2345e30f) *(f32x4*)(op + 8 * qd) = v[qd];
-            fs = ws_add(fs, ws_add(ws_add(v[qd][0], v[qd][1]), ws_add(v[qd][2], v[qd][3])));
+            fs += (v[qd][0] + v[qd][1]) + (v[qd][2] + v[qd][3]);
             // Sum of squares as an fma chain into its own register, NOT as in-place squares of v: with the squares
             // written over v's registers (`v_mul_f32 v48, v48, v48` right behind the `global_store_dwordx4 v[48:51]`),
             // a slice executed while the other consumer group's MFMAs run on the same SIMD lost one lane's
@@ -1062,7 +1053,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
           for (int qd = 0; qd < 4; ++qd) {
             const f32x4 v = (f32x4){acc[blk][4 * qd], acc[blk][4 * qd + 1], acc[blk][4 * qd + 2], acc[blk][4 * qd + 3]};
             if (!(WS_ABL & 128) || v[0] == 1.2345e30f) *(f32x4*)(op + 8 * qd) = v;
-            fs = ws_add(fs, ws_add(ws_add(v[0], v[1]), ws_add(v[2], v[3])));
+            fs += (v[0] + v[1]) + (v[2] + v[3]);
             fq = __builtin_fmaf(v[0], v[0], fq);  // (an fma chain into its own register: see epi_blocks)
             fq = __builtin_fmaf(v[1], v[1], fq);
             fq = __builtin_fmaf(v[2], v[2], fq);

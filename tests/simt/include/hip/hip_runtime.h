@@ -96,8 +96,6 @@ template <class V> inline void ws_aload(V& dst, const V* src) { dst = *src; }
 template <bool FIRST, class V> inline void ws_aload(V& dst, const void* base, unsigned voff) { dst = *(const V*)((const char*)base + voff); }
 template <int N, class V> inline void ws_await(V&) {}
 inline unsigned ws_low_pair(float x0, float x1, unsigned h01) { return simt_split_low_pair(x0, x1, h01); }
-inline float ws_add(float a, float b) { return a + b; }
-inline float ws_add1(float a) { return 1.0f + a; }
 template <int N, class V, int M> inline void ws_await_set(V (&)[M]) {}
 template <int N, class V, int M> inline void ws_use_all(V (&)[M]) {}
 #define WS_OPAQUE(t) ((void)(t))

@@ -33,9 +33,22 @@ def regs(text):
     return out
 
 
+def extra_flags(src_path):
+    """per-source hipcc flags on top of the common ones (diamond_amd/csrc/extra_flags.txt, shared with build.sh)"""
+    import os
+    d = os.path.dirname(os.path.abspath(src_path))
+    try:
+        for line in open(os.path.join(d, "extra_flags.txt")):
+            if not line.startswith("#") and line.split()[:1] == [os.path.basename(src_path)]:
+                return line.split()[1:]
+    except OSError:
+        pass
+    return []
+
+
 def compile_s():
     d = tempfile.mkdtemp(prefix="asm_lint_")
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip", "-c", SRC,
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", *extra_flags(SRC), "-x", "hip", "-c", SRC,
            "-save-temps", "-o", os.path.join(d, "x.o")]
     subprocess.check_call(cmd, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     for f in os.listdir(d):

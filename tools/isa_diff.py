@@ -27,11 +27,24 @@ def kernels(asm_path):
     return out
 
 
+def extra_flags(src_path):
+    """per-source hipcc flags on top of the common ones (diamond_amd/csrc/extra_flags.txt, shared with build.sh)"""
+    import os
+    d = os.path.dirname(os.path.abspath(src_path))
+    try:
+        for line in open(os.path.join(d, "extra_flags.txt")):
+            if not line.startswith("#") and line.split()[:1] == [os.path.basename(src_path)]:
+                return line.split()[1:]
+    except OSError:
+        pass
+    return []
+
+
 def compile_tree(csrc, outdir):
     procs = []
     for f in sorted(glob.glob(os.path.join(csrc, "*.hip"))):
         o = os.path.join(outdir, os.path.basename(f)[:-4] + ".s")
-        procs.append(subprocess.Popen(["hipcc", *FLAGS, f, "-o", o], stderr=subprocess.DEVNULL, cwd=csrc))
+        procs.append(subprocess.Popen(["hipcc", *FLAGS, *extra_flags(f), f, "-o", o], stderr=subprocess.DEVNULL, cwd=csrc))
     for p in procs:
         p.wait()
     res = {}

@@ -25,8 +25,21 @@ def demangle(names):
         return names
 
 
+def extra_flags(src_path):
+    """per-source hipcc flags on top of the common ones (diamond_amd/csrc/extra_flags.txt, shared with build.sh)"""
+    import os
+    d = os.path.dirname(os.path.abspath(src_path))
+    try:
+        for line in open(os.path.join(d, "extra_flags.txt")):
+            if not line.startswith("#") and line.split()[:1] == [os.path.basename(src_path)]:
+                return line.split()[1:]
+    except OSError:
+        pass
+    return []
+
+
 def usage(path):
-    r = subprocess.run(["hipcc"] + FLAGS + ["-x", "hip", "-c", path, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"],
+    r = subprocess.run(["hipcc"] + FLAGS + extra_flags(os.path.join(CSRC, path) if not os.path.isabs(path) else path) + ["-x", "hip", "-c", path, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"],
                        capture_output=True, text=True, cwd=CSRC)
     rows, cur = [], None
     for line in r.stderr.splitlines():
