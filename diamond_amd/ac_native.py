@@ -49,10 +49,33 @@ def _maxpool_bwd(dp: Tensor, arg: Tensor) -> Tensor:
     return dx
 
 
+class WgradBatch:
+    """Weight gradients whose reductions wait for ONE launch per 32 of them (`dmd_wgrad_reduce_jobs`, ABI v10): the backward of a
+    denoiser training step holds ~60 weight gradients nobody reads before it is over, and their reductions were ~140 launches
+    of a few microseconds of work.  The sums are formed in the undeferred order: bit-identical gradients."""
+
+    def __init__(self) -> None:
+        self.jobs: List[nv.WgradReduceJob] = []
+        self._keep: List[Tensor] = []  # the workspaces holding the partials (and the outputs) until flush()
+
+    def add(self, job: "nv.WgradReduceJob", *keep: Tensor) -> None:
+        self.jobs.append(job)
+        self._keep.extend(keep)
+
+    def flush(self) -> None:
+        if self.jobs:
+            table = (nv.WgradReduceJob * len(self.jobs))(*self.jobs)
+            nv.check(nv.lib().dmd_wgrad_reduce_jobs(table, len(self.jobs), nv.stream()), "dmd_wgrad_reduce_jobs")
+        self.jobs, self._keep = [], []
+
+
 def _wgrad(x: Act, prologue: int, spec: Optional[NormSpec], dy: Tensor, taps: int, cin_real: int,
-           want_bias: bool = True, split: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+           want_bias: bool = True, split: bool = False, batch: Optional[WgradBatch] = None, dw_out: Optional[Tensor] = None,
+           c0: int = 0, db_out: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
     """dW, db of a convolution.  split: operands as split-fp16 pairs (needs dy pre-scaled to O(1): the callers' 2^k scaling);
-    False: exact fp32 fma chain."""
+    False: exact fp32 fma chain.  batch: the reduction of the partial sums is left to batch.flush(); then dw_out (rows of a
+    contiguous OIHW tensor whose input-channel extent may be wider than this source: the gradient lands in channels
+    [c0, c0 + cin_real)) and db_out (or None) name where the gradient goes."""
     n, h, w, cout = dy.shape
     k = 3 if taps == 9 else 1
     p = nv.WgradParams()
@@ -67,6 +90,19 @@ def _wgrad(x: Act, prologue: int, spec: Optional[NormSpec], dy: Tensor, taps: in
         p.valid_h, p.valid_w = x.valid
     p.dy = nv.ptr(dy)
     p.precision = nv.PRECISION_F16X2 if split else nv.PRECISION_F32
+    if batch is not None:
+        assert dw_out is not None and dw_out.is_contiguous() and dw_out.shape[0] >= cout and tuple(dw_out.shape[2:]) == (k, k) \
+            and c0 + cin_real <= dw_out.shape[1] and (db_out is None or (db_out.is_contiguous() and db_out.numel() >= cout))
+        p.dw, p.dbias, p.defer_reduce = nv.ptr(dw_out), nv.ptr(db_out), 1
+        job = nv.WgradReduceJob()
+        nv.check(nv.lib().dmd_wgrad_job(C.byref(p), C.byref(job)), "dmd_wgrad_job")
+        # (the partials only, and they stay alive until the flush: the plan's workgroups, not the 1024 the query sizes for)
+        ws = torch.empty(job.num_wg * (job.NB * job.NCO * 256 + job.NCO * 16), device=dy.device, dtype=torch.float32)
+        p.workspace = job.partials = nv.ptr(ws)
+        job.ld_cin, job.c0 = dw_out.shape[1], c0
+        nv.check(nv.lib().dmd_conv2d_wgrad(C.byref(p), nv.stream()), "dmd_conv2d_wgrad")
+        batch.add(job, ws, dw_out) if db_out is None else batch.add(job, ws, dw_out, db_out)
+        return dw_out, db_out
     ws = torch.empty(int(nv.lib().dmd_wgrad_workspace_floats(C.byref(p))), device=dy.device, dtype=torch.float32)
     dw = torch.empty(cout, cin_real, k, k, device=dy.device, dtype=torch.float32)
     db = torch.empty(cout, device=dy.device, dtype=torch.float32) if want_bias else None
@@ -219,11 +255,22 @@ class _EncoderFn(torch.autograd.Function):
             dfeat = torch.nn.functional.pad(dfeat, (0, wb - wl, 0, hb - hl))
         dcur = E.nchw_to_nhwc(dfeat.contiguous())
         grads_rev: List[Optional[Tensor]] = []
+        # (the reductions of this backward's weight gradients as ONE launch at its end instead of two per gradient: same sums)
+        batch = WgradBatch() if os.environ.get("DIAMOND_WGRAD_DEFER", "1") == "1" else None
+
+        def wgrad(src, prologue, spec_, dy_, taps, cin):
+            if batch is None:
+                return _wgrad(src, prologue, spec_, dy_, taps, cin, split=split)
+            kk = 3 if taps == 9 else 1
+            return _wgrad(src, prologue, spec_, dy_, taps, cin, split=split, batch=batch,
+                          dw_out=torch.empty(dy_.shape[-1], cin, kk, kk, device=dy_.device, dtype=torch.float32),
+                          db_out=torch.empty(dy_.shape[-1], device=dy_.device, dtype=torch.float32))
+
         for (blk, pool), (x, arg) in zip(reversed(plan.blocks), reversed(ctx.saved)):
             gn, conv = blk.f[0].norm, blk.f[2]
             spec = NormSpec(mul=cache.f32(gn.weight), add=cache.f32(gn.bias))
             dy = _maxpool_bwd(dcur, arg) if pool else dcur
-            dw, db = _wgrad(x, nv.PROLOGUE_NORM_SILU, spec, dy, 9, conv.in_channels, split=split)
+            dw, db = wgrad(x, nv.PROLOGUE_NORM_SILU, spec, dy, 9, conv.in_channels)
             vy = x.valid  # (a stride-1 block: its output exists where its input does; dy is zero elsewhere, and is treated so)
             da = E.conv2d([(Act(dy, valid=vy), nv.PROLOGUE_NONE, None)], _dgrad_weight(cache, conv), None, conv.in_channels,
                           want_stats=False, w_f16=_dgrad_w16(cache, conv)).t
@@ -232,7 +279,7 @@ class _EncoderFn(torch.autograd.Function):
             if isinstance(sp, nn.Identity):
                 dskip = dy
             else:
-                dws, dbs = _wgrad(x, nv.PROLOGUE_NONE, None, dy, 1, sp.in_channels, split=split)
+                dws, dbs = wgrad(x, nv.PROLOGUE_NONE, None, dy, 1, sp.in_channels)
                 dskip = E.conv2d([(Act(dy, valid=vy), nv.PROLOGUE_NONE, None)], _dgrad_weight(cache, sp), None, sp.in_channels, taps=1,
                                  want_stats=False).t
                 g_skip = [dws, dbs]
@@ -242,7 +289,9 @@ class _EncoderFn(torch.autograd.Function):
             grads_rev += list(reversed([dms[0], dms[1], dw, db] + g_skip))
             dcur = dx
         ci = plan.conv_in
-        dw_in, db_in = _wgrad(ctx.x16, nv.PROLOGUE_NONE, None, dcur, 9, ctx.cimg, split=split)
+        dw_in, db_in = wgrad(ctx.x16, nv.PROLOGUE_NONE, None, dcur, 9, ctx.cimg)
+        if batch is not None:
+            batch.flush()
         # (one multi-tensor launch instead of one broadcast multiplication per gradient: 18 per step, 270 per window)
         grads = torch._foreach_mul([dw_in, db_in] + list(reversed(grads_rev)), inv_scale)
         return (None, None, None, *grads)

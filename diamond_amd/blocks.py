@@ -233,17 +233,20 @@ class ResBlock(nn.Module):
             r = xs[0]
         elif E.proj_fusable(xs, cout, ctx.precision, ctx.naive):
             # the up path's 128 -> 64 skip projection rides in conv2's write-out (no HBM round trip of its result)
-            proj = (list(xs), ctx.w16(self.proj), ctx.cache.conv_bias(self.proj))
-        else:
-            r = E.conv2d([(a, nv.PROLOGUE_NONE, None) for a in xs], ctx.cache.conv_weight(self.proj),
-                         ctx.cache.conv_bias(self.proj), cout, taps=1, want_stats=False, naive=ctx.naive,
-                         w_f16=ctx.w16(self.proj), module=self.proj)
+            proj = (list(xs), ctx.w16(self.proj), ctx.cache.conv_bias(self.proj), self.proj)
         srcs, c0 = [], 0
         for a in xs:
             srcs.append((a, nv.PROLOGUE_NORM_SILU, ctx.film_spec(self.norm1, c0)))
             c0 += a.C
         h = E.conv2d(srcs, ctx.cache.conv_weight(self.conv1), ctx.cache.conv_bias(self.conv1), cout, naive=ctx.naive,
                      w_f16=ctx.w16(self.conv1), fast_math=ctx.fast_math, module=self.conv1)
+        if r is None and proj is None:
+            # the projection as its own launch (training, fp32).  BEHIND conv1 on purpose: the recorded backward walks the launches
+            # in reverse, so the projection's input gradients exist when conv1's GroupNorm backward runs and are added inside that
+            # kernel (its dskip operand) instead of by one torch addition per source afterwards -- 24 launches per training step
+            r = E.conv2d([(a, nv.PROLOGUE_NONE, None) for a in xs], ctx.cache.conv_weight(self.proj),
+                         ctx.cache.conv_bias(self.proj), cout, taps=1, want_stats=False, naive=ctx.naive,
+                         w_f16=ctx.w16(self.proj), module=self.proj)
         h = E.conv2d([(h, nv.PROLOGUE_NORM_SILU, ctx.film_spec(self.norm2))], ctx.cache.conv_weight(self.conv2),
                      ctx.cache.conv_bias(self.conv2), cout, residual=r, naive=ctx.naive, w_f16=ctx.w16(self.conv2),
                      fast_math=ctx.fast_math, module=self.conv2, proj=proj)

@@ -10,6 +10,7 @@
 //   * GroupNorm+SiLU backward = two passes (group reductions, then elementwise apply);
 //   * MaxPool backward = scatter by the saved argmax.
 #include <stdlib.h>
+#include <string.h>
 
 #include "dmd_common.h"
 
@@ -640,6 +641,51 @@ __global__ void wgrad_reduce2_kernel(const float* __restrict__ ws2, int nslices,
   }
 }
 
+// The same two reductions for MANY weight gradients in one launch (dmd_wgrad_reduce_jobs): a training step's backward holds ~60
+// weight gradients whose reductions are ~140 launches of a few microseconds of work each, and nobody reads a weight gradient
+// before the backward is over.  blockIdx.y = job (the table travels BY VALUE in the kernel arguments: no device table to
+// upload, nothing a hipGraph replay could find stale), one thread per element, the additions of an element in exactly the
+// order of the two kernels above (slice sums in fp32 in workgroup order, the slices in fp64 in slice order; few partials:
+// directly in fp64) -- the gradients are bit-identical to the undeferred launches.  ld_cin / c0: the element lands in
+// dw[(co * ld_cin + c0 + ci) * taps + tap], so the sources of a convolution over concatenated inputs write the slices of ONE
+// OIHW tensor (no torch.cat afterwards).
+#define WGRAD_JOBS_PER_LAUNCH 32
+struct wgrad_job_batch {
+  dmd_wgrad_reduce_job job[WGRAD_JOBS_PER_LAUNCH];
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_jobs_kernel(const wgrad_job_batch b) {
+  const dmd_wgrad_reduce_job& j = b.job[blockIdx.y];
+  const int per = j.NB * j.NCO * 256;
+  const int per_total = per + j.NCO * 16;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= per_total) return;
+  const float* __restrict__ ws = j.partials;
+  double s = 0.0;
+  if (j.num_wg <= 4 * WGRAD_SLICES) {
+#pragma unroll 4
+    for (int w = 0; w < j.num_wg; ++w) s += (double)ws[(size_t)w * per_total + idx];
+  } else {
+    for (int sl = 0; sl < WGRAD_SLICES; ++sl) {
+      float f = 0.f;
+#pragma unroll 4
+      for (int w = sl; w < j.num_wg; w += WGRAD_SLICES) f += ws[(size_t)w * per_total + idx];  // (loads ahead, additions in order)
+      s += (double)f;
+    }
+  }
+  if (idx < per) {
+    const int r = idx & 3, lane = (idx >> 2) & 63;
+    const int blk = idx >> 8;
+    const int cob = blk % j.NCO, bb = blk / j.NCO;
+    const int tap = bb / j.NCI, cib = bb - tap * j.NCI;
+    const int co = cob * 16 + 4 * (lane >> 4) + r;
+    const int ci = cib * 16 + (lane & 15);
+    if (ci < j.cin_real) j.dw[((size_t)co * j.ld_cin + j.c0 + ci) * j.taps + tap] = (float)s;
+  } else if (j.dbias) {
+    j.dbias[idx - per] = (float)s;
+  }
+}
+
 static int wgrad_plan(const dmd_wgrad_params* p, int* tiles, int* num_wg, int* tpw) {
   const int sub = p->N * (p->H / 8) * (p->W / 8);
   *tiles = (sub + 1) / 2;
@@ -684,6 +730,7 @@ static int launch_wgrad(const dmd_wgrad_params& p, hipStream_t st) {
   else
     hipLaunchKernelGGL((wgrad_kernel<G, false>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
   const int per_total = G::NB * NCO * 256 + NCO * 16;
+  if (p.defer_reduce) return 0;  // (the partials stay in the workspace: dmd_wgrad_job describes them, dmd_wgrad_reduce_jobs sums them)
   float* ws2 = p.workspace + (size_t)num_wg * per_total;
   const int single = 4 * WGRAD_SLICES;
   if (num_wg <= single) {
@@ -700,8 +747,54 @@ static int launch_wgrad(const dmd_wgrad_params& p, hipStream_t st) {
   return 0;
 }
 
+extern "C" int dmd_wgrad_job(const dmd_wgrad_params* p, dmd_wgrad_reduce_job* job) {
+  DMD_CHECK_ARG(p && job, "wgrad job: null");  // (workspace / dw / dbias may still be null: the caller fills the job's pointers)
+  DMD_CHECK_ARG(p->taps == 9 || p->taps == 1, "wgrad job: taps");
+  DMD_CHECK_ARG(p->Cout % 16 == 0 && p->src.C % 16 == 0 && p->cin_real > 0 && p->cin_real <= p->src.C, "wgrad job: channels");
+  int tiles, num_wg, tpw;
+  wgrad_plan(p, &tiles, &num_wg, &tpw);
+  job->partials = p->workspace;
+  job->dw = p->dw;
+  job->dbias = p->dbias;
+  job->num_wg = num_wg;
+  job->NCI = p->src.C / 16;
+  job->NCO = p->Cout / 16;
+  job->NB = p->taps * job->NCI;
+  job->taps = p->taps;
+  job->cin_real = p->cin_real;
+  job->ld_cin = p->cin_real;  // (the caller widens these two for a gradient that is a slice of a larger OIHW tensor)
+  job->c0 = 0;
+  return 0;
+}
+
+extern "C" int dmd_wgrad_reduce_jobs(const dmd_wgrad_reduce_job* jobs, int njobs, dmd_stream_t stream) {
+  DMD_CHECK_ARG(njobs >= 0 && (jobs || njobs == 0), "wgrad reduce jobs: null");
+  hipStream_t st = (hipStream_t)stream;
+  for (int j0 = 0; j0 < njobs; j0 += WGRAD_JOBS_PER_LAUNCH) {
+    wgrad_job_batch b;
+    memset(&b, 0, sizeof(b));
+    const int n = njobs - j0 < WGRAD_JOBS_PER_LAUNCH ? njobs - j0 : WGRAD_JOBS_PER_LAUNCH;
+    int max_total = 0;
+    for (int i = 0; i < n; ++i) {
+      const dmd_wgrad_reduce_job& j = jobs[j0 + i];
+      DMD_CHECK_ARG(j.partials && j.dw && j.num_wg > 0 && j.num_wg <= 1024 && j.NCO > 0 && j.NCI > 0 && (j.taps == 9 || j.taps == 1) &&
+                        j.NB == j.taps * j.NCI,
+                    "wgrad reduce jobs: job %d malformed", j0 + i);
+      DMD_CHECK_ARG(j.cin_real > 0 && j.cin_real <= 16 * j.NCI && j.c0 >= 0 && j.c0 + j.cin_real <= j.ld_cin,
+                    "wgrad reduce jobs: job %d: channels [%d, %d) outside a row of %d", j0 + i, j.c0, j.c0 + j.cin_real, j.ld_cin);
+      b.job[i] = j;
+      const int per_total = j.NB * j.NCO * 256 + j.NCO * 16;
+      if (per_total > max_total) max_total = per_total;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_jobs_kernel, dim3((max_total + 255) / 256, n), dim3(256), 0, st, b);
+  }
+  DMD_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int dmd_conv2d_wgrad(const dmd_wgrad_params* p, dmd_stream_t stream) {
   DMD_CHECK_ARG(p && p->src.x && p->dy && p->workspace && p->dw, "wgrad: null");
+  DMD_CHECK_ARG(p->defer_reduce == 0 || p->defer_reduce == 1, "wgrad: defer_reduce is 0 or 1");
   DMD_CHECK_ARG(p->N > 0 && p->H % 8 == 0 && p->W % 8 == 0, "wgrad: H, W must be multiples of 8 (%d x %d)", p->H, p->W);
   DMD_CHECK_ARG(p->taps == 9 || p->taps == 1, "wgrad: taps");
   DMD_CHECK_ARG(p->valid_h >= 0 && p->valid_h <= p->H && p->valid_w >= 0 && p->valid_w <= p->W && (p->valid_h == 0) == (p->valid_w == 0),

@@ -565,8 +565,8 @@ def conv2d(
     if proj is not None:
         # `proj(cat(sources)) + conv(...)` in one launch (ResBlock.forward, blocks.py:147); dmd_conv2d fails loudly
         # on parameters dmd_conv2d_proj_eligible() rejects -- the caller asks proj_fusable() first
-        p_srcs, p_w16, p_bias = proj
-        assert TAPE is None and residual is None and len(p_srcs) == 2
+        p_srcs, p_w16, p_bias, p_module = proj
+        assert residual is None and len(p_srcs) == 2
         p.proj_nsrc = len(p_srcs)
         for i, a in enumerate(p_srcs):
             assert a.t.is_contiguous() and a.t.dtype == torch.float32 and tuple(a.shape[:3]) == (n, h, w)
@@ -593,6 +593,13 @@ def conv2d(
     result = Act(out, stats, tiles, valid=valid)
     if TAPE is not None:
         assert module is not None, "recording a conv launch that does not name its nn.Conv2d"
+        if proj is not None:
+            # recorded as what it computes -- the projection as a launch of its own in front of this one, its result this launch's
+            # residual.  The backward of a convolution needs its inputs and the gradient of its output, never the output: a
+            # one-element tensor stands for the result that was not materialised (the gradient dictionary is keyed by storage).
+            ghost = Act(torch.empty(1, device=dev, dtype=torch.float32))
+            TAPE.append(ConvRecord([(a, nv.PROLOGUE_NONE, None) for a in proj[0]], proj[3], 1, 1, False, None, None, ghost, False))
+            residual = ghost
         TAPE.append(ConvRecord(list(srcs), module, taps, stride, upsample, residual, residual_norm, result, out_nchw))
     return result
 
@@ -601,9 +608,11 @@ FUSE_PROJ = True  # skip projections inside conv2's launch (dmd_conv_f16ws.hip: 
 
 
 def proj_fusable(xs: Sequence[Act], cout: int, precision: str, naive: Optional[bool]) -> bool:
-    """Mirror of dmd_conv2d_proj_eligible() for a ResBlock whose conv2 is cout -> cout: split-fp16 inference launch (no
-    tape), cout == 64, H, W multiples of 16, two 64-channel projection sources."""
-    if not FUSE_PROJ or precision != "f16x2" or naive or _USE_NAIVE or TAPE is not None:
+    """Mirror of dmd_conv2d_proj_eligible() for a ResBlock whose conv2 is cout -> cout: split-fp16 launch (inference, or a
+    recorded training forward), cout == 64, H, W multiples of 16, two 64-channel projection sources."""
+    if not FUSE_PROJ or precision != "f16x2" or naive or _USE_NAIVE:
+        return False
+    if TAPE is not None and os.environ.get("DIAMOND_TRAIN_FUSE_PROJ", "1") != "1":  # (A/B switch: recorded forwards unfused, as before)
         return False
     n, hh, ww, _ = xs[0].shape
     if any(a.valid is not None for a in xs):

@@ -61,7 +61,13 @@ class GnBwdParams(C.Structure):
 class WgradParams(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cout", C.c_int32), ("taps", C.c_int32),
                 ("cin_real", C.c_int32), ("src", ConvSrc), ("dy", C.c_void_p), ("workspace", C.c_void_p), ("dw", C.c_void_p),
-                ("dbias", C.c_void_p), ("precision", C.c_int32), ("valid_h", C.c_int32), ("valid_w", C.c_int32), ("reserved", C.c_int32)]
+                ("dbias", C.c_void_p), ("precision", C.c_int32), ("valid_h", C.c_int32), ("valid_w", C.c_int32), ("defer_reduce", C.c_int32)]
+
+
+class WgradReduceJob(C.Structure):
+    _fields_ = [("partials", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p), ("num_wg", C.c_int32), ("NB", C.c_int32),
+                ("NCO", C.c_int32), ("NCI", C.c_int32), ("taps", C.c_int32), ("cin_real", C.c_int32), ("ld_cin", C.c_int32),
+                ("c0", C.c_int32)]
 
 
 class PackJob(C.Structure):
@@ -103,14 +109,15 @@ EXPORTS = (
     "dmd_edm_pack_input", "dmd_cond_embed", "dmd_edm_denoised", "dmd_euler_step", "dmd_heun_step", "dmd_quantize_u8", "dmd_reset_state",
     "dmd_dequant_gather", "dmd_nchw_to_nhwc",
     "dmd_nhwc_to_nchw", "dmd_gn_stats", "dmd_gn_stats_valid", "dmd_maxpool2", "dmd_lstm_pointwise", "dmd_lstm_pointwise_bwd", "dmd_categorical_sample",
-    "dmd_maxpool2_bwd", "dmd_gn_bwd_workspace_bytes", "dmd_gn_silu_bwd", "dmd_wgrad_workspace_floats", "dmd_conv2d_wgrad",
+    "dmd_maxpool2_bwd", "dmd_gn_bwd_workspace_bytes", "dmd_gn_silu_bwd", "dmd_wgrad_workspace_floats", "dmd_conv2d_wgrad", "dmd_wgrad_job", "dmd_wgrad_reduce_jobs",
     "dmd_lowres_chain", "dmd_lowres_chain32", "dmd_last_error", "dmd_abi_version", "dmd_reload_env",
 )
 
 # entry points that launch kernels (everything except queries / packing helpers that bench.py does not time)
 LAUNCHERS = frozenset(n for n in EXPORTS if n not in (
     "dmd_conv2d_kernel_name", "dmd_conv_stat_tiles", "dmd_conv2d_f16x2_eligible", "dmd_conv1x1_stream_eligible",
-    "dmd_conv2d_proj_eligible", "dmd_attention_bwd_workspace_floats", "dmd_gn_bwd_workspace_bytes", "dmd_wgrad_workspace_floats", "dmd_last_error", "dmd_abi_version", "dmd_reload_env"))
+    "dmd_conv2d_proj_eligible", "dmd_attention_bwd_workspace_floats", "dmd_gn_bwd_workspace_bytes", "dmd_wgrad_workspace_floats", "dmd_wgrad_job", "dmd_last_error",
+    "dmd_abi_version", "dmd_reload_env"))
 
 
 class LaunchProfiler:
@@ -225,6 +232,8 @@ def declare_signatures(L: C.CDLL) -> None:
     L.dmd_wgrad_workspace_floats.argtypes = [C.POINTER(WgradParams)]
     L.dmd_wgrad_workspace_floats.restype = C.c_int64
     L.dmd_conv2d_wgrad.argtypes = [C.POINTER(WgradParams), C.c_void_p]
+    L.dmd_wgrad_job.argtypes = [C.POINTER(WgradParams), C.POINTER(WgradReduceJob)]
+    L.dmd_wgrad_reduce_jobs.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.dmd_lowres_chain.argtypes = [C.POINTER(LowresChainParams), C.c_void_p]
     L.dmd_lowres_chain32.argtypes = [C.POINTER(LowresChainParams), C.c_void_p]
 

@@ -21,6 +21,7 @@ returned here flows on into the 44 AdaGroupNorm linears, `cond_proj` and `act_em
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -28,7 +29,7 @@ from torch import Tensor, nn
 
 from . import engine as E
 from . import native as nv
-from .ac_native import _gn_silu_bwd, _transposed, _wgrad
+from .ac_native import WgradBatch, _gn_silu_bwd, _transposed, _wgrad
 from .engine import Act, AttnRecord, ConvRecord, NormSpec
 
 TRAIN_PRECISION = "f16x2"  # arithmetic of the forward, dgrad and wgrad convolutions (split-fp16 operands, fp32 accumulate); "f32" = exact
@@ -161,6 +162,9 @@ def backward_tape(tape: List, cache: E.PackCache, d_out: Tensor, table: Tensor, 
     grads = _Grads()
     pg = _ParamGrads(table)
     pending_norm: Dict[int, Tensor] = {}  # gradient w.r.t. GN_affine(x) handed over by a residual_norm consumer
+    # the reductions of ALL weight gradients as one launch per 32 at the end (bit-identical sums), every source / 64-channel piece
+    # of a convolution writing its slice of ONE OIHW tensor; DIAMOND_WGRAD_DEFER=0: reduced per call and concatenated, as before
+    batch = WgradBatch() if os.environ.get("DIAMOND_WGRAD_DEFER", "1") == "1" else None
     if out_nhwc is None:
         last = tape[-1]
         assert isinstance(last, ConvRecord) and last.out_nchw, "the tape must end with the NCHW head convolution"
@@ -201,12 +205,21 @@ def backward_tape(tape: List, cache: E.PackCache, d_out: Tensor, table: Tensor, 
         dws: List[Tensor] = []
         db: Optional[Tensor] = None
         c0 = 0
+        if batch is not None:  # (rows: the channel count dy carries -- the head's 3 output channels travel padded to 16)
+            dw_all = torch.empty(dy_k.shape[-1], conv.in_channels, k, k, device=dy_k.device, dtype=torch.float32)
+            db = torch.empty(dy_k.shape[-1], device=dy_k.device, dtype=torch.float32)
         for si, (a, prologue, spec) in enumerate(rec.srcs):
             ci_pad = a.C
             ci_real = min(ci_pad, conv.in_channels - c0)
             src = Act(_upsample_nearest(a.t)) if rec.upsample else a
             assert not (rec.upsample and prologue != nv.PROLOGUE_NONE)
-            if cout > 64 and not head:  # qkv (192 channels): the wgrad instances take at most 64 output channels
+            if batch is not None:
+                step = 64 if cout > 64 and not head else dy_k.shape[-1]  # (the wgrad instances take at most 64 output channels: qkv)
+                for o in range(0, dy_k.shape[-1], step):
+                    dy_o = dy_k if step == dy_k.shape[-1] else dy_k[..., o:o + step].contiguous()
+                    _wgrad(src, prologue, spec, dy_o, rec.taps, ci_real, split=use_f16, batch=batch, dw_out=dw_all[o:o + step], c0=c0,
+                           db_out=db[o:o + step] if si == 0 else None)
+            elif cout > 64 and not head:  # qkv (192 channels): the wgrad instances take at most 64 output channels
                 parts = []
                 for o in range(0, cout, 64):
                     dwp, dbp = _wgrad(src, prologue, spec, dy_k[..., o:o + 64].contiguous(), rec.taps, ci_real, split=use_f16)
@@ -215,9 +228,10 @@ def backward_tape(tape: List, cache: E.PackCache, d_out: Tensor, table: Tensor, 
                 db_i = torch.cat([p_[1] for p_ in parts], dim=0)
             else:
                 dw_i, db_i = _wgrad(src, prologue, spec, dy_k, rec.taps, ci_real, split=use_f16)
-            dws.append(dw_i[:cout])
-            if si == 0:
-                db = db_i[:cout]
+            if batch is None:
+                dws.append(dw_i[:cout])
+                if si == 0:
+                    db = db_i[:cout]
             if a.needs_grad:
                 wp, w16 = _dgrad_weights(cache, conv, c0, c0 + ci_real, cpad, use_f16)
                 da = E.conv2d([(Act(dy_k), nv.PROLOGUE_NONE, None)], wp, None, ci_real, taps=rec.taps, want_stats=False, w_f16=w16,
@@ -234,9 +248,17 @@ def backward_tape(tape: List, cache: E.PackCache, d_out: Tensor, table: Tensor, 
                     grads.g[_key(a.t)] = dx  # dx already contains the gradient accumulated so far (dskip)
                     pg.norm_terms(spec, dmul, dadd)
             c0 += ci_real
-        pg.add_param(conv.weight, torch.cat(dws, dim=1) if len(dws) > 1 else dws[0])
+        if batch is not None:
+            if id(conv.weight) in pg.by_param:  # a convolution recorded twice: its gradients are ADDED, so they have to exist
+                batch.flush()
+            pg.add_param(conv.weight, dw_all[:cout])
+            db = db[:cout]
+        else:
+            pg.add_param(conv.weight, torch.cat(dws, dim=1) if len(dws) > 1 else dws[0])
         if conv.bias is not None and db is not None:
             pg.add_param(conv.bias, db)
+    if batch is not None:
+        batch.flush()
     assert not pending_norm, "a normalised residual was never matched with its pre-norm consumer"
     return pg
 

@@ -356,10 +356,33 @@ typedef struct dmd_wgrad_params {
   int32_t precision;   /* DMD_PRECISION_F32 (exact fp32 fma chain) | DMD_PRECISION_F16X2 (split-fp16 operands, fp32 accumulate) */
   /* VALID EXTENT (ABI v8; both 0: the whole tensor): rows < valid_h, columns < valid_w of src and dy exist; positions outside are
    * the convolution's zero padding (input, after the prologue) / contribute nothing (dy), GroupNorm counts the valid pixels. */
-  int32_t valid_h, valid_w, reserved;
+  int32_t valid_h, valid_w;
+  /* ABI v10 (was reserved, 0): 1 = stop after the per-workgroup partials; they stay in `workspace` (which the caller keeps alive)
+   * until a dmd_wgrad_reduce_jobs launch sums them into dw / dbias -- the job comes from dmd_wgrad_job(p). */
+  int32_t defer_reduce;
 } dmd_wgrad_params;
 int64_t dmd_wgrad_workspace_floats(const dmd_wgrad_params* p);
 int dmd_conv2d_wgrad(const dmd_wgrad_params* p, dmd_stream_t stream);
+
+/* Deferred reductions of weight gradients (ABI v10).  The reference leaves every weight gradient to autograd's per-layer kernels
+ * (src/models/diffusion/denoiser.py:93-122 -> loss.backward(), src/trainer.py:349-388); here the partial sums of ALL layers of a
+ * backward are reduced by one launch per 32 gradients once the last dmd_conv2d_wgrad(defer_reduce = 1) is issued.  The sums are
+ * formed in the order of the undeferred call: the gradients are bit-identical.  A job names where its gradient lands:
+ * element (co, ci, tap) -> dw[(co * ld_cin + c0 + ci) * taps + tap], so the sources of a convolution over concatenated inputs
+ * (ld_cin = all input channels, c0 = this source's first) and the 64-channel pieces of a wide output (dw offset by whole rows)
+ * fill ONE OIHW tensor.  The table is HOST memory: it travels in the kernel arguments. */
+typedef struct dmd_wgrad_reduce_job {
+  const float* partials; /* the workspace of the deferred dmd_conv2d_wgrad */
+  float* dw;
+  float* dbias;          /* or NULL */
+  int32_t num_wg, NB, NCO, NCI, taps, cin_real; /* filled by dmd_wgrad_job */
+  int32_t ld_cin, c0;    /* dmd_wgrad_job: cin_real, 0 */
+} dmd_wgrad_reduce_job;
+/* The job of dmd_conv2d_wgrad(p, defer_reduce = 1): its pointers are p's (which may still be null -- a deferred call needs only
+ * num_wg * (NB * NCO * 256 + NCO * 16) floats of workspace, less than dmd_wgrad_workspace_floats, and the caller may size it from
+ * the job before it sets p->workspace and job->partials). */
+int dmd_wgrad_job(const dmd_wgrad_params* p, dmd_wgrad_reduce_job* job);
+int dmd_wgrad_reduce_jobs(const dmd_wgrad_reduce_job* jobs, int njobs, dmd_stream_t stream);
 
 const char* dmd_last_error(void);
 int dmd_abi_version(void);

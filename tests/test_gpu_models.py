@@ -615,6 +615,68 @@ def test_denoiser_training_step_vs_reference_golden():
         assert not bad, (precision, bad)
 
 
+def denoiser_training_gradients(attn_depths=(0, 0, 1, 1)):
+    """{DIAMOND_WGRAD_DEFER: {parameter: gradient}} of one Denoiser.forward + backward on the same inputs and the same noise"""
+    from types import SimpleNamespace
+    import diamond_amd as D
+    from diamond_amd.testing import synthetic_actions, synthetic_frames
+
+    ag = make_agent(attn_depths)
+    den = ag.denoiser
+    den.train()
+    den.setup_training(D.SigmaDistributionConfig(loc=-0.4, scale=1.2, sigma_min=2e-3, sigma_max=20))
+    g = torch.Generator().manual_seed(5)
+    obs = synthetic_frames(g, 2, 5, 3, 64, 64).to(DEV)
+    act = synthetic_actions(g, 4, 2, 5).to(DEV)
+    batch = SimpleNamespace(obs=obs, act=act, mask_padding=torch.ones(2, 5, dtype=torch.bool).to(DEV))
+    den.randn_fn = lambda shape: torch.randn(*shape)
+    out, saved = {}, os.environ.get("DIAMOND_WGRAD_DEFER")
+    try:
+        for defer in ("0", "1"):
+            os.environ["DIAMOND_WGRAD_DEFER"] = defer
+            torch.manual_seed(77)
+            den.zero_grad()
+            loss, _ = den(batch)
+            loss.backward()
+            out[defer] = {k: p.grad.detach().clone() for k, p in den.named_parameters()}
+    finally:
+        os.environ.pop("DIAMOND_WGRAD_DEFER", None)
+        if saved is not None:
+            os.environ["DIAMOND_WGRAD_DEFER"] = saved
+    return out
+
+
+def test_deferred_wgrad_reductions_leave_every_gradient_bitwise():
+    """f2: the reductions of a backward's weight gradients as one table (dmd_wgrad_reduce_jobs, the default) against one pair of
+    reduction launches per gradient + torch.cat of the sources' pieces (DIAMOND_WGRAD_DEFER=0): every gradient of the denoiser --
+    attention (qkv: three 64-row pieces), the up path's convolutions over concatenated inputs, the padded head -- bit-identical."""
+    got = denoiser_training_gradients()
+    assert len(got["0"]) > 200
+    diff = [k for k in got["0"] if not torch.equal(got["0"][k], got["1"][k])]
+    assert not diff, diff
+
+
+def test_deferred_wgrad_reductions_leave_the_actor_critic_gradients_bitwise(agent, monkeypatch):
+    """a10: the encoder backward of the actor-critic (two chained predict_act_value calls) with its weight gradients reduced by one
+    table launch per backward against two reduction launches per gradient: bit-identical gradients."""
+    from diamond_amd.testing import synthetic_frames
+
+    ac = agent.actor_critic
+    got = {}
+    for defer in ("0", "1"):
+        monkeypatch.setenv("DIAMOND_WGRAD_DEFER", defer)
+        g = torch.Generator().manual_seed(31)
+        obs, obs2 = synthetic_frames(g, 3, 3, 64, 64).to(DEV), synthetic_frames(g, 3, 3, 64, 64).to(DEV)
+        hx, cx = (torch.randn(3, 512, generator=g) * 0.3).to(DEV), (torch.randn(3, 512, generator=g) * 0.3).to(DEV)
+        ac.zero_grad()
+        o1 = ac.predict_act_value(obs, (hx, cx))
+        o2 = ac.predict_act_value(obs2, o1.hx_cx)
+        (o2.logits_act.square().sum() + o2.val.sum() + o1.val.square().sum()).backward()
+        got[defer] = {k: p.grad.detach().clone() for k, p in ac.named_parameters()}
+    diff = [k for k in got["0"] if not torch.equal(got["0"][k], got["1"][k])]
+    assert not diff and len(got["0"]) > 20, diff
+
+
 @pytest.mark.parametrize("attn_depths,b", [((0, 0, 0, 0), 5), ((0, 0, 0, 1), 2)])
 def test_lowres_chain_matches_launch_by_launch(attn_depths, b):
     """dmd_lowres_chain (the 8x8 level of the U-Net -- down blocks, attention mid blocks, up blocks with concatenated skips

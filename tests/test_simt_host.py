@@ -65,6 +65,15 @@ def test_denoiser_training_step_vs_reference_golden_on_the_interpreter(models, d
     bad = {k: v for k, v in errs.items() if v >= 1e-4}
     assert not bad, bad
     assert counter.n.get("dmd_conv2d_wgrad", 0) > 100 and counter.n.get("dmd_gn_silu_bwd", 0) > 50, counter.n
+    # (the reductions of those weight gradients: deferred to one table per backward, three launches of <= 32 jobs each)
+    assert 1 <= counter.n.get("dmd_wgrad_reduce_jobs", 0) <= 4, counter.n
+
+
+def test_deferred_wgrad_reductions_are_bitwise_on_the_interpreter(models, monkeypatch):
+    M, counter = models
+    M.test_deferred_wgrad_reductions_leave_every_gradient_bitwise()
+    M.test_deferred_wgrad_reductions_leave_the_actor_critic_gradients_bitwise(M.make_agent(), monkeypatch)
+    assert counter.n.get("dmd_wgrad_reduce_jobs", 0) >= 1, counter.n
 
 
 def test_rew_end_model_and_actor_critic_vs_goldens_on_the_interpreter(models):

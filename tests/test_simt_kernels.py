@@ -317,6 +317,72 @@ def test_conv2d_wgrad_many_partials(dmd_env):
     assert np.abs(got["0"] - got["256"]).max() <= 1e-6 * np.abs(want).max()
 
 
+@pytest.mark.parametrize("max_wg", [32, 1024], ids=["single_pass", "two_passes"])
+def test_wgrad_deferred_reductions_are_bit_identical(max_wg, dmd_env):
+    """dmd_conv2d_wgrad(defer_reduce = 1) + dmd_wgrad_reduce_jobs (ABI v10) against the undeferred call: the same bits, for few
+    partials (one fp64 pass) and many (fp32 slices, then fp64), with the gradients of two sources landing in the channel slices of
+    ONE OIHW tensor, a 64-row piece of a wider output, 15 real input channels, a missing bias -- and 33 jobs, so that the table
+    takes two launches."""
+    rng = np.random.default_rng(14)
+    L = S.lib()
+    dmd_env(DIAMOND_WGRAD_MAX_WG=max_wg)
+    n, h, w = 34, 16, 16  # 136 8x8 blocks = 68 tiles: 68 partials at max_wg = 1024 (two passes), 32 at 32 (one)
+    keep, jobs, checks = [], [], []
+
+    def one(cin, cin_real, cout, k, dw_all, row0, c0, db_all):
+        x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+        x[..., cin_real:] = 0
+        dy = rng.standard_normal((n, h, w, cout)).astype(np.float32)
+        p = nv.WgradParams()
+        p.N, p.H, p.W, p.Cout, p.taps, p.cin_real, p.precision = n, h, w, cout, k * k, cin_real, 1
+        p.src.x, p.src.C, p.src.prologue, p.dy = S.ptr(x), cin, 0, S.ptr(dy)
+        ws = np.full(L.dmd_wgrad_workspace_floats(p), np.nan, dtype=np.float32)
+        dw, db = np.full((cout, cin_real, k, k), np.nan, dtype=np.float32), np.full(cout, np.nan, dtype=np.float32)
+        p.workspace, p.dw, p.dbias = S.ptr(ws), S.ptr(dw), S.ptr(db)
+        S.check(L.dmd_conv2d_wgrad(p, None), "dmd_conv2d_wgrad")  # the undeferred gradient
+        view = dw_all[row0:row0 + cout]
+        p.workspace, p.dw, p.dbias, p.defer_reduce = None, view.ctypes.data, None if db_all is None else db_all[row0:].ctypes.data, 1
+        job = nv.WgradReduceJob()
+        S.check(L.dmd_wgrad_job(p, job), "dmd_wgrad_job")
+        assert (job.num_wg > 64) == (max_wg == 1024) and job.ld_cin == cin_real and job.c0 == 0
+        # the partials alone (less than dmd_wgrad_workspace_floats), against a guard page: a write past them faults
+        ws2 = G(np.full(job.num_wg * (job.NB * job.NCO * 256 + job.NCO * 16), np.nan, dtype=np.float32))
+        assert ws2.size < ws.size
+        p.workspace = job.partials = S.ptr(ws2)
+        job.ld_cin, job.c0 = dw_all.shape[1], c0
+        S.check(L.dmd_conv2d_wgrad(p, None), "dmd_conv2d_wgrad")
+        keep.extend([x, dy, ws2])
+        jobs.append(job)
+        checks.append((dw, db, view, c0, cin_real, None if db_all is None else db_all[row0:row0 + cout]))
+
+    two = np.full((64, 96, 3, 3), np.nan, dtype=np.float32)  # a convolution over cat(64, 32) channels
+    db_two = np.full(64, np.nan, dtype=np.float32)
+    one(64, 64, 64, 3, two, 0, 0, db_two)
+    one(32, 32, 64, 3, two, 0, 64, None)
+    wide = np.full((128, 32, 1, 1), np.nan, dtype=np.float32)  # two 64-row pieces of a 1x1 convolution with 128 outputs
+    db_wide = np.full(128, np.nan, dtype=np.float32)
+    one(32, 32, 64, 1, wide, 0, 0, db_wide)
+    one(32, 32, 64, 1, wide, 64, 0, db_wide)
+    head = np.full((16, 64, 3, 3), np.nan, dtype=np.float32)
+    one(64, 64, 16, 3, head, 0, 0, np.full(16, np.nan, dtype=np.float32))
+    first = np.full((64, 15, 3, 3), np.nan, dtype=np.float32)
+    one(16, 15, 64, 3, first, 0, 0, None)
+    small = [np.full((32, 32, 3, 3), np.nan, dtype=np.float32) for _ in range(27)]
+    for t in small:
+        one(32, 32, 32, 3, t, 0, 0, np.full(32, np.nan, dtype=np.float32))
+    assert len(jobs) == 33
+    table = (nv.WgradReduceJob * len(jobs))(*jobs)
+    S.check(L.dmd_wgrad_reduce_jobs(table, len(jobs), None), "dmd_wgrad_reduce_jobs")
+    for dw, db, view, c0, cin_real, dbv in checks:
+        assert np.isfinite(dw).all() and np.array_equal(view[:, c0:c0 + cin_real], dw)
+        if dbv is not None:
+            assert np.array_equal(dbv, db)
+    assert np.isfinite(two).all() and np.isfinite(wide).all() and np.isfinite(db_wide).all()
+    bad = nv.WgradReduceJob.from_buffer_copy(bytes(jobs[1]))
+    bad.c0 = 80  # channels [80, 112) of a 96-channel row
+    assert L.dmd_wgrad_reduce_jobs((nv.WgradReduceJob * 1)(bad), 1, None) != 0
+
+
 # ---- attention -------------------------------------------------------------------------------------------------------------------
 def _ref_attention(qkv, c, mask=None):
     n, t, _ = qkv.shape
