@@ -236,6 +236,107 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const dmd_gn_bwd_para
   }
 }
 
+// HW <= 256 (the 16x16 and 8x8 levels: half of a training step's normalisations): ONE workgroup holds a whole image, so both
+// passes are one launch -- pass A's sums stay in LDS, nothing goes through the workspace.  Every sum is formed as the two kernels
+// above form it (T = 1: their "sums over tiles" are one term), every element is computed by the same expression: the results
+// are bit-identical to the two launches (DIAMOND_GN_BWD_FUSED=0 takes those: test hook).
+__global__ __launch_bounds__(256) void gn_bwd_fused_kernel(const dmd_gn_bwd_params p) {
+  __shared__ float g_mean[GN_BWD_MAXG], g_rstd[GN_BWD_MAXG], g_m1[GN_BWD_MAXG], g_m2[GN_BWD_MAXG];
+  __shared__ double red[4][GN_BWD_MAXG][2];
+  __shared__ float cred[256][8];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int C = p.C, CQ = C / 4, G = C / DMD_GN_GROUP > 0 ? C / DMD_GN_GROUP : 1;
+  const int gsz = C / G;
+  const double cnt = (double)gsz * gn_bwd_count(p);
+  if (tid < G) {
+    float m, r;
+    dmd_finalize_stats(p.norm.stats + ((size_t)(n * G + tid) * p.norm.stat_tiles) * 2, p.norm.stat_tiles, cnt, &m, &r);
+    g_mean[tid] = m;
+    g_rstd[tid] = r;
+  }
+  __syncthreads();
+  const int q = tid % CQ;
+  const int c0 = 4 * q;
+  const int g = c0 / gsz;
+  const float mean = g_mean[g], rstd = g_rstd[g];
+  float mul[4], add[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float m = p.norm.mul ? p.norm.mul[(size_t)n * p.norm.mul_stride + c0 + e] : 1.0f;
+    if (p.norm.mul_plus_one) m = 1.0f + m;
+    mul[e] = m;
+    add[e] = p.norm.add ? p.norm.add[(size_t)n * p.norm.add_stride + c0 + e] : 0.0f;
+  }
+  double s1 = 0.0, s2 = 0.0;
+  float dm[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int pix = tid / CQ; pix < p.HW; pix += 256 / CQ) {
+    if (!gn_bwd_exists(p, pix)) continue;
+    const size_t off = ((size_t)n * p.HW + pix) * C + c0;
+    const f32x4 xv = *(const f32x4*)(p.x + off);
+    const f32x4 dv = *(const f32x4*)(p.da + off);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const GnBwdElem r = gn_bwd_elem(xv[e], dv[e], mean, rstd, mul[e], add[e], p.identity_activation == 0);
+      s1 += (double)r.dxh;
+      s2 += (double)r.dxh * (double)r.xh;
+      dm[e] += r.du * r.xh;
+      db[e] += r.du;
+    }
+  }
+  for (int gg = 0; gg < G; ++gg) {
+    const double a = dmd_wave_sum(g == gg ? s1 : 0.0);
+    const double b = dmd_wave_sum(g == gg ? s2 : 0.0);
+    if ((tid & 63) == 0) {
+      red[tid >> 6][gg][0] = a;
+      red[tid >> 6][gg][1] = b;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    cred[tid][e] = dm[e];
+    cred[tid][4 + e] = db[e];
+  }
+  __syncthreads();
+  if (tid < G) {
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < 4; ++w) {
+      a += red[w][tid][0];
+      b += red[w][tid][1];
+    }
+    g_m1[tid] = (float)(a / cnt);
+    g_m2[tid] = (float)(b / cnt);
+  }
+  if (tid < C) {
+    const int qq = tid >> 2, e = tid & 3;
+    float a = 0.f, b = 0.f;
+    for (int l = 0; l < 256 / CQ; ++l) {
+      a += cred[l * CQ + qq][e];
+      b += cred[l * CQ + qq][4 + e];
+    }
+    p.dmul[(size_t)n * C + tid] = a;
+    p.dadd[(size_t)n * C + tid] = b;
+  }
+  __syncthreads();
+  const float m1 = g_m1[g], m2 = g_m2[g];
+  for (int pix = tid / CQ; pix < p.HW; pix += 256 / CQ) {
+    const size_t off = ((size_t)n * p.HW + pix) * C + c0;
+    if (!gn_bwd_exists(p, pix)) {
+      *(f32x4*)(p.dx + off) = (f32x4){0.f, 0.f, 0.f, 0.f};
+      continue;
+    }
+    const f32x4 xv = *(const f32x4*)(p.x + off);
+    const f32x4 dv = *(const f32x4*)(p.da + off);
+    f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.dskip) o = *(const f32x4*)(p.dskip + off);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const GnBwdElem r = gn_bwd_elem(xv[e], dv[e], mean, rstd, mul[e], add[e], p.identity_activation == 0);
+      o[e] += rstd * (r.dxh - m1 - r.xh * m2);
+    }
+    *(f32x4*)(p.dx + off) = o;
+  }
+}
+
 static inline int gn_bwd_tiles(int HW) { return (HW + GN_BWD_PIX - 1) / GN_BWD_PIX; }
 
 extern "C" int64_t dmd_gn_bwd_workspace_bytes(int N, int HW, int C) {
@@ -258,6 +359,12 @@ extern "C" int dmd_gn_silu_bwd(const dmd_gn_bwd_params* pp, dmd_stream_t stream)
   double* group_partial = (double*)p.workspace;
   float* chan_partial = (float*)((char*)p.workspace + (size_t)p.N * G * T * 2 * 8);
   hipStream_t st = (hipStream_t)stream;
+  static DmdEnvInt fused_env{"DIAMOND_GN_BWD_FUSED", 1};
+  if (T == 1 && fused_env.get() != 0) {
+    hipLaunchKernelGGL(gn_bwd_fused_kernel, dim3(p.N), dim3(256), 0, st, p);
+    DMD_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(T, p.N), dim3(256), 0, st, p, T, group_partial, chan_partial);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(T, p.N), dim3(256), 0, st, p, T, (const double*)group_partial, (const float*)chan_partial);
   DMD_LAUNCH_CHECK();

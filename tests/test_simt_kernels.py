@@ -459,7 +459,8 @@ def test_linear(m, n, k, acc, silu):
 # ---- dmd_gn_silu_bwd: fp64 finite-difference-free truth from the closed form in the header --------------------------------------
 @pytest.mark.parametrize("n,hw,c,identity,skip", [(2, 64, 64, 0, True), (1, 300, 32, 0, False), (2, 256, 128, 1, True), (1, 64, 16, 0, False),
                                                   (3, 1024, 64, 0, True)])
-def test_gn_silu_bwd(n, hw, c, identity, skip):
+def test_gn_silu_bwd(n, hw, c, identity, skip, dmd_env):
+    """hw <= 256: the one-launch form (a workgroup holds an image) -- and, bitwise, the two launches it replaces"""
     rng = np.random.default_rng(hw + c)
     L = S.lib()
     x = (rng.standard_normal((n, hw, 1, c)) * 1.4 + 0.3).astype(np.float32)
@@ -495,6 +496,45 @@ def test_gn_silu_bwd(n, hw, c, identity, skip):
     assert np.abs(dx - want).max() <= 1e-5 * np.abs(want).max()
     np.testing.assert_allclose(dmul, (du * xh).sum(axis=1), rtol=0, atol=2e-5 * np.abs(du * xh).sum(axis=1).max())
     np.testing.assert_allclose(dadd, du.sum(axis=1), rtol=0, atol=2e-5 * np.abs(du).sum(axis=1).max())
+    if hw <= 256:
+        dmd_env(DIAMOND_GN_BWD_FUSED=0)
+        dx2 = G(np.full_like(x, np.nan))
+        dmul2, dadd2 = G(np.full((n, c), np.nan, dtype=np.float32)), G(np.full((n, c), np.nan, dtype=np.float32))
+        p.dx, p.dmul, p.dadd = S.ptr(dx2), S.ptr(dmul2), S.ptr(dadd2)
+        S.check(L.dmd_gn_silu_bwd(p, None), "dmd_gn_silu_bwd")
+        assert np.array_equal(dx, dx2) and np.array_equal(dmul, dmul2) and np.array_equal(dadd, dadd2)
+        assert ws.any()  # (the two launches went through the workspace; the fused one had left it untouched)
+    else:
+        assert ws.any()
+
+
+def test_gn_silu_bwd_one_launch_on_a_valid_extent_is_bitwise_the_two_launches(dmd_env):
+    """the 9x9 valid part of a 16x16 buffer (the actor-critic encoder's last level at 72x72 frames): one launch against two"""
+    rng = np.random.default_rng(3)
+    L = S.lib()
+    n, h, w, c, vh, vw = 3, 16, 16, 64, 9, 9
+    x = (rng.standard_normal((n, h * w, 1, c)) * 1.4 + 0.3).astype(np.float32)
+    da = rng.standard_normal((n, h * w, 1, c)).astype(np.float32)
+    dskip = rng.standard_normal((n, h * w, 1, c)).astype(np.float32)
+    mul, add = (rng.standard_normal((n, c)) * 0.3).astype(np.float32), (rng.standard_normal((n, c)) * 0.3).astype(np.float32)
+    v = x.astype(np.float64).reshape(n, h, w, 2, 32)[:, :vh, :vw]
+    st = np.ascontiguousarray(np.stack([v.sum(axis=(1, 2, 4)), (v * v).sum(axis=(1, 2, 4))], axis=-1)[:, :, None, :])  # (N, G, 1 tile, 2)
+    got = {}
+    for fused in (1, 0):
+        dmd_env(DIAMOND_GN_BWD_FUSED=fused)
+        p = nv.GnBwdParams()
+        p.N, p.HW, p.C, p.identity_activation, p.W, p.valid_h, p.valid_w = n, h * w, c, 0, w, vh, vw
+        p.x, p.norm, p.da, p.dskip = S.ptr(x), _norm(st, 1, mul, add, plus_one=True), S.ptr(da), S.ptr(dskip)
+        dx = G(np.full_like(x, np.nan))
+        dmul, dadd = G(np.full((n, c), np.nan, dtype=np.float32)), G(np.full((n, c), np.nan, dtype=np.float32))
+        ws = G(np.zeros(L.dmd_gn_bwd_workspace_bytes(n, h * w, c), dtype=np.uint8))
+        p.dx, p.workspace, p.dmul, p.dadd = S.ptr(dx), S.ptr(ws), S.ptr(dmul), S.ptr(dadd)
+        S.check(L.dmd_gn_silu_bwd(p, None), "dmd_gn_silu_bwd")
+        assert bool(ws.any()) == (fused == 0)
+        got[fused] = (dx.copy(), dmul.copy(), dadd.copy())
+    assert all(np.array_equal(a_, b_) for a_, b_ in zip(got[0], got[1]))
+    dxv = got[1][0].reshape(n, h, w, c)
+    assert np.isfinite(dxv).all() and not dxv[:, vh:].any() and not dxv[:, :, vw:].any() and dxv[:, :vh, :vw].any()
 
 
 # ---- dmd_pack_jobs: every packed layout against its definition -------------------------------------------------------------------

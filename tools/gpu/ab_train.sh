@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}; cd $R
 TAG=$1; shift
 O=$R/gpurun_out/$TAG; mkdir -p $O
 export TMPDIR=/tmp
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
   for s in "$@"; do
     for b in ${BATCHES:-32 256}; do
       echo "== [$s] batch $b"
