@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}; cd $R
 O=$R/gpurun_out/$TAG; mkdir -p $O
 export TMPDIR=/tmp
 OLD="DIAMOND_WGRAD_DEFER=0 DIAMOND_TRAIN_FUSE_PROJ=0 DIAMOND_GN_BWD_FUSED=0"
-timeout 600 python -m pytest tests -m gpu -q -p no:cacheprovider -x > $O/tests.log 2>&1; echo "pytest rc=$?"; tail -3 $O/tests.log
+timeout 600 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/tests.log 2>&1; echo "pytest rc=$?"; tail -3 $O/tests.log
 BATCHES="32 256" STEPS=40 bash tools/gpu/ab_train.sh $TAG "$OLD" ""
 for s in "$OLD" "" "$OLD" ""; do
   echo "== window [$s]"
