@@ -565,8 +565,8 @@ def conv2d(
     if proj is not None:
         # `proj(cat(sources)) + conv(...)` in one launch (ResBlock.forward, blocks.py:147); dmd_conv2d fails loudly
         # on parameters dmd_conv2d_proj_eligible() rejects -- the caller asks proj_fusable() first
-        p_srcs, p_w16, p_bias, p_module = proj
-        assert residual is None and len(p_srcs) == 2
+        p_srcs, p_w16, p_bias = proj[:3]  # (+ the projection's nn.Conv2d as a fourth element when the launch is recorded)
+        assert residual is None and len(p_srcs) == 2 and (TAPE is None or len(proj) == 4)
         p.proj_nsrc = len(p_srcs)
         for i, a in enumerate(p_srcs):
             assert a.t.is_contiguous() and a.t.dtype == torch.float32 and tuple(a.shape[:3]) == (n, h, w)
