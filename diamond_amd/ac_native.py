@@ -69,6 +69,82 @@ class WgradBatch:
         self.jobs, self._keep = [], []
 
 
+# (output channels / 16, input channels / 16) the weight-gradient kernel is instantiated for (csrc/dmd_backward.hip:
+# dmd_conv2d_wgrad's dispatch): the shapes of the default configuration's networks
+_WGRAD_INSTANCES = {9: {(2, 1), (4, 1), (1, 4), (2, 2), (4, 2), (4, 4)}, 1: {(4, 2), (2, 2), (4, 4)}}
+
+
+def _wgrad_instance(cout: int, cin: int, taps: int) -> bool:
+    return cout % 16 == 0 and cin % 16 == 0 and (cout // 16, cin // 16) in _WGRAD_INSTANCES[taps]
+
+
+def _pad_channels(t: Tensor, c0: int, c1: int, to: int) -> Tensor:
+    """Channels [c0, c1) of an NHWC tensor as a contiguous tensor of `to` channels (zeros behind the slice)."""
+    if c1 - c0 == to:
+        return t[..., c0:c1].contiguous()
+    out = torch.zeros(t.shape[:-1] + (to,), device=t.device, dtype=t.dtype)
+    out[..., :c1 - c0] = t[..., c0:c1]
+    return out
+
+
+def _norm_slice(x: Act, spec: NormSpec, c0: int, c1: int, to: int) -> Tuple[Tensor, int, NormSpec]:
+    """Statistics and multiplicative / additive parameters of channels [c0, c1) of a normalised source, zero-padded to `to`
+    channels: (partial sums, tiles, spec).  A padded group has sums 0 and parameters 0: its activated value is 0."""
+    g = nv.GN_GROUP
+    assert c0 % g == 0 and (c1 - c0) % g == 0 and to % g == 0 and x.stats is not None, \
+        f"normalised source of {x.C} channels cut at [{c0}, {c1}): not whole GroupNorm groups"
+    stats = x.stats[:, c0 // g:c1 // g]
+    if to != c1 - c0:
+        stats = torch.cat([stats, torch.zeros(stats.shape[0], (to - (c1 - c0)) // g, *stats.shape[2:], device=stats.device, dtype=stats.dtype)], 1)
+
+    def cut(t: Optional[Tensor], stride: int):
+        if t is None:
+            return None, 0
+        rows = t if t.ndim == 2 else t[None]
+        rows = rows[:, c0:c1] if stride != 0 else rows[:1, c0:c1]
+        out = torch.zeros(rows.shape[0], to, device=t.device, dtype=torch.float32)
+        out[:, :c1 - c0] = rows
+        return out, (to if stride != 0 else 0)
+
+    mul, ms = cut(spec.mul, spec.mul_stride)
+    add, as_ = cut(spec.add, spec.add_stride)
+    return stats.contiguous(), x.tiles, NormSpec(mul, add, ms, as_, spec.plus_one)
+
+
+def _wgrad_tiled(x: Act, prologue: int, spec: Optional[NormSpec], dy: Tensor, taps: int, cin_real: int, want_bias: bool, split: bool,
+                 batch: Optional["WgradBatch"], dw_out: Optional[Tensor], c0: int, db_out: Optional[Tensor]):
+    """Weight gradient of a convolution the kernel has no instance for (networks wider or narrower than the default
+    configuration's 32 / 64 channels: the reference takes any `channels` list, blocks.py:183-222, actor_critic.py:101-113): the
+    gradient of output-channel block i w.r.t. input-channel block j depends on those two blocks only, so the (Cout, Cin) plane is
+    tiled with the 64 x 64 instance on contiguous, zero-padded channel slices (whole GroupNorm groups of a normalised source,
+    with their partial sums and parameters).  Reduced per tile (nothing deferred): the correct path for such shapes, not a fast one."""
+    n, h, w, cout = dy.shape
+    k = 3 if taps == 9 else 1
+    T = 64
+    if batch is not None:
+        dw, db = dw_out, db_out
+    else:
+        dw = torch.empty(cout, cin_real, k, k, device=dy.device, dtype=torch.float32)
+        db = torch.empty(cout, device=dy.device, dtype=torch.float32) if want_bias else None
+        c0 = 0
+    for ci0 in range(0, cin_real, T):
+        ci1 = min(cin_real, ci0 + T)
+        cw = (ci1 - ci0 + 15) // 16 * 16  # (the source's own padding: conv_in's 15 channels travel as 16)
+        if prologue == nv.PROLOGUE_NONE:
+            xt, spec_t = Act(_pad_channels(x.t, ci0, min(x.C, ci0 + cw), T), valid=x.valid), None
+        else:
+            stats, tiles, spec_t = _norm_slice(x, spec, ci0, ci1, T)
+            xt = Act(_pad_channels(x.t, ci0, ci1, T), stats, tiles, valid=x.valid)
+        for co0 in range(0, cout, T):
+            co1 = min(cout, co0 + T)
+            dw_t, db_t = _wgrad(xt, prologue, spec_t, _pad_channels(dy, co0, co1, T), taps, ci1 - ci0,
+                                want_bias=db is not None and ci0 == 0, split=split)
+            dw[co0:co1, c0 + ci0:c0 + ci1] = dw_t[:co1 - co0]
+            if db is not None and ci0 == 0:
+                db[co0:co1] = db_t[:co1 - co0]
+    return dw, db
+
+
 def _wgrad(x: Act, prologue: int, spec: Optional[NormSpec], dy: Tensor, taps: int, cin_real: int,
            want_bias: bool = True, split: bool = False, batch: Optional[WgradBatch] = None, dw_out: Optional[Tensor] = None,
            c0: int = 0, db_out: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
@@ -78,6 +154,8 @@ def _wgrad(x: Act, prologue: int, spec: Optional[NormSpec], dy: Tensor, taps: in
     [c0, c0 + cin_real)) and db_out (or None) name where the gradient goes."""
     n, h, w, cout = dy.shape
     k = 3 if taps == 9 else 1
+    if not _wgrad_instance(cout, x.C, taps):  # (never at the default configuration)
+        return _wgrad_tiled(x, prologue, spec, dy, taps, cin_real, want_bias, split, batch, dw_out, c0, db_out)
     p = nv.WgradParams()
     p.N, p.H, p.W, p.Cout, p.taps, p.cin_real = n, h, w, cout, taps, cin_real
     assert x.t.is_contiguous() and dy.is_contiguous() and tuple(x.shape[:3]) == (n, h, w)
@@ -111,8 +189,39 @@ def _wgrad(x: Act, prologue: int, spec: Optional[NormSpec], dy: Tensor, taps: in
     return dw, db
 
 
+def _gn_bwd_instance(c: int) -> bool:
+    """channel counts dmd_gn_silu_bwd takes (csrc/dmd_backward.hip): 4 ... 256 in powers of two"""
+    return c % 4 == 0 and c <= 256 and 256 % (c // 4) == 0 and (c % nv.GN_GROUP == 0 or c < nv.GN_GROUP)
+
+
+def gn_bwd_sliced(fn, x: Act, spec: NormSpec, da: Tensor, dskip: Optional[Tensor]) -> Tuple[Tensor, Tensor, Tensor]:
+    """GroupNorm backward over a channel count the kernel has no instance for (96, 160, 512 ...: networks wider than the default
+    configuration): a group's backward involves its own 32 channels only, so the channels are cut into 256 / 128 / 64 / 32-wide
+    runs of whole groups and `fn` (the kernel call for a supported count) runs on contiguous copies of each."""
+    n, h, w, c = x.shape
+    g = nv.GN_GROUP
+    assert c % g == 0, f"GroupNorm backward over {c} channels"
+    dx = torch.empty_like(x.t)
+    dma = torch.empty(2, n, c, device=da.device, dtype=torch.float32)
+    c0 = 0
+    while c0 < c:
+        step = next(s for s in (256, 128, 64, 32) if s <= c - c0)
+        c1 = c0 + step
+        cut = lambda t: None if t is None else t[..., c0:]
+        xs = Act(x.t[..., c0:c1].contiguous(), x.stats[:, c0 // g:c1 // g].contiguous(), x.tiles, valid=x.valid)
+        spec_s = NormSpec(cut(spec.mul), cut(spec.add), spec.mul_stride, spec.add_stride, spec.plus_one)
+        dx_s, dmul_s, dadd_s = fn(xs, spec_s, da[..., c0:c1].contiguous(), None if dskip is None else dskip[..., c0:c1].contiguous())
+        dx[..., c0:c1] = dx_s
+        dma[0, :, c0:c1] = dmul_s
+        dma[1, :, c0:c1] = dadd_s
+        c0 = c1
+    return dx, dma[0], dma[1]
+
+
 def _gn_silu_bwd(x: Act, spec: NormSpec, da: Tensor, dskip: Optional[Tensor]) -> Tuple[Tensor, Tensor, Tensor]:
     n, h, w, c = x.shape
+    if not _gn_bwd_instance(c):  # (never at the default configuration)
+        return gn_bwd_sliced(_gn_silu_bwd, x, spec, da, dskip)
     p = nv.GnBwdParams()
     p.N, p.HW, p.C = n, h * w, c
     if x.valid is not None:  # sums and the count over the valid extent, dx zero outside it

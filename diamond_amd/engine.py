@@ -495,6 +495,69 @@ def new_stats(n: int, c: int, tiles: int, device) -> Tensor:
     return torch.empty(n, max(1, c // nv.GN_GROUP), tiles, 2, device=device, dtype=torch.float64)
 
 
+CONV_CIN_MAX = 256  # input channels (all sources together) of ONE dmd_conv2d launch: DMD_CIN_MAX, csrc/dmd_conv.hip
+
+
+def _channel_slice(a: Act, prologue: int, norm: Optional[NormSpec], c0: int, c1: int) -> Tuple[Act, int, Optional[NormSpec]]:
+    """Channels [c0, c1) of a source as a source of its own: a contiguous copy of the slice, the partial GroupNorm sums of its
+    groups (whole 32-channel groups: the statistics of a group do not depend on the others) and the matching columns of its
+    multiplicative / additive parameters (views: the kernels take pointer + row stride)."""
+    sub = Act(a.t[..., c0:c1].contiguous(), None, 0, a.needs_grad, a.valid)
+    if prologue == nv.PROLOGUE_NONE:
+        return sub, prologue, None
+    g = nv.GN_GROUP
+    assert c0 % g == 0 and c1 % g == 0 and a.stats is not None, f"normalised source of {a.C} channels cut at [{c0}, {c1}): not whole GroupNorm groups"
+    sub.stats, sub.tiles = a.stats[:, c0 // g:c1 // g].contiguous(), a.tiles
+    cut = lambda t: None if t is None else t[..., c0:]
+    return sub, prologue, NormSpec(cut(norm.mul), cut(norm.add), norm.mul_stride, norm.add_stride, norm.plus_one)
+
+
+def _conv2d_wide(srcs, w_packed, bias, cout, *, taps, stride, upsample, residual, residual_norm, want_stats, out_nchw, cout_padded,
+                 naive, fast_math, module) -> Act:
+    """A convolution over more than CONV_CIN_MAX input channels (U-Nets wider than the default configuration: the reference's
+    UNet takes any `channels` list, blocks.py:183-222, and its up path concatenates two of them, :174) as a chain of launches
+    over <= CONV_CIN_MAX channels each: the contraction is a sum over input channels, so
+        out = conv(piece_0) + bias + residual;   out = conv(piece_i) + out   (i = 1 ...),
+    the last launch emitting the GroupNorm partial sums of the finished output.  The packed weight is K-major
+    ([Cin / 16][taps][CoutPad][16], dmd_pack_conv_weight): a piece's weights are a contiguous range of it, nothing is re-packed.
+    A source wider than the limit on its own goes in as contiguous channel slices (_channel_slice).  Exact fp32 kernels (the
+    split-fp16 instances cover Cin <= 128); one launch per piece -- correctness for wide configurations, not their fast path."""
+    global TAPE
+    assert not out_nchw, "wide convolution with an NCHW result"
+    pieces = []  # (source triple, channels)
+    for a, prologue, norm in srcs:
+        if a.C <= CONV_CIN_MAX:
+            pieces.append(((a, prologue, norm), a.C))
+        else:
+            for c0 in range(0, a.C, CONV_CIN_MAX):
+                c1 = min(a.C, c0 + CONV_CIN_MAX)
+                pieces.append((_channel_slice(a, prologue, norm, c0, c1), c1 - c0))
+    launches, k0 = [], 0  # ([source triples], first input channel): consecutive pieces, at most two sources per launch
+    for triple, c in pieces:
+        assert c % 16 == 0, f"source of {c} channels inside a wide convolution (multiples of 16)"
+        if launches and len(launches[-1][0]) < 2 and launches[-1][2] + c <= CONV_CIN_MAX:
+            launches[-1][0].append(triple)
+            launches[-1][2] += c
+        else:
+            launches.append([[triple], k0, c])
+        k0 += c
+    cp = cout_padded or nv.cout_pad(cout)
+    tape, TAPE = TAPE, None  # the chain is ONE convolution to the recorded backward (below)
+    try:
+        acc = None
+        for i, (group, first, _) in enumerate(launches):
+            last = i == len(launches) - 1
+            acc = conv2d(group, w_packed[(first // 16) * taps * cp * 16:], bias if i == 0 else None, cout, taps=taps, stride=stride,
+                         upsample=upsample, residual=residual if i == 0 else acc, residual_norm=residual_norm if i == 0 else None,
+                         want_stats=want_stats and last, cout_padded=cout_padded, naive=naive, fast_math=fast_math)
+    finally:
+        TAPE = tape
+    if TAPE is not None:
+        assert module is not None, "recording a conv launch that does not name its nn.Conv2d"
+        TAPE.append(ConvRecord(list(srcs), module, taps, stride, upsample, residual, residual_norm, acc, out_nchw))
+    return acc
+
+
 def conv2d(
     srcs: Sequence[Tuple[Act, int, Optional[NormSpec]]],  # (activation, prologue, norm)
     w_packed: Tensor,
@@ -515,6 +578,11 @@ def conv2d(
     module: Optional[nn.Module] = None,
     proj: Optional[Tuple[Sequence[Act], Tensor, Optional[Tensor]]] = None,  # fused skip projection: (sources, w_f16 (k = 1), bias)
 ) -> Act:
+    if sum(a.C for a, _, _ in srcs) > CONV_CIN_MAX:  # (never at the default configuration: 128 channels at most)
+        assert proj is None, "fused skip projection on a wide convolution"
+        return _conv2d_wide(srcs, w_packed, bias, cout, taps=taps, stride=stride, upsample=upsample, residual=residual,
+                            residual_norm=residual_norm, want_stats=want_stats, out_nchw=out_nchw, cout_padded=cout_padded, naive=naive,
+                            fast_math=fast_math or w_f16 is not None, module=module)
     a0 = srcs[0][0]
     n, hs, ws, _ = a0.shape
     if upsample:

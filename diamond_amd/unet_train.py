@@ -29,7 +29,7 @@ from torch import Tensor, nn
 
 from . import engine as E
 from . import native as nv
-from .ac_native import WgradBatch, _gn_silu_bwd, _transposed, _wgrad
+from .ac_native import WgradBatch, _gn_bwd_instance, _gn_silu_bwd, _transposed, _wgrad, gn_bwd_sliced
 from .engine import Act, AttnRecord, ConvRecord, NormSpec
 
 TRAIN_PRECISION = "f16x2"  # arithmetic of the forward, dgrad and wgrad convolutions (split-fp16 operands, fp32 accumulate); "f32" = exact
@@ -96,6 +96,8 @@ def _gn_bwd(x: Act, spec: NormSpec, da: Tensor, dskip: Optional[Tensor], identit
     if not identity:
         return _gn_silu_bwd(x, spec, da, dskip)
     n, h, w, c = x.shape
+    if not _gn_bwd_instance(c):  # (never at the default configuration)
+        return gn_bwd_sliced(lambda *a: _gn_bwd(*a, True), x, spec, da, dskip)
     p = nv.GnBwdParams()
     p.N, p.HW, p.C = n, h * w, c
     p.identity_activation = 1

@@ -206,14 +206,14 @@ class _FakeLoader:
             yield Batch(obs=obs, act=act, rew=None, end=None, trunc=None, mask_padding=None, info=None, segment_ids=None)
 
 
-def gen_window(name="window.pt", size=64, b=4, horizon=4, t=6):
+def gen_window(name="window.pt", size=64, b=4, horizon=4, t=6, agent=None):
     """Two BPTT windows of ActorCritic.forward()+backward through the reference's own
     WorldModelEnv and env_loop, default RNG seeded (draw order: SURVEY App. A.5)."""
     from envs import WorldModelEnv, WorldModelEnvConfig
     from models.actor_critic import ActorCriticLossConfig
     from models.diffusion import DiffusionSamplerConfig, SigmaDistributionConfig
 
-    agent = ref_agent(img_size=size)
+    agent = agent or ref_agent(img_size=size)
     env = WorldModelEnv(agent.denoiser, agent.rew_end_model, _FakeLoader(b, seed=21, size=size),
                         WorldModelEnvConfig(horizon=horizon, num_batches_to_preload=2,
                                             diffusion_sampler=DiffusionSamplerConfig(num_steps_denoising=3)))
@@ -379,7 +379,82 @@ def gen_offgrid_72():
     gen_window("window_72x72.pt", size=72, b=3, horizon=3, t=4)  # whole path: sampler, reward / end model, resets, AC fwd + bwd
 
 
+def gen_wide():
+    """Configurations wider than the default one (tests/wide_configs.py): the reference's Denoiser (model output, training loss and
+    gradients), RewEndModel and ActorCritic (forward + gradients) as standalone modules, name-keyed weights."""
+    from data import Batch
+    from models.actor_critic import ActorCritic, ActorCriticConfig
+    from models.diffusion import Denoiser, DenoiserConfig, InnerModelConfig, SigmaDistributionConfig
+    from models.rew_end_model import RewEndModel, RewEndModelConfig
+    from tests import wide_configs as W
+
+    s = W.SIZE
+    out = {}
+    # -- denoiser: inference
+    den = Denoiser(DenoiserConfig(inner_model=InnerModelConfig(**W.DENOISER), sigma_data=0.5, sigma_offset_noise=0.3))
+    fill_module_(den, W.WEIGHT_SEED)
+    den.eval()
+    g = torch.Generator().manual_seed(5)
+    obs, act, x = synthetic_frames(g, 2, 12, s, s), synthetic_actions(g, 4, 2, 4), torch.randn(2, 3, s, s, generator=g)
+    with torch.no_grad():
+        for i, sigma in enumerate((torch.tensor(0.7), torch.tensor([0.05, 3.0]))):
+            out[f"model_output_{i}"] = den.compute_model_output(x, obs, act, den.compute_conditioners(sigma)).clone()
+    # -- denoiser: training step
+    den.train()
+    den.setup_training(SigmaDistributionConfig(**W.SIGMA_DIST))
+    g = torch.Generator().manual_seed(31)
+    obs, act = synthetic_frames(g, 1, 5, 3, s, s), synthetic_actions(g, 4, 1, 5)
+    den.zero_grad()
+    torch.manual_seed(77)
+    loss, _ = den(Batch(obs=obs, act=act, rew=None, end=None, trunc=None, mask_padding=torch.ones(1, 5, dtype=torch.bool), info=None,
+                        segment_ids=None))
+    loss.backward()
+    out["train"] = {"loss": loss.detach().clone(), "grad_norms": {k: p.grad.double().norm() for k, p in den.named_parameters()},
+                    "grads": {k: W.sample_grad(p.grad) for k, p in den.named_parameters()}}
+    # -- reward / end model
+    m = RewEndModel(RewEndModelConfig(**W.REW_END))
+    fill_module_(m, W.WEIGHT_SEED + 1)
+    m.eval()
+    g = torch.Generator().manual_seed(9)
+    obs, act = synthetic_frames(g, 2, 3, 3, s, s), synthetic_actions(g, 4, 2, 2)
+    with torch.no_grad():
+        lr, le, (h, c) = m.predict_rew_end(obs[:, :-1], act, obs[:, 1:])
+    out["rew_end"] = {"logits_rew": lr.clone(), "logits_end": le.clone(), "h": h.clone(), "c": c.clone()}
+    # -- actor-critic: forward + backward
+    ac = ActorCritic(ActorCriticConfig(**W.ACTOR_CRITIC))
+    fill_module_(ac, W.WEIGHT_SEED + 2)
+    g = torch.Generator().manual_seed(11)
+    obs = synthetic_frames(g, 2, 3, s, s)
+    o = ac.predict_act_value(obs, None)
+    (o.logits_act.square().sum() + o.val.sum()).backward()
+    out["actor_critic"] = {"logits": o.logits_act.detach().clone(), "val": o.val.detach().clone(),
+                           "grad_norms": {k: p.grad.double().norm() for k, p in ac.named_parameters()},
+                           "grads": {k: W.sample_grad(p.grad) for k, p in ac.named_parameters()}}
+    save("wide.pt", out)
+
+
+def ref_wide_agent():
+    """the reference's Agent on the wide configurations of tests/wide_configs.py"""
+    from agent import Agent, AgentConfig
+    from models.actor_critic import ActorCriticConfig
+    from models.diffusion import DenoiserConfig, InnerModelConfig
+    from models.rew_end_model import RewEndModelConfig
+    from tests import wide_configs as W
+
+    agent = Agent(W.agent_config(AgentConfig, DenoiserConfig, InnerModelConfig, RewEndModelConfig, ActorCriticConfig))
+    fill_module_(agent, WEIGHT_SEED)
+    return agent.eval()
+
+
 def main():
+    if "--wide" in sys.argv:
+        gen_wide()
+        return
+    if "--wide-window" in sys.argv:  # the whole path (sampler, reward / end model, resets, actor-critic forward + backward) on the wide networks
+        from tests import wide_configs as W
+
+        gen_window("window_wide.pt", size=W.SIZE, b=3, horizon=3, t=4, agent=ref_wide_agent())
+        return
     if "--offgrid" in sys.argv:
         gen_offgrid_72()
         return

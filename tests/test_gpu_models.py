@@ -376,16 +376,17 @@ def test_full_window_72x72_vs_reference_golden():
     test_full_window_vs_reference_golden("window_72x72.pt")
 
 
-def test_full_window_vs_reference_golden(fixture="window.pt"):
+def test_full_window_vs_reference_golden(fixture="window.pt", ag=None):
     """ActorCritic.forward() + backward over two BPTT windows through WorldModelEnv /
     env_loop with host-injected draws (reference RNG order): integer
-    trajectories bit-exact as long as the frames stay on the reference's uint8 levels."""
+    trajectories bit-exact as long as the frames stay on the reference's uint8 levels.
+    (ag: an agent of another configuration, for a fixture generated from it: tests/test_wide_configs.py)"""
     import random
     import diamond_amd as D
 
     gold = load_golden(fixture)
     size = gold.get("size", 64)
-    ag = make_agent(img_size=size)
+    ag = ag or make_agent(img_size=size)
     b, t = gold["b"], gold["backup_every"]
     env = D.WorldModelEnv(ag.denoiser, ag.rew_end_model, _Loader(b, gold["pool_seed"], size),
                           D.WorldModelEnvConfig(horizon=gold["horizon"], num_batches_to_preload=gold["preload"],
