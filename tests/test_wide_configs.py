@@ -6,8 +6,8 @@ GroupNorm groups).  Held against fixtures produced by EXECUTING THE REFERENCE on
 (tests/golden/make_golden.py --wide -> tests/golden/wide.pt), at the bars of the default configuration's tests (1e-4).
 
 These run the product's host code against the SIMT-interpreter build of the kernels (tests/simt: test infrastructure) -- the wide
-paths have NOT been run on a GPU (they were written after the round's GPU budget was spent; DESIGN.md says so), which is why there
-is no `-m gpu` twin of this file.  The kernel-level test at the end checks the decomposition itself against fp64 torch."""
+paths have NOT been run on a GPU (they were written after the round's GPU budget was spent; DESIGN.md says so), which is why their
+`-m gpu` twins are opt-in (BACKENDS below).  The kernel-level test at the end checks the decomposition itself against fp64 torch."""
 import os
 
 import pytest
@@ -18,6 +18,18 @@ from tests import wide_configs as W
 from tests.simt.host_harness import engine_on_interpreter
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "wide.pt")
+# Every test below runs on the interpreter (the CPU suite) and has an OPT-IN twin on the device: DIAMOND_WIDE_GPU_TESTS=1 pytest -m gpu
+# tests/test_wide_configs.py.  Opt-in because these branches have never been run on a GPU: the round's GPU suite must not
+# depend on code its author could not run there.
+BACKENDS = ["interpreter", pytest.param("cuda", marks=[pytest.mark.gpu, pytest.mark.skipif(
+    os.environ.get("DIAMOND_WIDE_GPU_TESTS") != "1", reason="the wide-configuration branches were never run on a GPU: DIAMOND_WIDE_GPU_TESTS=1 opts in")])]
+
+
+def _backend(kind):
+    """(context manager under which the product's host code runs, device of the tensors)"""
+    import contextlib
+
+    return (engine_on_interpreter(), "cpu") if kind == "interpreter" else (contextlib.nullcontext(), "cuda")
 
 
 def rel(a, b):
@@ -53,19 +65,21 @@ def _denoiser():
     return den
 
 
-def test_wide_denoiser_model_output_vs_reference_golden(gold, monkeypatch):
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_wide_denoiser_model_output_vs_reference_golden(gold, monkeypatch, backend):
     from diamond_amd import native as nv
     from diamond_amd.testing import synthetic_actions, synthetic_frames
 
-    den = _denoiser().eval()
+    ctx, dev = _backend(backend)
+    den = _denoiser().eval().to(dev)
     s = W.SIZE
     g = torch.Generator().manual_seed(5)
-    obs, act, x = synthetic_frames(g, 2, 12, s, s), synthetic_actions(g, 4, 2, 4), torch.randn(2, 3, s, s, generator=g)
+    obs, act, x = synthetic_frames(g, 2, 12, s, s).to(dev), synthetic_actions(g, 4, 2, 4).to(dev), torch.randn(2, 3, s, s, generator=g).to(dev)
     counter = _Count()
     monkeypatch.setattr(nv, "PROFILER", counter)
-    with engine_on_interpreter(), torch.no_grad():
+    with ctx, torch.no_grad():
         for i, sigma in enumerate((torch.tensor(0.7), torch.tensor([0.05, 3.0]))):
-            f = den.compute_model_output(x, obs, act, sigma)
+            f = den.compute_model_output(x, obs, act, sigma.to(dev)).cpu()
             err = rel(f, gold[f"model_output_{i}"])
             assert err < 1e-4, (i, err)
     # the wide convolutions really ran as chains: more launches than the network has convolutions (2 forwards)
@@ -73,7 +87,8 @@ def test_wide_denoiser_model_output_vs_reference_golden(gold, monkeypatch):
     assert counter.n["dmd_conv2d"] > 2 * convs, (counter.n, convs)
 
 
-def test_wide_denoiser_training_step_vs_reference_golden(gold):
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_wide_denoiser_training_step_vs_reference_golden(gold, backend):
     """Denoiser.forward + loss.backward(): loss, every gradient tensor (sampled) and every gradient norm of the recorded forward
     + hand-written backward against the reference's autograd, split-fp16 and exact fp32 arithmetic"""
     from types import SimpleNamespace
@@ -82,26 +97,27 @@ def test_wide_denoiser_training_step_vs_reference_golden(gold):
     from diamond_amd import unet_train as UT
     from diamond_amd.testing import synthetic_actions, synthetic_frames
 
-    den = _denoiser().train()
+    ctx, dev = _backend(backend)
+    den = _denoiser().train().to(dev)
     den.setup_training(D.SigmaDistributionConfig(**W.SIGMA_DIST))
     s = W.SIZE
     g = torch.Generator().manual_seed(31)
-    obs, act = synthetic_frames(g, 1, 5, 3, s, s), synthetic_actions(g, 4, 1, 5)
-    batch = SimpleNamespace(obs=obs, act=act, mask_padding=torch.ones(1, 5, dtype=torch.bool))
+    obs, act = synthetic_frames(g, 1, 5, 3, s, s).to(dev), synthetic_actions(g, 4, 1, 5).to(dev)
+    batch = SimpleNamespace(obs=obs, act=act, mask_padding=torch.ones(1, 5, dtype=torch.bool).to(dev))
     den.randn_fn = lambda shape: torch.randn(*shape)  # CPU default generator: the stream the reference consumed
     ref = gold["train"]
     try:
         for precision in ("f16x2", "f32"):
             UT.TRAIN_PRECISION = precision
-            with engine_on_interpreter():
+            with _backend(backend)[0]:
                 torch.manual_seed(77)
                 den.zero_grad()
                 loss, _ = den(batch)
                 loss.backward()
-            errs = {"loss": rel(loss.detach(), ref["loss"])}
+            errs = {"loss": rel(loss.detach().cpu(), ref["loss"])}
             for k, p in den.named_parameters():
                 assert p.grad is not None, f"no gradient for {k}"
-                errs["grad " + k] = rel(W.sample_grad(p.grad), ref["grads"][k])
+                errs["grad " + k] = rel(W.sample_grad(p.grad).cpu(), ref["grads"][k])
                 n = float(ref["grad_norms"][k])
                 errs["|grad| " + k] = abs(float(p.grad.double().norm()) - n) / (n + 1e-30)
             bad = {k: v for k, v in errs.items() if v >= 1e-4}
@@ -110,42 +126,45 @@ def test_wide_denoiser_training_step_vs_reference_golden(gold):
         UT.TRAIN_PRECISION = "f16x2"
 
 
-def test_wide_rew_end_model_and_actor_critic_vs_reference_golden(gold):
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_wide_rew_end_model_and_actor_critic_vs_reference_golden(gold, backend):
     from diamond_amd.actor_critic import ActorCritic, ActorCriticConfig
     from diamond_amd.rew_end_model import RewEndModel, RewEndModelConfig
     from diamond_amd.testing import fill_module_, synthetic_actions, synthetic_frames
 
     s = W.SIZE
+    ctx, dev = _backend(backend)
     m = RewEndModel(RewEndModelConfig(**W.REW_END))
     fill_module_(m, W.WEIGHT_SEED + 1)
-    m.eval()
+    m.eval().to(dev)
     g = torch.Generator().manual_seed(9)
-    obs, act = synthetic_frames(g, 2, 3, 3, s, s), synthetic_actions(g, 4, 2, 2)
-    with engine_on_interpreter(), torch.no_grad():
-        lr, le, (h, c) = m.predict_rew_end(obs[:, :-1], act, obs[:, 1:])
+    obs, act = synthetic_frames(g, 2, 3, 3, s, s).to(dev), synthetic_actions(g, 4, 2, 2).to(dev)
+    with ctx, torch.no_grad():
+        lr, le, (h, c) = [t.cpu() if torch.is_tensor(t) else tuple(u.cpu() for u in t) for t in m.predict_rew_end(obs[:, :-1], act, obs[:, 1:])]
     r = gold["rew_end"]
     errs = {"logits_rew": rel(lr, r["logits_rew"]), "logits_end": rel(le, r["logits_end"]), "h": rel(h, r["h"]), "c": rel(c, r["c"])}
     assert max(errs.values()) < 1e-4, errs
 
     ac = ActorCritic(ActorCriticConfig(**W.ACTOR_CRITIC))
     fill_module_(ac, W.WEIGHT_SEED + 2)
+    ac.to(dev)
     g = torch.Generator().manual_seed(11)
-    obs = synthetic_frames(g, 2, 3, s, s)
-    with engine_on_interpreter():
+    obs = synthetic_frames(g, 2, 3, s, s).to(dev)
+    with _backend(backend)[0]:
         o = ac.predict_act_value(obs, None)
         (o.logits_act.square().sum() + o.val.sum()).backward()
     r = gold["actor_critic"]
-    errs = {"logits": rel(o.logits_act.detach(), r["logits"]), "val": rel(o.val.detach(), r["val"])}
+    errs = {"logits": rel(o.logits_act.detach().cpu(), r["logits"]), "val": rel(o.val.detach().cpu(), r["val"])}
     for k, p in ac.named_parameters():
-        errs["grad " + k] = rel(W.sample_grad(p.grad), r["grads"][k])
+        errs["grad " + k] = rel(W.sample_grad(p.grad).cpu(), r["grads"][k])
         n = float(r["grad_norms"][k])
         errs["|grad| " + k] = abs(float(p.grad.double().norm()) - n) / (n + 1e-30)
     bad = {k: v for k, v in errs.items() if v >= 1e-4}
     assert not bad, bad
 
 
-@pytest.mark.skipif(os.environ.get("DIAMOND_SLOW_CPU_TESTS") != "1", reason="3-4 minutes on 8 cores: DIAMOND_SLOW_CPU_TESTS=1 runs it")
-def test_wide_full_window_vs_reference_golden(monkeypatch):
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_wide_full_window_vs_reference_golden(monkeypatch, backend):
     """The whole north-star path on the wide networks: two BPTT windows of ActorCritic.forward() + backward through WorldModelEnv /
     env_loop / DiffusionSampler / the reward-end model with resets and burn-in, the reference's RNG order -- sampled actions,
     rewards, ends and truncations BIT-exact against the reference's own rollout (tests/golden/make_golden.py --wide-window)."""
@@ -156,15 +175,19 @@ def test_wide_full_window_vs_reference_golden(monkeypatch):
     from diamond_amd.testing import fill_module_
     from tests import test_gpu_models as M
 
-    monkeypatch.setattr(M, "DEV", "cpu")
+    if backend == "interpreter" and os.environ.get("DIAMOND_SLOW_CPU_TESTS") != "1":
+        pytest.skip("3-4 minutes on 8 cores: DIAMOND_SLOW_CPU_TESTS=1 runs it")
+    ctx, dev = _backend(backend)
+    monkeypatch.setattr(M, "DEV", dev)
     ag = D.Agent(W.agent_config(D.AgentConfig, D.DenoiserConfig, InnerModelConfig, RewEndModelConfig, ActorCriticConfig))
     fill_module_(ag, M.WEIGHT_SEED)
-    with engine_on_interpreter():
-        M.test_full_window_vs_reference_golden("window_wide.pt", ag.eval())
+    with ctx:
+        M.test_full_window_vs_reference_golden("window_wide.pt", ag.eval().to(dev))
 
 
 @pytest.mark.parametrize("case", ["cat 320 + 64, 3x3", "one 512-channel source, 1x1", "stride 2", "upsample"])
-def test_wide_convolution_decomposition_vs_fp64(case):
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_wide_convolution_decomposition_vs_fp64(case, backend):
     """engine._conv2d_wide on its own: GroupNorm(+affine)+SiLU prologue on a source wider than one launch takes, a second raw
     source, bias, residual, the emitted statistics of the finished output -- against fp64 torch ops on the same values"""
     from diamond_amd import engine as E
@@ -192,15 +215,17 @@ def test_wide_convolution_decomposition_vs_fp64(case):
     if upsample:
         xin = F.interpolate(xin, scale_factor=2, mode="nearest")
     ref = F.conv2d(xin, wt.double(), bias.double(), stride=stride, padding=k // 2) + res.double().permute(0, 3, 1, 2)
-    with engine_on_interpreter():
-        sa = E.gn_stats(a.contiguous()) if prologue != nv.PROLOGUE_NONE else Act(a.contiguous())
-        srcs = [(sa, prologue, NormSpec(mul=gamma, add=beta) if prologue != nv.PROLOGUE_NONE else None)]
+    ctx, dev = _backend(backend)
+    on = lambda t: t.contiguous().to(dev)
+    with ctx:
+        sa = E.gn_stats(on(a)) if prologue != nv.PROLOGUE_NONE else Act(on(a))
+        srcs = [(sa, prologue, NormSpec(mul=on(gamma), add=on(beta)) if prologue != nv.PROLOGUE_NONE else None)]
         if b is not None:
-            srcs.append((Act(b.contiguous()), nv.PROLOGUE_NONE, None))
-        out = E.conv2d(srcs, nv.pack_conv_weight(wt), bias, cout, taps=taps, stride=stride, upsample=upsample, residual=Act(res.contiguous()))
-    got = out.t.double().permute(0, 3, 1, 2)
+            srcs.append((Act(on(b)), nv.PROLOGUE_NONE, None))
+        out = E.conv2d(srcs, nv.pack_conv_weight(on(wt)), on(bias), cout, taps=taps, stride=stride, upsample=upsample, residual=Act(on(res)))
+    got = out.t.cpu().double().permute(0, 3, 1, 2)
     assert rel(got, ref) < 2e-6, rel(got, ref)
     # the partial sums the last launch emitted describe the finished output
-    sums = out.stats.sum(2)  # (n, groups, 2)
+    sums = out.stats.cpu().sum(2)  # (n, groups, 2)
     want = ref.reshape(n, cout // 32, 32 * h * w)
     assert rel(sums[..., 0], want.sum(-1)) < 1e-5 and rel(sums[..., 1], want.square().sum(-1)) < 1e-5
