@@ -258,3 +258,47 @@ def test_reference_bytecode_runs_a_window():
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     d = json.loads(out.stdout.decode().strip().splitlines()[-1])
     assert d["kind"] == "reference" and d["value"] > 0 and d["cores"] == 4 and "15 imagined steps" in d["sample"]
+
+
+def test_oracle_on_configurations_wider_than_the_default_one():
+    """The oracle is spec-driven (depths / channels / attention per level): pinned here against the reference on the wide
+    configurations of tests/wide_configs.py (tests/golden/wide.pt, make_golden.py --wide) -- denoiser model output at a scalar and
+    a per-sample sigma, reward / end logits and LSTM state, actor-critic logits and values."""
+    import diamond_amd as D
+    from diamond_amd.actor_critic import ActorCritic, ActorCriticConfig
+    from diamond_amd.inner_model import InnerModelConfig
+    from diamond_amd.rew_end_model import RewEndModel, RewEndModelConfig
+    from diamond_amd.testing import fill_module_
+    from tests import wide_configs as W
+
+    gold = load_golden("wide.pt")
+    s = W.SIZE
+    pick = lambda cfg, *ks: {k: tuple(cfg[k]) if isinstance(cfg[k], list) else cfg[k] for k in ks}
+    # (the package's modules only as parameter containers: names and shapes of the state dict, filled by name)
+    den = D.Denoiser(D.DenoiserConfig(inner_model=InnerModelConfig(**W.DENOISER), sigma_data=0.5, sigma_offset_noise=0.3))
+    fill_module_(den, W.WEIGHT_SEED)
+    spec = O.DenoiserSpec(**pick(W.DENOISER, "img_channels", "num_steps_conditioning", "cond_channels", "depths", "channels", "attn_depths"))
+    g = torch.Generator().manual_seed(5)
+    obs, act, x = synthetic_frames(g, 2, 12, s, s), synthetic_actions(g, 4, 2, 4), torch.randn(2, 3, s, s, generator=g)
+    for i, sigma in enumerate((torch.tensor(0.7), torch.tensor([0.05, 3.0]))):
+        f = O.model_output(dict(den.state_dict()), spec, x, sigma, obs, act)
+        assert rel_err(f, gold[f"model_output_{i}"]) < 2e-5, i
+
+    m = RewEndModel(RewEndModelConfig(**W.REW_END))
+    fill_module_(m, W.WEIGHT_SEED + 1)
+    rspec = O.RewEndSpec(**pick(W.REW_END, "lstm_dim", "img_channels", "img_size", "cond_channels", "depths", "channels", "attn_depths"))
+    g = torch.Generator().manual_seed(9)
+    obs, act = synthetic_frames(g, 2, 3, 3, s, s), synthetic_actions(g, 4, 2, 2)
+    lr, le, (h, c) = O.rew_end_predict(dict(m.state_dict()), rspec, obs[:, :-1], act, obs[:, 1:])
+    r = gold["rew_end"]
+    assert max(rel_err(lr, r["logits_rew"]), rel_err(le, r["logits_end"]), rel_err(h, r["h"]), rel_err(c, r["c"])) < 2e-5
+
+    ac = ActorCritic(ActorCriticConfig(**W.ACTOR_CRITIC))
+    fill_module_(ac, W.WEIGHT_SEED + 2)
+    aspec = O.ActorCriticSpec(**pick(W.ACTOR_CRITIC, "lstm_dim", "img_channels", "img_size", "channels", "down"))
+    g = torch.Generator().manual_seed(11)
+    obs = synthetic_frames(g, 2, 3, s, s)
+    z = torch.zeros(2, aspec.lstm_dim)
+    logits, val, _ = O.ac_predict({k: v.detach() for k, v in ac.state_dict().items()}, aspec, obs, z, z)
+    r = gold["actor_critic"]
+    assert max(rel_err(logits, r["logits"]), rel_err(val, r["val"])) < 2e-5
