@@ -177,7 +177,8 @@ class Denoiser(nn.Module):
                                precision: Optional[str] = None) -> Tensor:
         """F = inner_model(x * c_in, c_noise, obs / sigma_data, act) (:74-77) differentiable w.r.t. every parameter:
         the U-Net forward runs on the HIP kernels while its launches are recorded, its backward is
-        unet_train.UNetTrainFn; the cond vector / FiLM table (tiny GEMMs) are torch ops under autograd."""
+        unet_train.UNetTrainFn; the cond vector / FiLM table (three small GEMMs) run on dmd_linear through lstm_native.LinearFn,
+        whose backward is dmd_linear as well (torch autograd only carries the gradient between the nodes)."""
         import math
         import torch.nn.functional as F
         from . import unet_train as UT
