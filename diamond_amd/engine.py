@@ -520,8 +520,9 @@ def _conv2d_wide(srcs, w_packed, bias, cout, *, taps, stride, upsample, residual
         out = conv(piece_0) + bias + residual;   out = conv(piece_i) + out   (i = 1 ...),
     the last launch emitting the GroupNorm partial sums of the finished output.  The packed weight is K-major
     ([Cin / 16][taps][CoutPad][16], dmd_pack_conv_weight): a piece's weights are a contiguous range of it, nothing is re-packed.
-    A source wider than the limit on its own goes in as contiguous channel slices (_channel_slice).  Exact fp32 kernels (the
-    split-fp16 instances cover Cin <= 128); one launch per piece -- correctness for wide configurations, not their fast path."""
+    A source wider than the limit on its own goes in as contiguous channel slices (_channel_slice).  The pieces run on the generic
+    kernel (conv_mfma_kernel: its split-fp16 instance where the caller's precision asks for it, exact fp32 otherwise -- the
+    wave-specialised kernel covers Cin <= 128); one launch per piece -- correctness for wide configurations, not their fast path."""
     global TAPE
     assert not out_nchw, "wide convolution with an NCHW result"
     pieces = []  # (source triple, channels)
