@@ -63,6 +63,17 @@ class _no_random_draws:
         return False
 
 
+def _without_torch_compile(fn, default):
+    """`fn` unless it is a torch.compile(...) wrapper (dynamo marks those with `_torchdynamo_orig_callable`): then what it wraps --
+    `default` (the env's own bound method) when that is the function inside, as in trainer.py:182-184."""
+    orig = getattr(fn, "_torchdynamo_orig_callable", None)
+    if orig is None:
+        return fn
+    if orig is getattr(default, "__func__", None):
+        return default  # (only the method's function survived the wrapping)
+    return orig
+
+
 GRAPH_SAMPLER_MAX_ENVS = 8  # below this the sampler is launch-latency-bound and runs as a replayed hipGraph ...
 GRAPH_SAMPLER_MAX_PIXELS = 8 * 64 * 64  # ... if its launches are small: 8 envs at 256x256 are not (configs[4]: eager + speculation
 #                                         measured 367-370 frames/s against 364-365 replayed, same box, alternating)
@@ -582,8 +593,32 @@ class WorldModelEnv:
         b, _, _, h, w = self._ctx.shape
         return b * h * w <= GRAPH_SAMPLER_MAX_PIXELS
 
+    # -- the two callables trainer.py:182-184 re-assigns -----------------------------------------------------------------
+    # `rl_env.predict_next_obs = torch.compile(rl_env.predict_next_obs, mode="reduce-overhead")` (and the same for predict_rew_end) is
+    # what the reference does under its DEFAULT configuration (config/trainer.yaml:60 `compile_wm: True`).  Both are sequences of
+    # HIP launches through ctypes: there is nothing for a tracing compiler in them, and letting dynamo trace the host code around
+    # the launches costs a minute of compilation, hits its recompilation limit on the per-layer host objects and moves the
+    # initial-noise draw into a compiled region (another random stream).  So they are properties: any callable may be assigned
+    # (wrappers, spies: called like the reference's attribute), and a torch.compile wrapper is undone on assignment
+    # (_without_torch_compile) -- the no-op wrapper SURVEY 8(b) asks for; the trainer runs unchanged either way.
+    @property
+    def predict_next_obs(self):
+        return self.__dict__.get("_predict_next_obs_fn") or self._predict_next_obs
+
+    @predict_next_obs.setter
+    def predict_next_obs(self, fn) -> None:
+        self.__dict__["_predict_next_obs_fn"] = _without_torch_compile(fn, self._predict_next_obs)
+
+    @property
+    def predict_rew_end(self):
+        return self.__dict__.get("_predict_rew_end_fn") or self._predict_rew_end
+
+    @predict_rew_end.setter
+    def predict_rew_end(self, fn) -> None:
+        self.__dict__["_predict_rew_end_fn"] = _without_torch_compile(fn, self._predict_rew_end)
+
     @torch.no_grad()
-    def predict_next_obs(self) -> Tuple[Tensor, List[Tensor]]:
+    def _predict_next_obs(self) -> Tuple[Tensor, List[Tensor]]:
         """Reference signature (world_model_env.py:91-93).  The initial noise step_begin drew for this call, if any, waits in
         `_next_noise`; a direct call draws its own."""
         noise, self._next_noise = getattr(self, "_next_noise", None), None
@@ -592,7 +627,7 @@ class WorldModelEnv:
         return self.sampler.sample_ring(self._ctx, self._act, self._head, self._head, noise)
 
     @torch.no_grad()
-    def predict_rew_end(self, next_obs: Tensor, e_rew: Optional[Tensor] = None, e_end: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    def _predict_rew_end(self, next_obs: Tensor, e_rew: Optional[Tensor] = None, e_end: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
         """e_rew / e_end: exponential draws made earlier (step_begin); None: drawn here."""
         newest = self._slot(-1)
         logits_rew, logits_end, (self.hx_rew_end, self.cx_rew_end) = self.rew_end_model.predict_rew_end(

@@ -124,3 +124,47 @@ def test_fused_burn_in_on_the_interpreter(models):
     """lstm_native.LstmBurnInFn (one autograd node for the policy-side burn-in of a reset) against chained per-frame calls"""
     M, counter = models
     M.test_fused_burn_in_is_bitwise_the_frame_by_frame_one()
+
+
+def test_torch_compile_of_the_env_callables_is_a_no_op(models):
+    """trainer.py:182-184 under the reference's DEFAULT configuration (config/trainer.yaml:60, compile_wm: True) re-assigns
+    rl_env.predict_next_obs / predict_rew_end with torch.compile(..., mode="reduce-overhead") objects.  They are HIP launch
+    sequences: the env undoes the wrapper on assignment -- dynamo never sees a frame of the host code (it used to trace it for a
+    minute, hit its recompilation limit and move the initial-noise draw into a compiled region), results and the random stream
+    are bitwise those of the unwrapped env.  Plain wrappers (spies) are kept and called, like an attribute of the reference's env."""
+    import torch._dynamo.utils as U
+
+    import diamond_amd as D
+
+    M, counter = models
+    ag = M.make_agent()
+
+    def rollout(compiled):
+        env = D.WorldModelEnv(ag.denoiser, ag.rew_end_model, M._Loader(1, 21, 64),
+                              D.WorldModelEnvConfig(horizon=2, num_batches_to_preload=1, diffusion_sampler=D.DiffusionSamplerConfig(num_steps_denoising=1)))
+        env.sampler.noise_fn = lambda shape, dev: torch.randn(*shape)
+        calls = []
+        if compiled == "torch.compile":
+            env.predict_next_obs = torch.compile(env.predict_next_obs, mode="reduce-overhead")
+            env.predict_rew_end = torch.compile(env.predict_rew_end, mode="reduce-overhead")
+            assert not hasattr(env.predict_next_obs, "_torchdynamo_orig_callable") and not hasattr(env.predict_rew_end, "_torchdynamo_orig_callable")
+        elif compiled == "spy":
+            inner_obs, inner_re = env.predict_next_obs, env.predict_rew_end
+            env.predict_next_obs = lambda: (calls.append("obs"), inner_obs())[1]
+            env.predict_rew_end = lambda *a, **k: (calls.append("rew_end"), inner_re(*a, **k))[1]
+        torch.manual_seed(5)
+        env.reset()
+        out = []
+        for _ in range(2):  # (horizon 2: the second step ends with a truncation reset)
+            obs, rew, end, trunc, _ = env.step(torch.randint(0, 4, (1,)))
+            out += [obs, rew, end, trunc]
+        return out + [torch.rand(1)], calls  # (+ where the CPU generator stands afterwards)
+
+    plain, _ = rollout(None)
+    frames = dict(U.counters["frames"])
+    wrapped, _ = rollout("torch.compile")
+    assert dict(U.counters["frames"]) == frames, "dynamo traced host code of the env"
+    spied, calls = rollout("spy")
+    for a, b, c in zip(plain, wrapped, spied):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    assert calls == ["obs", "rew_end"] * 2, calls
