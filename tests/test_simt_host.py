@@ -168,3 +168,61 @@ def test_torch_compile_of_the_env_callables_is_a_no_op(models):
     for a, b, c in zip(plain, wrapped, spied):
         assert torch.equal(a, b) and torch.equal(a, c)
     assert calls == ["obs", "rew_end"] * 2, calls
+
+
+def test_trainer_usage_patterns_of_the_denoiser_on_the_interpreter():
+    """What an UNCHANGED src/trainer.py does with a world-model component besides `loss.backward()`: `test_component` runs
+    `model(batch)` in eval mode under torch.no_grad() (trainer.py:391-399), `train_component` accumulates `grad_acc_steps`
+    backward passes before the optimizer step (:363-375), and under DDP the model is `DistributedDataParallel(model)` (:110).  All
+    three on a small denoiser against its own plain training step (which tests/test_wide_configs.py pins to the reference): same
+    loss, no graph under no_grad; two accumulated backward passes = exactly twice the gradients; DDP at world size 1 (gloo) =
+    bitwise the gradients without it."""
+    import os
+    from types import SimpleNamespace
+
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    import diamond_amd as D
+    from diamond_amd.inner_model import InnerModelConfig
+    from diamond_amd.testing import fill_module_, synthetic_actions, synthetic_frames
+    from tests import wide_configs as W
+
+    cfg = dict(W.DENOISER, depths=[1, 1], channels=[64, 96], attn_depths=[0, 1])  # (two levels at 16 x 16: seconds per step)
+    den = D.Denoiser(D.DenoiserConfig(inner_model=InnerModelConfig(**cfg), sigma_data=0.5, sigma_offset_noise=0.3))
+    fill_module_(den, W.WEIGHT_SEED)
+    den.setup_training(D.SigmaDistributionConfig(**W.SIGMA_DIST))
+    den.randn_fn = lambda shape: torch.randn(*shape)
+    g = torch.Generator().manual_seed(31)
+    batch = SimpleNamespace(obs=synthetic_frames(g, 2, 6, 3, 16, 16), act=synthetic_actions(g, 4, 2, 6), mask_padding=torch.ones(2, 6, dtype=torch.bool))
+
+    def step(model, times=1):
+        den.zero_grad()
+        for _ in range(times):
+            torch.manual_seed(77)
+            loss, _ = model(batch)
+            loss.backward()
+        return loss.detach().clone(), {k: p.grad.clone() for k, p in den.named_parameters()}
+
+    with engine_on_interpreter():
+        den.train()
+        loss, grads = step(den)
+        _, twice = step(den, times=2)
+        den.eval()
+        with torch.no_grad():
+            torch.manual_seed(77)
+            loss_eval, metrics = den(batch)
+        assert not loss_eval.requires_grad and torch.equal(loss_eval, loss) and "loss_denoising" in metrics
+        for k in grads:
+            assert torch.equal(twice[k], 2 * grads[k]), k
+        den.train()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29537")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        try:
+            loss_ddp, grads_ddp = step(DDP(den))
+        finally:
+            dist.destroy_process_group()
+        assert torch.equal(loss_ddp, loss)
+        for k in grads:
+            assert torch.equal(grads_ddp[k], grads[k]), k
