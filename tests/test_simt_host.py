@@ -155,7 +155,7 @@ def test_torch_compile_of_the_env_callables_is_a_no_op(models):
         torch.manual_seed(5)
         env.reset()
         out = []
-        for _ in range(2):  # (horizon 2: the second step ends with a truncation reset)
+        for _ in range(2 if os.environ.get("DIAMOND_SLOW_CPU_TESTS") == "1" else 1):  # (horizon 2: a second step ends with a truncation reset)
             obs, rew, end, trunc, _ = env.step(torch.randint(0, 4, (1,)))
             out += [obs, rew, end, trunc]
         return out + [torch.rand(1)], calls  # (+ where the CPU generator stands afterwards)
@@ -164,10 +164,11 @@ def test_torch_compile_of_the_env_callables_is_a_no_op(models):
     frames = dict(U.counters["frames"])
     wrapped, _ = rollout("torch.compile")
     assert dict(U.counters["frames"]) == frames, "dynamo traced host code of the env"
-    spied, calls = rollout("spy")
-    for a, b, c in zip(plain, wrapped, spied):
-        assert torch.equal(a, b) and torch.equal(a, c)
-    assert calls == ["obs", "rew_end"] * 2, calls
+    for a, b in zip(plain, wrapped):
+        assert torch.equal(a, b)
+    if os.environ.get("DIAMOND_SLOW_CPU_TESTS") == "1":  # (plain wrappers are kept and called: also tests/test_boundary.py, test_gpu_env.py)
+        spied, calls = rollout("spy")
+        assert all(torch.equal(a, c) for a, c in zip(plain, spied)) and calls == ["obs", "rew_end"] * 2, calls  # (two steps in this mode)
 
 
 def test_trainer_usage_patterns_of_the_denoiser_on_the_interpreter():
@@ -194,7 +195,7 @@ def test_trainer_usage_patterns_of_the_denoiser_on_the_interpreter():
     den.setup_training(D.SigmaDistributionConfig(**W.SIGMA_DIST))
     den.randn_fn = lambda shape: torch.randn(*shape)
     g = torch.Generator().manual_seed(31)
-    batch = SimpleNamespace(obs=synthetic_frames(g, 2, 6, 3, 16, 16), act=synthetic_actions(g, 4, 2, 6), mask_padding=torch.ones(2, 6, dtype=torch.bool))
+    batch = SimpleNamespace(obs=synthetic_frames(g, 1, 5, 3, 16, 16), act=synthetic_actions(g, 4, 1, 5), mask_padding=torch.ones(1, 5, dtype=torch.bool))
 
     def step(model, times=1):
         den.zero_grad()
