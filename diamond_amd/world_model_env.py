@@ -603,7 +603,8 @@ class WorldModelEnv:
     # (_without_torch_compile) -- the no-op wrapper SURVEY 8(b) asks for; the trainer runs unchanged either way.
     @property
     def predict_next_obs(self):
-        return self.__dict__.get("_predict_next_obs_fn") or self._predict_next_obs
+        fn = self.__dict__.get("_predict_next_obs_fn")
+        return self._predict_next_obs if fn is None else fn
 
     @predict_next_obs.setter
     def predict_next_obs(self, fn) -> None:
@@ -611,7 +612,8 @@ class WorldModelEnv:
 
     @property
     def predict_rew_end(self):
-        return self.__dict__.get("_predict_rew_end_fn") or self._predict_rew_end
+        fn = self.__dict__.get("_predict_rew_end_fn")
+        return self._predict_rew_end if fn is None else fn
 
     @predict_rew_end.setter
     def predict_rew_end(self, fn) -> None:
