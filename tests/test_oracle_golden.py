@@ -302,3 +302,43 @@ def test_oracle_on_configurations_wider_than_the_default_one():
     logits, val, _ = O.ac_predict({k: v.detach() for k, v in ac.state_dict().items()}, aspec, obs, z, z)
     r = gold["actor_critic"]
     assert max(rel_err(logits, r["logits"]), rel_err(val, r["val"])) < 2e-5
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="needs the reference (build container only)")
+def test_committed_fixtures_regenerate_from_the_reference(tmp_path, monkeypatch):
+    """The committed fixtures ARE what the reference computes here and now: a subset of them (the cheap ones: seconds) regenerated
+    by the committed generator into a scratch directory and compared tensor by tensor with tests/golden/.  (All of them were
+    regenerated and compared this way at the end of round 5: 0 differing tensors)"""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    committed = mg.HERE
+    monkeypatch.setattr(mg, "HERE", str(tmp_path))
+    agent = mg.ref_agent()
+    names = ["rew_end.pt", "actor_critic.pt"]
+    mg.gen_rew_end(agent)
+    mg.gen_actor_critic(agent)
+    if os.environ.get("DIAMOND_SLOW_CPU_TESTS") == "1":  # (another minute)
+        mg.gen_denoiser(agent, "default")
+        mg.gen_wide()
+        names += ["denoiser_default.pt", "wide.pt"]
+
+    def flat(o, pre=""):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                yield from flat(v, f"{pre}/{k}")
+        elif isinstance(o, (list, tuple)):
+            for i, v in enumerate(o):
+                yield from flat(v, f"{pre}/{i}")
+        else:
+            yield pre, o
+
+    for name in names:
+        a = dict(flat(torch.load(os.path.join(committed, name), weights_only=False)))
+        b = dict(flat(torch.load(os.path.join(str(tmp_path), name), weights_only=False)))
+        assert a.keys() == b.keys(), name
+        for k, v in a.items():
+            same = torch.equal(v, b[k]) if torch.is_tensor(v) else v == b[k]
+            assert same, (name, k)
