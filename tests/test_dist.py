@@ -140,3 +140,76 @@ def test_bench_self_launch_command():
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], env=dict(env, WORLD_SIZE="2", RANK="0"),
                         capture_output=True, text=True, timeout=300)
     assert "self_launch" not in r2.stdout
+
+
+def _ddp_worker(rank, world, port, q):
+    """One rank of torch's own DistributedDataParallel over the package's Denoiser (what an unchanged trainer.py does at N > 1:
+    utils.py:105-106, trainer.py:110) -- the product's recorded forward + hand-written backward, kernels on the SIMT interpreter."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from types import SimpleNamespace
+
+    import diamond_amd as D
+    from diamond_amd.inner_model import InnerModelConfig
+    from diamond_amd.testing import fill_module_, synthetic_actions, synthetic_frames
+    from tests import wide_configs as W
+    from tests.simt.host_harness import engine_on_interpreter
+
+    torch.set_num_threads(2)
+    cfg = dict(W.DENOISER, depths=[1, 1], channels=[64, 96], attn_depths=[0, 1])  # (two levels at 16 x 16: seconds per step)
+    den = D.Denoiser(D.DenoiserConfig(inner_model=InnerModelConfig(**cfg), sigma_data=0.5, sigma_offset_noise=0.3))
+    fill_module_(den, 3 + rank)  # different values per rank: DDP's constructor broadcasts rank 0's
+    den.setup_training(D.SigmaDistributionConfig(**W.SIGMA_DIST))
+    den.randn_fn = lambda shape: torch.randn(*shape)
+
+    def batch_of(r):
+        g = torch.Generator().manual_seed(50 + r)
+        return SimpleNamespace(obs=synthetic_frames(g, 1, 5, 3, 16, 16), act=synthetic_actions(g, 4, 1, 5), mask_padding=torch.ones(1, 5, dtype=torch.bool))
+
+    def step(model, r):
+        den.zero_grad()
+        torch.manual_seed(70 + r)  # (sigma and noise of rank r's batch)
+        loss, _ = model(batch_of(r))
+        loss.backward()
+        return torch.cat([p.grad.reshape(-1) for p in den.parameters()]).clone()
+
+    with engine_on_interpreter():
+        ddp = torch.nn.parallel.DistributedDataParallel(den)
+        mine = step(ddp, rank)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        if rank == 0:
+            same = all(torch.equal(g_, gathered[0]) for g_ in gathered)
+            # without DDP (the module itself, rank 0's = everybody's weights): the mean of the ranks' own gradients
+            ref = sum(step(den, r) for r in range(world)) / world
+            q.put(float((mine - ref).abs().max() / ref.abs().max()))
+            q.put(bool(same))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_of_the_denoiser_world2_on_the_interpreter():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    port = 29500 + (os.getpid() + 331) % 1000
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    import queue
+    import time
+
+    got, deadline = [], time.time() + 300
+    while len(got) < 2:
+        try:
+            got.append(q.get(timeout=2))
+        except queue.Empty:
+            assert time.time() < deadline, "timed out"
+            assert all(p.exitcode in (None, 0) for p in procs), "a rank died: " + str([p.exitcode for p in procs])
+    err, same = got
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert same and err < 1e-6, (same, err)
