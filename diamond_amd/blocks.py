@@ -37,7 +37,12 @@ def conv1x1(cin: int, cout: int) -> nn.Conv2d:
 
 
 def _groups(c: int) -> int:
-    return max(1, c // GN_GROUP_SIZE)
+    # The reference forms max(1, C // 32) groups of C / groups channels (blocks.py:27,38): groups of exactly 32 whenever C is a
+    # multiple of 32 -- the only case the kernels implement (DMD_GN_GROUP).  Say so where the network is built, not at its first launch.
+    assert c % GN_GROUP_SIZE == 0, (f"normalisation over {c} channels: diamond_amd's kernels normalise in groups of {GN_GROUP_SIZE} channels, "
+                                    f"so every normalised width has to be a multiple of {GN_GROUP_SIZE} (the reference would form "
+                                    f"{max(1, c // GN_GROUP_SIZE)} group(s) of {c / max(1, c // GN_GROUP_SIZE):g} here)")
+    return c // GN_GROUP_SIZE
 
 
 class RunCtx:
