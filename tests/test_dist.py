@@ -194,7 +194,11 @@ def test_ddp_of_the_denoiser_world2_on_the_interpreter():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     world = 2
-    port = 29500 + (os.getpid() + 331) % 1000
+    import socket
+
+    with socket.socket() as sk:  # (a port nobody holds right now, not one derived from the pid)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()

@@ -217,9 +217,12 @@ def test_trainer_usage_patterns_of_the_denoiser_on_the_interpreter():
         for k in grads:
             assert torch.equal(twice[k], 2 * grads[k]), k
         den.train()
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29537")
-        dist.init_process_group("gloo", rank=0, world_size=1)
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
         try:
             loss_ddp, grads_ddp = step(DDP(den))
         finally:
