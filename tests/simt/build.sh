@@ -25,5 +25,14 @@ done
 rc=0
 for p in "${pids[@]:-}"; do [ -n "$p" ] && { wait "$p" || rc=1; }; done
 [ $rc -eq 0 ] || { echo "simt build failed"; exit 1; }
-$CXX -shared -fPIC _build/*.o -o _build/libdiamond_simt.so -lpthread -lm
-echo "built $(realpath _build/libdiamond_simt.so)"
+# link only when an object is newer than the library, into a scratch name that is then renamed over it: a process that has the
+# library mapped keeps its (old) file, one that is about to dlopen it never finds it missing or half written
+OUT=_build/libdiamond_simt.so
+need=0
+[ -f "$OUT" ] || need=1
+for o in _build/*.o; do [ "$o" -nt "$OUT" ] && need=1; done
+if [ $need -eq 1 ]; then
+  $CXX -shared -fPIC _build/*.o -o "$OUT.$$.tmp" -lpthread -lm
+  mv -f "$OUT.$$.tmp" "$OUT"
+fi
+echo "built $(realpath $OUT)"

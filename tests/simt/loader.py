@@ -18,7 +18,14 @@ _lib: Optional[C.CDLL] = None
 
 
 def build() -> None:
-    subprocess.run(["bash", os.path.join(_HERE, "build.sh")], check=True, stdout=subprocess.DEVNULL)
+    """build.sh under an exclusive file lock: several processes may get here at once (the ranks of a gloo test, pytest-xdist
+    workers) and must not compile the same objects side by side."""
+    import fcntl
+
+    os.makedirs(os.path.join(_HERE, "_build"), exist_ok=True)
+    with open(os.path.join(_HERE, "_build", ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        subprocess.run(["bash", os.path.join(_HERE, "build.sh")], check=True, stdout=subprocess.DEVNULL)
 
 
 def lib() -> C.CDLL:
