@@ -94,6 +94,7 @@ class InitialConditionPool:
     preloaded (each one burns the reward/end LSTM in on its first T-1 transitions, :123-124)."""
 
     _warned_fp32 = False  # one warning per process when a pool falls back to fp32 (off-grid frames)
+    PAD_AWARE = True  # (False: the loader's zero-padded frames count as off-grid values, as before -- A/B and the tests' reference arm)
 
     def __init__(self, rew_end_model, data_loader, num_batches: int, device_fn: Callable[[], torch.device]) -> None:
         self._model = rew_end_model
@@ -109,6 +110,13 @@ class InitialConditionPool:
         self._cursor = 0
         self._watch_cpu_rng = False  # (WorldModelEnv sets it while draws are injected from the CPU generator: tests)
         self._generation = 0  # counts preload rounds (a peeked plan is void once the pool it pointed into was replaced)
+        # (P, T) bool, True = a PADDED frame of the uint8 pool, or None when the pool holds none.  The reference's segments are
+        # zero-padded in front of an episode's first step (data/utils.py:18-41, data/batch_sampler.py:63-68: "padding allowed only
+        # before start") and WorldModelEnv uses those zero frames as they are (world_model_env.py:116-131 ignores mask_padding);
+        # 0.0 is level 127.5, i.e. off the uint8 grid -- with real data nearly every preload round holds a few, and the whole pool
+        # would fall back to fp32.  Frames the loader itself marks as padding (batch.mask_padding False) and that ARE zero are
+        # therefore stored as a stand-in level and put back as exact zeros behind the dequantising gather.
+        self.pad: Optional[Tensor] = None
 
     @property
     def size(self) -> int:
@@ -119,8 +127,10 @@ class InitialConditionPool:
         if self._iter is None:
             self._iter = iter(self._loader)
         dev = self._device_fn()
-        q_, f_, act_, hx_, cx_ = [], [], [], [], []
+        q_, f_, act_, hx_, cx_, pad_ = [], [], [], [], [], []
         off_grid = torch.zeros(1, dtype=torch.int32, device=dev)
+        pad_count = torch.zeros(1, dtype=torch.int64, device=dev)  # padded frames / values in them that are not zero
+        pad_nonzero = torch.zeros(1, dtype=torch.int64, device=dev)
         for _ in range(self._num_batches):
             with _no_random_draws(dev, "the initial-condition loader", cpu=self._watch_cpu_rng):
                 batch = next(self._iter)
@@ -128,17 +138,31 @@ class InitialConditionPool:
             act = batch.act.to(dev, non_blocking=True)
             *_, (hx, cx) = self._model.predict_rew_end(obs[:, :-1], act[:, :-1], obs[:, 1:])
             assert hx.size(0) == cx.size(0) == 1
+            mask = getattr(batch, "mask_padding", None) if self.PAD_AWARE else None
+            pad = None if mask is None else ~mask.to(dev, non_blocking=True).bool()
+            src = obs
+            if pad is not None:  # (the stand-in is level 0; what the frames really hold is checked below, with the same sync)
+                where = pad[:, :, None, None, None]
+                pad_count += pad.sum()
+                pad_nonzero += (obs.masked_fill(~where, 0.0) != 0).sum()
+                src = obs.masked_fill(where, -1.0)
             q = torch.empty(obs.shape, dtype=torch.uint8, device=dev)
-            nv.check(nv.lib().dmd_quantize_u8(nv.fptr(obs), nv.ptr(q), nv.ptr(off_grid), obs.numel(), nv.stream()),
+            nv.check(nv.lib().dmd_quantize_u8(nv.fptr(src), nv.ptr(q), nv.ptr(off_grid), obs.numel(), nv.stream()),
                      "dmd_quantize_u8")
             q_.append(q)
             f_.append(obs)
             act_.append(act)
             hx_.append(hx[0])
             cx_.append(cx[0])
-        if int(off_grid.item()) == 0:  # one sync per preload round
+            pad_.append(pad if pad is not None else torch.zeros(obs.shape[:2], dtype=torch.bool, device=dev))
+        n_off, n_pad, n_pad_nonzero = torch.cat([off_grid.long(), pad_count, pad_nonzero]).tolist()  # one sync per preload round
+        self.pad = None
+        if n_off == 0 and n_pad_nonzero == 0:
             self.frames_u8, self.frames_f32 = torch.cat(q_), None
+            if n_pad:
+                self.pad = torch.cat(pad_)
         else:
+            off_grid = torch.tensor([n_off + n_pad_nonzero])
             if not InitialConditionPool._warned_fp32:
                 InitialConditionPool._warned_fp32 = True
                 import warnings
@@ -191,6 +215,11 @@ class InitialConditionPool:
         if self.frames_u8 is not None:
             nv.check(nv.lib().dmd_dequant_gather(nv.ptr(self.frames_u8), nv.ptr(idx), nv.ptr(rows), nv.fptr(ring),
                                                  idx.numel(), t, per_frame, head, nv.stream()), "dmd_dequant_gather")
+            if self.pad is not None:  # the loader's zero-padded frames, stored as a stand-in level: exact zeros again
+                cols = (head + torch.arange(t, device=ring.device)) % t
+                r = rows if rows is not None else torch.arange(idx.numel(), device=ring.device)
+                at = (r[:, None], cols[None, :])
+                ring[at] = ring[at].masked_fill_(self.pad.index_select(0, idx)[:, :, None, None, None], 0.0)
         else:  # fp32 pool (off-grid frames): plain indexed copy
             cols = (head + torch.arange(t, device=ring.device)) % t
             r = rows if rows is not None else torch.arange(b, device=ring.device)

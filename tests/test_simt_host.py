@@ -230,3 +230,55 @@ def test_trainer_usage_patterns_of_the_denoiser_on_the_interpreter():
         assert torch.equal(loss_ddp, loss)
         for k in grads:
             assert torch.equal(grads_ddp[k], grads[k]), k
+
+
+def test_uint8_pool_keeps_the_loaders_zero_padded_frames(models, monkeypatch):
+    """The reference's segments are ZERO-padded in front of an episode's first step (data/utils.py:18-41; the actor-critic's batch
+    sampler allows padding before the start, data/batch_sampler.py:63-68) and its WorldModelEnv uses those frames as they are.
+    0.0 is not a uint8 level, so real data used to send the whole initial-condition pool to its fp32 fallback; frames the
+    loader marks as padding (mask_padding False) now travel as a stand-in level and come back as exact zeros: the uint8 pool
+    (and with it the one-launch reset) serves real data, bitwise the fp32 pool's frames."""
+    from types import SimpleNamespace
+
+    import diamond_amd as D
+    from diamond_amd.testing import initial_condition_batches
+    from diamond_amd.world_model_env import InitialConditionPool
+
+    M, counter = models
+    ag = M.make_agent()
+
+    class PaddedLoader:
+        batch_sampler = SimpleNamespace(batch_size=3)
+
+        def __iter__(self):
+            for obs, act in initial_condition_batches(21, 3, 4):
+                mask = torch.ones(3, 4, dtype=torch.bool)
+                mask[0, :2] = False  # row 0 starts two steps before its episode, row 2 one step
+                mask[2, :1] = False
+                obs, act = obs.clone(), act.clone()
+                obs[~mask] = 0.0
+                act[~mask] = 0
+                yield SimpleNamespace(obs=obs, act=act, mask_padding=mask)
+
+    def run(pad_aware):
+        monkeypatch.setattr(InitialConditionPool, "PAD_AWARE", pad_aware)
+        monkeypatch.setattr(InitialConditionPool, "_warned_fp32", True)  # (the fallback's warning is not the subject)
+        env = D.WorldModelEnv(ag.denoiser, ag.rew_end_model, PaddedLoader(),
+                              D.WorldModelEnvConfig(horizon=1, num_batches_to_preload=2, diffusion_sampler=D.DiffusionSamplerConfig(num_steps_denoising=1)))
+        env.sampler.noise_fn = lambda shape, dev: torch.randn(*shape)
+        torch.manual_seed(5)
+        obs0, _ = env.reset()
+        out = [obs0, env.obs_buffer.clone(), env.act_buffer.clone()]
+        obs, rew, end, trunc, info = env.step(torch.tensor([1, 2, 3]))  # horizon 1: every env truncates and is reset from the pool
+        out += [obs, rew, end, trunc, info["burnin_obs"], info["final_observation"], env.obs_buffer.clone(), env.act_buffer.clone(),
+                env.hx_rew_end.clone(), env.cx_rew_end.clone(), env.pool.gather_frames(torch.tensor([0, 2, 5]))]
+        return out, env.pool
+
+    aware, pool = run(True)
+    assert pool.frames_u8 is not None and pool.pad is not None and int(pool.pad.sum()) == 2 * 3, "the padded pool did not stay uint8"
+    assert float(aware[1][0, :2].abs().max()) == 0 and float(aware[1][0, 2:].abs().min()) > 0  # zeros exactly where the loader padded
+    plain, pool32 = run(False)
+    assert pool32.frames_u8 is None and pool32.frames_f32 is not None
+    for a, b in zip(aware, plain):
+        assert torch.equal(a, b)
+    assert counter.n.get("dmd_reset_state", 0) >= 1, counter.n  # (the fused reset needs the uint8 pool)
