@@ -216,6 +216,7 @@ class Denoiser(nn.Module):
         """Denoising loss over a segment with autoregressive refresh of the context (reference :93-122)."""
         import torch.nn.functional as F
 
+        nv.check_current_device(batch.obs.device)
         n = self.cfg.inner_model.num_steps_conditioning
         seq_length = batch.obs.size(1) - n
         all_obs = batch.obs.clone()

@@ -267,6 +267,16 @@ def stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def check_current_device(dev: torch.device) -> None:
+    """Every launch goes to the CURRENT device's stream with raw pointers (stream() above): a module that lives on another GPU
+    than the current one would launch on the wrong device.  torch ops switch devices by themselves, ctypes launches cannot; the
+    coarse entry points (an env reset, a training forward) check it once and say what to do.  (The reference's Trainer sets the
+    device per rank, trainer.py:52-53.)"""
+    if dev.type == "cuda" and dev.index is not None and dev.index != torch.cuda.current_device():
+        raise RuntimeError(f"diamond_amd: the module lives on {dev} but the current device is cuda:{torch.cuda.current_device()}: "
+                           f"call torch.cuda.set_device({dev.index}) (or wrap the call in torch.cuda.device({dev.index}))")
+
+
 def require_gpu(t: Tensor) -> None:
     """The one place that says it: there is no CPU path."""
     if not t.is_cuda:

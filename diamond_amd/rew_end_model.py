@@ -245,6 +245,7 @@ class RewEndModel(nn.Module):
         rew_end_model.py:57-90).  Returns (loss, metrics) with the reference's metric names."""
         import torch.nn.functional as F
 
+        nv.check_current_device(batch.obs.device)
         obs = batch.obs[:, :-1]
         act = batch.act[:, :-1]
         next_obs = batch.obs[:, 1:]

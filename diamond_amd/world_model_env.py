@@ -324,6 +324,7 @@ class WorldModelEnv:
     # -- gym-style API ---------------------------------------------------------------------------
     @torch.no_grad()
     def reset(self, **kwargs) -> Tuple[Tensor, Dict[str, Any]]:
+        nv.check_current_device(self.device)
         idx = self.pool.take(self.num_envs)
         dev = idx.device
         frames = self.pool.frames_u8 if self.pool.frames_u8 is not None else self.pool.frames_f32

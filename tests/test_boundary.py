@@ -388,3 +388,16 @@ def test_actor_critic_encoder_takes_its_own_size_unpadded():
     ac = D.Agent(D.default_agent_config()).actor_critic
     plan = _Plan(ac.encoder.encoder)
     assert plan.grid_multiple == 64 and 64 % plan.grid_multiple == 0 and 72 % plan.grid_multiple != 0
+
+
+def test_a_module_on_another_gpu_than_the_current_one_is_refused(monkeypatch):
+    """ctypes launches go to the CURRENT device's stream with raw pointers: an agent on cuda:1 while device 0 is current would
+    launch on the wrong GPU (torch ops switch devices by themselves).  The coarse entry points check it and say what to do."""
+    from diamond_amd import native as nv
+
+    nv.check_current_device(torch.device("cpu"))
+    nv.check_current_device(torch.device("cuda"))  # (no index: nothing to compare)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    nv.check_current_device(torch.device("cuda", 0))
+    with pytest.raises(RuntimeError, match=r"set_device\(1\)"):
+        nv.check_current_device(torch.device("cuda", 1))
