@@ -5,9 +5,9 @@ channels in runs of <= 256; ac_native._wgrad_tiled: the (Cout, Cin) plane in 64 
 GroupNorm groups).  Held against fixtures produced by EXECUTING THE REFERENCE on the same configurations
 (tests/golden/make_golden.py --wide -> tests/golden/wide.pt), at the bars of the default configuration's tests (1e-4).
 
-These run the product's host code against the SIMT-interpreter build of the kernels (tests/simt: test infrastructure) -- the wide
-paths have NOT been run on a GPU (they were written after the round's GPU budget was spent; DESIGN.md says so), which is why their
-`-m gpu` twins are opt-in (BACKENDS below).  The kernel-level test at the end checks the decomposition itself against fp64 torch."""
+Every test runs twice: the product's host code against the SIMT-interpreter build of the kernels (tests/simt: test infrastructure,
+the CPU suite) and on the device (`-m gpu`, part of the round's GPU suite since round 6: the branches were written in a session without
+a GPU and ran there for the first time in round 6).  The kernel-level test at the end checks the decomposition itself against fp64 torch."""
 import os
 
 import pytest
@@ -18,11 +18,8 @@ from tests import wide_configs as W
 from tests.simt.host_harness import engine_on_interpreter
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "wide.pt")
-# Every test below runs on the interpreter (the CPU suite) and has an OPT-IN twin on the device: DIAMOND_WIDE_GPU_TESTS=1 pytest -m gpu
-# tests/test_wide_configs.py.  Opt-in because these branches have never been run on a GPU: the round's GPU suite must not
-# depend on code its author could not run there.
-BACKENDS = ["interpreter", pytest.param("cuda", marks=[pytest.mark.gpu, pytest.mark.skipif(
-    os.environ.get("DIAMOND_WIDE_GPU_TESTS") != "1", reason="the wide-configuration branches were never run on a GPU: DIAMOND_WIDE_GPU_TESTS=1 opts in")])]
+# Every test below runs on the interpreter (the CPU suite) and on the device (`pytest -m gpu`).
+BACKENDS = ["interpreter", pytest.param("cuda", marks=[pytest.mark.gpu])]
 
 
 def _backend(kind):

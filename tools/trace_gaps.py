@@ -70,3 +70,16 @@ if stretch:  # the kernels of the MEDIAN stretch, in order: name, duration us, s
     short = lambda n: re.sub(r"at::native::|\(anonymous namespace\)::|void |std::array<char\*, \d+ul> ?|<unnamed>::", "", n)[:90]
     for n_, d_, off in med[4]:
         print(f"  {off/1e3:8.1f} : {short(n_)}  {d_/1e3:.1f}")
+
+# TRACE_GAPS_DUMP=<k>: every kernel of the stretch whose kernel count is the most frequent one >= k (the typical per-step stretch)
+dump = os.environ.get("TRACE_GAPS_DUMP")
+if dump and stretch:
+    from collections import Counter
+    cnt = Counter(c[2] for c in stretch if c[2] >= int(dump))
+    if cnt:
+        mode = cnt.most_common(1)[0][0]
+        pick = sorted([c for c in stretch if c[2] == mode], key=lambda c: c[1] - c[0])
+        med = pick[len(pick) // 2]
+        print(f"the typical stretch of {mode} kernels ({len(pick)} of them; this one {(med[1]-med[0])/1e6:.2f} ms wall, {med[3]/1e6:.2f} ms busy), in order:")
+        for n_, d_, off in med[4]:
+            print(f"  {off/1e3:8.1f} : {short(n_)}  {d_/1e3:.1f}")
