@@ -18,6 +18,7 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
 
+from . import native as nv
 from .blocks import SmallResBlock, conv3x3
 from .env_loop import make_env_loop
 from .rew_end_model import init_lstm
@@ -91,6 +92,7 @@ class ActorCritic(nn.Module):
         if self._native_encoder is None:
             from .ac_native import NativeEncoder
             self._native_encoder = NativeEncoder(self.encoder.encoder)
+        nv.check_current_device(obs.device)  # (ctypes launches go to the CURRENT device's stream: a policy on another GPU raises)
         return self._native_encoder(obs)
 
     def predict_act_value(self, obs: Tensor, hx_cx: Optional[Tuple[Tensor, Tensor]]) -> ActorCriticOutput:
@@ -110,6 +112,7 @@ class ActorCritic(nn.Module):
         """predict_act_value behind the encoder: LSTM cell + heads on features `encode` produced (env_loop encodes the burn-in
         frames of a reset in ONE pass and steps the LSTM over them)."""
         from .lstm_native import lstm_heads
+        nv.check_current_device(x.device)
         hx, cx = hx_cx
         logits, val, hx, cx = lstm_heads(self._native_encoder.cache, x, hx, cx, self.lstm, self.actor_linear, self.critic_linear)
         return ActorCriticOutput(logits, val, (hx, cx))

@@ -96,6 +96,7 @@ class Denoiser(nn.Module):
         ring = (obs_head, act_head): `obs` is then the PHYSICAL ring (N, T, C, H, W) of conditioning frames and `act`
         the physical (N, T) ring of actions of a WorldModelEnv (logical step t at slot (head + t) % T); the ring
         order is resolved inside dmd_edm_pack_input / dmd_cond_embed, nothing is rolled or copied."""
+        nv.check_current_device(noisy_next_obs.device)  # (ctypes launches go to the CURRENT device's stream)
         n, cx, h, w = noisy_next_obs.shape
         t_ring, obs_head, act_head = 1, 0, 0
         if ring is not None:

@@ -78,6 +78,8 @@ class DiffusionSampler:
         # they point to was replaced (frees_epoch) or an arithmetic / routing switch changed.
         from . import blocks as BL
         from . import engine as E
+
+        nv.check_current_device(ctx_obs.device)
         from .train_graph import _refresh_weight_caches, _weight_caches
 
         # (the module walk of `parameters()` is ~350 us of Python per call, a tenth of a B = 1 frame: the lists are kept and
@@ -119,6 +121,7 @@ class DiffusionSampler:
         calls every step, so its context is never rolled (world_model_env.py:74-75).  noise: the initial draw (B, C, H, W),
         made by the caller (WorldModelEnv keeps it to repeat a dropped speculative step with the same draw)."""
         device = ctx_obs.device
+        nv.check_current_device(device)  # (ctypes launches go to the CURRENT device's stream: a sampler on another GPU raises)
         b, t, c, h, w = ctx_obs.size()
         ctx_obs = ctx_obs.contiguous()
         ring = (obs_head, act_head)

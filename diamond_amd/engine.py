@@ -173,7 +173,8 @@ class WeightAudit:
         i = self._row.get(id(p))
         if i is not None and self._refs[i]() is p and self._ptr[i] == p.data_ptr() and self._table is not None and self._table.device == p.device:
             return i
-        assert not self._capturing(), f"WeightAudit({self.what}): a new parameter inside a hipGraph capture (warm the step up eagerly first)"
+        assert not self._capturing(), (f"WeightAudit({self.what}): a parameter that is new, or whose storage moved, inside a hipGraph capture "
+                                       "(its job-table row is a host upload: warm the step up eagerly first)")
         if self._table is None or self._table.device != p.device:
             self._table = torch.zeros(self.CAPACITY * C.sizeof(nv.ChecksumJob), dtype=torch.uint8, device=p.device)
             self._rec = torch.zeros(self.CAPACITY, nv.CHECKSUM_PARTS, dtype=torch.int64, device=p.device)
@@ -181,11 +182,16 @@ class WeightAudit:
             self._refs, self._row, self._ptr, self._stamps, self._pending = [], {}, [], [], None
             i = None
         if i is None or self._refs[i]() is not p:
-            i = len(self._refs)
-            assert i < self.CAPACITY, f"WeightAudit({self.what}): more than {self.CAPACITY} parameters"
-            self._refs.append(weakref.ref(p))
-            self._ptr.append(0)
-            self._stamps.append(None)
+            # a row of its own: one whose parameter is gone is taken over (replaced parameter objects must not use the table up)
+            i = next((j for j, ref in enumerate(self._refs) if ref() is None), None)
+            if i is None:
+                i = len(self._refs)
+                assert i < self.CAPACITY, f"WeightAudit({self.what}): more than {self.CAPACITY} live parameters"
+                self._refs.append(None)
+                self._ptr.append(0)
+                self._stamps.append(None)
+            self._row = {k: v for k, v in self._row.items() if v != i}
+            self._refs[i] = weakref.ref(p)
             self._row[id(p)] = i
         assert p.element_size() == 4 and p.is_contiguous(), "audited parameters are contiguous 32-bit tensors"
         job = nv.ChecksumJob()
@@ -239,7 +245,15 @@ class WeightAudit:
             believed.append(p is not None and self._stamps[i] is not None and self._stamps[i] == _stamp(p))
         if not any(believed):
             return
-        self._launch(0, n, self._live)
+        # only runs of believed rows are read: the job of a row whose parameter is gone (or was replaced unseen) points at
+        # memory that may have been returned to the driver since
+        start = None
+        for i, b in enumerate(believed + [False]):
+            if b and start is None:
+                start = i
+            elif not b and start is not None:
+                self._launch(start, i - start, self._live)
+                start = None
         bad = (self._live[:n] != self._rec[:n]).any(dim=1)
         self.audits += 1
         if bad.is_cuda:

@@ -258,15 +258,18 @@ def make_env_loop(env, model, epsilon: float = 0.0, expo_fn: Optional[Callable[[
     # small launches.  If an episode did end, the speculative result is dropped and the step is recomputed after the reset,
     # with the SAME exponential draws: every random stream is consumed in the reference's order either way.
     spec_mode = os.environ.get("DIAMOND_SPECULATIVE_POLICY", "1")  # "0": neither speculation, "policy": the policy step only
+    assert spec_mode in ("0", "1", "policy"), f"DIAMOND_SPECULATIVE_POLICY={spec_mode!r}: one of 0, 1, policy"
     two_phase = hasattr(env, "step_begin") and spec_mode != "0"
     # ... and, where the env can hand its synchronisation over (WorldModelEnv.step_end_issue / step_end_finish), the NEXT
     # step's imagined frame as well: env.step_begin(act of step n + 1) is issued before the host asks whether an episode
     # ended in step n.  The device then holds a whole sampler step of queued work while the host waits, instead of running
     # dry until the host has issued the first launches of the next step (~1-2 ms per step on a 20 ms step).  A speculation an
-    # ended episode voids is dropped by the env, which keeps its draws for the repetition; after such a step the env
-    # declines to speculate for a while (may_speculate).  Not with epsilon-greedy actions (the override of step n + 1 is
-    # drawn at the top of that step: the speculated action could change).
-    three_phase = two_phase and spec_mode != "policy" and epsilon == 0.0 and all(hasattr(env, a) for a in ("step_end_issue", "step_end_finish", "may_speculate"))
+    # ended episode voids is DROPPED by such an env, which keeps its draws for the repetition.  That is the protocol of an env
+    # WITHOUT step_begin_repair (the toy envs of tests/test_env_loop_host.py): WorldModelEnv keeps a voided half-step pending and
+    # expects step_begin_repair (_pipelined_env_loop above), so it never takes this branch.  Not with epsilon-greedy actions
+    # either (the override of step n + 1 is drawn at the top of that step: the speculated action could change).
+    three_phase = (two_phase and spec_mode != "policy" and epsilon == 0.0 and not hasattr(env, "step_begin_repair")
+                   and all(hasattr(env, a) for a in ("step_end_issue", "step_end_finish", "may_speculate")))
 
     def draw_expo(logits: Tensor) -> Tensor:
         if expo_fn is not None:

@@ -154,6 +154,7 @@ class RewEndModel(nn.Module):
                         hx_cx: Optional[Tuple[Tensor, Tensor]] = None) -> Tuple[Tensor, Tensor, Tuple[Tensor, Tensor]]:
         b, t, c, h, w = obs.shape
         dev = obs.device
+        nv.check_current_device(dev)  # (ctypes launches go to the CURRENT device's stream)
         x = torch.cat((obs.reshape(b * t, c, h, w), next_obs.reshape(b * t, c, h, w)), dim=1)
         # sizes whose levels leave the kernels' tile grid (the reference runs any size its three stride-2 convolutions halve
         # evenly, rew_end_model.py:33: 72 -> 36 -> 18 -> 9): the VALID EXTENT of a zero-padded buffer, like the denoiser

@@ -135,7 +135,7 @@ class InitialConditionPool:
             with _no_random_draws(dev, "the initial-condition loader", cpu=self._watch_cpu_rng):
                 batch = next(self._iter)
             obs = batch.obs.to(dev, non_blocking=True).float().contiguous()  # async when the loader pins its batches
-            act = batch.act.to(dev, non_blocking=True)
+            act = batch.act.to(dev, non_blocking=True).long()  # (a loader may yield int32 / uint8 actions: the rings are int64)
             *_, (hx, cx) = self._model.predict_rew_end(obs[:, :-1], act[:, :-1], obs[:, 1:])
             assert hx.size(0) == cx.size(0) == 1
             mask = getattr(batch, "mask_padding", None) if self.PAD_AWARE else None
@@ -351,7 +351,9 @@ class WorldModelEnv:
         with _no_random_draws(self._ctx.device, "WorldModelEnv._reset_rows"):
             self.pool.scatter_frames(idx, rows, self._ctx, self._head)
             hx, cx, pool = self.hx_rew_end, self.cx_rew_end, self.pool
-            if (pool.frames_u8 is not None and hx.dtype == torch.float32 and hx.is_contiguous() and cx.is_contiguous()
+            f32, i64 = torch.float32, torch.long  # (dmd_reset_state reads raw pointers: int64 actions / counters, fp32 states)
+            if (pool.frames_u8 is not None and hx.dtype == cx.dtype == pool.hx.dtype == pool.cx.dtype == f32
+                    and self._act.dtype == pool.act.dtype == self.ep_len.dtype == i64 and hx.is_contiguous() and cx.is_contiguous()
                     and pool.hx.is_contiguous() and pool.cx.is_contiguous() and self._act.is_contiguous() and pool.act.is_contiguous()):
                 # action ring, reward/end LSTM state and episode length of the rows in ONE launch (this sits on the step's
                 # critical path, right behind its host synchronisation: the four indexed assignments below are ~12 launches)
@@ -545,11 +547,13 @@ class WorldModelEnv:
             rows_host = np.flatnonzero(dead.numpy())
         any_dead = rows_host.size > 0
         unforeseen = int(rows_host.size)
+        plan, self._plan = self._plan, None
         if self._ep_len_host is not None:
             self._ep_len_host += 1
-            unforeseen = int(np.count_nonzero(self._ep_len_host[rows_host] < self.horizon))  # (not a truncation: an `end`)
+            if plan is not None or not self._use_graph():  # (with a replayed sampler graph nothing is ever planned: plan_resets;
+                #                                             every death then voids a speculated policy step, truncations too)
+                unforeseen = int(np.count_nonzero(self._ep_len_host[rows_host] < self.horizon))  # (not a truncation: an `end`)
             self._ep_len_host[rows_host] = 0
-        plan, self._plan = self._plan, None
         obs = next_obs  # a fresh tensor every step: never aliases the ring
         info["any_dead"] = any_dead  # (so that the caller does not have to synchronise again for the same answer)
         info["dead"] = dead

@@ -401,3 +401,12 @@ def test_a_module_on_another_gpu_than_the_current_one_is_refused(monkeypatch):
     nv.check_current_device(torch.device("cuda", 0))
     with pytest.raises(RuntimeError, match=r"set_device\(1\)"):
         nv.check_current_device(torch.device("cuda", 1))
+    # every public entry point that launches through ctypes has the check in front of its first launch (round 5 guarded three)
+    import inspect
+
+    import diamond_amd as D
+    from diamond_amd.rew_end_model import RewEndModel
+
+    for fn in (D.ActorCritic.encode, D.ActorCritic.predict_from_features, D.DiffusionSampler.sample_ring, D.DiffusionSampler.sample_ring_graphed,
+               D.Denoiser.compute_model_output, D.Denoiser.forward, RewEndModel.predict_rew_end, RewEndModel.forward, D.WorldModelEnv.reset):
+        assert "check_current_device" in inspect.getsource(fn), fn.__qualname__
