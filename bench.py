@@ -98,6 +98,14 @@ class _Loader:
 END_LOGIT_BIAS_NOTE = ("end-logits of the synthetic reward/end model are biased so that episodes end by horizon truncation "
                        "(as a trained world model's do) instead of ~50 % of the envs dying at every step: all 256 envs reset "
                        "+ burn in together at the window boundary, no mid-window resets; same kernels and FLOPs per frame")
+# The headline regime since round 6: the STEADY STATE of the reference's training loop.  With horizon == backup_every == 15
+# (config/trainer.yaml:68,136) every sampled `end` desynchronises its env for good, so a batch's episode lengths spread over the
+# horizon and batch / horizon envs truncate at EVERY step; on top of that every env ends with probability p per step.
+STEADY_STATE_END_RATE = 0.003
+STEADY_STATE_NOTE = ("the steady state of the reference's training loop: episode lengths spread over the horizon (batch / horizon = 17 "
+                     "truncation resets at EVERY step) and every env ends with probability {p} per step (through the synthetic reward/end "
+                     "head): resets, V(final observation) and burn-in inside every step of the timed windows "
+                     "(world_model_env.py:77-82, env_loop.py:45-56); --no-ends is the round-1..5 headline (nobody ends mid-window)")
 
 
 def set_end_rate(agent, p=None):
@@ -435,8 +443,51 @@ def stagger_episodes(env, horizon):
         env.ep_len = (torch.arange(env.num_envs) % horizon).to(env.ep_len.device)
 
 
+def _is_split(key):
+    """kernels that run split-fp16 arithmetic (3 f16 MFMAs per algorithmic MAC) are priced against the f16 peak"""
+    return (key.startswith("conv_f16ws") or key.startswith("attention_f16x2") or key.startswith("lowres_chain")
+            or ((key.startswith("conv1x1_stream") or key.startswith("conv_mfma")) and key.endswith("true>"))
+            or (key.startswith("wgrad_kernel") and key.endswith("true>")))
+
+
+def kernel_table(summ, pmc_all, sq_all, top=8, cover=0.9):
+    """`roofline.kernels`: the kernels of the instrumented window by measured time -- at least `top`, and as many as it takes to
+    cover `cover` of the window's launch time -- each with its own roofline entry from the SAME LaunchProfiler pass: calls, average
+    duration (HIP events), algorithmic GFLOP and bytes per launch (annotated by the host code that launches it), the fraction of
+    the peak that bounds it, the PMC traffic ratio and the matrix-pipe busy share where the committed counter passes hold that
+    kernel (profiles/pmc_traffic*.json, profiles/sq_counters.json)."""
+    total_ms = sum(v["ms"] for v in summ.values())
+    rows, acc = [], 0.0
+    for key, d in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
+        if len(rows) >= top and acc >= cover * total_ms:
+            break
+        acc += d["ms"]
+        sec = d["ms"] * 1e-3
+        tflops, gbs = d["flops"] / sec / 1e12, d["bytes"] / sec / 1e9
+        split = _is_split(key)
+        peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+        frac_mfma, frac_hbm = tflops / peak, gbs / HBM_PEAK_GBS
+        bound = "mfma" if (d["flops"] > 0 and frac_mfma * (3.0 if split else 1.0) >= frac_hbm) else ("hbm" if d["bytes"] > 0 else None)
+        row = {"kernel": key, "calls": d["launches"], "avg_us": round(1e3 * d["ms"] / d["launches"], 2), "share_of_launch_time": round(d["ms"] / total_ms, 4),
+               "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 4), "algorithmic_mb_per_launch": round(d["bytes"] / d["launches"] / 1e6, 3),
+               "bound": bound, "achieved_tflops": round(tflops, 2), "achieved_gbs": round(gbs, 1),
+               "frac": None if bound is None else round(frac_mfma if bound == "mfma" else frac_hbm, 4),
+               "peak": None if bound is None else (peak if bound == "mfma" else HBM_PEAK_GBS), "unit": None if bound is None else ("TFLOP/s" if bound == "mfma" else "GB/s"),
+               "executed_mfma_frac": round((3.0 if split else 1.0) * frac_mfma, 4) if d["flops"] > 0 else None}
+        pmc = (pmc_all or {}).get(key)
+        if pmc is not None and d["bytes"] > 0:
+            row["traffic_mb_per_launch"] = round(pmc["hbm_bytes_per_launch"] / 1e6, 3)
+            row["traffic_ratio"] = round(pmc["hbm_bytes_per_launch"] / (d["bytes"] / d["launches"]), 3)
+        sq = (sq_all or {}).get(key)
+        if sq is not None and sq.get("mfma_busy") is not None:
+            row["mfma_busy"] = sq["mfma_busy"]
+        rows.append(row)
+    return rows, acc / total_ms
+
+
 def dominant_kernel_roofline(window, nv, config_idx, world=1, custom=False):
-    """One instrumented window (HIP events around every C-ABI launch) -> the `roofline` object of the dominant kernel."""
+    """One instrumented window (HIP events around every C-ABI launch) -> the `roofline` object: the dominant kernel's entry at the
+    top level (the contract's shape) and `kernels`, the same for every kernel that matters (kernel_table)."""
     nv.PROFILER = nv.LaunchProfiler()
     try:
         window()
@@ -446,15 +497,19 @@ def dominant_kernel_roofline(window, nv, config_idx, world=1, custom=False):
     key = max(summ, key=lambda k: summ[k]["ms"])
     d = summ[key]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-    # kernels that run split-fp16 arithmetic (3 f16 MFMAs per algorithmic MAC) are priced against the f16 peak
-    split = (key.startswith("conv_f16ws") or key.startswith("attention_f16x2") or key.startswith("lowres_chain")
-             or ((key.startswith("conv1x1_stream") or key.startswith("conv_mfma")) and key.endswith("true>")))
+    split = _is_split(key)
     peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
-    pmc = None
+    pmc = pmc_all = sq_all = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json" if config_idx == 1 else f"pmc_traffic_cfg{config_idx}.json")
-    if os.path.exists(pmc_path) and world == 1 and not custom:
-        pmc = json.load(open(pmc_path)).get(key)  # keyed by the rocprofv3 kernel name (tools/pmc_to_profile.py)
+    if os.path.exists(pmc_path) and world == 1:
+        pmc_all = json.load(open(pmc_path))
+        pmc = pmc_all.get(key) if not custom else None  # keyed by the rocprofv3 kernel name (tools/pmc_to_profile.py)
+    sq_path = os.path.join(ROOT, "profiles", "sq_counters.json")
+    if os.path.exists(sq_path) and config_idx == 1:
+        sq = json.load(open(sq_path))
+        sq_all, sq_src = sq.get("kernels", {}), f"profiles/sq_counters.json [{sq.get('profile_set')}]: rocprofv3 --pmc SQ counters over denoiser forwards at batch 256 (tools/pmc_sq.sh)"
     total_ms = sum(v["ms"] for v in summ.values())
+    kernels, covered = kernel_table(summ, pmc_all, sq_all)
     return {
         "kernel": key, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
         # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB units;
@@ -475,6 +530,12 @@ def dominant_kernel_roofline(window, nv, config_idx, world=1, custom=False):
         "executed_frac_of_power_limited_peak": (3.0 * achieved / F16_MFMA_SUSTAINED_TFLOPS) if split else None,
         "frac_of_fp32_direct_conv_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
         "kernel_share_of_launch_time": d["ms"] / total_ms,
+        # the matrix pipe's busy share of the kernel's busy cycles, from the committed SQ counter passes (clock-free: both counters
+        # tick in the same throttled domain) -- north_star's "rocprof MFMA utilisation"
+        "mfma_busy": None if not sq_all or key not in sq_all else sq_all[key].get("mfma_busy"),
+        "mfma_busy_source": None if not sq_all else sq_src,
+        # every kernel that matters, each with its own roofline entry, from the same LaunchProfiler pass
+        "kernels": kernels, "kernels_cover_launch_time": round(covered, 4),
         # every C-ABI entry point / kernel instantiation of the window, by measured time (the dominant one is chosen over ALL)
         "launch_time_ms": {k: round(v["ms"], 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])},
     }
@@ -521,11 +582,13 @@ def also_lines(device, args):
             before = dict(env.stats)
             dt, ms = measured_windows(w, 3, 1)
             st = env_stats(env, before)
-            res[name] = {"value": 256 * 15 / dt, "step_ms": ms, "vs_no_ends": base_dt / dt,
-                         "steps_with_deaths": st["steps_with_deaths"] / max(1, st["steps"]),
-                         "dead_rows_per_step": (st["planned_rows"] + st["void_rows"]) / max(1, st["steps"]),
-                         "planned_share_of_resets": st["planned_rows"] / max(1, st["planned_rows"] + st["void_rows"]),
-                         "speculated_sampler_steps": st["speculated"] / max(1, st["steps"]), "repairs": st["repairs"]}
+            n = max(1, st["steps"])
+            res[name] = {"value": 256 * 15 / dt, "step_ms": ms, "vs_no_ends": base_dt / dt, "steps_with_deaths": st["steps_with_deaths"] / n,
+                         # (slots loop: deaths resolved on the device into reset slots; the pipelined loop of round 5 counts planned / void rows)
+                         "dead_rows_per_step": (st.get("dead_rows", 0) + st["planned_rows"] + st["void_rows"]) / n,
+                         "reset_slots_per_step": st.get("slots", 0) / n, "slot_overflows": st.get("slot_overflows", 0),
+                         "steps_that_waited_for_their_own_report": st.get("sync_steps", 0),
+                         "speculated_sampler_steps": st["speculated"] / n, "repairs": st["repairs"]}
         res["unit"] = "frames/s"
         res["workload"] = ("configs[1], end probability p per env-step through the synthetic reward/end head, 2 + 1 warm-up and 3 timed "
                            "windows per line; vs_no_ends = this line / the no-ends line measured by the same agent in the same process")
@@ -634,7 +697,11 @@ def main():
                     help="every env ends with this probability per step (through the synthetic reward/end head): mid-window resets at a stated rate")
     ap.add_argument("--stagger", action="store_true",
                     help="start the timed windows from episode lengths spread over the horizon (the steady state of the reference's "
-                         "training loop: batch / horizon truncations at every step)")
+                         "training loop: batch / horizon truncations at every step); the default of configs[1] together with "
+                         f"--end-rate {STEADY_STATE_END_RATE}")
+    ap.add_argument("--no-ends", action="store_true",
+                    help="configs[1] as rounds 1-5 measured it: synchronised episodes, nobody ends mid-window (all envs truncate together "
+                         "at the window boundary)")
     ap.add_argument("--foreach-adamw", action="store_true", help="--config train: the capturable FOREACH AdamW instead of the fused one (A/B)")
     ap.add_argument("--no-also", action="store_true", help="skip the extra measurements the default configs[1] line carries (`also`)")
     ap.add_argument("--pmc-calibrate", action="store_true",
@@ -660,6 +727,10 @@ def main():
         return
     args.config = int(args.config)
     preset = CONFIGS[args.config]
+    # configs[1] with no regime flag = the steady state of the reference's loop (STEADY_STATE_NOTE)
+    steady_default = (args.config == 1 and not (args.no_ends or args.no_end_logit_bias or args.stagger or args.end_rate is not None))
+    if steady_default:
+        args.stagger, args.end_rate = True, STEADY_STATE_END_RATE
     for k, v in preset.items():
         if getattr(args, k) is None:
             setattr(args, k, v)
@@ -714,6 +785,8 @@ def main():
             print(f"[bench +{time.perf_counter() - t_start:.1f}s] {msg}", file=sys.stderr, flush=True)
 
     progress("setup done")
+    if args.stagger and args.warmup == 0:
+        args.warmup = 1  # (the staggered state is set behind the env's first window: there is no env state before it)
     for i in range(args.warmup):
         window()
         if args.stagger and i == 0:
@@ -758,7 +831,8 @@ def main():
     else:
         replicas_in_sync, dist_info = None, None
     progress(f"timed region done: {elapsed:.2f}s for {args.steps} steps")
-    custom = any(getattr(args, k) != v for k, v in preset.items()) or args.no_end_logit_bias or args.end_rate is not None or args.stagger
+    custom = any(getattr(args, k) != v for k, v in preset.items()) or args.no_end_logit_bias or \
+        ((args.end_rate is not None or args.stagger or args.no_ends) and not steady_default)
     custom_flags = custom
     cfg_idx = args.config if world == 1 or args.config != 1 else 2
     cfg_name = f"configs[{cfg_idx}]" + (" (modified by flags)" if custom else "") + \
@@ -782,9 +856,13 @@ def main():
                                f"{', denoiser attention at levels ' + args.attn_depths if any(attn) else ''}; step = "
                                f"ActorCritic.forward()+backward+all-reduce+clip+AdamW over one {args.horizon}-step imagined window; "
                                + ("UNBIASED synthetic end-logits: mid-window resets and burn-in inside the timed region" if args.no_end_logit_bias
+                                  else STEADY_STATE_NOTE.format(p=args.end_rate) if steady_default
                                   else f"every env ends with probability {args.end_rate} per step (synthetic reward/end head)" if args.end_rate is not None
                                   else END_LOGIT_BIAS_NOTE)
-                               + ("; episode lengths staggered over the horizon" if args.stagger else ""),
+                               + ("; episode lengths staggered over the horizon" if args.stagger and not steady_default else ""),
+                   "regime": ("steady_state p=%g" % args.end_rate) if (args.stagger and args.end_rate is not None) else
+                             ("unbiased" if args.no_end_logit_bias else ("p=%g" % args.end_rate if args.end_rate is not None else "no_ends")),
+                   "env_loop": os.environ.get("DIAMOND_ENV_LOOP", "slots"),
                    "env_stats": dict(getattr(window.env, "stats", {})),
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (batch-sharded envs, flat-bucket "
                    "RCCL all-reduce of actor-critic grads)", "actor_critic_backend": ac.backend,

@@ -168,6 +168,13 @@ def _wgrad(x: Act, prologue: int, spec: Optional[NormSpec], dy: Tensor, taps: in
         p.valid_h, p.valid_w = x.valid
     p.dy = nv.ptr(dy)
     p.precision = nv.PRECISION_F16X2 if split else nv.PRECISION_F32
+    if nv.PROFILER is not None:  # (algorithmic work of a weight gradient: the forward conv's MACs; x and dy read once)
+        def note():
+            # (spelled like rocprofv3's kernel trace: bench.py's records and profiles/*pmc*.json share one key)
+            nv.PROFILER.annotate(f"wgrad_kernel<WgradGeom<{cout // 16}, {x.C // 16}, {taps}>, {'true' if split else 'false'}>",
+                                 2.0 * taps * cin_real * cout * n * h * w, 4.0 * n * h * w * (x.C + cout))
+    else:
+        note = lambda: None
     if batch is not None:
         assert dw_out is not None and dw_out.is_contiguous() and dw_out.shape[0] >= cout and tuple(dw_out.shape[2:]) == (k, k) \
             and c0 + cin_real <= dw_out.shape[1] and (db_out is None or (db_out.is_contiguous() and db_out.numel() >= cout))
@@ -178,6 +185,7 @@ def _wgrad(x: Act, prologue: int, spec: Optional[NormSpec], dy: Tensor, taps: in
         ws = torch.empty(job.num_wg * (job.NB * job.NCO * 256 + job.NCO * 16), device=dy.device, dtype=torch.float32)
         p.workspace = job.partials = nv.ptr(ws)
         job.ld_cin, job.c0 = dw_out.shape[1], c0
+        note()
         nv.check(nv.lib().dmd_conv2d_wgrad(C.byref(p), nv.stream()), "dmd_conv2d_wgrad")
         batch.add(job, ws, dw_out) if db_out is None else batch.add(job, ws, dw_out, db_out)
         return dw_out, db_out
@@ -185,6 +193,7 @@ def _wgrad(x: Act, prologue: int, spec: Optional[NormSpec], dy: Tensor, taps: in
     dw = torch.empty(cout, cin_real, k, k, device=dy.device, dtype=torch.float32)
     db = torch.empty(cout, device=dy.device, dtype=torch.float32) if want_bias else None
     p.workspace, p.dw, p.dbias = nv.ptr(ws), nv.ptr(dw), nv.ptr(db)
+    note()
     nv.check(nv.lib().dmd_conv2d_wgrad(C.byref(p), nv.stream()), "dmd_conv2d_wgrad")
     return dw, db
 
@@ -235,6 +244,8 @@ def _gn_silu_bwd(x: Act, spec: NormSpec, da: Tensor, dskip: Optional[Tensor]) ->
     dma = torch.empty(2, n, c, device=da.device, dtype=torch.float32)  # [dmul; dadd]: callers that only need the sums over the batch
     dmul, dadd = dma[0], dma[1]                                        # reduce both with one launch (dmul.sum(0) and dadd.sum(0) = dma.sum(1))
     p.dx, p.workspace, p.dmul, p.dadd = nv.ptr(dx), nv.ptr(ws), nv.ptr(dmul), nv.ptr(dadd)
+    if nv.PROFILER is not None:  # (HBM-bound: x and da read, dx written, the skip gradient read when there is one)
+        nv.PROFILER.annotate("dmd_gn_silu_bwd", 0.0, 4.0 * x.t.numel() * (3 + (dskip is not None)))
     nv.check(nv.lib().dmd_gn_silu_bwd(C.byref(p), nv.stream()), "dmd_gn_silu_bwd")
     return dx, dmul, dadd
 

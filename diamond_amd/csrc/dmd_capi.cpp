@@ -14,7 +14,7 @@ void dmd_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* dmd_last_error(void) { return g_err; }
-extern "C" int dmd_abi_version(void) { return 10; }
+extern "C" int dmd_abi_version(void) { return 11; }
 
 // environment switches are cached by their readers (DmdEnvInt, dmd_common.h) and re-read after this call
 static int g_env_generation = 0;

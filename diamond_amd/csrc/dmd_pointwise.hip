@@ -431,6 +431,213 @@ extern "C" int dmd_reset_state(const int64_t* idx, const int64_t* rows, int coun
   return 0;
 }
 
+// ---- the deaths of an imagined step resolved ON THE DEVICE (ABI v11) -----------------------------------------------------
+// The reference asks the host once per step which episodes ended (`if dead.any()`, world_model_env.py:77; env_loop.py:45) and
+// shapes what follows by the answer.  Here the answer stays on the device: the step works on K SLOTS (K chosen by the host
+// before it knows the step's deaths), the dead rows are assigned to slots in ascending row order -- the order in which the
+// reference's boolean masks enumerate them and its pool serves them (world_model_env.py:56-57,133-139) -- and everything
+// downstream is fixed-shape over the slots; an unused slot is marked -1.  The host reads `report` one step LATE (episode-length
+// mirror, pool cursor, slot overflow), behind a full step of queued work.
+//   per row r:  ep_len[r] += 1; trunc[r] = ep_len[r] >= horizon; dead[r] = end[r] | trunc[r]; ep_len[r] = 0 where dead
+//   slot_row[j] = j-th dead row (-1: unused slot);  row_slot[r] = slot of a dead row (-1: alive, or no slot left)
+//   report = {dead[0..B) as int32, k = number of dead rows, number of rows with end != 0, k > K, K}
+__global__ __launch_bounds__(256) void resolve_deaths_kernel(const int64_t* __restrict__ end, int64_t* __restrict__ ep_len, int horizon,
+                                                             int64_t* __restrict__ trunc, uint8_t* __restrict__ dead, int B, int K,
+                                                             int64_t* __restrict__ slot_row, int32_t* __restrict__ row_slot,
+                                                             int32_t* __restrict__ report) {
+  __shared__ int flag[256];
+  __shared__ int eflag[256];
+  const int tid = threadIdx.x;
+  int base = 0, ends = 0;
+  for (int r0 = 0; r0 < B; r0 += 256) {
+    const int r = r0 + tid;
+    bool d = false, e = false;
+    if (r < B) {
+      const int64_t l = ep_len[r] + 1;
+      const bool t = l >= (int64_t)horizon;
+      e = end[r] != 0;
+      d = e || t;
+      trunc[r] = t ? 1 : 0;
+      dead[r] = d ? 1 : 0;
+      ep_len[r] = d ? 0 : l;
+      report[r] = d ? 1 : 0;
+    }
+    flag[tid] = d ? 1 : 0;
+    eflag[tid] = e ? 1 : 0;
+    __syncthreads();
+    int before = 0, total = 0, etotal = 0;  // (256 LDS reads per thread: a one-workgroup kernel of a few microseconds)
+    for (int i = 0; i < 256; ++i) {
+      before += i < tid ? flag[i] : 0;
+      total += flag[i];
+      etotal += eflag[i];
+    }
+    if (r < B) {
+      const int slot = base + before;
+      const bool has = d && slot < K;
+      row_slot[r] = has ? slot : -1;
+      if (has) slot_row[slot] = r;
+    }
+    base += total;
+    ends += etotal;
+    __syncthreads();
+  }
+  for (int j = base + tid; j < K; j += 256) slot_row[j] = -1;
+  if (tid == 0) {
+    report[B] = base;
+    report[B + 1] = ends;
+    report[B + 2] = base > K ? 1 : 0;
+    report[B + 3] = K;
+  }
+}
+
+extern "C" int dmd_resolve_deaths(const int64_t* end, int64_t* ep_len, int horizon, int64_t* trunc, uint8_t* dead, int B, int K,
+                                  int64_t* slot_row, int32_t* row_slot, int32_t* report, dmd_stream_t stream) {
+  DMD_CHECK_ARG(end && ep_len && trunc && dead && row_slot && report && (slot_row || K == 0), "resolve_deaths: null");
+  DMD_CHECK_ARG(B >= 1 && K >= 0 && horizon >= 1, "resolve_deaths: B %d, K %d, horizon %d", B, K, horizon);
+  hipLaunchKernelGGL(resolve_deaths_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, end, ep_len, horizon, trunc, dead, B, K, slot_row,
+                     row_slot, report);
+  DMD_LAUNCH_CHECK();
+  return 0;
+}
+
+// Ring advance + reset of the dead rows + the policy's next input, one launch over B + T * K frames (grid.y):
+//   frame f <  B          env row f: its newest frame -- the imagined one, or (dead row with a slot) the newest frame of its NEW
+//                         episode -- into enc_in[f] AND into the ring slot the advance frees (logical T - 1 at the new head)
+//   frame f <  B + K      slot j = f - B: the FINAL observation of the ended episode (the imagined frame of row slot_row[j])
+//   frame f >= B + K      burn-in frame t of slot j (frame-major: f = B + K + t * K + j, t < T - 1): the new episode's context
+//                         frame t, into enc_in[f] AND into ring slot (head + t) % T of the row
+// A slot's new episode is pool row pool_base + j (dequantised: (u8 / 255) * 2 - 1, exact zeros where pool_pad marks a padded
+// frame; or an fp32 pool).  Unused slots (slot_row -1) receive copies of row 0's imagined frame: finite values nobody reads.
+template <bool U8>
+__global__ __launch_bounds__(256) void reset_slot_frames_kernel(dmd_reset_slots_params p) {
+  const int64_t q4 = p.per_frame >> 2;
+  const int64_t e4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e4 >= q4) return;
+  const int f = blockIdx.y;
+  const int B = p.B, K = p.K, T = p.T;
+  int64_t pool_row = -1, obs_row = 0, ring_row = -1;
+  int pool_t = 0, ring_slot = 0;
+  if (f < B) {
+    const int s = p.row_slot[f];
+    ring_row = f;
+    ring_slot = (p.head + T - 1) % T;
+    if (s >= 0) {
+      pool_row = p.pool_base + s;
+      pool_t = T - 1;
+    } else {
+      obs_row = f;
+    }
+  } else if (f < B + K) {
+    const int64_t r = p.slot_row[f - B];
+    obs_row = r >= 0 ? r : 0;
+  } else {
+    const int g = f - B - K;
+    const int t = g / K, j = g - t * K;
+    const int64_t r = p.slot_row[j];
+    if (r >= 0) {
+      pool_row = p.pool_base + j;
+      pool_t = t;
+      ring_row = r;
+      ring_slot = (p.head + t) % T;
+    }
+  }
+  f32x4 v;
+  if (pool_row >= 0) {
+    const int64_t pf = pool_row * T + pool_t;
+    if (U8) {
+      const uint32_t pk = *(const uint32_t*)((const uint8_t*)p.pool_frames + pf * p.per_frame + e4 * 4);
+      const bool pad = p.pool_pad && p.pool_pad[pf];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = pad ? 0.0f : ((float)((pk >> (8 * e)) & 0xff) / 255.0f) * 2.0f - 1.0f;
+    } else {
+      v = *(const f32x4*)((const float*)p.pool_frames + pf * p.per_frame + e4 * 4);
+    }
+  } else {
+    v = *(const f32x4*)(p.next_obs + obs_row * p.per_frame + e4 * 4);
+  }
+  *(f32x4*)(p.enc_in + (int64_t)f * p.per_frame + e4 * 4) = v;
+  if (ring_row >= 0) *(f32x4*)(p.ctx + (ring_row * T + ring_slot) * p.per_frame + e4 * 4) = v;
+}
+
+// the small state of the slots' resets: action ring, reward/end LSTM state (reset_state_kernel with the slot indirection;
+// ep_len was zeroed by resolve_deaths_kernel)
+__global__ __launch_bounds__(256) void reset_slot_state_kernel(dmd_reset_slots_params p) {
+  const int j = blockIdx.x;
+  const int64_t r = p.slot_row[j];
+  if (r < 0) return;
+  const int64_t q = p.pool_base + j;
+  const int hd = p.hd, T = p.T;
+  for (int i = threadIdx.x; i < hd; i += 256) {
+    p.hx[r * hd + i] = p.pool_hx[q * hd + i];
+    p.cx[r * hd + i] = p.pool_cx[q * hd + i];
+  }
+  if ((int)threadIdx.x < T) p.act_ring[r * T + (p.head + threadIdx.x) % T] = p.pool_act[q * T + threadIdx.x];
+}
+
+extern "C" int dmd_reset_slots(const dmd_reset_slots_params* pp, dmd_stream_t stream) {
+  const dmd_reset_slots_params& p = *pp;
+  DMD_CHECK_ARG(p.B >= 1 && p.K >= 0 && p.T >= 1 && p.T <= 256 && p.head >= 0 && p.head < p.T && p.per_frame > 0 && p.per_frame % 4 == 0,
+                "reset_slots: B %d, K %d, T %d, head %d, per_frame %lld", p.B, p.K, p.T, p.head, (long long)p.per_frame);
+  DMD_CHECK_ARG(p.row_slot && p.next_obs && p.ctx && p.enc_in, "reset_slots: null");
+  DMD_CHECK_ARG(p.K == 0 || (p.slot_row && p.pool_frames && p.pool_act && p.pool_hx && p.pool_cx && p.act_ring && p.hx && p.cx && p.hd >= 1 &&
+                             p.pool_base >= 0), "reset_slots: null pool / state argument with K = %d slots", p.K);
+  const int frames = p.B + p.T * p.K;
+  DMD_CHECK_ARG(frames <= 65535, "reset_slots: %d frames in one launch", frames);
+  const dim3 grid((unsigned)nblk((size_t)(p.per_frame / 4), 256), (unsigned)frames);
+  if (p.pool_is_f32)
+    hipLaunchKernelGGL(reset_slot_frames_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(reset_slot_frames_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  DMD_LAUNCH_CHECK();
+  if (p.K > 0) {
+    hipLaunchKernelGGL(reset_slot_state_kernel, dim3((unsigned)p.K), dim3(256), 0, (hipStream_t)stream, p);
+    DMD_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// out[r] = alive row ? base[r] : slots[row_slot[r]]   (rows of D floats): the burnt-in LSTM state of the reset rows merged into
+// the batch's state (reference env_loop.py:51-56: gate to zero, then burn in) -- and its transpose for the backward:
+// d_base[r] = alive ? d_out[r] : 0;  d_slots[j] = slot used ? d_out[slot_row[j]] : 0
+__global__ void merge_slots_kernel(const float* __restrict__ base, const float* __restrict__ slots, const int32_t* __restrict__ row_slot,
+                                   float* __restrict__ out, int B, int D) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * D) return;
+  const int r = i / D, c = i - (int64_t)r * D;
+  const int s = row_slot[r];
+  out[i] = s >= 0 ? slots[(int64_t)s * D + c] : base[i];
+}
+
+__global__ void merge_slots_bwd_kernel(const float* __restrict__ d_out, const int32_t* __restrict__ row_slot, const int64_t* __restrict__ slot_row,
+                                       float* __restrict__ d_base, float* __restrict__ d_slots, int B, int K, int D) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (int64_t)B * D) {
+    const int r = i / D;
+    if (d_base) d_base[i] = row_slot[r] >= 0 ? 0.0f : d_out[i];
+  } else if (i < (int64_t)(B + K) * D) {
+    const int64_t k = i - (int64_t)B * D;
+    const int j = k / D, c = k - (int64_t)j * D;
+    const int64_t r = slot_row[j];
+    d_slots[k] = r >= 0 ? d_out[r * D + c] : 0.0f;
+  }
+}
+
+extern "C" int dmd_merge_slots(const float* base, const float* slots, const int32_t* row_slot, float* out, int B, int D, dmd_stream_t stream) {
+  DMD_CHECK_ARG(base && slots && row_slot && out && B >= 1 && D >= 1, "merge_slots: args");
+  hipLaunchKernelGGL(merge_slots_kernel, dim3(nblk((size_t)B * D, 256)), dim3(256), 0, (hipStream_t)stream, base, slots, row_slot, out, B, D);
+  DMD_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dmd_merge_slots_bwd(const float* d_out, const int32_t* row_slot, const int64_t* slot_row, float* d_base, float* d_slots, int B,
+                                   int K, int D, dmd_stream_t stream) {
+  DMD_CHECK_ARG(d_out && row_slot && slot_row && d_slots && B >= 1 && K >= 1 && D >= 1, "merge_slots_bwd: args");
+  hipLaunchKernelGGL(merge_slots_bwd_kernel, dim3(nblk((size_t)(B + K) * D, 256)), dim3(256), 0, (hipStream_t)stream, d_out, row_slot,
+                     slot_row, d_base, d_slots, B, K, D);
+  DMD_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int dmd_nchw_to_nhwc(const float* in, float* out, int N, int C, int H, int W, int CPad, dmd_stream_t stream) {
   DMD_CHECK_ARG(in && out && CPad % 4 == 0 && CPad >= C, "nchw_to_nhwc: args");
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(nblk((size_t)N * H * W * (CPad / 4), 256)), dim3(256), 0, (hipStream_t)stream, in,

@@ -239,12 +239,122 @@ def _pipelined_env_loop(env, model, expo_fn: Optional[Callable[[Tensor], Tensor]
         num_steps = yield (*stacked, infos)
 
 
+SLOTS_PROTOCOL = ("step_begin", "step_end_slots", "slots_finish", "slots_snapshot", "slots_restore", "slots_can_repeat")
+
+
+def _policy_step_slots(model, obs_ext: Tensor, hx: Tensor, cx: Tensor, slots):
+    """The policy's step on the batch -- and, in the SAME encoder pass, what the previous step's resets ask of it (reference
+    env_loop.py:45-56), fixed-shape over the reset SLOTS the device filled (WorldModelEnv.step_end_slots): obs_ext =
+    [B newest frames | K final observations | (T - 1) * K burn-in frames, frame-major].  V(final observation) without grad on the
+    state the episode ended with (:49); the LSTM's burn-in over the new episode's context frames WITH grad from a zero state
+    (:51-56, one autograd node); the burnt-in states merged into the batch's (slots.merge); then the step for everybody.  Unused
+    slots hold finite stand-in frames, their results go nowhere and receive zero gradient.  Per row the arithmetic of the
+    reference's separate calls (batch-invariant kernels).  Returns (logits, val, (h, c), (h0, c0) the state the step started
+    from, V(final observation) spread over the batch | None)."""
+    if slots is None:
+        logits, val, hc = model.predict_act_value(obs_ext, (hx, cx))
+        return logits, val, hc, (hx, cx), None
+    b, k = hx.shape[0], slots.K
+    tb = (obs_ext.shape[0] - b) // k - 1
+    feats = model.encode(obs_ext)
+    g = slots.gather_rows
+    with torch.no_grad():
+        _, val_final, _ = model.predict_from_features(feats[b:b + k], (hx.index_select(0, g), cx.index_select(0, g)))
+    if tb > 0:
+        hz, cz = model.burn_in_from_features(feats[b + k:], tb)
+    else:
+        hz, cz = torch.zeros_like(hx[:k]), torch.zeros_like(cx[:k])
+    h0, c0 = slots.merge(hx, hz), slots.merge(cx, cz)
+    logits, val, hc = model.predict_from_features(feats[:b], (h0, c0))
+    return logits, val, hc, (h0, c0), slots.merge(torch.zeros_like(val.detach()), val_final.detach())
+
+
+def _slots_env_loop(env, model, expo_fn: Optional[Callable[[Tensor], Tensor]], num_steps: int):
+    """make_env_loop for an env that resolves a step's deaths on the device (SLOTS_PROTOCOL: WorldModelEnv), epsilon = 0.
+
+    The reference has ONE data-dependent branch per imagined step (`if dead.any()`, world_model_env.py:77, env_loop.py:45): a host
+    wait, behind which the host issues the reset and the policy's next step into an idle device.  Here the host never asks about
+    the step it is issuing: env.step_end_slots() hands back device-side reset slots, the policy's next step carries them in its
+    encoder pass (_policy_step_slots), and the env reads a step's report while the NEXT step is already queued.  The only waits are
+    for the previous step (never idle: the device holds a full step of work) and one per window, before the loss.
+    Bitwise the sequential rollout: per row the same arithmetic on batch-invariant kernels, every random stream consumed in the
+    reference's order (action draws, then the env's noise / reward / end draws; a reset draws nothing).  A step with more deaths
+    than slots (SlotOverflow; the env sizes the slots so that this is a once-in-1e7-steps event) restores the window's
+    snapshot -- env, pool position, random generators -- and repeats the window with a slot per env."""
+    from .world_model_env import SlotOverflow
+
+    dev = model.device
+    b = env.num_envs
+    hx = torch.zeros(b, model.lstm_dim, device=dev)
+    cx = torch.zeros(b, model.lstm_dim, device=dev)
+    seed = random.randint(0, 2 ** 31 - 1)
+    obs, _ = env.reset(seed=[seed + i for i in range(b)])
+    slots = None  # the resets of the last step: they ride in the next policy step
+
+    def draw_expo(logits: Tensor) -> Tensor:
+        e = expo_fn(logits) if expo_fn is not None else None
+        if e is None:
+            return torch.empty(logits.shape, device=logits.device, dtype=torch.float32).exponential_(1)
+        return e.to(device=logits.device, dtype=torch.float32)  # (hook-injected draws may come from the CPU generator)
+
+    def window(obs, slots, hx, cx, steps: int, all_slots: bool):
+        rows_out, infos = [], []
+        prev_dead = prev_vfinal = None
+        for n in range(steps):
+            logits_act, val, (hx, cx), _, vfin = _policy_step_slots(model, obs, hx, cx, slots)
+            if slots is not None:
+                prev_dead, prev_vfinal = slots.dead, vfin
+            act = sample_categorical(logits_act, draw_expo(logits_act))
+            if n > 0:  # the bootstrap value of step n-1 is this step's value, V(final observation) where the episode ended (:39-43)
+                vb = val.detach().clone()
+                rows_out[-1][-1] = vb if prev_dead is None else torch.where(prev_dead, prev_vfinal, vb)
+            prev_dead = prev_vfinal = None
+            env.step_begin(act)
+            nxt, rew, end, trunc, slots, info = env.step_end_slots(all_slots)
+            rows_out.append([obs[:b], act, rew, end, trunc, logits_act, val, None])
+            infos.append(info)
+            obs = nxt
+        with torch.no_grad():
+            _, vb, _, (h0, c0), vfin = _policy_step_slots(model, obs, hx, cx, slots)
+        if slots is not None:  # deaths at the window's last step: the state the next window starts from is the burnt-in one
+            vb = torch.where(slots.dead, vfin, vb)
+            hx, cx = h0, c0
+        rows_out[-1][-1] = vb
+        env.slots_finish()  # (the one wait of a window for its own last step: an overflow must show before the window is used)
+        stacked = tuple(torch.stack(col, dim=1) for col in zip(*rows_out))
+        return (*stacked, infos), (obs[:b], None, hx, cx)
+
+    while True:
+        hx, cx = hx.detach(), cx.detach()  # BPTT window boundary
+        hooks = expo_fn is not None and getattr(model, "expo_fn", True) is not None  # (ActorCritic passes a forwarding lambda)
+        can_repeat = env.slots_can_repeat() and not hooks
+        snap = env.slots_snapshot() if can_repeat else None
+        try:
+            out, (obs_n, slots_n, hx_n, cx_n) = window(obs, slots, hx, cx, num_steps, not can_repeat)
+        except SlotOverflow:
+            if snap is None:
+                raise
+            env.slots_restore(snap)
+            out, (obs_n, slots_n, hx_n, cx_n) = window(obs, slots, hx, cx, num_steps, True)
+        obs, slots, hx, cx = obs_n, slots_n, hx_n, cx_n
+        num_steps = yield out
+
+
 @coroutine
 def make_env_loop(env, model, epsilon: float = 0.0, expo_fn: Optional[Callable[[Tensor], Tensor]] = None):
     num_steps = yield
-    if epsilon == 0.0 and os.environ.get("DIAMOND_SPECULATIVE_POLICY", "1") == "1" and all(hasattr(env, a) for a in PIPELINE_PROTOCOL):
-        yield from _pipelined_env_loop(env, model, expo_fn, num_steps)
-        return
+    if epsilon == 0.0 and os.environ.get("DIAMOND_SPECULATIVE_POLICY", "1") == "1":
+        # DIAMOND_ENV_LOOP: "slots" (default: the step's deaths resolved on the device), "pipelined" (round 5: host-planned resets
+        # and speculation), "sequential" (the reference's order of calls)
+        kind = os.environ.get("DIAMOND_ENV_LOOP", "slots")
+        assert kind in ("slots", "pipelined", "sequential"), f"DIAMOND_ENV_LOOP={kind!r}"
+        separable = all(hasattr(model, a) for a in ("encode", "predict_from_features", "burn_in_from_features"))
+        if kind == "slots" and separable and all(hasattr(env, a) for a in SLOTS_PROTOCOL):
+            yield from _slots_env_loop(env, model, expo_fn, num_steps)
+            return
+        if kind != "sequential" and all(hasattr(env, a) for a in PIPELINE_PROTOCOL):
+            yield from _pipelined_env_loop(env, model, expo_fn, num_steps)
+            return
     dev = model.device
     hx = torch.zeros(env.num_envs, model.lstm_dim, device=dev)
     cx = torch.zeros(env.num_envs, model.lstm_dim, device=dev)

@@ -207,3 +207,37 @@ def lstm_heads(cache: E.PackCache, x: Tensor, hx: Tensor, cx: Tensor, lstm, acto
     heads, h, c = LstmHeadsFn.apply(cache, x, hx, cx, lstm.weight_ih, lstm.weight_hh, lstm.bias_ih, lstm.bias_hh, w_heads, b_heads)
     a = actor_linear.out_features
     return heads[:, :a], heads[:, a], h, c
+
+
+class MergeSlotsFn(torch.autograd.Function):
+    """out[r] = base[r] for a live row, values[slot of r] for a row that was reset (dmd_merge_slots; env_loop: the burnt-in LSTM state
+    of the new episodes merged into the batch's state, reference env_loop.py:51-56).  Rows of any trailing shape."""
+
+    @staticmethod
+    def forward(ctx, base: Tensor, values: Tensor, row_slot: Tensor, slot_row: Tensor):
+        b, k = base.shape[0], values.shape[0]
+        base2 = base.detach().float().contiguous().reshape(b, -1)
+        val2 = values.detach().float().contiguous().reshape(k, -1)
+        out = torch.empty_like(base2)
+        nv.check(nv.lib().dmd_merge_slots(nv.fptr(base2), nv.fptr(val2), nv.ptr(row_slot), nv.fptr(out), b, base2.shape[1], nv.stream()),
+                 "dmd_merge_slots")
+        ctx.save_for_backward(row_slot, slot_row)
+        ctx.shapes = (tuple(base.shape), tuple(values.shape))
+        return out.reshape(base.shape)
+
+    @staticmethod
+    def backward(ctx, d_out: Tensor):
+        row_slot, slot_row = ctx.saved_tensors
+        (bs, vs) = ctx.shapes
+        b, k = bs[0], vs[0]
+        g = d_out.detach().float().contiguous().reshape(b, -1)
+        d_base = torch.empty_like(g) if ctx.needs_input_grad[0] else None
+        d_val = torch.empty(k, g.shape[1], device=g.device, dtype=torch.float32)
+        nv.check(nv.lib().dmd_merge_slots_bwd(nv.fptr(g), nv.ptr(row_slot), nv.ptr(slot_row), nv.fptr(d_base), nv.fptr(d_val), b, k, g.shape[1],
+                                              nv.stream()), "dmd_merge_slots_bwd")
+        return (None if d_base is None else d_base.reshape(bs)), d_val.reshape(vs), None, None
+
+
+def merge_slots(base: Tensor, values: Tensor, row_slot: Tensor, slot_row: Tensor) -> Tensor:
+    nv.require_gpu(base)
+    return MergeSlotsFn.apply(base, values, row_slot, slot_row)

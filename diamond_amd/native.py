@@ -85,6 +85,15 @@ class ChecksumJob(C.Structure):
 
 CHECKSUM_PARTS = 8
 
+
+class ResetSlotsParams(C.Structure):
+    _fields_ = [("B", C.c_int32), ("K", C.c_int32), ("T", C.c_int32), ("head", C.c_int32), ("per_frame", C.c_int64),
+                ("pool_frames", C.c_void_p), ("pool_pad", C.c_void_p), ("pool_is_f32", C.c_int32), ("hd", C.c_int32),
+                ("pool_base", C.c_int64), ("pool_act", C.c_void_p), ("pool_hx", C.c_void_p), ("pool_cx", C.c_void_p),
+                ("slot_row", C.c_void_p), ("row_slot", C.c_void_p), ("next_obs", C.c_void_p), ("ctx", C.c_void_p),
+                ("act_ring", C.c_void_p), ("hx", C.c_void_p), ("cx", C.c_void_p), ("enc_in", C.c_void_p)]
+
+
 CHAIN_MAX_BLOCKS = 8
 
 
@@ -107,7 +116,7 @@ EXPORTS = (
     "dmd_conv1x1_stream_eligible", "dmd_conv2d_proj_eligible", "dmd_pack_jobs", "dmd_checksums",
     "dmd_pack_conv_weight_f16x2", "dmd_linear", "dmd_attention", "dmd_attention_valid", "dmd_attention_bwd", "dmd_attention_bwd_workspace_floats",
     "dmd_edm_pack_input", "dmd_cond_embed", "dmd_edm_denoised", "dmd_euler_step", "dmd_heun_step", "dmd_quantize_u8", "dmd_reset_state",
-    "dmd_dequant_gather", "dmd_nchw_to_nhwc",
+    "dmd_dequant_gather", "dmd_resolve_deaths", "dmd_reset_slots", "dmd_merge_slots", "dmd_merge_slots_bwd", "dmd_nchw_to_nhwc",
     "dmd_nhwc_to_nchw", "dmd_gn_stats", "dmd_gn_stats_valid", "dmd_maxpool2", "dmd_lstm_pointwise", "dmd_lstm_pointwise_bwd", "dmd_categorical_sample",
     "dmd_maxpool2_bwd", "dmd_gn_bwd_workspace_bytes", "dmd_gn_silu_bwd", "dmd_wgrad_workspace_floats", "dmd_conv2d_wgrad", "dmd_wgrad_job", "dmd_wgrad_reduce_jobs",
     "dmd_lowres_chain", "dmd_lowres_chain32", "dmd_last_error", "dmd_abi_version", "dmd_reload_env",
@@ -211,6 +220,11 @@ def declare_signatures(L: C.CDLL) -> None:
                                      C.c_int, C.c_void_p]
     L.dmd_reset_state.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.dmd_resolve_deaths.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]
+    L.dmd_reset_slots.argtypes = [C.POINTER(ResetSlotsParams), C.c_void_p]
+    L.dmd_merge_slots.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.dmd_merge_slots_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.dmd_edm_denoised.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64,
                                    C.c_void_p]
     L.dmd_euler_step.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]

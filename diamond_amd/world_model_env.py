@@ -19,6 +19,7 @@ structures behind it are designed for the GPU instead of transcribed:
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 from dataclasses import dataclass
 from typing import Any, Callable, Dict, Iterator, List, Optional, Tuple
@@ -74,6 +75,51 @@ def _without_torch_compile(fn, default):
     return orig
 
 
+class SlotOverflow(RuntimeError):
+    """More episodes ended in a step than the step had reset slots for (step_end_slots): the rows beyond the last slot were not
+    reset.  env_loop restores the window's snapshot and repeats the window with a slot for every env."""
+
+
+class ResetSlots:
+    """The deaths of one step as the device resolved them (dmd_resolve_deaths): K slots, the j-th dead row in slot j (ascending row
+    order: the order of the reference's boolean masks and of its pool), -1 for unused slots.  Everything the policy does for a
+    reset (reference env_loop.py:45-56) is fixed-shape over the slots."""
+
+    def __init__(self, k: int, slot_row: Tensor, row_slot: Tensor, dead: Tensor) -> None:
+        self.K, self.slot_row, self.row_slot, self.dead = k, slot_row, row_slot, dead
+        self._gather: Optional[Tensor] = None
+
+    @property
+    def gather_rows(self) -> Tensor:
+        """(K,) row index per slot for GATHERS (unused slots read row 0: finite values nobody uses)"""
+        if self._gather is None:
+            self._gather = self.slot_row.clamp_min(0)
+        return self._gather
+
+    def merge(self, base: Tensor, values: Tensor) -> Tensor:
+        """base (B, ...) with the rows of the used slots replaced by values (K, ...); differentiable in both."""
+        from .lstm_native import merge_slots
+
+        return merge_slots(base, values, self.row_slot, self.slot_row)
+
+
+def _poisson_quantile(mean: float, tail: float = 1e-7) -> int:
+    """smallest x with P(X > x) < tail for X ~ Poisson(mean)"""
+    import math
+
+    if mean <= 0:
+        return 0
+    if mean > 50:  # normal approximation with a continuity margin
+        return int(math.ceil(mean + 5.5 * math.sqrt(mean) + 1))
+    term = math.exp(-mean)
+    cdf, x = term, 0
+    while 1.0 - cdf >= tail and x < 1000:
+        x += 1
+        term *= mean / x
+        cdf += term
+    return x
+
+
 GRAPH_SAMPLER_MAX_ENVS = 8  # below this the sampler is launch-latency-bound and runs as a replayed hipGraph ...
 GRAPH_SAMPLER_MAX_PIXELS = 8 * 64 * 64  # ... if its launches are small: 8 envs at 256x256 are not (configs[4]: eager + speculation
 #                                         measured 367-370 frames/s against 364-365 replayed, same box, alternating)
@@ -122,8 +168,36 @@ class InitialConditionPool:
     def size(self) -> int:
         return 0 if self.act is None else self.act.shape[0]
 
+    _FIELDS = ("frames_u8", "frames_f32", "act", "hx", "cx", "pad", "_cursor", "_generation")
+
+    def snapshot(self):
+        """What a window's repetition needs to see the same pool again (env_loop repeats a window after a SlotOverflow): the
+        current round and cursor; the rounds preloaded from now on are remembered and served again after `restore` -- the
+        loader's iterator cannot be rewound."""
+        self._recorded: List[tuple] = []
+        return tuple(getattr(self, f) for f in self._FIELDS)
+
+    def restore(self, snap) -> None:
+        for f, v in zip(self._FIELDS, snap):
+            setattr(self, f, v)
+        self._replay = list(getattr(self, "_recorded", [])) + list(getattr(self, "_replay", []))
+        self._recorded = []
+
     @torch.no_grad()
     def _preload(self) -> None:
+        replay = getattr(self, "_replay", None)
+        if replay:  # a round a repeated window already preloaded once
+            for f, v in zip(self._FIELDS, replay.pop(0)):
+                setattr(self, f, v)
+            if hasattr(self, "_recorded"):
+                self._recorded.append(tuple(getattr(self, f) for f in self._FIELDS))
+            return
+        self._preload_from_loader()
+        if hasattr(self, "_recorded"):
+            self._recorded.append(tuple(getattr(self, f) for f in self._FIELDS))
+
+    @torch.no_grad()
+    def _preload_from_loader(self) -> None:
         if self._iter is None:
             self._iter = iter(self._loader)
         dev = self._device_fn()
@@ -263,6 +337,7 @@ class WorldModelEnv:
         self._dead_host: Optional[Tensor] = None  # pinned (B,) copy of a step's `dead` mask: THE host synchronisation of a step
         self._flag_event = None
         self._rows_pinned: Optional[Tensor] = None
+        self._report_host: Optional[Tensor] = None  # pinned ring of step reports (step_end_slots)
         self._ep_len_host: Optional[np.ndarray] = None  # host mirror of ep_len (truncations are predictable: plan_resets)
         self._reset_speculation()
 
@@ -274,7 +349,10 @@ class WorldModelEnv:
         self._plan: Optional[Dict[str, Any]] = None       # a planned reset (predicted truncations of the current step)
         self._repair_rows: Optional[Tensor] = None        # rows of the pending speculative half-step an unplanned death voided
         self._void_events, self._void_frac = 0.0, 0.0     # running averages: steps with unplanned deaths, their share of the rows
-        self.stats = {"steps": 0, "steps_with_deaths": 0, "planned_rows": 0, "void_rows": 0, "repairs": 0, "speculated": 0}
+        self._slots_inflight = None                       # (event, pinned report, K, pool token) of the last step_end_slots
+        self._end_mean = getattr(self, "_end_mean", 0.0)  # running mean of sampled `end`s per step (survives a reset())
+        self.stats = {"steps": 0, "steps_with_deaths": 0, "planned_rows": 0, "void_rows": 0, "repairs": 0, "speculated": 0,
+                      "slots": 0, "dead_rows": 0, "slot_overflows": 0, "sync_steps": 0}
 
     @property
     def device(self) -> torch.device:
@@ -616,6 +694,166 @@ class WorldModelEnv:
             self._repair_rows = info["void_rows"]
             info["repair_pending"] = True
         return obs, rew, end, trunc, info
+
+    # -- the step's deaths resolved on the device (env_loop._slots_env_loop) ------------------------------------------------------
+    # The reference's one data-dependent branch per step (`if dead.any()`, :77) costs a host round trip, and whatever the host
+    # issues behind it starts on an idle device.  Here the branch is taken ON THE DEVICE: a step works on K reset SLOTS, K chosen
+    # before its deaths are known -- the truncations the host can count from its mirror of ep_len, plus a margin for sampled `end`s
+    # -- dmd_resolve_deaths assigns the dead rows to slots in row order, dmd_reset_slots resets them from the next pool rows and
+    # builds the policy's next input, and the host reads the step's report while it issues the NEXT step: always one step behind
+    # a device that holds a full step of queued work.  Exact: per row the reference's arithmetic and pool order; no random draw
+    # depends on it.  More deaths than slots (SlotOverflow, about once in 1e7 steps by the margin's design) repeats the window.
+    DR_END_TAIL = 1e-7  # per-step probability the margin for sampled ends accepts of running out of slots
+
+    def slot_count(self, all_slots: bool = False) -> int:
+        """Reset slots of the pending step: the truncations it WILL have (host mirror of ep_len, exact) + a Poisson-tail margin for
+        the `end`s the reward/end model may sample, from the running mean of ends per step; multiples of 8, at most one per env."""
+        b = self.num_envs
+        if all_slots or self._ep_len_host is None:
+            return b
+        n_trunc = int(np.count_nonzero(self._ep_len_host + 1 >= self.horizon))
+        m = self._end_mean
+        k = n_trunc + (0 if m < 1e-3 else _poisson_quantile(m, self.DR_END_TAIL))
+        return 0 if k == 0 else min(b, (k + 7) // 8 * 8)
+
+    def slots_can_repeat(self) -> bool:
+        """Can a window be repeated after a SlotOverflow?  Not when random draws come from stateful hooks (the tests' injected
+        draws) or from inside a replayed sampler graph: then every step gets a slot per env (no overflow is possible)."""
+        return self.expo_fn is None and self.sampler.noise_fn is None and not self._use_graph()
+
+    @torch.no_grad()
+    def step_end_slots(self, all_slots: bool = False):
+        """Second half of a step with its deaths resolved on the device.  Returns (obs_ext, rew, end, trunc, slots, info):
+        obs_ext (B + T * K, C, H, W) = [every env's newest frame (a reset row: of its new episode) | the K slots' final observations
+        | their T - 1 burn-in frames, frame-major]; slots None when the step has no slots (K = 0).  Waits only for the PREVIOUS
+        step's report (slots_finish)."""
+        next_obs, denoising_trajectory, e_rew, e_end, _ = self._pending
+        self._pending, self._pending_speculative = None, False
+        rew, end = self.predict_rew_end(next_obs.unsqueeze(1), e_rew, e_end)
+        self.slots_finish()  # the previous step's report: episode-length mirror, pool cursor, overflow
+        dev, b = next_obs.device, self.num_envs
+        t = self._ctx.shape[1]
+        k = self.slot_count(all_slots)
+        end = end.long().contiguous()
+        if self.ep_len.dtype != torch.long or not self.ep_len.is_contiguous():
+            self.ep_len = self.ep_len.long().contiguous()
+        trunc = torch.empty(b, dtype=torch.long, device=dev)
+        dead = torch.empty(b, dtype=torch.uint8, device=dev)
+        slot_row = torch.empty(max(k, 1), dtype=torch.long, device=dev)
+        row_slot = torch.empty(b, dtype=torch.int32, device=dev)
+        report = torch.empty(b + 4, dtype=torch.int32, device=dev)
+        lib = nv.lib()
+        nv.check(lib.dmd_resolve_deaths(nv.ptr(end), nv.ptr(self.ep_len), int(self.horizon), nv.ptr(trunc), nv.ptr(dead), b, k, nv.ptr(slot_row),
+                                        nv.ptr(row_slot), nv.ptr(report), nv.stream()), "dmd_resolve_deaths")
+        if report.is_cuda:
+            if self._report_host is None or self._report_host.shape[1] != b + 4:
+                self._report_host = torch.zeros(4, b + 4, dtype=torch.int32).pin_memory()
+                self._report_slot = 0
+            self._report_slot = (self._report_slot + 1) % self._report_host.shape[0]
+            host = self._report_host[self._report_slot]
+            host.copy_(report, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record()
+        else:
+            host, event = report.clone(), None
+        pool = self.pool
+        token = None
+        if k > 0:
+            if pool.size == 0:
+                pool._preload()
+            if pool._cursor + k <= pool.size:  # whatever dies, no preload decision depends on it
+                token = (pool._generation, pool._cursor)
+                base = pool._cursor
+                self._slots_inflight = (event, host, k, token)
+            else:
+                # the pool may run short: whether it is replaced depends on the exact count (the reference drops the remainder and
+                # preloads when a request does not fit, :133-139) -- this step waits for its own report (rare: once per pool round)
+                self.stats["sync_steps"] += 1
+                if event is not None:
+                    event.synchronize()
+                n_dead = int(host[b])
+                base, token = pool.peek_start(min(n_dead, k)) if n_dead else (pool._cursor, (pool._generation, pool._cursor))
+                self._slots_account(host.numpy(), k, token)
+        else:
+            base = 0
+            self._slots_inflight = (event, host, k, None)
+        frames = pool.frames_u8 if pool.frames_u8 is not None else pool.frames_f32
+        oldest = self._head
+        self._head = (self._head + 1) % t
+        enc_in = torch.empty((b + t * k,) + tuple(next_obs.shape[1:]), dtype=torch.float32, device=dev)
+        nxt = next_obs if (next_obs.dtype == torch.float32 and next_obs.is_contiguous()) else next_obs.float().contiguous()
+        p = nv.ResetSlotsParams()
+        p.B, p.K, p.T, p.head, p.per_frame = b, k, t, self._head, nxt[0].numel()
+        p.row_slot, p.next_obs, p.ctx, p.enc_in = nv.ptr(row_slot), nv.fptr(nxt), nv.fptr(self._ctx), nv.fptr(enc_in)
+        if k > 0:
+            assert frames.is_contiguous() and pool.act.dtype == torch.long and pool.act.is_contiguous() and self._act.is_contiguous()
+            p.pool_frames, p.pool_is_f32, p.pool_base = nv.ptr(frames), int(pool.frames_u8 is None), int(base)
+            p.pool_pad = nv.ptr(pool.pad.view(torch.uint8)) if (pool.pad is not None and pool.frames_u8 is not None) else None
+            p.pool_act, p.pool_hx, p.pool_cx, p.hd = nv.ptr(pool.act), nv.fptr(pool.hx), nv.fptr(pool.cx), pool.hx.shape[-1]
+            p.slot_row, p.act_ring, p.hx, p.cx = nv.ptr(slot_row), nv.ptr(self._act), nv.fptr(self.hx_rew_end), nv.fptr(self.cx_rew_end)
+        with _no_random_draws(dev, "WorldModelEnv.step_end_slots"):
+            nv.check(lib.dmd_reset_slots(C.byref(p), nv.stream()), "dmd_reset_slots")
+        dead_b = dead.view(torch.bool)
+        info: Dict[str, Any] = {"dead": dead_b}
+        if self.return_denoising_trajectory:
+            info["denoising_trajectory"] = torch.stack(denoising_trajectory, dim=1)
+        self.stats["steps"] += 1
+        self.stats["slots"] += k
+        slots = ResetSlots(k, slot_row[:k], row_slot, dead_b) if k > 0 else None
+        return enc_in, rew, end, trunc, slots, info
+
+    def slots_finish(self) -> None:
+        """Read the report of the last step_end_slots (waits for that step: the device is then a full step of queued work ahead,
+        except at a window's end): episode-length mirror, pool cursor, running mean of ends, slot overflow (raises)."""
+        inflight, self._slots_inflight = self._slots_inflight, None
+        if inflight is None:
+            return
+        event, host, k, token = inflight
+        if event is not None:
+            event.synchronize()
+            check_weight_audits()  # (the host is synchronised anyway: did an audit of the packed weight copies find a silent write?)
+        self._slots_account(host.numpy(), k, token)
+
+    def _slots_account(self, report: np.ndarray, k: int, token) -> None:
+        b = self.num_envs
+        n_dead, n_end, overflow = int(report[b]), int(report[b + 1]), int(report[b + 2])
+        rows_host = np.flatnonzero(report[:b])
+        if self._ep_len_host is not None:
+            self._ep_len_host += 1
+            self._ep_len_host[rows_host] = 0
+        self._end_mean = 0.98 * self._end_mean + 0.02 * n_end
+        self.stats["dead_rows"] += n_dead
+        if n_dead:
+            self.stats["steps_with_deaths"] += 1
+        if overflow:
+            self.stats["slot_overflows"] += 1
+            raise SlotOverflow(f"{n_dead} episodes ended in a step with {k} reset slots")
+        if n_dead:
+            self.pool.commit(token, n_dead)
+
+    @torch.no_grad()
+    def slots_snapshot(self):
+        """Everything a repetition of the coming window starts from (env state, pool position, random generators)."""
+        self.slots_finish()
+        dev = self._ctx.device
+        return {"ctx": self._ctx.clone(), "act": self._act.clone(), "head": self._head, "hx": self.hx_rew_end.clone(), "cx": self.cx_rew_end.clone(),
+                "ep_len": self.ep_len.clone(), "ep_host": None if self._ep_len_host is None else self._ep_len_host.copy(),
+                "pool": self.pool.snapshot(), "cpu_rng": torch.get_rng_state(),
+                "dev_rng": torch.cuda.get_rng_state(dev) if dev.type == "cuda" else None}
+
+    @torch.no_grad()
+    def slots_restore(self, snap) -> None:
+        self._slots_inflight = None
+        self._pending = None
+        self._ctx.copy_(snap["ctx"])
+        self._act.copy_(snap["act"])
+        self._head = snap["head"]
+        self.hx_rew_end, self.cx_rew_end, self.ep_len = snap["hx"].clone(), snap["cx"].clone(), snap["ep_len"].clone()
+        self._ep_len_host = None if snap["ep_host"] is None else snap["ep_host"].copy()
+        self.pool.restore(snap["pool"])
+        torch.set_rng_state(snap["cpu_rng"])
+        if snap["dev_rng"] is not None:
+            torch.cuda.set_rng_state(snap["dev_rng"], self._ctx.device)
 
     def _use_graph(self) -> bool:
         # (no replay while a launch profiler is installed: a replayed graph issues no launches it could time, and a first

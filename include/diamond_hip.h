@@ -282,6 +282,53 @@ int dmd_dequant_gather(const uint8_t* pool, const int64_t* idx, const int64_t* r
 int dmd_reset_state(const int64_t* idx, const int64_t* rows, int count, const int64_t* pool_act, int64_t* act_ring, int T, int head,
                     const float* pool_hx, const float* pool_cx, float* hx, float* cx, int hd, int64_t* ep_len, dmd_stream_t stream);
 
+/* ---- ABI v11: the deaths of an imagined step resolved on the device -----------------------------------------------------
+ * Replaces the reference's per-step host round trip `if dead.any(): reset_dead(dead)` (envs/world_model_env.py:77-83, :56-62) and
+ * what coroutines/env_loop.py:45-56 does with its answer: the step works on K SLOTS chosen by the host BEFORE it knows the step's
+ * deaths; dead rows take slots in ascending row order (the order of the reference's boolean masks and of its pool,
+ * world_model_env.py:133-139), unused slots are -1, and the host reads `report` one step late.
+ *   ep_len[r] += 1; trunc[r] = ep_len[r] >= horizon (:71-72); dead[r] = end[r] | trunc[r]; ep_len[r] = 0 where dead (:61)
+ *   slot_row (K) int64: j-th dead row or -1;  row_slot (B) int32: slot of a dead row, -1 if alive (or no slot was left)
+ *   report (B + 4) int32: dead[0..B), k = number of dead rows, rows with end != 0, k > K (slot overflow), K */
+int dmd_resolve_deaths(const int64_t* end, int64_t* ep_len, int horizon, int64_t* trunc, uint8_t* dead, int B, int K,
+                       int64_t* slot_row, int32_t* row_slot, int32_t* report, dmd_stream_t stream);
+
+/* Ring advance (world_model_env.py:74-75, as a ring: the oldest slot receives the imagined frame), reset of the slots' rows
+ * from pool rows pool_base + j (:56-62: context frames, actions, reward/end LSTM state), and the policy's next input
+ * enc_in (B + T * K, per_frame) = [ newest frame of every env (a reset row: of its NEW episode)
+ *                                  | final observation of slot j (env_loop.py:49)
+ *                                  | burn-in frame t of slot j, frame-major, t < T - 1 (env_loop.py:53-56) ]
+ * in one call (two launches).  head = the ring's head AFTER the advance.  pool_frames: (P, T, per_frame) uint8 (dequantised as
+ * dmd_dequant_gather does; pool_pad (P, T) uint8, optional: frames that are exact zeros) or fp32 (pool_is_f32).  Unused slots
+ * produce copies of row 0's imagined frame in enc_in and touch nothing else. */
+typedef struct dmd_reset_slots_params {
+  int32_t B, K, T, head;
+  int64_t per_frame; /* C * H * W, a multiple of 4 */
+  const void* pool_frames;
+  const uint8_t* pool_pad;
+  int32_t pool_is_f32, hd; /* hd: width of the reward/end LSTM state */
+  int64_t pool_base;
+  const int64_t* pool_act; /* (P, T) */
+  const float* pool_hx;    /* (P, hd) */
+  const float* pool_cx;
+  const int64_t* slot_row; /* (K), from dmd_resolve_deaths */
+  const int32_t* row_slot; /* (B) */
+  const float* next_obs;   /* (B, per_frame): the imagined frames of this step */
+  float* ctx;              /* (B, T, per_frame) context ring */
+  int64_t* act_ring;       /* (B, T) */
+  float* hx;               /* (B, hd) reward/end LSTM state */
+  float* cx;
+  float* enc_in;           /* (B + T * K, per_frame) */
+} dmd_reset_slots_params;
+int dmd_reset_slots(const dmd_reset_slots_params* p, dmd_stream_t stream);
+
+/* out[r] = row_slot[r] >= 0 ? slots[row_slot[r]] : base[r]  (rows of D floats): the burnt-in policy LSTM state of the reset rows
+ * merged into the batch's state (env_loop.py:51-56), and the transposed operation for its backward:
+ * d_base[r] = row_slot[r] >= 0 ? 0 : d_out[r] (d_base may be NULL);  d_slots[j] = slot_row[j] >= 0 ? d_out[slot_row[j]] : 0 */
+int dmd_merge_slots(const float* base, const float* slots, const int32_t* row_slot, float* out, int B, int D, dmd_stream_t stream);
+int dmd_merge_slots_bwd(const float* d_out, const int32_t* row_slot, const int64_t* slot_row, float* d_base, float* d_slots, int B, int K,
+                        int D, dmd_stream_t stream);
+
 /* NCHW (N, C, H, W) -> NHWC (N, H, W, CPad), zero padded channels */
 int dmd_nchw_to_nhwc(const float* in, float* out, int N, int C, int H, int W, int CPad, dmd_stream_t stream);
 int dmd_nhwc_to_nchw(const float* in, float* out, int N, int C, int H, int W, int CPad, dmd_stream_t stream);

@@ -109,7 +109,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     for sym in sorted(declared):
         assert hasattr(lib, sym), f"{sym} declared in include/diamond_hip.h but not exported"
     assert set(native.EXPORTS) == declared
-    assert lib.dmd_abi_version() == 10
+    assert lib.dmd_abi_version() == 11
     assert lib.dmd_conv_stat_tiles(64, 64) == 32 and lib.dmd_conv_stat_tiles(8, 8) == 1
 
 
@@ -123,12 +123,13 @@ def test_struct_layouts_match_the_header():
     structs = [("dmd_norm", native.Norm), ("dmd_conv_src", native.ConvSrc), ("dmd_conv_params", native.ConvParams),
                ("dmd_linear_params", native.LinearParams), ("dmd_gn_bwd_params", native.GnBwdParams),
                ("dmd_wgrad_params", native.WgradParams), ("dmd_wgrad_reduce_job", native.WgradReduceJob), ("dmd_chain_block", native.ChainBlock),
-               ("dmd_lowres_chain_params", native.LowresChainParams)]
+               ("dmd_lowres_chain_params", native.LowresChainParams), ("dmd_reset_slots_params", native.ResetSlotsParams)]
     offsets = [("dmd_conv_params", native.ConvParams, "w_f16"), ("dmd_conv_params", native.ConvParams, "precision"),
                ("dmd_wgrad_params", native.WgradParams, "precision"), ("dmd_wgrad_params", native.WgradParams, "defer_reduce"),
                ("dmd_wgrad_reduce_job", native.WgradReduceJob, "ld_cin"), ("dmd_chain_block", native.ChainBlock, "w1"),
                ("dmd_chain_block", native.ChainBlock, "bo"), ("dmd_lowres_chain_params", native.LowresChainParams, "table_stride"),
-               ("dmd_lowres_chain_params", native.LowresChainParams, "blocks")]
+               ("dmd_lowres_chain_params", native.LowresChainParams, "blocks"), ("dmd_reset_slots_params", native.ResetSlotsParams, "pool_base"),
+               ("dmd_reset_slots_params", native.ResetSlotsParams, "enc_in")]
     body = "".join(f'printf("%zu ", sizeof({c}));' for c, _ in structs)
     body += "".join(f'printf("%zu ", offsetof({c}, {f}));' for c, _, f in offsets)
     src = f'#include <stdio.h>\n#include <stddef.h>\n#include "diamond_hip.h"\nint main(){{{body}return 0;}}'

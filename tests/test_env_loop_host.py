@@ -492,3 +492,163 @@ def test_pipelined_loop_gradients_match_the_sequential_ones(monkeypatch):
         (c[5].square().sum() + c[6].sum()).backward()
         outs.append(pol.w.grad.clone())
     assert torch.allclose(outs[0], outs[1], rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The slots loop (env_loop._slots_env_loop): a step's deaths resolved "on the device" into fixed-shape reset slots, the host one
+# step behind, a window repeated from its snapshot when a step had more deaths than slots -- against the sequential loop on the
+# same pool-served toy env.
+
+
+class ToySlots:
+    def __init__(self, k, slot_row, row_slot, dead):
+        self.K, self.slot_row, self.row_slot, self.dead = k, slot_row, row_slot, dead
+        self.gather_rows = slot_row.clamp_min(0)
+
+    def merge(self, base, values):
+        sel = values.index_select(0, self.row_slot.clamp_min(0))
+        return torch.where((self.row_slot >= 0).view(-1, *[1] * (base.ndim - 1)), sel, base)
+
+
+class SlotsEnv(PoolEnv):
+    """PoolEnv behind env_loop.SLOTS_PROTOCOL: K slots per step = the truncations the host mirror foresees + `margin` (the env's
+    guess for sampled ends), dead rows into slots in row order, the report read one step late (an overflow shows at the NEXT
+    slots_finish), snapshot / restore of env + pool cursor + the shared random stream."""
+
+    def __init__(self, b, p_end, horizon, stagger=False, margin=1):
+        super().__init__(b, p_end, horizon, stagger)
+        self.margin = margin
+        self._pending = self._inflight = None
+        self.counts = {"overflows": 0, "slots": 0, "dead": 0, "restores": 0}
+
+    def reset(self, **kw):
+        out = super().reset(**kw)
+        self.t_host = self.t.clone()
+        return out
+
+    def slots_can_repeat(self):
+        return True
+
+    def step_begin(self, act):
+        assert self._pending is None
+        self.log.append("begin")
+        noise, e_rew, e_end = self._draw()
+        self._pending = (self._dynamics(self.ctx, act, noise), e_rew, e_end)
+        return self._pending[0]
+
+    def step_end_slots(self, all_slots=False):
+        nxt, e_rew, e_end = self._pending
+        self._pending = None
+        rew, end = self._rew_end(nxt, e_rew, e_end)
+        self.slots_finish()
+        b = self.num_envs
+        k = b if all_slots else min(b, int((self.t_host + 1 >= self.horizon).sum()) + self.margin)
+        self.t += 1
+        trunc = (self.t >= self.horizon).long()
+        dead = torch.logical_or(end, trunc)
+        rows = dead.nonzero(as_tuple=True)[0]
+        n_dead = int(rows.numel())
+        self.t[dead] = 0
+        used = rows[:k]
+        slot_row = torch.full((max(k, 1),), -1, dtype=torch.long)
+        slot_row[:used.numel()] = used
+        row_slot = torch.full((b,), -1, dtype=torch.long)
+        row_slot[used] = torch.arange(used.numel())
+        self.ctx = torch.cat([self.ctx[:, 1:], nxt[:, None]], 1)
+        fresh = torch.stack([_pool_row(self.cursor + j) for j in range(used.numel())]) if used.numel() else self.ctx[:0]
+        fin = nxt[:1].repeat(k, 1, 1)
+        burn = nxt[:1].repeat(3 * k, 1, 1).reshape(3, k, *nxt.shape[1:])
+        if used.numel():
+            self.ctx[used] = fresh
+            fin[:used.numel()] = nxt[used]
+            burn[:, :used.numel()] = fresh[:, :-1].transpose(0, 1)
+        self._inflight = (dead.clone(), n_dead, k)
+        self.counts["slots"] += k
+        obs_ext = torch.cat([self.ctx[:, -1], fin, burn.reshape(3 * k, *nxt.shape[1:])])
+        slots = ToySlots(k, slot_row[:k], row_slot, dead) if k > 0 else None
+        return obs_ext, rew, end, trunc, slots, {"dead": dead}
+
+    def slots_finish(self):
+        inflight, self._inflight = self._inflight, None
+        if inflight is None:
+            return
+        dead, n_dead, k = inflight
+        self.t_host += 1
+        self.t_host[dead] = 0
+        self.counts["dead"] += n_dead
+        if n_dead > k:
+            self.counts["overflows"] += 1
+            raise EL_SlotOverflow(f"{n_dead} > {k}")
+        self.cursor += n_dead
+
+    def slots_snapshot(self):
+        self.slots_finish()
+        return (self.ctx.clone(), self.t.clone(), self.t_host.clone(), self.cursor, torch.get_rng_state(), len(self.log))
+
+    def slots_restore(self, snap):
+        self.counts["restores"] += 1
+        self._inflight = self._pending = None
+        self.ctx, self.t, self.t_host, self.cursor = snap[0].clone(), snap[1].clone(), snap[2].clone(), snap[3]
+        torch.set_rng_state(snap[4])
+        del self.log[snap[5]:]
+
+
+from diamond_amd.world_model_env import SlotOverflow as EL_SlotOverflow  # noqa: E402
+
+
+class SlotsPolicy(SeparablePolicy):
+    def __init__(self):
+        super().__init__(True)
+
+    def burn_in_from_features(self, x, num_frames):
+        k = x.shape[0] // num_frames
+        hz, cz = torch.zeros(k, self.lstm_dim), torch.zeros(k, self.lstm_dim)
+        for i in range(num_frames):
+            _, _, (hz, cz) = self.predict_from_features(x[i * k:(i + 1) * k], (hz, cz))
+        return hz, cz
+
+
+@pytest.mark.parametrize("margin", [0, 1, 3, 100])
+@pytest.mark.parametrize("p_end,horizon,stagger", [(0.0, 6, False), (0.0, 7, True), (0.02, 7, True), (0.12, 7, True), (0.35, 5, False), (0.6, 9, True)])
+def test_slots_loop_is_bitwise_the_sequential_one(monkeypatch, p_end, horizon, stagger, margin):
+    """deaths resolved into reset slots with the host one step behind: truncations, sampled ends (in front of truncating rows: pool
+    order), deaths at a window's last step, unused slots, and windows REPEATED from their snapshot after a slot overflow -- all on
+    ONE shared random stream against the reference's order of operations"""
+    b, t, windows = 9, 6, 5
+    monkeypatch.setenv("DIAMOND_ENV_LOOP", "sequential")
+    seq = _windows(PoolEnv(b, p_end, horizon, stagger), SlotsPolicy(), windows, t, monkeypatch, "1")
+    monkeypatch.setenv("DIAMOND_ENV_LOOP", "slots")
+    env = SlotsEnv(b, p_end, horizon, stagger, margin)
+    got = _windows(env, SlotsPolicy(), windows, t, monkeypatch, "1")
+    names = ("obs", "act", "rew", "end", "trunc", "logits", "val", "val_bootstrap")
+    for w, (wa, wb) in enumerate(zip(seq, got)):
+        for name, a, b_ in zip(names, wa, wb):
+            assert torch.equal(a, b_), (w, name)
+    c = env.counts
+    assert c["restores"] == c["overflows"]
+    if margin == 100:
+        assert c["overflows"] == 0
+    if margin == 0 and p_end >= 0.12:
+        assert c["overflows"] > 0, "the repeated-window path was not exercised"
+    if p_end > 0 or stagger or horizon % t:
+        assert c["dead"] > 0
+
+
+def test_slots_loop_gradients_match_the_sequential_ones(monkeypatch):
+    """the burn-in of the reset rows rides in the policy's next encoder pass, unused slots included: the gradients of a window's
+    loss w.r.t. the policy's parameter are those of the sequential graph"""
+    grads = []
+    for kind, make in (("sequential", lambda: PoolEnv(9, 0.12, 7, True)), ("slots", lambda: SlotsEnv(9, 0.12, 7, True, 2))):
+        monkeypatch.setenv("DIAMOND_ENV_LOOP", kind)
+        monkeypatch.setattr(EL, "sample_categorical", lambda logits, expo: (torch.softmax(logits.detach(), -1) / expo).argmax(-1))
+        torch.manual_seed(11)
+        random.seed(5)
+        pol = SlotsPolicy()
+        pol.w.requires_grad_(True)
+        loop = EL.make_env_loop(make(), pol, epsilon=0.0)
+        for _ in range(2):
+            obs, act, rew, end, trunc, logits, val, vb, _ = loop.send(6)
+        loss = (logits.logsumexp(-1) * 0.3 + (val - vb) ** 2).mean()
+        (g,) = torch.autograd.grad(loss, pol.w)
+        grads.append(g)
+    assert torch.allclose(grads[0], grads[1], rtol=1e-6, atol=1e-7), float((grads[0] - grads[1]).abs().max())

@@ -895,7 +895,7 @@ def test_fused_burn_in_is_bitwise_the_frame_by_frame_one():
 
 @pytest.mark.parametrize("spec,policy", [("1", "1"), ("0", "1"), ("0", "0"), ("auto", "auto")])
 @pytest.mark.parametrize("b,horizon,p_end,stagger", [(24, 5, 0.03, True), (12, 7, 0.25, False), (16, 6, 0.0, True)])
-def test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon, p_end, stagger, spec, policy):
+def test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon, p_end, stagger, spec, policy, loop="pipelined", tail=None):
     """env_loop's pipelined form (planned truncation resets inside the speculated pipeline, unplanned deaths repaired row by row on
     a small batch: env_loop._pipelined_env_loop, WorldModelEnv.plan_resets / step_begin_repair) against the reference's sequential
     order of operations (DIAMOND_SPECULATIVE_POLICY=0), three windows on the DEVICE random generator at batches the graphed
@@ -911,6 +911,7 @@ def test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon,
     runs, stats, grads = [], None, []
     for mode in ("1", "0"):
         monkeypatch.setenv("DIAMOND_SPECULATIVE_POLICY", mode)
+        monkeypatch.setenv("DIAMOND_ENV_LOOP", loop)
         for k, v in (("DIAMOND_SPEC_SAMPLER", spec), ("DIAMOND_SPEC_POLICY", policy)):  # pinned modes, or the env's own running averages
             monkeypatch.delenv(k, raising=False) if v == "auto" else monkeypatch.setenv(k, v)
         monkeypatch.setenv("DIAMOND_CHECK_RESET_RNG", "1")
@@ -919,6 +920,8 @@ def test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon,
         env = D.WorldModelEnv(ag.denoiser, ag.rew_end_model, _Loader(b, 77),
                               D.WorldModelEnvConfig(horizon=horizon, num_batches_to_preload=2,
                                                     diffusion_sampler=D.DiffusionSamplerConfig(num_steps_denoising=2)))
+        if tail is not None:
+            env.DR_END_TAIL = tail
         ag.setup_training(D.SigmaDistributionConfig(-0.4, 1.2, 2e-3, 20),
                           D.ActorCriticLossConfig(backup_every=t, gamma=0.985, lambda_=0.95, weight_value_loss=1.0,
                                                   weight_entropy_loss=0.001), env)
@@ -948,6 +951,8 @@ def test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon,
     gerr = {k: float((grads[0][k] - g).abs().max() / g.abs().max().clamp_min(1e-30)) for k, g in grads[1].items()}
     print("pipelined vs sequential gradient rel diff:", f"{max(gerr.values()):.2e}")
     assert max(gerr.values()) < 1e-4, {k: f"{v:.1e}" for k, v in gerr.items() if v >= 1e-4}
+    if loop == "slots":
+        return stats
     if policy == "1":
         assert stats["planned_rows"] > 0, stats
         if p_end > 0:
@@ -955,6 +960,24 @@ def test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon,
         assert (stats["speculated"] > 0) == (spec == "1"), stats
     elif policy == "0":  # the reference's order with one encoder pass per step: nothing planned, nothing speculated
         assert stats["planned_rows"] == 0 and stats["speculated"] == 0 and stats["repairs"] == 0, stats
+
+
+@pytest.mark.parametrize("tail", [1e-7, 0.9])
+@pytest.mark.parametrize("b,horizon,p_end,stagger", [(24, 5, 0.03, True), (24, 7, 0.25, True), (12, 7, 0.25, False), (16, 6, 0.0, True), (16, 6, 0.0, False)])
+def test_slots_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon, p_end, stagger, tail):
+    """env_loop's default form -- a step's deaths resolved ON THE DEVICE into reset slots (dmd_resolve_deaths / dmd_reset_slots /
+    dmd_merge_slots), the host one step behind (env_loop._slots_env_loop, WorldModelEnv.step_end_slots) -- against the reference's
+    sequential order of operations: three windows on the DEVICE random generator, every output bitwise identical, gradients to
+    rounding.  tail = 0.9 sizes the slots with no margin for sampled ends: windows overflow, are restored from their snapshot
+    (env state, pool position, device generator) and repeated."""
+    stats = test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon, p_end, stagger, "auto", "auto", loop="slots", tail=tail)
+    assert stats["steps"] >= 18 and stats["speculated"] == 0 and stats["planned_rows"] == 0, stats
+    if p_end > 0 or stagger:
+        assert stats["dead_rows"] > 0 and stats["slots"] >= stats["dead_rows"] - 24 * stats["slot_overflows"], stats
+    if tail == 0.9 and p_end >= 0.25:
+        assert stats["slot_overflows"] > 0, f"the repeated-window path was not exercised: {stats}"
+    if tail == 1e-7 and p_end <= 0.03:
+        assert stats["slot_overflows"] <= 1, stats  # (at most the very first end: the running mean starts at zero)
 
 
 @pytest.mark.parametrize("num_actions", [6, 18])

@@ -82,15 +82,20 @@ def _run(E, nv, xs, prologue, mul, add, cin, wgt, bias, cout, taps, up, res, hea
                     residual=r_act, want_stats=(cout % 32 == 0) and not stream, w_f16=w16, fast_math=precision_f16)
 
 
-@pytest.mark.parametrize("case", TPW_CASES, ids=[c[0] for c in TPW_CASES])
-@pytest.mark.parametrize("precision", ["f16x2", "f32"])
+def _streams(case):
+    return case[6] == 1 and case[8] == 0 and not case[9]
+
+
+# (the exact-fp32 arm only exists for the streaming 1x1 kernel here: conv_mfma is not persistent)
+TPW_PARAMS = [pytest.param(c, prec, id=f"{prec}-{c[0]}") for prec in ("f16x2", "f32") for c in TPW_CASES if prec == "f16x2" or _streams(c)]
+
+
+@pytest.mark.parametrize("case,precision", TPW_PARAMS)
 def test_conv2d_production_tiles_per_wg(case, precision):
     from diamond_amd import engine as E, native as nv
 
     name, n, h, w, cins, cout, taps, up, prologue, use_res, head = case
-    stream = taps == 1 and prologue == 0 and not use_res
-    if precision == "f32" and not stream:
-        pytest.skip("exact-fp32 arm only exists for the streaming 1x1 kernel here (conv_mfma is not persistent)")
+    stream = _streams(case)
     cin = sum(cins)
     k = 3 if taps == 9 else 1
     ho, wo = (2 * h, 2 * w) if up else (h, w)

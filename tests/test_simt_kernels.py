@@ -698,6 +698,124 @@ def test_uint8_pool_round_trip():
     assert np.isnan(dst[2]).all()
 
 
+def _resolve_np(end, ep_len, horizon, K):
+    """numpy restatement of dmd_resolve_deaths (reference world_model_env.py:71-72,77-83 + the slot assignment in row order)"""
+    ep = ep_len + 1
+    trunc = (ep >= horizon).astype(np.int64)
+    dead = (end != 0) | (trunc != 0)
+    rows = np.flatnonzero(dead)
+    slot_row = np.full(K, -1, dtype=np.int64)
+    slot_row[:min(K, rows.size)] = rows[:K]
+    row_slot = np.full(end.size, -1, dtype=np.int32)
+    row_slot[rows[:K]] = np.arange(min(K, rows.size))
+    report = np.concatenate([dead.astype(np.int32), np.array([rows.size, int((end != 0).sum()), int(rows.size > K), K], dtype=np.int32)])
+    return np.where(dead, 0, ep), trunc, dead.astype(np.uint8), slot_row, row_slot, report
+
+
+@pytest.mark.parametrize("b,k,p_end", [(9, 4, 0.2), (256, 24, 0.02), (256, 0, 0.0), (300, 300, 0.5), (700, 16, 0.05), (5, 8, 1.0)])
+def test_resolve_deaths_matches_the_row_order_of_the_reference(b, k, p_end):
+    """the step's deaths resolved on the device: truncation, dead mask, episode lengths, slots in ascending row order, unused slots,
+    the report the host reads a step late -- overflow (more deaths than slots) included; batches above one 256-row chunk"""
+    rng = np.random.default_rng(b * 131 + k)
+    L = S.lib()
+    horizon = 7
+    end = (rng.random(b) < p_end).astype(np.int64)
+    ep_len = rng.integers(0, horizon, b).astype(np.int64)
+    want = _resolve_np(end, ep_len, horizon, k)
+    ep = ep_len.copy()
+    trunc, dead = np.full(b, -1, dtype=np.int64), np.full(b, 7, dtype=np.uint8)
+    slot_row, row_slot, report = np.full(max(k, 1), -9, dtype=np.int64), np.full(b, -9, dtype=np.int32), np.full(b + 4, -9, dtype=np.int32)
+    S.check(L.dmd_resolve_deaths(S.ptr(end), S.ptr(ep), horizon, S.ptr(trunc), S.ptr(dead), b, k, S.ptr(slot_row), S.ptr(row_slot),
+                                 S.ptr(report), None), "resolve_deaths")
+    for got, w, name in zip((ep, trunc, dead, slot_row[:k], row_slot, report), want, ("ep_len", "trunc", "dead", "slot_row", "row_slot", "report")):
+        assert np.array_equal(got, w), name
+    assert (report[b + 2] == 1) == (int(want[2].sum()) > k)
+
+
+@pytest.mark.parametrize("u8,pad", [(True, False), (True, True), (False, False)])
+def test_reset_slots_is_the_ring_advance_plus_the_reference_reset(u8, pad):
+    """dmd_reset_slots against the sequence it replaces: ring advance (the oldest slot receives the imagined frame), the reference's
+    reset_dead for the dead rows (context frames, actions, reward/end LSTM state from pool rows served in row order), and the policy's
+    next input [newest frames | final observations | burn-in frames, frame-major]; unused slots touch nothing"""
+    from diamond_amd import native as nv
+    import ctypes as C
+
+    rng = np.random.default_rng(77 + u8 + 2 * pad)
+    L = S.lib()
+    b, k, t, per, hd, p_, head_old, base = 7, 5, 4, 24, 12, 11, 2, 3
+    levels = rng.integers(0, 256, (p_, t, per)).astype(np.uint8)
+    padm = (rng.random((p_, t)) < 0.3).astype(np.uint8) if pad else None
+    frames = (levels.astype(f32) / f32(255)) * f32(2) - f32(1)
+    if pad:
+        frames[padm.astype(bool)] = 0.0
+    pool = levels if u8 else frames.copy()
+    pool_act = rng.integers(0, 18, (p_, t)).astype(np.int64)
+    pool_hx, pool_cx = rng.standard_normal((p_, hd)).astype(f32), rng.standard_normal((p_, hd)).astype(f32)
+    ctx = rng.standard_normal((b, t, per)).astype(f32)
+    act = rng.integers(0, 18, (b, t)).astype(np.int64)
+    hx, cx = rng.standard_normal((b, hd)).astype(f32), rng.standard_normal((b, hd)).astype(f32)
+    nxt = rng.standard_normal((b, per)).astype(f32)
+    dead_rows = np.array([1, 4, 6])
+    slot_row = np.full(k, -1, dtype=np.int64)
+    slot_row[:3] = dead_rows
+    row_slot = np.full(b, -1, dtype=np.int32)
+    row_slot[dead_rows] = np.arange(3)
+    head = (head_old + 1) % t
+    # the reference's order of operations on a ring
+    w_ctx, w_act, w_hx, w_cx = ctx.copy(), act.copy(), hx.copy(), cx.copy()
+    w_ctx[:, head_old] = nxt
+    cols = (head + np.arange(t)) % t
+    idx = base + np.arange(3)
+    w_ctx[dead_rows[:, None], cols[None, :]] = frames[idx]
+    w_act[dead_rows[:, None], cols[None, :]] = pool_act[idx]
+    w_hx[dead_rows], w_cx[dead_rows] = pool_hx[idx], pool_cx[idx]
+    obs = nxt.copy()
+    obs[dead_rows] = frames[idx, t - 1]
+    fin = np.repeat(nxt[:1], k, 0)
+    fin[:3] = nxt[dead_rows]
+    burn = np.repeat(nxt[None, :1], t - 1, 0).repeat(k, 1)  # (t - 1, k, per) frame-major
+    burn[:, :3] = frames[idx, :t - 1].transpose(1, 0, 2)
+    want_enc = np.concatenate([obs, fin, burn.reshape(-1, per)])
+    enc = np.full((b + t * k, per), np.nan, dtype=f32)
+    p = nv.ResetSlotsParams()
+    p.B, p.K, p.T, p.head, p.per_frame, p.hd, p.pool_base, p.pool_is_f32 = b, k, t, head, per, hd, base, 0 if u8 else 1
+    p.pool_frames, p.pool_pad, p.pool_act, p.pool_hx, p.pool_cx = S.ptr(pool), S.ptr(padm) if (pad and u8) else None, S.ptr(pool_act), S.ptr(pool_hx), S.ptr(pool_cx)
+    p.slot_row, p.row_slot, p.next_obs, p.ctx, p.act_ring, p.hx, p.cx, p.enc_in = (S.ptr(a) for a in (slot_row, row_slot, nxt, ctx, act, hx, cx, enc))
+    S.check(L.dmd_reset_slots(C.byref(p), None), "reset_slots")
+    for got, w, name in zip((ctx, act, hx, cx, enc), (w_ctx, w_act, w_hx, w_cx, want_enc), ("ctx", "act", "hx", "cx", "enc_in")):
+        assert np.array_equal(got, w), name
+    # no slots at all: the ring advance and a copy of the imagined frames
+    ctx2, enc2 = rng.standard_normal((b, t, per)).astype(f32), np.full((b, per), np.nan, dtype=f32)
+    w2 = ctx2.copy()
+    w2[:, head_old] = nxt
+    none = np.full(b, -1, dtype=np.int32)
+    p.K, p.row_slot, p.ctx, p.enc_in = 0, S.ptr(none), S.ptr(ctx2), S.ptr(enc2)
+    S.check(L.dmd_reset_slots(C.byref(p), None), "reset_slots K=0")
+    assert np.array_equal(ctx2, w2) and np.array_equal(enc2, nxt)
+
+
+def test_merge_slots_and_its_backward():
+    rng = np.random.default_rng(5)
+    L = S.lib()
+    b, k, d = 9, 4, 40
+    base, slots, g = (rng.standard_normal(sh).astype(f32) for sh in ((b, d), (k, d), (b, d)))
+    slot_row = np.array([2, 7, -1, -1], dtype=np.int64)
+    row_slot = np.full(b, -1, dtype=np.int32)
+    row_slot[[2, 7]] = [0, 1]
+    out = np.full((b, d), np.nan, dtype=f32)
+    S.check(L.dmd_merge_slots(S.ptr(base), S.ptr(slots), S.ptr(row_slot), S.ptr(out), b, d, None), "merge_slots")
+    want = base.copy()
+    want[[2, 7]] = slots[:2]
+    assert np.array_equal(out, want)
+    d_base, d_slots = np.full((b, d), np.nan, dtype=f32), np.full((k, d), np.nan, dtype=f32)
+    S.check(L.dmd_merge_slots_bwd(S.ptr(g), S.ptr(row_slot), S.ptr(slot_row), S.ptr(d_base), S.ptr(d_slots), b, k, d, None), "merge_slots_bwd")
+    wb = g.copy()
+    wb[[2, 7]] = 0
+    ws = np.zeros((k, d), dtype=f32)
+    ws[:2] = g[[2, 7]]
+    assert np.array_equal(d_base, wb) and np.array_equal(d_slots, ws)
+
+
 def test_reset_state_and_parameter_checksums():
     """dmd_reset_state (the action ring, reward/end LSTM state and episode length of the reset rows in one launch: reference
     world_model_env.py:56-62) against the indexed assignments it replaces; dmd_checksums (fingerprints of parameter storage for
