@@ -389,7 +389,8 @@ def rollout_setup(device, rank, img_size, batch, horizon, denoise_steps, order, 
                                                  weight_value_loss=1.0, weight_entropy_loss=0.001), env)
     ac = agent.actor_critic
     opt = torch.optim.AdamW(ac.parameters(), lr=1e-4, eps=1e-8, weight_decay=0.0)
-    reducer = GradAllReducer(list(ac.parameters())) if use_dist else None
+    # (LSTM + heads: their gradients are final before the encoder's last backward -- all-reduced from inside backward(), dist.py)
+    reducer = GradAllReducer(list(ac.parameters()), early=[p for n, p in ac.named_parameters() if not n.startswith("encoder.")]) if use_dist else None
 
     def window():
         loss, metrics = ac()
@@ -574,6 +575,7 @@ def also_lines(device, args):
         for name, p, stagger in (("p=0.003", 0.003, False), ("p=0.01", 0.01, False), ("p=0.5", 0.5, False),
                                  ("steady_state p=0", 1e-9, True), ("steady_state p=0.003", 0.003, True), ("steady_state p=0.01", 0.01, True)):
             set_end_rate(agent, p)
+            env.reset_statistics()  # (a new regime: the env's running mean of ends per step starts over)
             if stagger:
                 stagger_episodes(env, 15)
             else:
@@ -824,7 +826,8 @@ def main():
         dist_info = {"rccl_world_size": dist.get_world_size(), "backend": dist.get_backend(),
                      "per_rank_step_ms": [round(float(t[0]), 2) for t in per_rank],
                      "allreduce_ms_per_step": [round(float(t[1]), 3) for t in per_rank],
-                     "grad_bucket_mb": window.reducer.bucket.numel() * 4 / 1e6}
+                     "grad_bucket_mb": window.reducer.bucket.numel() * 4 / 1e6,
+                     "early_slice_mb": window.reducer.early_numel * 4 / 1e6, "early_slice_allreduces_inside_backward": window.reducer.early_launches}
         if not replicas_in_sync and rank == 0:
             print(f"[bench] WARNING: replicas diverged: checksums {[float(g) for g in gathered]}", file=sys.stderr, flush=True)
 

@@ -30,7 +30,7 @@
 //     current tile -- no per-tile pipeline fill.
 // One s_barrier per chunk separates "consumers read buffer j, producers fill buffer j + 1".
 //
-// Round 3 (what the ISA of the round-2 kernel showed):
+// Round 3 (what the ISA of the round-2 kernel showed, HISTORY.md §3):
 //   * PRODUCERS.  hipcc's s_waitcnt insertion lost track of the two register sets across the loop's branches and
 //     emitted `s_waitcnt vmcnt(0)` both in front of the re-issue of a set and inside the staging of the other one: every
 //     step waited for the loads issued ONE step earlier, i.e. the "two chunks ahead" prefetch was one chunk deep and the
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     // prologue (the tables hold a = 1, b = 0 where there is no normalisation and an exponent of -126 where there is no
     // SiLU): with several instances hipcc assigns the pending registers differently per instance and copies them --
     // before the wait -- where the paths meet.  34 VALU instructions per item (54 in round 2): every VALU instruction
-    // of a staging wave delays the MFMA issue of the consumer wave on its SIMD by a few cycles.
+    // of a staging wave delays the MFMA issue of the consumer wave on its SIMD by a few cycles (HISTORY.md §3).
     // NEWER (ASM_LOADS) = loads issued after this set's: they may stay in flight.
     // e_next >= 0: the register set is re-issued for that element (two steps ahead) as soon as the set has been read -- right
     // after the first arithmetic phase where one batch covers the whole set: the loads then leave one by one while the

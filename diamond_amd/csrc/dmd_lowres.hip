@@ -4,7 +4,7 @@
 //
 // Why: at 8x8 a convolution of the whole batch is 1.2 GFLOP; launched on its own it is a ~25 us latency chain (launch,
 // GroupNorm tables, pipeline fill, 4-8 chunk steps, write-out) on 64 of the 256 CUs, and the level is 14 such launches
-// plus 1x1s and attention per denoiser call: 520 us for 1.5 % of the FLOPs.  Here every activation of the
+// plus 1x1s and attention per denoiser call: 520 us for 1.5 % of the FLOPs (HISTORY.md).  Here every activation of the
 // chain (64 pixels x 64 channels fp32 = 16 KiB) stays in LDS, GroupNorm statistics are two-group reductions inside the
 // workgroup, and the only global traffic is the chain input / output and the (L2-resident) weights.
 //

@@ -506,15 +506,24 @@ extern "C" int dmd_resolve_deaths(const int64_t* end, int64_t* ep_len, int horiz
 //   frame f <  B + K      slot j = f - B: the FINAL observation of the ended episode (the imagined frame of row slot_row[j])
 //   frame f >= B + K      burn-in frame t of slot j (frame-major: f = B + K + t * K + j, t < T - 1): the new episode's context
 //                         frame t, into enc_in[f] AND into ring slot (head + t) % T of the row
-// A slot's new episode is pool row pool_base + j (dequantised: (u8 / 255) * 2 - 1, exact zeros where pool_pad marks a padded
-// frame; or an fp32 pool).  Unused slots (slot_row -1) receive copies of row 0's imagined frame: finite values nobody reads.
-template <bool U8>
+// A slot's new episode is row base + j of a pool round (dequantised: (u8 / 255) * 2 - 1, exact zeros where `pad` marks a padded
+// frame; or an fp32 round).  Which round: pool[0] from pool_base on, or -- when the step's deaths do not fit what is left of it,
+// the reference's rule (world_model_env.py:133-139) -- pool[1] from row 0 (ws_pool_select: the count is on the device only).
+// Unused slots (slot_row -1) receive copies of row 0's imagined frame: finite values nobody reads.
+__device__ __forceinline__ int ws_pool_select(const dmd_reset_slots_params& p, int64_t* base) {
+  const bool second = p.pool[1].frames && p.num_dead && (p.pool_base + (int64_t)*p.num_dead > (int64_t)p.pool[0].rows);
+  *base = second ? 0 : p.pool_base;
+  return second ? 1 : 0;
+}
+
 __global__ __launch_bounds__(256) void reset_slot_frames_kernel(dmd_reset_slots_params p) {
   const int64_t q4 = p.per_frame >> 2;
   const int64_t e4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e4 >= q4) return;
   const int f = blockIdx.y;
   const int B = p.B, K = p.K, T = p.T;
+  int64_t base = 0;
+  const dmd_pool_round& pool = p.pool[K > 0 ? ws_pool_select(p, &base) : 0];
   int64_t pool_row = -1, obs_row = 0, ring_row = -1;
   int pool_t = 0, ring_slot = 0;
   if (f < B) {
@@ -522,7 +531,7 @@ __global__ __launch_bounds__(256) void reset_slot_frames_kernel(dmd_reset_slots_
     ring_row = f;
     ring_slot = (p.head + T - 1) % T;
     if (s >= 0) {
-      pool_row = p.pool_base + s;
+      pool_row = base + s;
       pool_t = T - 1;
     } else {
       obs_row = f;
@@ -535,7 +544,7 @@ __global__ __launch_bounds__(256) void reset_slot_frames_kernel(dmd_reset_slots_
     const int t = g / K, j = g - t * K;
     const int64_t r = p.slot_row[j];
     if (r >= 0) {
-      pool_row = p.pool_base + j;
+      pool_row = base + j;
       pool_t = t;
       ring_row = r;
       ring_slot = (p.head + t) % T;
@@ -544,13 +553,13 @@ __global__ __launch_bounds__(256) void reset_slot_frames_kernel(dmd_reset_slots_
   f32x4 v;
   if (pool_row >= 0) {
     const int64_t pf = pool_row * T + pool_t;
-    if (U8) {
-      const uint32_t pk = *(const uint32_t*)((const uint8_t*)p.pool_frames + pf * p.per_frame + e4 * 4);
-      const bool pad = p.pool_pad && p.pool_pad[pf];
+    if (!pool.is_f32) {
+      const uint32_t pk = *(const uint32_t*)((const uint8_t*)pool.frames + pf * p.per_frame + e4 * 4);
+      const bool pad = pool.pad && pool.pad[pf];
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = pad ? 0.0f : ((float)((pk >> (8 * e)) & 0xff) / 255.0f) * 2.0f - 1.0f;
     } else {
-      v = *(const f32x4*)((const float*)p.pool_frames + pf * p.per_frame + e4 * 4);
+      v = *(const f32x4*)((const float*)pool.frames + pf * p.per_frame + e4 * 4);
     }
   } else {
     v = *(const f32x4*)(p.next_obs + obs_row * p.per_frame + e4 * 4);
@@ -565,13 +574,15 @@ __global__ __launch_bounds__(256) void reset_slot_state_kernel(dmd_reset_slots_p
   const int j = blockIdx.x;
   const int64_t r = p.slot_row[j];
   if (r < 0) return;
-  const int64_t q = p.pool_base + j;
+  int64_t base;
+  const dmd_pool_round& pool = p.pool[ws_pool_select(p, &base)];
+  const int64_t q = base + j;
   const int hd = p.hd, T = p.T;
   for (int i = threadIdx.x; i < hd; i += 256) {
-    p.hx[r * hd + i] = p.pool_hx[q * hd + i];
-    p.cx[r * hd + i] = p.pool_cx[q * hd + i];
+    p.hx[r * hd + i] = pool.hx[q * hd + i];
+    p.cx[r * hd + i] = pool.cx[q * hd + i];
   }
-  if ((int)threadIdx.x < T) p.act_ring[r * T + (p.head + threadIdx.x) % T] = p.pool_act[q * T + threadIdx.x];
+  if ((int)threadIdx.x < T) p.act_ring[r * T + (p.head + threadIdx.x) % T] = pool.act[q * T + threadIdx.x];
 }
 
 extern "C" int dmd_reset_slots(const dmd_reset_slots_params* pp, dmd_stream_t stream) {
@@ -579,15 +590,16 @@ extern "C" int dmd_reset_slots(const dmd_reset_slots_params* pp, dmd_stream_t st
   DMD_CHECK_ARG(p.B >= 1 && p.K >= 0 && p.T >= 1 && p.T <= 256 && p.head >= 0 && p.head < p.T && p.per_frame > 0 && p.per_frame % 4 == 0,
                 "reset_slots: B %d, K %d, T %d, head %d, per_frame %lld", p.B, p.K, p.T, p.head, (long long)p.per_frame);
   DMD_CHECK_ARG(p.row_slot && p.next_obs && p.ctx && p.enc_in, "reset_slots: null");
-  DMD_CHECK_ARG(p.K == 0 || (p.slot_row && p.pool_frames && p.pool_act && p.pool_hx && p.pool_cx && p.act_ring && p.hx && p.cx && p.hd >= 1 &&
-                             p.pool_base >= 0), "reset_slots: null pool / state argument with K = %d slots", p.K);
+  const dmd_pool_round& p0 = p.pool[0];
+  DMD_CHECK_ARG(p.K == 0 || (p.slot_row && p0.frames && p0.act && p0.hx && p0.cx && p.act_ring && p.hx && p.cx && p.hd >= 1 && p.pool_base >= 0),
+                "reset_slots: null pool / state argument with K = %d slots", p.K);
+  const dmd_pool_round& p1 = p.pool[1];
+  DMD_CHECK_ARG(p.K == 0 || !p1.frames || (p.num_dead && p1.act && p1.hx && p1.cx && p0.rows >= 1), "reset_slots: second pool round without "
+                "its actions / states, the first round's row count or the device's death count");
   const int frames = p.B + p.T * p.K;
   DMD_CHECK_ARG(frames <= 65535, "reset_slots: %d frames in one launch", frames);
   const dim3 grid((unsigned)nblk((size_t)(p.per_frame / 4), 256), (unsigned)frames);
-  if (p.pool_is_f32)
-    hipLaunchKernelGGL(reset_slot_frames_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
-  else
-    hipLaunchKernelGGL(reset_slot_frames_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(reset_slot_frames_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
   DMD_LAUNCH_CHECK();
   if (p.K > 0) {
     hipLaunchKernelGGL(reset_slot_state_kernel, dim3((unsigned)p.K), dim3(256), 0, (hipStream_t)stream, p);

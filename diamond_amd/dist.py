@@ -18,12 +18,33 @@ from torch import Tensor, nn
 
 
 class GradAllReducer:
-    def __init__(self, params: Sequence[nn.Parameter], group=None) -> None:
-        self.params: List[nn.Parameter] = [p for p in params if p.requires_grad]
+    """early: parameters whose gradients are FINAL before the backward pass is over (the actor-critic's LSTM and heads: autograd
+    walks the window from its last step to its first and, inside a step, from the heads through the LSTM to the encoder -- so the
+    LSTM / head gradients are complete when step 0's LSTM node has run, while step 0's encoder backward is still to come).  They sit
+    at the front of the bucket, and as soon as autograd has accumulated the last of them (post-accumulate-grad hooks: each fires
+    once per backward, after the parameter's last use) their slice is all-reduced on a SIDE stream, under the rest of the backward
+    pass -- what DDP's bucket hooks do for the reference (utils.py:105-106), specialised to the two moments this path has.  At
+    64x64 the slice is 12.6 of 12.9 MB and the encoder's last backward ~1.4 ms; at 256x256 (configs[4]) it is 134 of 138.7 MB
+    (`lstm.weight_ih` is 2048 x 16384) against an encoder backward of tens of milliseconds.  all_reduce_mean() then reduces the rest
+    and waits for the early slice.  (One backward pass per all_reduce_mean(): with gradient accumulation over several passes
+    construct it without `early`.)"""
+
+    def __init__(self, params: Sequence[nn.Parameter], group=None, early: Sequence[nn.Parameter] = ()) -> None:
+        early_ids = {id(p) for p in early if p.requires_grad}
+        ps = [p for p in params if p.requires_grad]
+        self.params: List[nn.Parameter] = [p for p in ps if id(p) in early_ids] + [p for p in ps if id(p) not in early_ids]
         self.group = group
+        self.num_early = sum(1 for p in self.params if id(p) in early_ids)
+        self.early_numel = sum(p.numel() for p in self.params[:self.num_early])
+        self._early_left = self.num_early
+        self._early_work = None   # (async work handle, side stream | None) of the early slice's all-reduce in flight
+        self._side = None
+        self.early_launches = 0   # (tests: the early slice went out from inside backward())
         total = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.bucket = torch.zeros(total, device=ref.device, dtype=ref.dtype)
+        for p in self.params[:self.num_early]:
+            p.register_post_accumulate_grad_hook(self._early_ready)
         # measurement hook (bench.py): with `timing` on, every all_reduce_mean is bracketed by two events on the current
         # stream (the collective runs on RCCL's own stream, but a blocking dist.all_reduce makes the current stream wait
         # for it, so the pair spans it); `elapsed_ms()` reads them after a synchronisation
@@ -49,9 +70,38 @@ class GradAllReducer:
                 p.grad = view
             off += n
 
+    def _early_ready(self, p: Tensor) -> None:
+        """post-accumulate-grad hook of an early parameter: the last one of a backward pass sends the early slice off"""
+        self._early_left -= 1
+        if self._early_left > 0:
+            return
+        self._early_left = self.num_early
+        if not (dist.is_available() and dist.is_initialized()) or self._early_work is not None:
+            return
+        # the gradients must have been accumulated INTO the bucket's views (a replaced .grad is copied back by _ensure_views
+        # in all_reduce_mean: then this backward's early slice goes with the rest)
+        off = 0
+        for q in self.params[:self.num_early]:
+            if q.grad is None or q.grad.data_ptr() != self.bucket.data_ptr() + off * self.bucket.element_size():
+                return
+            off += q.numel()
+        sl = self.bucket[:self.early_numel]
+        if self.bucket.is_cuda:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.bucket.device)
+            self._side.wait_stream(torch.cuda.current_stream())  # the accumulations are on the current stream
+            with torch.cuda.stream(self._side):
+                work = dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            work = dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._early_work = work
+        self.early_launches += 1
+
     @torch.no_grad()
     def all_reduce_mean(self) -> Tensor:
-        self._ensure_views()
+        early_done, self._early_work = self._early_work, None
+        if early_done is None:
+            self._ensure_views()
         # (also at world size 1: the same RCCL call on the same bucket, so that a 1-GPU run of the distributed path
         #  exercises everything an N-GPU run does)
         if dist.is_available() and dist.is_initialized():
@@ -59,7 +109,13 @@ class GradAllReducer:
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group)
+            rest = self.bucket if early_done is None else self.bucket[self.early_numel:]
+            if rest.numel():
+                dist.all_reduce(rest, op=dist.ReduceOp.SUM, group=self.group)
+            if early_done is not None:
+                early_done.wait()  # (RCCL: the current stream waits for the collective's stream; gloo: the host does)
+                if self._side is not None:
+                    torch.cuda.current_stream().wait_stream(self._side)
             if dist.get_world_size(self.group) > 1:
                 self.bucket.div_(dist.get_world_size(self.group))
             if timed:

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import time
 import weakref
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Sequence, Tuple
@@ -150,6 +151,10 @@ class WeightAudit:
     Capturable: a replayed training step (GraphedTrainStep) rebuilds copies and re-records fingerprints inside the graph."""
 
     AUDIT_EVERY = 16384  # (lookups of one cache group between audits: about one audit per imagined window; 14 us per launch)
+    # ... and a byte budget: an audit reads every audited parameter once (eight workgroups per tensor), which is 14 us for the 64x64
+    # networks but 6.5 ms where `lstm.weight_ih` is 2048 x 32768 (configs[4]: 2 % of a window) -- at most AUDIT_BYTES_PER_S of
+    # parameter bytes are re-read per second of wall time, i.e. large models are audited every few windows instead of every window
+    AUDIT_BYTES_PER_S = 256e6
     CAPACITY = 4096
 
     def __init__(self, what: str) -> None:
@@ -164,6 +169,7 @@ class WeightAudit:
         self._pending = None
         self.ticks = 0
         self.audits = 0
+        self._last_run = 0.0  # time.monotonic() of the last tick-driven audit
 
     @staticmethod
     def _capturing() -> bool:
@@ -231,7 +237,11 @@ class WeightAudit:
     def tick(self) -> None:
         self.ticks += 1
         if self.ticks % self.AUDIT_EVERY == 0:
-            self.run()
+            now = time.monotonic()
+            nbytes = 4 * sum(p.numel() for p in (r() for r in self._refs) if p is not None)
+            if now - self._last_run >= nbytes / self.AUDIT_BYTES_PER_S:
+                self._last_run = now
+                self.run()
 
     def run(self) -> None:
         """Fingerprint the live parameters and compare with what the copies were built from (asynchronous; `check` reads it)."""

@@ -314,13 +314,15 @@ def _slots_env_loop(env, model, expo_fn: Optional[Callable[[Tensor], Tensor]], n
             rows_out.append([obs[:b], act, rew, end, trunc, logits_act, val, None])
             infos.append(info)
             obs = nxt
+        # the one wait of a window for its OWN last step (an overflow must show before the window is used) -- in front of the
+        # bootstrap pass, which then keeps the device busy while the host stacks the window and builds the loss
+        env.slots_finish()
         with torch.no_grad():
             _, vb, _, (h0, c0), vfin = _policy_step_slots(model, obs, hx, cx, slots)
         if slots is not None:  # deaths at the window's last step: the state the next window starts from is the burnt-in one
             vb = torch.where(slots.dead, vfin, vb)
             hx, cx = h0, c0
         rows_out[-1][-1] = vb
-        env.slots_finish()  # (the one wait of a window for its own last step: an overflow must show before the window is used)
         stacked = tuple(torch.stack(col, dim=1) for col in zip(*rows_out))
         return (*stacked, infos), (obs[:b], None, hx, cx)
 

@@ -86,10 +86,14 @@ class ChecksumJob(C.Structure):
 CHECKSUM_PARTS = 8
 
 
+class PoolRound(C.Structure):
+    _fields_ = [("frames", C.c_void_p), ("pad", C.c_void_p), ("act", C.c_void_p), ("hx", C.c_void_p), ("cx", C.c_void_p),
+                ("is_f32", C.c_int32), ("rows", C.c_int32)]
+
+
 class ResetSlotsParams(C.Structure):
     _fields_ = [("B", C.c_int32), ("K", C.c_int32), ("T", C.c_int32), ("head", C.c_int32), ("per_frame", C.c_int64),
-                ("pool_frames", C.c_void_p), ("pool_pad", C.c_void_p), ("pool_is_f32", C.c_int32), ("hd", C.c_int32),
-                ("pool_base", C.c_int64), ("pool_act", C.c_void_p), ("pool_hx", C.c_void_p), ("pool_cx", C.c_void_p),
+                ("hd", C.c_int32), ("reserved", C.c_int32), ("pool", PoolRound * 2), ("pool_base", C.c_int64), ("num_dead", C.c_void_p),
                 ("slot_row", C.c_void_p), ("row_slot", C.c_void_p), ("next_obs", C.c_void_p), ("ctx", C.c_void_p),
                 ("act_ring", C.c_void_p), ("hx", C.c_void_p), ("cx", C.c_void_p), ("enc_in", C.c_void_p)]
 

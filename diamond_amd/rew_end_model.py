@@ -200,8 +200,8 @@ class RewEndModel(nn.Module):
     def logits_with_grad(self, obs: Tensor, act: Tensor, next_obs: Tensor, precision: Optional[str] = None) -> Tensor:
         """predict_rew_end's logits (B, T, 5), from a zero LSTM state, differentiable w.r.t. every parameter.  Encoder:
         the inference kernels under a recorded tape with the hand-written backward (unet_train.EncoderTrainFn);
-        LSTM over the segment and the head: lstm_native.LinearFn / LstmStepFn; action embedding and the FiLM table
-        (tiny gathers / GEMMs) are torch ops under autograd."""
+        LSTM over the segment, the head and the FiLM-table GEMM: lstm_native.LinearFn / LstmStepFn (dmd_linear forward and
+        backward); the action embedding (a gather) is a torch op under autograd."""
         import torch.nn.functional as F
         from . import unet_train as UT
         from .blocks import AdaGroupNorm
@@ -214,8 +214,10 @@ class RewEndModel(nn.Module):
         if self._film is None:
             self._film = FilmTable(self.encoder)
         film = self._film
-        table = F.linear(cond, torch.cat([m.linear.weight for m in film.norms], dim=0),
-                         torch.cat([m.linear.bias for m in film.norms], dim=0))
+        # (the FiLM table of all AdaGroupNorm layers as ONE GEMM, forward and backward on dmd_linear like the denoiser's
+        #  training step; autograd carries the table gradient into the concatenated weights -- torch.cat's backward is a split)
+        table = LinearFn.apply(self._cache, cond, torch.cat([m.linear.weight for m in film.norms], dim=0),
+                               torch.cat([m.linear.bias for m in film.norms], dim=0))
         if self._train_params is None:
             skip = {id(p) for m in self.encoder.modules() if isinstance(m, AdaGroupNorm) for p in m.parameters()}
             self._train_params = [p for p in self.encoder.parameters() if id(p) not in skip]

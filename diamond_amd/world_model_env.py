@@ -132,6 +132,46 @@ class WorldModelEnvConfig:
     diffusion_sampler: DiffusionSamplerConfig
 
 
+class _Round:
+    """One preloaded round of initial conditions.  Whether it is kept as uint8 levels or as fp32 frames depends on three device
+    counters (values off the 256-level grid, padded frames, padded frames that are not zero): they travel to a pinned buffer
+    behind the round's kernels and are read when the round is first USED -- a prefetched round costs no host wait."""
+
+    def __init__(self, q_, f_, act: Tensor, hx: Tensor, cx: Tensor, pad_, counters: Tensor) -> None:
+        self._q, self._f, self.act, self.hx, self.cx, self._pad = q_, f_, act, hx, cx, pad_
+        self._fields = None
+        if counters.is_cuda:
+            self._host = torch.zeros(3, dtype=torch.int64).pin_memory()
+            self._host.copy_(counters, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
+        else:
+            self._host, self._event = counters.clone(), None
+
+    def fields(self):
+        """(frames_u8, frames_f32, act, hx, cx, pad) -- decided once"""
+        if self._fields is None:
+            if self._event is not None:
+                self._event.synchronize()
+            n_off, n_pad, n_pad_nonzero = self._host.tolist()
+            pad = None
+            if n_off == 0 and n_pad_nonzero == 0:
+                frames_u8, frames_f32 = torch.cat(self._q), None
+                if n_pad:
+                    pad = torch.cat(self._pad)
+            else:
+                if not InitialConditionPool._warned_fp32:
+                    InitialConditionPool._warned_fp32 = True
+                    import warnings
+
+                    warnings.warn(f"initial-condition pool: {n_off + n_pad_nonzero} preloaded values are not on the uint8 grid "
+                                  "(x = k / 255 * 2 - 1): keeping this pool in fp32 (4x the memory; results are unchanged)")
+                frames_u8, frames_f32 = None, torch.cat(self._f)
+            self._fields = (frames_u8, frames_f32, self.act, self.hx, self.cx, pad)
+            self._q = self._f = self._pad = None
+        return self._fields
+
+
 class InitialConditionPool:
     """Device-resident queue of (context frames, context actions, burnt-in reward/end LSTM state).
 
@@ -163,18 +203,20 @@ class InitialConditionPool:
         # would fall back to fp32.  Frames the loader itself marks as padding (batch.mask_padding False) and that ARE zero are
         # therefore stored as a stand-in level and put back as exact zeros behind the dequantising gather.
         self.pad: Optional[Tensor] = None
+        self._next: Optional[_Round] = None  # the prefetched next round (prefetch)
+        self._copy_stream = None
 
     @property
     def size(self) -> int:
         return 0 if self.act is None else self.act.shape[0]
 
-    _FIELDS = ("frames_u8", "frames_f32", "act", "hx", "cx", "pad", "_cursor", "_generation")
+    _FIELDS = ("frames_u8", "frames_f32", "act", "hx", "cx", "pad", "_cursor", "_generation", "_next")
 
     def snapshot(self):
         """What a window's repetition needs to see the same pool again (env_loop repeats a window after a SlotOverflow): the
-        current round and cursor; the rounds preloaded from now on are remembered and served again after `restore` -- the
-        loader's iterator cannot be rewound."""
-        self._recorded: List[tuple] = []
+        current round, the cursor and the prefetched round; rounds loaded from now on are remembered and served again, in order,
+        after `restore` -- the loader's iterator cannot be rewound."""
+        self._recorded: List["_Round"] = []
         return tuple(getattr(self, f) for f in self._FIELDS)
 
     def restore(self, snap) -> None:
@@ -183,21 +225,29 @@ class InitialConditionPool:
         self._replay = list(getattr(self, "_recorded", [])) + list(getattr(self, "_replay", []))
         self._recorded = []
 
-    @torch.no_grad()
-    def _preload(self) -> None:
+    def _next_round(self) -> "_Round":
         replay = getattr(self, "_replay", None)
-        if replay:  # a round a repeated window already preloaded once
-            for f, v in zip(self._FIELDS, replay.pop(0)):
-                setattr(self, f, v)
-            if hasattr(self, "_recorded"):
-                self._recorded.append(tuple(getattr(self, f) for f in self._FIELDS))
-            return
-        self._preload_from_loader()
+        r = replay.pop(0) if replay else self._load_round()  # (a round a repeated window already loaded once)
         if hasattr(self, "_recorded"):
-            self._recorded.append(tuple(getattr(self, f) for f in self._FIELDS))
+            self._recorded.append(r)
+        return r
+
+    def prefetch(self) -> None:
+        """Load the NEXT round now (loader batches, upload, reward/end burn-in, quantisation: all asynchronous) without touching
+        the current one.  The rounds are what the reference's generator would preload, in its order; only the moment differs."""
+        if self._next is None:
+            self._next = self._next_round()
 
     @torch.no_grad()
-    def _preload_from_loader(self) -> None:
+    def _preload(self) -> None:
+        """The current round is replaced by the next one (reference :133-139: the remainder is dropped)."""
+        r, self._next = (self._next if self._next is not None else self._next_round()), None
+        self.frames_u8, self.frames_f32, self.act, self.hx, self.cx, self.pad = r.fields()
+        self._cursor = 0
+        self._generation += 1
+
+    @torch.no_grad()
+    def _load_round(self) -> "_Round":
         if self._iter is None:
             self._iter = iter(self._loader)
         dev = self._device_fn()
@@ -205,17 +255,33 @@ class InitialConditionPool:
         off_grid = torch.zeros(1, dtype=torch.int32, device=dev)
         pad_count = torch.zeros(1, dtype=torch.int64, device=dev)  # padded frames / values in them that are not zero
         pad_nonzero = torch.zeros(1, dtype=torch.int64, device=dev)
+        side = None
+        if dev.type == "cuda":  # uploads on a stream of their own: the copy engine works while the compute queue drains
+            if self._copy_stream is None:
+                self._copy_stream = torch.cuda.Stream(device=dev)
+            side = self._copy_stream
         for _ in range(self._num_batches):
             with _no_random_draws(dev, "the initial-condition loader", cpu=self._watch_cpu_rng):
                 batch = next(self._iter)
-            obs = batch.obs.to(dev, non_blocking=True).float().contiguous()  # async when the loader pins its batches
-            act = batch.act.to(dev, non_blocking=True).long()  # (a loader may yield int32 / uint8 actions: the rings are int64)
+            mask = getattr(batch, "mask_padding", None) if self.PAD_AWARE else None
+            if side is not None:
+                with torch.cuda.stream(side):
+                    obs_up = batch.obs.to(dev, non_blocking=True)  # async when the loader pins its batches
+                    act_up = batch.act.to(dev, non_blocking=True)
+                    mask_up = None if mask is None else mask.to(dev, non_blocking=True)
+                torch.cuda.current_stream().wait_stream(side)
+                for t_ in (obs_up, act_up, mask_up):
+                    if t_ is not None:
+                        t_.record_stream(torch.cuda.current_stream())
+            else:
+                obs_up, act_up, mask_up = batch.obs.to(dev), batch.act.to(dev), None if mask is None else mask.to(dev)
+            obs = obs_up.float().contiguous()
+            act = act_up.long()  # (a loader may yield int32 / uint8 actions: the rings are int64)
             *_, (hx, cx) = self._model.predict_rew_end(obs[:, :-1], act[:, :-1], obs[:, 1:])
             assert hx.size(0) == cx.size(0) == 1
-            mask = getattr(batch, "mask_padding", None) if self.PAD_AWARE else None
-            pad = None if mask is None else ~mask.to(dev, non_blocking=True).bool()
+            pad = None if mask_up is None else ~mask_up.bool()
             src = obs
-            if pad is not None:  # (the stand-in is level 0; what the frames really hold is checked below, with the same sync)
+            if pad is not None:  # (the stand-in is level 0; what the frames really hold is checked when the round is first used)
                 where = pad[:, :, None, None, None]
                 pad_count += pad.sum()
                 pad_nonzero += (obs.masked_fill(~where, 0.0) != 0).sum()
@@ -229,24 +295,7 @@ class InitialConditionPool:
             hx_.append(hx[0])
             cx_.append(cx[0])
             pad_.append(pad if pad is not None else torch.zeros(obs.shape[:2], dtype=torch.bool, device=dev))
-        n_off, n_pad, n_pad_nonzero = torch.cat([off_grid.long(), pad_count, pad_nonzero]).tolist()  # one sync per preload round
-        self.pad = None
-        if n_off == 0 and n_pad_nonzero == 0:
-            self.frames_u8, self.frames_f32 = torch.cat(q_), None
-            if n_pad:
-                self.pad = torch.cat(pad_)
-        else:
-            off_grid = torch.tensor([n_off + n_pad_nonzero])
-            if not InitialConditionPool._warned_fp32:
-                InitialConditionPool._warned_fp32 = True
-                import warnings
-
-                warnings.warn(f"initial-condition pool: {int(off_grid.item())} preloaded values are not on the uint8 grid "
-                              "(x = k / 255 * 2 - 1): keeping this pool in fp32 (4x the memory; results are unchanged)")
-            self.frames_u8, self.frames_f32 = None, torch.cat(f_)
-        self.act, self.hx, self.cx = torch.cat(act_), torch.cat(hx_), torch.cat(cx_)
-        self._cursor = 0
-        self._generation += 1
+        return _Round(q_, f_, torch.cat(act_), torch.cat(hx_), torch.cat(cx_), pad_, torch.cat([off_grid.long(), pad_count, pad_nonzero]))
 
     def peek(self, count: int) -> Tuple[Tensor, Tuple[int, int]]:
         """Device index vector of the next `count` pool rows WITHOUT serving them (preloading when the pool runs short, exactly
@@ -351,8 +400,9 @@ class WorldModelEnv:
         self._void_events, self._void_frac = 0.0, 0.0     # running averages: steps with unplanned deaths, their share of the rows
         self._slots_inflight = None                       # (event, pinned report, K, pool token) of the last step_end_slots
         self._end_mean = getattr(self, "_end_mean", 0.0)  # running mean of sampled `end`s per step (survives a reset())
+        self._end_last = getattr(self, "_end_last", 0)    # ... and the last step's count
         self.stats = {"steps": 0, "steps_with_deaths": 0, "planned_rows": 0, "void_rows": 0, "repairs": 0, "speculated": 0,
-                      "slots": 0, "dead_rows": 0, "slot_overflows": 0, "sync_steps": 0}
+                      "slots": 0, "dead_rows": 0, "slot_overflows": 0, "sync_steps": 0, "pool_rounds": 0}
 
     @property
     def device(self) -> torch.device:
@@ -703,18 +753,26 @@ class WorldModelEnv:
     # builds the policy's next input, and the host reads the step's report while it issues the NEXT step: always one step behind
     # a device that holds a full step of queued work.  Exact: per row the reference's arithmetic and pool order; no random draw
     # depends on it.  More deaths than slots (SlotOverflow, about once in 1e7 steps by the margin's design) repeats the window.
-    DR_END_TAIL = 1e-7  # per-step probability the margin for sampled ends accepts of running out of slots
+    # per-step probability the margin for sampled ends accepts of running out of slots: a repeated window per ~10,000 steps
+    # (0.15 % of the time) against four encoder frames per step and spare slot (forward and backward)
+    DR_END_TAIL = 1e-4
+    PREFETCH_STEPS = 6  # the next pool round is loaded when fewer than this many steps' worth of slots is left in the current one
 
     def slot_count(self, all_slots: bool = False) -> int:
         """Reset slots of the pending step: the truncations it WILL have (host mirror of ep_len, exact) + a Poisson-tail margin for
-        the `end`s the reward/end model may sample, from the running mean of ends per step; multiples of 8, at most one per env."""
+        the `end`s the reward/end model may sample, from the running mean of ends per step; multiples of 4, at most one per env."""
         b = self.num_envs
         if all_slots or self._ep_len_host is None:
             return b
         n_trunc = int(np.count_nonzero(self._ep_len_host + 1 >= self.horizon))
-        m = self._end_mean
+        m = max(self._end_mean, float(self._end_last))  # (fast attack: a regime whose ends jump up is believed at once)
         k = n_trunc + (0 if m < 1e-3 else _poisson_quantile(m, self.DR_END_TAIL))
-        return 0 if k == 0 else min(b, (k + 7) // 8 * 8)
+        return 0 if k == 0 else min(b, (k + 3) // 4 * 4)
+
+    def reset_statistics(self) -> None:
+        """Forget the running statistics the slot margin is sized from (a caller that CHANGES the regime, e.g. bench.py between its
+        end-rate lines; otherwise they adapt within ~20 steps)."""
+        self._end_mean, self._end_last = 0.0, 0
 
     def slots_can_repeat(self) -> bool:
         """Can a window be repeated after a SlotOverflow?  Not when random draws come from stateful hooks (the tests' injected
@@ -757,27 +815,18 @@ class WorldModelEnv:
         else:
             host, event = report.clone(), None
         pool = self.pool
-        token = None
+        token, two_rounds = None, False
         if k > 0:
             if pool.size == 0:
                 pool._preload()
-            if pool._cursor + k <= pool.size:  # whatever dies, no preload decision depends on it
-                token = (pool._generation, pool._cursor)
-                base = pool._cursor
-                self._slots_inflight = (event, host, k, token)
-            else:
-                # the pool may run short: whether it is replaced depends on the exact count (the reference drops the remainder and
-                # preloads when a request does not fit, :133-139) -- this step waits for its own report (rare: once per pool round)
-                self.stats["sync_steps"] += 1
-                if event is not None:
-                    event.synchronize()
-                n_dead = int(host[b])
-                base, token = pool.peek_start(min(n_dead, k)) if n_dead else (pool._cursor, (pool._generation, pool._cursor))
-                self._slots_account(host.numpy(), k, token)
-        else:
-            base = 0
-            self._slots_inflight = (event, host, k, None)
-        frames = pool.frames_u8 if pool.frames_u8 is not None else pool.frames_f32
+            token = (pool._generation, pool._cursor)
+            # The reference drops the rest of a round and preloads the next one when a request does not fit (:133-139): whether that
+            # happens depends on this step's exact number of deaths.  If it MAY happen (k slots would not fit), the launch gets both
+            # rounds and the device picks by the count (dmd_reset_slots); the host follows when it reads the report.
+            two_rounds = pool._cursor + k > pool.size
+            if two_rounds:
+                pool.prefetch()  # (normally loaded steps ago, below)
+        self._slots_inflight = (event, host, k, token, two_rounds)
         oldest = self._head
         self._head = (self._head + 1) % t
         enc_in = torch.empty((b + t * k,) + tuple(next_obs.shape[1:]), dtype=torch.float32, device=dev)
@@ -785,11 +834,24 @@ class WorldModelEnv:
         p = nv.ResetSlotsParams()
         p.B, p.K, p.T, p.head, p.per_frame = b, k, t, self._head, nxt[0].numel()
         p.row_slot, p.next_obs, p.ctx, p.enc_in = nv.ptr(row_slot), nv.fptr(nxt), nv.fptr(self._ctx), nv.fptr(enc_in)
+        keep = []
         if k > 0:
-            assert frames.is_contiguous() and pool.act.dtype == torch.long and pool.act.is_contiguous() and self._act.is_contiguous()
-            p.pool_frames, p.pool_is_f32, p.pool_base = nv.ptr(frames), int(pool.frames_u8 is None), int(base)
-            p.pool_pad = nv.ptr(pool.pad.view(torch.uint8)) if (pool.pad is not None and pool.frames_u8 is not None) else None
-            p.pool_act, p.pool_hx, p.pool_cx, p.hd = nv.ptr(pool.act), nv.fptr(pool.hx), nv.fptr(pool.cx), pool.hx.shape[-1]
+            assert self._act.is_contiguous() and self._act.dtype == torch.long
+            rounds = [(pool.frames_u8, pool.frames_f32, pool.act, pool.hx, pool.cx, pool.pad)] + ([pool._next.fields()] if two_rounds else [])
+            for i, (fu8, ff32, pact, phx, pcx, ppad) in enumerate(rounds):
+                frames = fu8 if fu8 is not None else ff32
+                assert frames.is_contiguous() and pact.dtype == torch.long and pact.is_contiguous()
+                r = p.pool[i]
+                r.frames, r.is_f32, r.rows = nv.ptr(frames), int(fu8 is None), frames.shape[0]
+                if ppad is not None and fu8 is not None:
+                    pad_u8 = ppad.view(torch.uint8)
+                    keep.append(pad_u8)
+                    r.pad = nv.ptr(pad_u8)
+                r.act, r.hx, r.cx = nv.ptr(pact), nv.fptr(phx), nv.fptr(pcx)
+            if two_rounds:
+                assert k <= rounds[1][2].shape[0], "more simultaneous resets than one preload round holds"
+                p.num_dead = report.data_ptr() + 4 * b
+            p.pool_base, p.hd = int(pool._cursor), pool.hx.shape[-1]
             p.slot_row, p.act_ring, p.hx, p.cx = nv.ptr(slot_row), nv.ptr(self._act), nv.fptr(self.hx_rew_end), nv.fptr(self.cx_rew_end)
         with _no_random_draws(dev, "WorldModelEnv.step_end_slots"):
             nv.check(lib.dmd_reset_slots(C.byref(p), nv.stream()), "dmd_reset_slots")
@@ -800,6 +862,11 @@ class WorldModelEnv:
         self.stats["steps"] += 1
         self.stats["slots"] += k
         slots = ResetSlots(k, slot_row[:k], row_slot, dead_b) if k > 0 else None
+        # the next round ahead of need: its uploads, burn-in and quantisation are queued behind this step, steps before the round
+        # can be asked for (nothing waits for it; the loader's batches are consumed in the reference's order, only earlier)
+        if k > 0 and pool._next is None and pool.size - pool._cursor < self.PREFETCH_STEPS * k:
+            with _no_random_draws(dev, "the initial-condition pool's prefetch", cpu=False):
+                pool.prefetch()
         return enc_in, rew, end, trunc, slots, info
 
     def slots_finish(self) -> None:
@@ -808,20 +875,21 @@ class WorldModelEnv:
         inflight, self._slots_inflight = self._slots_inflight, None
         if inflight is None:
             return
-        event, host, k, token = inflight
+        event, host, k, token, two_rounds = inflight
         if event is not None:
             event.synchronize()
             check_weight_audits()  # (the host is synchronised anyway: did an audit of the packed weight copies find a silent write?)
-        self._slots_account(host.numpy(), k, token)
+        self._slots_account(host.numpy(), k, token, two_rounds)
 
-    def _slots_account(self, report: np.ndarray, k: int, token) -> None:
+    def _slots_account(self, report: np.ndarray, k: int, token, two_rounds: bool) -> None:
         b = self.num_envs
         n_dead, n_end, overflow = int(report[b]), int(report[b + 1]), int(report[b + 2])
         rows_host = np.flatnonzero(report[:b])
         if self._ep_len_host is not None:
             self._ep_len_host += 1
             self._ep_len_host[rows_host] = 0
-        self._end_mean = 0.98 * self._end_mean + 0.02 * n_end
+        self._end_mean = 0.95 * self._end_mean + 0.05 * n_end
+        self._end_last = n_end
         self.stats["dead_rows"] += n_dead
         if n_dead:
             self.stats["steps_with_deaths"] += 1
@@ -829,7 +897,13 @@ class WorldModelEnv:
             self.stats["slot_overflows"] += 1
             raise SlotOverflow(f"{n_dead} episodes ended in a step with {k} reset slots")
         if n_dead:
-            self.pool.commit(token, n_dead)
+            pool = self.pool
+            assert token == (pool._generation, pool._cursor), "pool rows were served between a step's launch and its report"
+            if pool._cursor + n_dead > pool.size:  # the device served this step from the next round (dmd_reset_slots): follow it
+                assert two_rounds
+                pool._preload()
+                self.stats["pool_rounds"] += 1
+            pool._cursor += n_dead
 
     @torch.no_grad()
     def slots_snapshot(self):

@@ -298,19 +298,27 @@ int dmd_resolve_deaths(const int64_t* end, int64_t* ep_len, int horizon, int64_t
  * enc_in (B + T * K, per_frame) = [ newest frame of every env (a reset row: of its NEW episode)
  *                                  | final observation of slot j (env_loop.py:49)
  *                                  | burn-in frame t of slot j, frame-major, t < T - 1 (env_loop.py:53-56) ]
- * in one call (two launches).  head = the ring's head AFTER the advance.  pool_frames: (P, T, per_frame) uint8 (dequantised as
- * dmd_dequant_gather does; pool_pad (P, T) uint8, optional: frames that are exact zeros) or fp32 (pool_is_f32).  Unused slots
- * produce copies of row 0's imagined frame in enc_in and touch nothing else. */
+ * in one call (two launches).  head = the ring's head AFTER the advance.  A pool round: frames (P, T, per_frame) uint8 (dequantised
+ * as dmd_dequant_gather does; pad (P, T) uint8, optional: frames that are exact zeros) or fp32 (is_f32), act (P, T) int64, hx / cx
+ * (P, hd) fp32.  TWO rounds may be given: the reference drops the rest of a round and preloads the next one when a request does not
+ * fit (world_model_env.py:133-139) -- a decision that depends on the step's number of deaths, which only the device knows at launch
+ * time: with pool[1].frames and num_dead set, the slots are served from pool[1] rows 0.. iff pool_base + *num_dead > pool[0].rows.
+ * Unused slots produce copies of row 0's imagined frame in enc_in and touch nothing else. */
+typedef struct dmd_pool_round {
+  const void* frames;
+  const uint8_t* pad;
+  const int64_t* act;
+  const float* hx;
+  const float* cx;
+  int32_t is_f32, rows;
+} dmd_pool_round;
 typedef struct dmd_reset_slots_params {
   int32_t B, K, T, head;
   int64_t per_frame; /* C * H * W, a multiple of 4 */
-  const void* pool_frames;
-  const uint8_t* pool_pad;
-  int32_t pool_is_f32, hd; /* hd: width of the reward/end LSTM state */
-  int64_t pool_base;
-  const int64_t* pool_act; /* (P, T) */
-  const float* pool_hx;    /* (P, hd) */
-  const float* pool_cx;
+  int32_t hd, reserved; /* hd: width of the reward/end LSTM state */
+  dmd_pool_round pool[2];
+  int64_t pool_base;       /* first row of pool[0] this step would be served from */
+  const int32_t* num_dead; /* device: the step's number of dead rows (dmd_resolve_deaths' report + B); NULL with one round */
   const int64_t* slot_row; /* (K), from dmd_resolve_deaths */
   const int32_t* row_slot; /* (B) */
   const float* next_obs;   /* (B, per_frame): the imagined frames of this step */

@@ -123,12 +123,13 @@ def test_struct_layouts_match_the_header():
     structs = [("dmd_norm", native.Norm), ("dmd_conv_src", native.ConvSrc), ("dmd_conv_params", native.ConvParams),
                ("dmd_linear_params", native.LinearParams), ("dmd_gn_bwd_params", native.GnBwdParams),
                ("dmd_wgrad_params", native.WgradParams), ("dmd_wgrad_reduce_job", native.WgradReduceJob), ("dmd_chain_block", native.ChainBlock),
-               ("dmd_lowres_chain_params", native.LowresChainParams), ("dmd_reset_slots_params", native.ResetSlotsParams)]
+               ("dmd_lowres_chain_params", native.LowresChainParams), ("dmd_reset_slots_params", native.ResetSlotsParams),
+               ("dmd_pool_round", native.PoolRound)]
     offsets = [("dmd_conv_params", native.ConvParams, "w_f16"), ("dmd_conv_params", native.ConvParams, "precision"),
                ("dmd_wgrad_params", native.WgradParams, "precision"), ("dmd_wgrad_params", native.WgradParams, "defer_reduce"),
                ("dmd_wgrad_reduce_job", native.WgradReduceJob, "ld_cin"), ("dmd_chain_block", native.ChainBlock, "w1"),
                ("dmd_chain_block", native.ChainBlock, "bo"), ("dmd_lowres_chain_params", native.LowresChainParams, "table_stride"),
-               ("dmd_lowres_chain_params", native.LowresChainParams, "blocks"), ("dmd_reset_slots_params", native.ResetSlotsParams, "pool_base"),
+               ("dmd_lowres_chain_params", native.LowresChainParams, "blocks"), ("dmd_reset_slots_params", native.ResetSlotsParams, "pool_base"), ("dmd_reset_slots_params", native.ResetSlotsParams, "num_dead"),
                ("dmd_reset_slots_params", native.ResetSlotsParams, "enc_in")]
     body = "".join(f'printf("%zu ", sizeof({c}));' for c, _ in structs)
     body += "".join(f'printf("%zu ", offsetof({c}, {f}));' for c, _, f in offsets)

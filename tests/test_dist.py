@@ -57,6 +57,21 @@ def _worker(rank, world, port, q):
     flat = red.all_reduce_mean().clone()
     views_ok = all(p.grad.data_ptr() >= red.bucket.data_ptr() and
                    p.grad.data_ptr() < red.bucket.data_ptr() + red.bucket.numel() * 4 for p in ac.parameters())
+    # the early slice (LSTM + heads, final before the encoder's backward is over) all-reduced from INSIDE backward() by the
+    # post-accumulate hooks, the rest afterwards: the same mean gradients as the one blocking call above
+    ac4 = D.ActorCritic(D.default_agent_config().actor_critic)
+    fill_module_(ac4, 5)
+    red4 = GradAllReducer(list(ac4.parameters()), early=[p_ for n_, p_ in ac4.named_parameters() if not n_.startswith("encoder.")])
+    early_ok = 0 < red4.num_early < len(red4.params) and red4.early_launches == 0
+    for rep in range(2):  # (twice: the hooks re-arm, zero_grad(set_to_none=False) keeps the bucket views)
+        logits, val = predict(ac4, obs)
+        (logits.square().mean() + val.mean()).backward()
+        early_ok = early_ok and red4.early_launches == rep + 1 and red4._early_work is not None
+        red4.all_reduce_mean()
+        early_ok = early_ok and red4._early_work is None and all(
+            bool(torch.allclose(p4.grad, p1.grad, rtol=1e-6, atol=1e-9)) for (n4, p4), (n1, p1) in zip(ac4.named_parameters(), ac.named_parameters()))
+        if rep == 0:
+            ac4.zero_grad(set_to_none=False)
     # the world-model parameters go through the same flat bucket (the reference DDP-wraps all three sub-models,
     # trainer.py:110): rank-dependent gradient pattern -> mean over the ranks; and torch's own DistributedDataParallel
     # constructor (utils.py:105-106: parameter verification + broadcast from rank 0) accepts the module
@@ -84,7 +99,7 @@ def _worker(rank, world, port, q):
         (logits.square().mean() + val.mean()).backward()
         ref = torch.cat([p.grad.reshape(-1) for p in ac2.parameters()])
         q.put(float((flat - ref).abs().max() / ref.abs().max()))
-        q.put(bool(views_ok and bumped and same_params and wm_ok and ddp_ok))
+        q.put(bool(views_ok and bumped and same_params and wm_ok and ddp_ok and early_ok))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -308,7 +308,7 @@ def test_oracle_on_configurations_wider_than_the_default_one():
 def test_committed_fixtures_regenerate_from_the_reference(tmp_path, monkeypatch):
     """The committed fixtures ARE what the reference computes here and now: a subset of them (the cheap ones: seconds) regenerated
     by the committed generator into a scratch directory and compared tensor by tensor with tests/golden/.  (All of them were
-    regenerated and compared this way at the end of round 5: 0 differing tensors)"""
+    regenerated and compared this way at the end of round 5: 0 differing tensors, HISTORY.md section 6.)"""
     import importlib.util
 
     spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))

@@ -777,13 +777,40 @@ def test_reset_slots_is_the_ring_advance_plus_the_reference_reset(u8, pad):
     burn[:, :3] = frames[idx, :t - 1].transpose(1, 0, 2)
     want_enc = np.concatenate([obs, fin, burn.reshape(-1, per)])
     enc = np.full((b + t * k, per), np.nan, dtype=f32)
+    def round_(frames_, pad_, act_, hx_, cx_, f32_):
+        r = nv.PoolRound()
+        r.frames, r.pad, r.act, r.hx, r.cx, r.is_f32, r.rows = S.ptr(frames_), S.ptr(pad_), S.ptr(act_), S.ptr(hx_), S.ptr(cx_), int(f32_), frames_.shape[0]
+        return r
+
     p = nv.ResetSlotsParams()
-    p.B, p.K, p.T, p.head, p.per_frame, p.hd, p.pool_base, p.pool_is_f32 = b, k, t, head, per, hd, base, 0 if u8 else 1
-    p.pool_frames, p.pool_pad, p.pool_act, p.pool_hx, p.pool_cx = S.ptr(pool), S.ptr(padm) if (pad and u8) else None, S.ptr(pool_act), S.ptr(pool_hx), S.ptr(pool_cx)
+    p.B, p.K, p.T, p.head, p.per_frame, p.hd, p.pool_base = b, k, t, head, per, hd, base
+    p.pool[0] = round_(pool, padm if (pad and u8) else None, pool_act, pool_hx, pool_cx, not u8)
     p.slot_row, p.row_slot, p.next_obs, p.ctx, p.act_ring, p.hx, p.cx, p.enc_in = (S.ptr(a) for a in (slot_row, row_slot, nxt, ctx, act, hx, cx, enc))
+    start = [a.copy() for a in (ctx, act, hx, cx)]
     S.check(L.dmd_reset_slots(C.byref(p), None), "reset_slots")
     for got, w, name in zip((ctx, act, hx, cx, enc), (w_ctx, w_act, w_hx, w_cx, want_enc), ("ctx", "act", "hx", "cx", "enc_in")):
         assert np.array_equal(got, w), name
+    # two rounds: the step's deaths fit what is left of the first one (rows base .. base + 3 <= p_) -> the same result; they do
+    # not (a first round of base + 2 rows) -> the SECOND round's rows 0.. (the reference drops the remainder and preloads, :133-139)
+    n_dead = np.array([3], dtype=np.int32)
+    other = (rng.integers(0, 256, (p_, t, per)).astype(np.uint8), rng.integers(0, 18, (p_, t)).astype(np.int64),
+             rng.standard_normal((p_, hd)).astype(f32), rng.standard_normal((p_, hd)).astype(f32))
+    p.num_dead = S.ptr(n_dead)
+    for first_is_short in (False, True):
+        for a, a0 in zip((ctx, act, hx, cx), start):
+            a[...] = a0
+        enc[...] = np.nan
+        if first_is_short:  # the round used above is now the SECOND one: served from its row 0
+            p.pool[1] = round_(pool[base:], padm[base:] if (pad and u8) else None, pool_act[base:], pool_hx[base:], pool_cx[base:], not u8)
+            p.pool[0] = round_(other[0][:base + 2], None, other[1], other[2], other[3], False)
+        else:
+            p.pool[1] = round_(*((other[0], None) + other[1:]), False)
+        S.check(L.dmd_reset_slots(C.byref(p), None), "reset_slots, two rounds")
+        for got, w, name in zip((ctx, act, hx, cx, enc), (w_ctx, w_act, w_hx, w_cx, want_enc), ("ctx", "act", "hx", "cx", "enc_in")):
+            assert np.array_equal(got, w), (first_is_short, name)
+    p.pool[0] = round_(pool, padm if (pad and u8) else None, pool_act, pool_hx, pool_cx, not u8)
+    p.pool[1] = nv.PoolRound()
+    p.num_dead = None
     # no slots at all: the ring advance and a copy of the imagined frames
     ctx2, enc2 = rng.standard_normal((b, t, per)).astype(f32), np.full((b, per), np.nan, dtype=f32)
     w2 = ctx2.copy()

@@ -98,6 +98,8 @@ def main():
             for name in arms:
                 env = arms[name][0]
                 ep = (torch.arange(256) % 15) if stagger else torch.zeros(256, dtype=torch.long)
+                if hasattr(env, "reset_statistics"):
+                    env.reset_statistics()
                 if hasattr(env, "set_episode_lengths"):
                     env.set_episode_lengths(ep)
                 else:

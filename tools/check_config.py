@@ -10,7 +10,7 @@ the same configuration and the same (name-keyed) weights, runs both on the same 
 Build container only: it imports /root/reference (tests/golden/_refimport.py) and, without a GPU, runs the product's host code
 against the SIMT-interpreter build of the kernels (tests/simt: test infrastructure -- correctness of the arithmetic and of the host
 orchestration, nothing about speed or the hardware's memory ordering).  With a GPU (`--device cuda`) the product runs as shipped.
-This is how the configurations listed in DESIGN.md section 4 ("Configurations other than the published one") were probed."""
+This is how the configurations listed in HISTORY.md section 4 ("Configurations other than the published one") were probed."""
 import argparse
 import contextlib
 import os

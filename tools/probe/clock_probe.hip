@@ -1,4 +1,4 @@
-// Which clock does the chip run, by instruction mix?  (round 4, DESIGN.md §3 "clock")  A counter-free measurement:
+// Which clock does the chip run, by instruction mix?  (round 4, HISTORY.md §3 "clock")  A counter-free measurement:
 // a kernel whose instruction count is known exactly runs for seconds; achieved rate / (work per cycle) = shader clock.
 //   mode mfma : every wave issues independent v_mfma_f32_32x32x16_f16 (4 accumulators) back to back: 32 cycles each per SIMD
 //               (8 passes x 4), i.e. 1024 FLOP / cycle / SIMD  ->  clock = FLOP/s / (1024 x SIMDs)

@@ -1,4 +1,4 @@
-// What does an instruction of a CO-RESIDENT wave cost the MFMA stream of a SIMD?  (round 3)
+// What does an instruction of a CO-RESIDENT wave cost the MFMA stream of a SIMD?  (round 3, HISTORY.md §3)
 // 768-thread workgroups, one per CU: waves 0-3 (one per SIMD) issue dependent-pair v_mfma_f32_32x32x16_f16 like the
 // consumers of conv_f16ws_kernel; waves 8-11 (their SIMD partners) issue K instructions of one kind per 108 MFMAs;
 // waves 4-7 idle at the barriers.  One s_barrier per "step" of 108 MFMAs, as in the real kernel.  Output: shader-clock

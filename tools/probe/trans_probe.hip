@@ -1,4 +1,4 @@
-// What does a transcendental cost on a gfx950 SIMD, and does it share the port with plain VALU work?  (round 4, DESIGN.md §6:
+// What does a transcendental cost on a gfx950 SIMD, and does it share the port with plain VALU work?  (round 4, HISTORY.md §6:
 // the attention kernel's bound at head_dim 8 is one exponential per (query, key) pair.)  s_memtime ticks are effective shader
 // cycles (profiles/r04_clock.json), so ticks / instruction of a dependency-free stream = issue cycles per wave64 instruction.
 //   exp, rcp       : 16 independent chains of v_exp_f32 / v_rcp_f32
