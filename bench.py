@@ -705,6 +705,9 @@ def main():
                     help="configs[1] as rounds 1-5 measured it: synchronised episodes, nobody ends mid-window (all envs truncate together "
                          "at the window boundary)")
     ap.add_argument("--foreach-adamw", action="store_true", help="--config train: the capturable FOREACH AdamW instead of the fused one (A/B)")
+    ap.add_argument("--gc", choices=("default", "off", "window"), default="default",
+                    help="A/B of python's cyclic garbage collector during the timed region: off = gc.disable(); window = disabled, with one "
+                         "gc.collect() between windows (outside no kernel's critical path)")
     ap.add_argument("--no-also", action="store_true", help="skip the extra measurements the default configs[1] line carries (`also`)")
     ap.add_argument("--pmc-calibrate", action="store_true",
                     help="two Heun updates over 256 MiB arrays before the window (tools/pmc_collect.sh: a known byte count for the FETCH_SIZE / "
@@ -787,6 +790,20 @@ def main():
             print(f"[bench +{time.perf_counter() - t_start:.1f}s] {msg}", file=sys.stderr, flush=True)
 
     progress("setup done")
+    if args.gc != "default":
+        import gc
+
+        gc.collect()
+        gc.disable()
+        if args.gc == "window":
+            inner = window
+
+            def window():  # noqa: F811
+                out = inner()
+                gc.collect()
+                return out
+
+            window.reducer, window.env = inner.reducer, inner.env
     if args.stagger and args.warmup == 0:
         args.warmup = 1  # (the staggered state is set behind the env's first window: there is no env state before it)
     for i in range(args.warmup):

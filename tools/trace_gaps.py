@@ -36,6 +36,15 @@ for s, e, n in rows[1:]:
 print("gap histogram:", {k: (v[0], round(v[1] / 1e6, 2)) for k, v in hist.items()})
 for (a, b), (c, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:12]:
     print(f"{t/1e6:8.2f} ms  {c:6d}x  {a}  ->  {b}")
+# the neighbourhood of every gap >= 3 ms: the 5 kernels in front of it and the 5 behind it (what was the host doing?)
+for i in range(1, len(rows)):
+    g = rows[i][0] - max(r[1] for r in rows[max(0, i - 4):i])
+    if g >= 3e6:
+        print(f"gap of {g/1e6:.2f} ms at -{(end - rows[i][0])/1e6:.1f} ms:")
+        for s_, e_, n_ in rows[max(0, i - 5):i]:
+            print(f"      before  {n_[:110]}  {(e_-s_)/1e3:.1f} us")
+        for s_, e_, n_ in rows[i:i + 5]:
+            print(f"      after   {n_[:110]}  {(e_-s_)/1e3:.1f} us")
 print(f"individual gaps >= {min_gap/1e3:.0f} us (ms before the end of the trace, gap ms, previous -> next):")
 for t, g, a, b in big[-80:]:
     print(f"  -{t:8.1f}  {g:7.2f}  {a}  ->  {b}")
