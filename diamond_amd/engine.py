@@ -187,6 +187,9 @@ class WeightAudit:
             self._live = torch.zeros_like(self._rec)
             self._refs, self._row, self._ptr, self._stamps, self._pending = [], {}, [], [], None
             i = None
+            # (the comparison's two torch kernels are loaded NOW, while the caches are built: their first use costs 20-100 ms of
+            #  lazy code-object loading, which otherwise shows as one hole in the middle of some later window -- profiles/r06d_*)
+            (self._live[:1] != self._rec[:1]).any(dim=1)
         if i is None or self._refs[i]() is not p:
             # a row of its own: one whose parameter is gone is taken over (replaced parameter objects must not use the table up)
             i = next((j for j, ref in enumerate(self._refs) if ref() is None), None)
