@@ -306,7 +306,10 @@ def latency_line(args, eager=True):
             "config": {"workload": "SURVEY §8 (f4): play.py's B=1 WorldModelEnv.step + host read of the reward per frame; the "
                                    "sampler's launches replayed as one hipGraph per ring head", "global_batch": 1},
             "frames_per_s": 1e3 / graph, "eager_ms_per_frame": eager, "sampler_only_graph_ms": graph_s,
-            "sampler_only_eager_ms": eager_s}
+            "sampler_only_eager_ms": eager_s,
+            # 3 denoiser forwards + the reward/end model per frame (3 x 6.0909 + 0.4477 GFLOP): launch-latency-bound at B = 1
+            "algorithmic_tflops": (3 * 6.0909e9 + 0.4477e9) / (graph * 1e-3) / 1e12,
+            "frac_f16_mfma_peak": (3 * 6.0909e9 + 0.4477e9) / (graph * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS}
 
 
 def train_line(args, eager=True):
@@ -362,6 +365,17 @@ def train_line(args, eager=True):
         loss, _ = gstep(batch)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    # per-kernel roofline of the step (one EAGER step under the launch profiler: a replayed graph issues no launches it could time)
+    from diamond_amd import native as nv
+
+    nv.PROFILER = nv.LaunchProfiler()
+    try:
+        step()
+        summ = nv.PROFILER.summary()
+    finally:
+        nv.PROFILER = None
+    kernels, covered = kernel_table(summ, None, None, top=6, cover=0.85)
+    c_abi_launches = sum(v["launches"] for v in summ.values())
     return {"metric": "denoiser training step (forward + backward + clip + AdamW), 64x64, 1 predicted frame per segment",
             "value": 1e3 * dt, "unit": "ms/step", "n_gpus": 1, "steps": steps, "warmup": max(args.warmup, 3), "ms_per_step": 1e3 * dt,
             "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f32 via split-f16 MFMA", "data": "synthetic",
@@ -369,7 +383,10 @@ def train_line(args, eager=True):
                                    "replayed as one hipGraph (GraphedTrainStep; torch.optim.AdamW(capturable=True, "
                                    f"fused={not getattr(args, 'foreach_adamw', False)}))", "global_batch": b},
             "frames_per_s": b / dt, "eager_ms_per_step": None if dt_eager is None else 1e3 * dt_eager, "loss": float(loss.detach()),
-            "algorithmic_tflops": 3 * 6.0909e9 * b / dt / 1e12}
+            # forward + dgrad + wgrad = 3 x the forward's 6.0909 GFLOP per frame, against the f16 MFMA peak the split kernels run on
+            "algorithmic_tflops": 3 * 6.0909e9 * b / dt / 1e12, "frac_f16_mfma_peak": 3 * 6.0909e9 * b / dt / 1e12 / F16_MFMA_PEAK_TFLOPS,
+            "roofline": {"kernels": kernels, "kernels_cover_launch_time": round(covered, 4), "c_abi_launches_per_eager_step": c_abi_launches,
+                         "launch_time_ms_eager_step": round(sum(v["ms"] for v in summ.values()), 3)}}
 
 
 def rollout_setup(device, rank, img_size, batch, horizon, denoise_steps, order, attn, use_dist=False, bias_end_logits=True, end_rate=None):
@@ -586,11 +603,9 @@ def also_lines(device, args):
             st = env_stats(env, before)
             n = max(1, st["steps"])
             res[name] = {"value": 256 * 15 / dt, "step_ms": ms, "vs_no_ends": base_dt / dt, "steps_with_deaths": st["steps_with_deaths"] / n,
-                         # (slots loop: deaths resolved on the device into reset slots; the pipelined loop of round 5 counts planned / void rows)
-                         "dead_rows_per_step": (st.get("dead_rows", 0) + st["planned_rows"] + st["void_rows"]) / n,
-                         "reset_slots_per_step": st.get("slots", 0) / n, "slot_overflows": st.get("slot_overflows", 0),
-                         "steps_that_waited_for_their_own_report": st.get("sync_steps", 0),
-                         "speculated_sampler_steps": st["speculated"] / n, "repairs": st["repairs"]}
+                         # (a step's deaths are resolved on the device into reset slots, sized before the deaths exist: env_loop.py)
+                         "dead_rows_per_step": st["dead_rows"] / n, "reset_slots_per_step": st["slots"] / n,
+                         "slot_overflows": st["slot_overflows"], "pool_rounds": st["pool_rounds"]}
         res["unit"] = "frames/s"
         res["workload"] = ("configs[1], end probability p per env-step through the synthetic reward/end head, 2 + 1 warm-up and 3 timed "
                            "windows per line; vs_no_ends = this line / the no-ends line measured by the same agent in the same process")
@@ -626,11 +641,13 @@ def also_lines(device, args):
 
     def latency():
         lat = latency_line(SimpleNamespace(steps=200, warmup=12), eager=False)
-        return dict({k: lat[k] for k in ("value", "unit", "steps", "frames_per_s", "sampler_only_graph_ms")}, workload=lat["config"]["workload"])
+        return dict({k: lat[k] for k in ("value", "unit", "steps", "frames_per_s", "sampler_only_graph_ms", "algorithmic_tflops", "frac_f16_mfma_peak")},
+                    workload=lat["config"]["workload"])
 
     def train():
         tr = train_line(SimpleNamespace(batch=32, steps=20, warmup=3), eager=False)
-        return dict({k: tr[k] for k in ("value", "unit", "steps", "frames_per_s", "loss")}, workload=tr["config"]["workload"] + ", batch 32")
+        return dict({k: tr[k] for k in ("value", "unit", "steps", "frames_per_s", "loss", "algorithmic_tflops", "frac_f16_mfma_peak", "roofline")},
+                    workload=tr["config"]["workload"] + ", batch 32")
 
     guarded("end_rate", regimes)
     guarded("unbiased_end_logits", unbiased)

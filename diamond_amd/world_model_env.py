@@ -35,8 +35,9 @@ from .env_loop import sample_categorical
 
 
 class _no_random_draws:
-    """Guard of the invariant the pipelined env loop relies on: a reset (pool preload included) draws from NO torch generator,
-    so planning / repeating / reordering resets cannot change the order in which the random streams are consumed.  With
+    """Guard of the invariant the slots env loop relies on: a reset (pool preload / prefetch included) draws from NO torch
+    generator, so resolving resets on the device, prefetching pool rounds and repeating a window from its snapshot cannot change
+    the order in which the random streams are consumed.  With
     DIAMOND_CHECK_RESET_RNG=1 (the test suites set it) the CPU and the device generator states are compared around the guarded
     block -- a loader or pool that draws from them fails loudly instead of silently reordering the streams."""
 
@@ -59,8 +60,8 @@ class _no_random_draws:
     def __exit__(self, *exc):
         if self.on and exc[0] is None:
             assert all(torch.equal(a, b) for a, b in zip(self.before, self._state())), \
-                f"{self.what} drew from a torch random generator: the env loop's pipelining (env_loop.py) requires resets to be RNG-free " \
-                "(DIAMOND_SPECULATIVE_POLICY=0 runs the sequential order)"
+                f"{self.what} drew from a torch random generator: the slots env loop (env_loop.py) requires resets to be RNG-free " \
+                "(DIAMOND_ENV_LOOP=sequential runs the reference's order of calls)"
         return False
 
 
@@ -121,8 +122,8 @@ def _poisson_quantile(mean: float, tail: float = 1e-7) -> int:
 
 
 GRAPH_SAMPLER_MAX_ENVS = 8  # below this the sampler is launch-latency-bound and runs as a replayed hipGraph ...
-GRAPH_SAMPLER_MAX_PIXELS = 8 * 64 * 64  # ... if its launches are small: 8 envs at 256x256 are not (configs[4]: eager + speculation
-#                                         measured 367-370 frames/s against 364-365 replayed, same box, alternating)
+GRAPH_SAMPLER_MAX_PIXELS = 8 * 64 * 64  # ... if its launches are small: 8 envs at 256x256 are not (configs[4]: eager measured
+#                                         367-370 frames/s against 364-365 replayed, same box, alternating: round 4)
 
 
 @dataclass
@@ -299,8 +300,7 @@ class InitialConditionPool:
 
     def peek(self, count: int) -> Tuple[Tensor, Tuple[int, int]]:
         """Device index vector of the next `count` pool rows WITHOUT serving them (preloading when the pool runs short, exactly
-        as `take` would for this count), and a token (pool generation, cursor) for `commit` / `still_valid`.  A planned reset
-        (WorldModelEnv.plan_resets) peeks; the rows are served once the host has confirmed the plan."""
+        as `take` would for this count), and a token (pool generation, cursor) for `commit`."""
         start, token = self.peek_start(count)
         return torch.arange(start, start + count, device=self.act.device), token
 
@@ -349,19 +349,6 @@ class InitialConditionPool:
             ring[r[:, None], cols[None, :]] = self.frames_f32[idx]
 
 
-# Sampler speculation (env_loop issues step n + 1's sampler before step n's host synchronisation): what an UNPLANNED death costs
-# with it -- the void rows' sampler step again on a small batch, latency-bound (~3 ms) plus their share of a full step (~19 ms
-# at batch 256) -- against the hole the device sits through without it (~2 ms per step while the host issues the first launches
-# of the sampler).  may_speculate() compares running averages of both; DIAMOND_SPEC_SAMPLER=0/1 pins the answer (A/B).
-SPEC_REPAIR_MS, SPEC_FULL_STEP_MS, SPEC_HOLE_MS = 3.0, 19.0, 0.5
-# Policy speculation (the policy's step n + 1 issued before step n's host synchronisation, planned resets included): an unforeseen
-# death costs a small-batch repetition of the reset chain for its rows (~2-3 ms, latency-bound, forward and backward) where the
-# unspeculated order would have carried those frames in the next step's encoder pass for free; a step without one saves the
-# ~2 ms the device waits while the host issues the policy's launches.  Worth it while fewer than this share of the steps has
-# an unforeseen death (DIAMOND_SPEC_POLICY=0/1 pins the answer).
-POLICY_SPEC_MAX_UNFORESEEN = 0.3
-
-
 class WorldModelEnv:
     def __init__(self, denoiser, rew_end_model, data_loader, cfg: WorldModelEnvConfig,
                  return_denoising_trajectory: bool = False, graph_sampler: Optional[bool] = None) -> None:
@@ -387,22 +374,15 @@ class WorldModelEnv:
         self._flag_event = None
         self._rows_pinned: Optional[Tensor] = None
         self._report_host: Optional[Tensor] = None  # pinned ring of step reports (step_end_slots)
-        self._ep_len_host: Optional[np.ndarray] = None  # host mirror of ep_len (truncations are predictable: plan_resets)
-        self._reset_speculation()
+        self._ep_len_host: Optional[np.ndarray] = None  # host mirror of ep_len (the truncations of a step are known ahead: slot_count)
+        self._reset_state()
 
-    def _reset_speculation(self) -> None:
-        self._pending = None
-        self._pending_speculative = False
-        self._predrawn = None
-        self._issued = None
-        self._plan: Optional[Dict[str, Any]] = None       # a planned reset (predicted truncations of the current step)
-        self._repair_rows: Optional[Tensor] = None        # rows of the pending speculative half-step an unplanned death voided
-        self._void_events, self._void_frac = 0.0, 0.0     # running averages: steps with unplanned deaths, their share of the rows
-        self._slots_inflight = None                       # (event, pinned report, K, pool token) of the last step_end_slots
+    def _reset_state(self) -> None:
+        self._pending = None                              # (imagined frame, trajectory, reward / end draws, noise) between the two halves of a step
+        self._slots_inflight = None                       # (event, pinned report, K, pool token, two rounds given) of the last step_end_slots
         self._end_mean = getattr(self, "_end_mean", 0.0)  # running mean of sampled `end`s per step (survives a reset())
         self._end_last = getattr(self, "_end_last", 0)    # ... and the last step's count
-        self.stats = {"steps": 0, "steps_with_deaths": 0, "planned_rows": 0, "void_rows": 0, "repairs": 0, "speculated": 0,
-                      "slots": 0, "dead_rows": 0, "slot_overflows": 0, "sync_steps": 0, "pool_rounds": 0}
+        self.stats = {"steps": 0, "steps_with_deaths": 0, "slots": 0, "dead_rows": 0, "slot_overflows": 0, "pool_rounds": 0}
 
     @property
     def device(self) -> torch.device:
@@ -462,7 +442,7 @@ class WorldModelEnv:
             self._ctx = torch.empty(shape, dtype=torch.float32, device=dev)
             self._act = torch.empty(shape[:2], dtype=torch.long, device=dev)
         self._head = 0
-        self._reset_speculation()
+        self._reset_state()
         self.pool.scatter_frames(idx, None, self._ctx, 0)
         self._act.copy_(self.pool.act[idx])
         self.hx_rew_end = self.pool.hx[idx].unsqueeze(0).clone()
@@ -474,7 +454,7 @@ class WorldModelEnv:
     @torch.no_grad()
     def _reset_rows(self, rows: Tensor, idx: Tensor) -> None:
         """Context / action ring / reward-end LSTM state / episode length of `rows` <- pool rows `idx` (reference reset_dead,
-        world_model_env.py:56-62).  INVARIANT (env_loop's speculation relies on it): no draw from torch's random generators
+        world_model_env.py:56-62).  INVARIANT (the slots env loop relies on it): no draw from torch's random generators
         happens here or in the pool's preload -- a reset consumes no random stream."""
         with _no_random_draws(self._ctx.device, "WorldModelEnv._reset_rows"):
             self.pool.scatter_frames(idx, rows, self._ctx, self._head)
@@ -497,7 +477,7 @@ class WorldModelEnv:
     @torch.no_grad()
     def reset_dead(self, dead: Tensor) -> Tensor:
         """Replace the state of the dead envs by fresh pool rows; returns the dead row indices (synchronises: prefer the
-        step_end_finish path, which knows the rows on the host)."""
+        step_end path, which knows the rows on the host)."""
         rows = dead.nonzero(as_tuple=True)[0]
         self._reset_rows(rows, self.pool.take(int(rows.numel())))
         if self._ep_len_host is not None:
@@ -522,120 +502,30 @@ class WorldModelEnv:
         return noise, e_rew, e_end
 
     @torch.no_grad()
-    def step_begin(self, act: Tensor, speculative: bool = False) -> Tensor:
+    def step_begin(self, act: Tensor) -> Tensor:
         """First half of `step`: the imagined next frame.  Nothing here waits for the device.  The random draws of the step
-        (initial noise of the sampler, reward / end samples) are made NOW, in the reference's order, so that a caller may
-        interleave its own draws between the two halves without changing the order in which the streams are consumed
-        (env_loop issues the policy's next step in between).
-        speculative: issued BEFORE the previous step's host synchronisation (between step_end_issue and step_end_finish), on
-        the assumption that no episode ends there that was not planned for (plan_resets).  If one did, step_end_finish keeps
-        this half-step and marks the rows it voided; the caller's step_begin_repair -- with the actions recomputed after the
-        reset -- redoes exactly those rows with the draws made here: every random stream is consumed in the same order either
-        way (no draw is made by a reset: `_reset_rows` and the pool preload use none)."""
-        assert self._pending is None, "step_begin twice without step_end (a speculative half-step is repaired, not repeated)"
+        (initial noise of the sampler, reward / end samples) are made NOW, in the reference's order (diffusion_sampler.py:36,
+        world_model_env.py:103-104)."""
+        assert self._pending is None, "step_begin twice without step_end / step_end_slots"
         newest = self._slot(-1)
         self._act[:, newest] = act
-        own_noise = not self._use_graph()  # (a captured sampler graph draws inside the graph: never speculated, see may_speculate)
-        drawn, self._predrawn = getattr(self, "_predrawn", None), None
-        noise, e_rew, e_end = drawn if drawn is not None else self._draw_step(own_noise)
+        own_noise = not self._use_graph()  # (a captured sampler graph draws inside the graph)
+        noise, e_rew, e_end = self._draw_step(own_noise)
         self._next_noise = noise  # (handed over out of band: predict_next_obs keeps the reference's zero-argument signature,
         next_obs, denoising_trajectory = self.predict_next_obs()  # trainer.py:182-184 re-assigns it with a wrapper)
         self._pending = (next_obs, denoising_trajectory, e_rew, e_end, noise)
-        self._pending_speculative = speculative
-        if speculative:
-            self.stats["speculated"] += 1
         return next_obs
-
-    @torch.no_grad()
-    def step_begin_repair(self, act: Tensor) -> Tensor:
-        """After a step_end_finish that reported `void_rows` while a speculative step_begin was pending: the imagined frame of
-        exactly those rows again -- their context is the new episode's now, `act` carries their recomputed actions -- on a
-        small batch with the rows' own initial noise; every other row keeps what the speculation computed.  The kernels are
-        batch-invariant (a sample's result does not depend on what else is in the launch:
-        tests/test_gpu_models.py::test_batch_shard_invariance_at_full_batch), so the patched frame is bitwise the one a full
-        repetition of the step would have produced."""
-        rows, self._repair_rows = self._repair_rows, None
-        assert rows is not None and self._pending is not None
-        next_obs, trajectory, _, _, noise = self._pending
-        newest = self._slot(-1)
-        self._act[rows, newest] = act.index_select(0, rows)
-        x, tr = self.sampler.sample_ring(self._ctx.index_select(0, rows), self._act.index_select(0, rows), self._head, self._head,
-                                         noise.index_select(0, rows))
-        next_obs.index_copy_(0, rows, x)
-        for full, part in zip(trajectory[1:], tr[1:]):  # (trajectory[0] is the noise itself)
-            if full is not next_obs:
-                full.index_copy_(0, rows, part)
-        self.stats["repairs"] += 1
-        return next_obs
-
-    @torch.no_grad()
-    def predraw(self) -> None:
-        """Make the NEXT step_begin's random draws now (initial noise, reward / end samples).  They depend on nothing but their
-        shapes, so a caller that does not speculate may issue them in front of the step's host synchronisation -- behind its own
-        draws for the next action, i.e. in the reference's order -- instead of behind it, on the critical path."""
-        if self._use_graph():
-            return
-        assert getattr(self, "_predrawn", None) is None and self._pending is None
-        self._predrawn = self._draw_step(True)
-
-    def may_speculate(self) -> bool:
-        """May the caller issue the NEXT step's step_begin before this step's step_end_finish?  Not with a captured sampler graph
-        (its noise is drawn inside the graph) or stochastic churn (more draws inside the sampler than this class keeps); and not
-        while unplanned deaths are frequent enough that repairing the speculation costs more than the hole it fills."""
-        if self._use_graph() or self.sampler.cfg.s_churn != 0:
-            return False
-        pin = os.environ.get("DIAMOND_SPEC_SAMPLER")
-        if pin in ("0", "1"):
-            return pin == "1"
-        return self._void_events * SPEC_REPAIR_MS + self._void_frac * SPEC_FULL_STEP_MS < SPEC_HOLE_MS
-
-    def policy_speculation_pays(self) -> bool:
-        """Should the caller issue the policy's NEXT step (with planned resets) before this step's host synchronisation?  Only
-        while deaths the host cannot foresee are rare: see POLICY_SPEC_MAX_UNFORESEEN."""
-        pin = os.environ.get("DIAMOND_SPEC_POLICY")
-        if pin in ("0", "1"):
-            return pin == "1"
-        return self._void_events < POLICY_SPEC_MAX_UNFORESEEN
-
-    @torch.no_grad()
-    def plan_resets(self) -> Optional[Dict[str, Any]]:
-        """Truncations are predictable: the envs whose episode reaches the horizon IN THE STEP THAT IS PENDING (between step_begin
-        and step_end_issue) are known on the host.  For them the reset is planned ahead: their pool rows are peeked (assuming no
-        other env dies in this step: pool rows are served in row order, world_model_env.py:56-57,133-139), and the caller gets
-        what it needs to run the policy's burn-in and next step on the new episodes BEFORE the step's host synchronisation:
-        {"rows": device index vector, "burnin_obs": (k, T-1, C, H, W), "obs": (k, C, H, W) newest frame of the new episodes}.
-        step_end_issue then performs the planned reset right after the ring advance -- so a speculative step_begin issued
-        behind it already sees the new episodes -- and step_end_finish checks the plan against what really died: rows an
-        unplanned death (`end`) mis-ordered get their proper pool rows and are reported as `void_rows`."""
-        assert self._pending is not None and self._plan is None
-        if self._ep_len_host is None or self._use_graph():
-            return None
-        rows_host = np.flatnonzero(self._ep_len_host + 1 >= self.horizon)
-        if rows_host.size == 0:
-            return None
-        idx, token = self.pool.peek(int(rows_host.size))
-        rows = self._rows_to_device(rows_host)
-        frames = self.pool.gather_frames(idx)
-        self._plan = {"rows_host": rows_host, "rows": rows, "idx": idx, "token": token, "frames": frames}
-        return {"rows": rows, "burnin_obs": frames[:, :-1], "obs": frames[:, -1]}
 
     @torch.no_grad()
     def step_end(self):
-        """Second half of `step`: reward / termination, ring bookkeeping and -- the one host synchronisation of a step -- the
-        check for finished episodes (`if dead.any()`, world_model_env.py:77-83)."""
-        self.step_end_issue()
-        return self.step_end_finish()
-
-    @torch.no_grad()
-    def step_end_issue(self) -> None:
-        """Everything of step_end that the host can issue without knowing whether an episode ended; the answer -- the step's
-        `dead` mask -- travels to the host asynchronously (pinned buffer + event).  The caller may issue more work -- the policy's
-        and the sampler's next step -- before it asks for it with step_end_finish: the device then never runs dry while the
-        host waits."""
+        """Second half of `step` in the REFERENCE's order (world_model_env.py:64-89): reward / termination, ring bookkeeping and
+        -- the one host synchronisation of such a step -- `if dead.any(): reset_dead`.  info: any_dead, dead, and where an
+        episode ended dead_rows (device index vector, ascending), final_observation, burnin_obs (both in dead_rows order, as
+        the reference's boolean-mask forms are).  (env_loop's default loop does not come here: step_end_slots below.)"""
         next_obs, denoising_trajectory, e_rew, e_end, _ = self._pending
-        self._pending, self._pending_speculative = None, False
+        self._pending = None
+        self.slots_finish()  # (a caller that mixes the two forms: the mirror and the pool cursor are current)
         rew, end = self.predict_rew_end(next_obs.unsqueeze(1), e_rew, e_end)
-
         self.ep_len += 1
         trunc = (self.ep_len >= self.horizon).long()
         # advance the rings: the oldest slot becomes the newest and receives the imagined frame (its action slot is
@@ -644,7 +534,6 @@ class WorldModelEnv:
         self._head = (self._head + 1) % self._ctx.shape[1]
         self._ctx[:, oldest] = next_obs
         dead = torch.logical_or(end, trunc)
-
         info: Dict[str, Any] = {}
         if self.return_denoising_trajectory:
             info["denoising_trajectory"] = torch.stack(denoising_trajectory, dim=1)
@@ -654,95 +543,33 @@ class WorldModelEnv:
                 self._flag_event = torch.cuda.Event()
             self._dead_host.copy_(dead, non_blocking=True)
             self._flag_event.record()
-        if self._plan is not None:  # the planned reset: behind the ring advance, in front of whatever the caller issues next
-            self._reset_rows(self._plan["rows"], self._plan["idx"])
-        self._issued = (next_obs, rew, end, trunc, dead, info)
-
-    @torch.no_grad()
-    def step_end_finish(self):
-        """THE host synchronisation of a step: which episodes ended?  Resets of the rows no plan covered (or covered with the
-        wrong pool rows); a speculative step_begin issued meanwhile stays pending, with those rows marked for
-        step_begin_repair.  info: any_dead, dead_rows (device index vector, ascending), final_observation, burnin_obs (both in
-        dead_rows order, as the reference's boolean-mask forms are), and -- only when some of the dead rows were not reset as
-        planned -- void_rows (device index vector) / void_pos (their positions within dead_rows)."""
-        next_obs, rew, end, trunc, dead, info = self._issued
-        self._issued = None
-        if dead.is_cuda:
-            self._flag_event.synchronize()
+            self._flag_event.synchronize()  # THE host synchronisation of a step in the reference's order
             rows_host = np.flatnonzero(self._dead_host.numpy())
             check_weight_audits()  # (the host is synchronised anyway: did an audit of the packed weight copies find a silent write?)
         else:
             rows_host = np.flatnonzero(dead.numpy())
-        any_dead = rows_host.size > 0
-        unforeseen = int(rows_host.size)
-        plan, self._plan = self._plan, None
         if self._ep_len_host is not None:
             self._ep_len_host += 1
-            if plan is not None or not self._use_graph():  # (with a replayed sampler graph nothing is ever planned: plan_resets;
-                #                                             every death then voids a speculated policy step, truncations too)
-                unforeseen = int(np.count_nonzero(self._ep_len_host[rows_host] < self.horizon))  # (not a truncation: an `end`)
             self._ep_len_host[rows_host] = 0
-        obs = next_obs  # a fresh tensor every step: never aliases the ring
-        info["any_dead"] = any_dead  # (so that the caller does not have to synchronise again for the same answer)
+        total = int(rows_host.size)
+        info["any_dead"] = total > 0  # (so that the caller does not have to synchronise again for the same answer)
         info["dead"] = dead
         self.stats["steps"] += 1
-        void_host = rows_host
-        if any_dead:
+        obs = next_obs  # a fresh tensor every step: never aliases the ring
+        if total:
             self.stats["steps_with_deaths"] += 1
-            total = int(rows_host.size)
-            rows = fresh = None  # fresh: (total, T, C, H, W) the new episodes' context frames in logical order, if at hand
-            if plan is not None:
-                planned = plan["rows_host"]
-                assert np.isin(planned, rows_host).all(), "a predicted truncation did not happen: ep_len was changed behind the env's back (use set_episode_lengths)"
-                if total == planned.size:  # exactly the plan
-                    self.pool.commit(plan["token"], total)
-                    rows, void_host, fresh = plan["rows"], rows_host[:0], plan["frames"]
-                else:
-                    # more deaths than planned: the reference serves ONE request for all of them in row order.  Planned rows in
-                    # front of the first unplanned death keep their pool rows (if the larger request still fits the pool that
-                    # was peeked into); everybody else is (re-)reset with the proper ones.
-                    idx_all, token = self.pool.peek(total)
-                    keep = 0
-                    if token == plan["token"]:
-                        first_unplanned = rows_host[~np.isin(rows_host, planned)][0]
-                        keep = int(np.searchsorted(planned, first_unplanned))
-                    self.pool.commit(token, total)
-                    void_host = rows_host[keep:] if keep else rows_host
-                    if keep:  # (rows_host[:keep] == planned[:keep]: both ascending, and nothing unplanned precedes them)
-                        self._reset_rows(self._rows_to_device(void_host), idx_all[keep:])
-                    else:
-                        self._reset_rows(self._rows_to_device(rows_host), idx_all)
-                    fresh_idx = idx_all
-            else:  # (the dead rows and their pool rows in ONE upload: this is the step's critical path)
-                start, token = self.pool.peek_start(total)
-                self.pool.commit(token, total)
-                both = self._rows_to_device(np.concatenate([rows_host, np.arange(start, start + total)]))
-                rows, fresh_idx = both[:total], both[total:]
-                self._reset_rows(rows, fresh_idx)
-            if rows is None:
-                rows = self._rows_to_device(rows_host)
-            if fresh is None:
-                fresh = self.pool.gather_frames(fresh_idx)  # (one launch; the same values the ring rows just received)
+            self.stats["dead_rows"] += total
+            # (the dead rows and their pool rows in ONE upload)
+            start, token = self.pool.peek_start(total)
+            self.pool.commit(token, total)
+            both = self._rows_to_device(np.concatenate([rows_host, np.arange(start, start + total)]))
+            rows, fresh_idx = both[:total], both[total:]
+            self._reset_rows(rows, fresh_idx)
+            fresh = self.pool.gather_frames(fresh_idx)  # (one launch; the same values the ring rows just received)
             info["dead_rows"] = rows  # device index list: the caller gathers / scatters with it (no further synchronisation)
             info["final_observation"] = next_obs.index_select(0, rows)
             info["burnin_obs"] = fresh[:, :-1]
             obs = next_obs.index_copy(0, rows, fresh[:, -1])  # dead envs now show the newest frame of their new episode
-            self.stats["planned_rows"] += total - int(void_host.size)
-            self.stats["void_rows"] += int(void_host.size)
-            if void_host.size:
-                if void_host.size == total:
-                    info["void_rows"], info["void_pos"] = rows, None  # (None: all of dead_rows)
-                else:
-                    info["void_rows"] = self._rows_to_device(void_host)
-                    info["void_pos"] = self._rows_to_device(np.arange(total - void_host.size, total))
-        n_void = int(void_host.size) if any_dead else 0
-        # running averages the speculation decisions are taken from: the share of steps with a death the host could not foresee
-        # (whatever was planned or speculated in THIS step), and the share of rows such steps void
-        self._void_events = 0.9 * self._void_events + 0.1 * (1.0 if unforeseen else 0.0)
-        self._void_frac = 0.9 * self._void_frac + 0.1 * ((n_void if plan is not None else unforeseen) / self.num_envs)
-        if self._pending is not None and self._pending_speculative and n_void:
-            self._repair_rows = info["void_rows"]
-            info["repair_pending"] = True
         return obs, rew, end, trunc, info
 
     # -- the step's deaths resolved on the device (env_loop._slots_env_loop) ------------------------------------------------------
@@ -786,7 +613,7 @@ class WorldModelEnv:
         | their T - 1 burn-in frames, frame-major]; slots None when the step has no slots (K = 0).  Waits only for the PREVIOUS
         step's report (slots_finish)."""
         next_obs, denoising_trajectory, e_rew, e_end, _ = self._pending
-        self._pending, self._pending_speculative = None, False
+        self._pending = None
         rew, end = self.predict_rew_end(next_obs.unsqueeze(1), e_rew, e_end)
         self.slots_finish()  # the previous step's report: episode-length mirror, pool cursor, overflow
         dev, b = next_obs.device, self.num_envs

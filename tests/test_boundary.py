@@ -249,106 +249,6 @@ def test_ring_env_bookkeeping_matches_roll_based_shadow_cpu():
     assert served["n"] == rnd + 1 and rnd >= 1
 
 
-def _fake_env(b, t, c, h, w, horizon, rounds):
-    """WorldModelEnv on CPU tensors without kernels: the re-assignable callables stubbed, an fp32 pool pre-filled per round"""
-    from types import SimpleNamespace
-    from diamond_amd.world_model_env import InitialConditionPool
-
-    loader = SimpleNamespace(batch_sampler=SimpleNamespace(batch_size=b))
-    env = D.WorldModelEnv.__new__(D.WorldModelEnv)
-
-    def sample_ring(ctx, act, oh, ah, noise):  # a deterministic "sampler": per-row function of (context, actions, noise)
-        cols = (oh + torch.arange(ctx.shape[1])) % ctx.shape[1]
-        x = ctx[:, cols].mean(1) * 0.5 + act[:, cols].float().mean(1).view(-1, 1, 1, 1) * 0.1 + noise
-        return x, [noise, x]
-
-    env.sampler = SimpleNamespace(denoiser=SimpleNamespace(device=torch.device("cpu")), noise_fn=None, cfg=SimpleNamespace(s_churn=0.0),
-                                  _randn=lambda shape, dev: torch.randn(*shape), sample_ring=sample_ring)
-    env.rew_end_model, env.horizon, env.return_denoising_trajectory, env.num_envs = None, horizon, False, b
-    env.graph_sampler, env.expo_fn, env._graph_forced = False, None, False
-    env._ctx = env._act = None
-    env._head = 0
-    env._dead_host = env._flag_event = env._rows_pinned = env._ep_len_host = None
-    pool = InitialConditionPool(None, loader, 2, lambda: torch.device("cpu"))
-    served = {"n": 0}
-
-    def preload():
-        obs, act = rounds[served["n"]]
-        served["n"] += 1
-        pool.frames_u8, pool.frames_f32, pool.act = None, obs, act
-        pool.hx, pool.cx = torch.arange(obs.shape[0] * 8).float().reshape(-1, 8) + 100 * served["n"], torch.zeros(obs.shape[0], 8)
-        pool._cursor = 0
-        pool._generation += 1
-
-    pool._preload = preload
-    env.pool = pool
-    return env, served
-
-
-@pytest.mark.parametrize("speculate", [False, True])
-def test_planned_resets_void_rows_and_repair_match_the_sequential_env_cpu(speculate):
-    """The pipelining protocol of WorldModelEnv (plan_resets -> step_end_issue -> [speculative step_begin] -> step_end_finish ->
-    [step_begin_repair]) on CPU tensors without kernels, against the SAME env class driven through plain `step` (the reference's
-    order): rings, reward/end LSTM state, episode lengths, returned observations, final_observation / burnin_obs and the imagined
-    frames identical at every step -- with truncations that are planned, `end`s that are not, `end`s in front of planned rows (the
-    pool is served in row order: the planned rows behind them get the next pool rows), and pool rounds that run out."""
-    b, t, c, h, w, horizon = 5, 4, 1, 2, 2, 4
-    g = torch.Generator().manual_seed(1)
-    rounds = [(torch.randn(2 * b, t, c, h, w, generator=g), torch.randint(0, 4, (2 * b, t), generator=g)) for _ in range(40)]
-    steps = 40
-    acts = torch.randint(0, 4, (steps + 1, b), generator=g)
-    ends = (torch.rand(steps, b, generator=g) < 0.12).long()
-    noise = torch.randn(steps + 1, b, c, h, w, generator=g)
-
-    def make():
-        env, served = _fake_env(b, t, c, h, w, horizon, rounds)
-        st = {"i": 0}
-        env.sampler._randn = lambda shape, dev: noise[st["i"]].clone()
-        env.predict_next_obs = lambda: env.sampler.sample_ring(env._ctx, env._act, env._head, env._head, env.__dict__.pop("_next_noise", None))
-        env.predict_rew_end = lambda next_obs, e_rew=None, e_end=None: (next_obs.flatten(1).sum(1).sign(), ends[st["i"] - 1])
-        return env, st
-
-    seq, st_s = make()
-    pipe, st_p = make()
-    seq.reset(), pipe.reset()
-    seq.set_episode_lengths(torch.arange(b) % horizon), pipe.set_episode_lengths(torch.arange(b) % horizon)
-    begun = None
-    for i in range(steps):
-        st_s["i"] = i
-        nxt_s = seq.step_begin(acts[i])
-        st_s["i"] = i + 1
-        o_s, r_s, e_s, tr_s, info_s = seq.step_end()
-        # the pipelined order
-        if begun is None:
-            st_p["i"] = i
-            nxt_p = pipe.step_begin(acts[i])
-        else:
-            nxt_p = begun
-        begun = None
-        plan = pipe.plan_resets()
-        st_p["i"] = i + 1
-        pipe.step_end_issue()
-        if speculate:
-            begun = pipe.step_begin(acts[i + 1], speculative=True)  # (st_p["i"] == i + 1: the next step's noise)
-        o_p, r_p, e_p, tr_p, info_p = pipe.step_end_finish()
-        if info_p.get("repair_pending"):
-            begun = pipe.step_begin_repair(acts[i + 1])
-        assert torch.equal(nxt_s, nxt_p), i
-        for a_, b_ in ((o_s, o_p), (r_s, r_p), (e_s, e_p), (tr_s, tr_p), (seq.obs_buffer, pipe.obs_buffer), (seq.ep_len, pipe.ep_len),
-                       (seq.hx_rew_end, pipe.hx_rew_end)):
-            assert torch.equal(a_, b_), i
-        assert torch.equal(seq.act_buffer[:, :-1], pipe.act_buffer[:, :-1]), i
-        assert info_s["any_dead"] == info_p["any_dead"]
-        if info_s["any_dead"]:
-            for k in ("dead_rows", "final_observation", "burnin_obs"):
-                assert torch.equal(info_s[k], info_p[k]), (i, k)
-            if plan is not None and "void_rows" not in info_p:
-                assert torch.equal(plan["rows"], info_p["dead_rows"]) and torch.equal(plan["burnin_obs"], info_p["burnin_obs"])
-    s = pipe.stats
-    assert s["planned_rows"] > 10 and s["void_rows"] > 5 and (s["repairs"] > 0) == speculate, s
-    assert seq.pool._generation == pipe.pool._generation > 2
-
-
 def test_confusion_matrix_matches_sklearn():
     """RewEndModel.forward's metrics (reference rew_end_model.py:84-85 via torcheval, absent here): rows = true class,
     columns = argmax prediction, checked against scikit-learn's definition."""

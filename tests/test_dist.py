@@ -63,7 +63,7 @@ def _worker(rank, world, port, q):
     fill_module_(ac4, 5)
     red4 = GradAllReducer(list(ac4.parameters()), early=[p_ for n_, p_ in ac4.named_parameters() if not n_.startswith("encoder.")])
     early_ok = 0 < red4.num_early < len(red4.params) and red4.early_launches == 0
-    for rep in range(2):  # (twice: the hooks re-arm, zero_grad(set_to_none=False) keeps the bucket views)
+    for rep in range(2 if world == 2 else 1):  # (twice at world 2: the hooks re-arm, zero_grad(set_to_none=False) keeps the bucket views)
         logits, val = predict(ac4, obs)
         (logits.square().mean() + val.mean()).backward()
         early_ok = early_ok and red4.early_launches == rep + 1 and red4._early_work is not None

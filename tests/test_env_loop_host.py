@@ -1,8 +1,9 @@
-"""Host logic of env_loop's speculative policy step on the CPU (no kernel: a torch toy policy, a toy two-phase env and a torch
-stand-in for the categorical-sample kernel): the policy's step n + 1 is issued between env.step_begin and env.step_end and dropped
-when an episode ended.  With ONE shared random stream for every draw (policy exponentials, env noise, reward / end
-exponentials) the rollout must be bitwise the sequential one -- i.e. the stream is consumed in the same order -- and the env
-must see exactly the same sequence of calls.  (The GPU twin with the real models: tests/test_gpu_models.py.)"""
+"""Host logic of env_loop on the CPU (no kernel: torch toy policies, toy envs and a torch stand-in for the categorical-sample
+kernel).  With ONE shared random stream for every draw (policy exponentials, env noise, reward / end exponentials) a rollout
+must be bitwise the sequential one -- i.e. the stream is consumed in the same order.  The sequential loop's batched burn-in
+(one encoder pass over all burn-in frames of a reset) against frame-by-frame calls; the slots loop (a step's deaths resolved
+into fixed-shape reset slots, the host one step behind, windows repeated after a slot overflow) against the sequential loop.
+(The GPU twins with the real models: tests/test_gpu_models.py.)"""
 import random
 
 import pytest
@@ -30,14 +31,11 @@ class ToyPolicy:
 
 
 class ToyEnv:
-    """WorldModelEnv's protocol: step = step_begin + step_end, deaths reset the row, info carries final_observation / any_dead."""
+    """the reference's env protocol: `step`, deaths reset the row, info carries final_observation / any_dead"""
     num_actions = 4
 
-    def __init__(self, b, p_end, two_phase):
+    def __init__(self, b, p_end):
         self.num_envs, self.p_end = b, p_end
-        if not two_phase:
-            self.step_begin = None  # (hasattr is what env_loop looks at)
-            del self.step_begin
         self.log = []
 
     def reset(self, **kw):
@@ -45,15 +43,10 @@ class ToyEnv:
         self.t = torch.zeros(self.num_envs, dtype=torch.long)
         return self.state.clone(), {}
 
-    def _begin(self, act):
-        self.log.append("begin")
+    def step(self, act):
+        self.log.append("step")
         nxt = self.state * 0.5 + act.float().view(-1, 1, 1) * 0.1 + torch.randn(self.num_envs, 2, 3)  # "denoiser noise"
-        self._pending = (nxt, torch.empty(self.num_envs, 3).exponential_(1), torch.empty(self.num_envs, 2).exponential_(1))
-        return nxt
-
-    def _end(self):
-        self.log.append("end")
-        nxt, e_rew, e_end = self._pending
+        e_rew, e_end = torch.empty(self.num_envs, 3).exponential_(1), torch.empty(self.num_envs, 2).exponential_(1)
         rew = (torch.zeros(self.num_envs, 3) / e_rew).argmax(1).float() - 1
         end = ((torch.tensor([1 - self.p_end, self.p_end]).log().expand(self.num_envs, 2).exp()) / e_end).argmax(1)
         self.t += 1
@@ -68,129 +61,8 @@ class ToyEnv:
             self.state[dead] = 7.0  # "fresh episode"
             self.t[dead] = 0
             obs = self.state.clone()
+        info["_dead"] = dead
         return obs, rew, end, trunc, info
-
-
-class ToyEnv3(ToyEnv):
-    """... with WorldModelEnv's third phase: step_end = step_end_issue + step_end_finish, a step_begin(act, speculative=True) may
-    be issued in between; an ended episode drops it and keeps its draws for the repetition (same bookkeeping as the real env)."""
-
-    def __init__(self, b, p_end):
-        super().__init__(b, p_end, True)
-        self._saved, self._spec, self.cool, self.wasted, self.used = None, False, 0, 0, 0
-
-    def step_begin(self, act, speculative=False):
-        self.log.append("begin-spec" if speculative else "begin")
-        if self._saved is not None:
-            noise, e_rew, e_end = self._saved
-            self._saved = None
-        else:
-            noise = torch.randn(self.num_envs, 2, 3)
-            e_rew, e_end = torch.empty(self.num_envs, 3).exponential_(1), torch.empty(self.num_envs, 2).exponential_(1)
-        nxt = self.state * 0.5 + act.float().view(-1, 1, 1) * 0.1 + noise
-        self._pending, self._spec = (nxt, e_rew, e_end, noise), speculative
-        return nxt
-
-    def may_speculate(self):
-        return self.cool == 0
-
-    def step_end_issue(self):
-        nxt, e_rew, e_end, _ = self._pending
-        self._pending, self._spec = None, False
-        rew = (torch.zeros(self.num_envs, 3) / e_rew).argmax(1).float() - 1
-        end = ((torch.tensor([1 - self.p_end, self.p_end]).log().expand(self.num_envs, 2).exp()) / e_end).argmax(1)
-        self.t += 1
-        trunc = (self.t >= (7 if self.p_end > 0 else 10 ** 6)).long()
-        self._issued = (nxt, rew, end, trunc, torch.logical_or(end, trunc))
-        self.state = nxt  # (the ring advance: device-side state the speculative step_begin reads)
-
-    def step_end_finish(self):
-        self.log.append("end")
-        nxt, rew, end, trunc, dead = self._issued
-        info = {"any_dead": bool(dead.any())}
-        self.cool = max(0, self.cool - 1)
-        if self._pending is not None and self._spec:
-            if info["any_dead"]:
-                self._saved = (self._pending[3], self._pending[1], self._pending[2])
-                self._pending, self._spec = None, False
-                self.wasted += 1
-            else:
-                self.used += 1
-        obs = nxt
-        if info["any_dead"]:
-            self.cool = 2
-            info["final_observation"] = nxt[dead]
-            self.state = nxt.clone()
-            self.state[dead] = 7.0
-            self.t[dead] = 0
-            obs = self.state.clone()
-        return obs, rew, end, trunc, info
-
-    def step_end(self):
-        self.step_end_issue()
-        return self.step_end_finish()
-
-
-def _make_env(b, p_end, two_phase):
-    if two_phase == 3:
-        return ToyEnv3(b, p_end)
-    env = ToyEnv(b, p_end, two_phase)
-    if two_phase:
-        env.step_begin, env.step_end = env._begin, env._end
-    env.step = lambda act: (env._begin(act), env._end())[1]
-    return env
-
-
-def _rollout(monkeypatch, two_phase, p_end, windows=3, t=6, b=5, epsilon=0.2):
-    monkeypatch.setattr(EL, "sample_categorical", lambda logits, expo: (torch.softmax(logits.detach(), -1) / expo).argmax(-1))
-    torch.manual_seed(11)
-    random.seed(5)
-    env, pol = _make_env(b, p_end, two_phase), ToyPolicy()
-    loop = EL.make_env_loop(env, pol, epsilon=epsilon)
-    outs = []
-    for _ in range(windows):
-        *cols, infos = loop.send(t)
-        outs.append([c.clone() for c in cols])
-    return outs, env, pol
-
-
-@pytest.mark.parametrize("p_end", [0.0, 0.35])
-def test_speculative_policy_step_consumes_the_streams_in_the_sequential_order(monkeypatch, p_end):
-    seq, env_s, pol_s = _rollout(monkeypatch, False, p_end)
-    spec, env_p, pol_p = _rollout(monkeypatch, True, p_end)
-    for wa, wb in zip(seq, spec):
-        for a, b in zip(wa, wb):
-            assert torch.equal(a, b)
-    assert env_s.log == env_p.log
-    deaths = sum(int(w[3].sum() + w[4].sum()) for w in seq)
-    if p_end == 0.0:
-        assert deaths == 0 and pol_p.calls == pol_s.calls  # nobody ends mid-window: every speculative step is used
-    else:
-        assert deaths > 0 and pol_p.calls > pol_s.calls  # dropped speculative steps were recomputed
-
-
-@pytest.mark.parametrize("p_end", [0.0, 0.12, 0.35])
-def test_speculative_sampler_step_consumes_the_streams_in_the_sequential_order(monkeypatch, p_end):
-    """the next step's env.step_begin issued between step_end_issue and step_end_finish (WorldModelEnv's third phase): bitwise the
-    sequential rollout on ONE shared random stream, whether the speculation is used or dropped and repeated"""
-    seq, env_s, pol_s = _rollout(monkeypatch, False, p_end, epsilon=0.0)
-    spec, env_p, pol_p = _rollout(monkeypatch, 3, p_end, epsilon=0.0)
-    for wa, wb in zip(seq, spec):
-        for a, b in zip(wa, wb):
-            assert torch.equal(a, b)
-    assert env_p.used > 0 or p_end > 0.3, "no speculative step was ever used"  # (5 envs at p = 0.35: somebody ends at almost every step)
-    if p_end == 0.0:
-        assert env_p.wasted == 0 and sorted(x.replace("-spec", "") for x in env_p.log) == sorted(env_s.log)
-    else:
-        assert env_p.wasted > 0, "the dropped-and-repeated path was not exercised"
-        # a dropped half-step shows as an extra begin: begin-spec (dropped) ... begin (repetition)
-        assert env_p.log.count("begin") + env_p.log.count("begin-spec") == env_s.log.count("begin") + env_p.wasted
-
-
-def test_epsilon_greedy_rollouts_do_not_speculate_the_sampler(monkeypatch):
-    """the epsilon override of step n + 1 is drawn at the top of that step: the action a speculative step_begin used could change"""
-    _, env, _ = _rollout(monkeypatch, 3, 0.0, epsilon=0.2)
-    assert "begin-spec" not in env.log
 
 
 class SeparablePolicy(ToyPolicy):
@@ -218,18 +90,18 @@ class SeparablePolicy(ToyPolicy):
         return SeparablePolicy.predict_from_features(self, self.encode(obs), hx_cx)
 
 
-class BurninEnv(ToyEnv3):
-    """ToyEnv3 + what WorldModelEnv hands over at a reset: burn-in frames of the new episodes and (optionally) the device index
+class BurninEnv(ToyEnv):
+    """ToyEnv + what WorldModelEnv hands over at a reset: burn-in frames of the new episodes and (optionally) the device index
     list of the dead rows"""
 
     def __init__(self, b, p_end, with_rows):
         super().__init__(b, p_end)
         self.with_rows = with_rows
 
-    def step_end_finish(self):
-        nxt, rew, end, trunc, dead = self._issued
-        out = super().step_end_finish()
+    def step(self, act):
+        out = super().step(act)
         info = out[4]
+        dead = info.pop("_dead")
         if info["any_dead"]:
             rows = dead.nonzero(as_tuple=True)[0]
             g = torch.Generator().manual_seed(int(rows.sum()) + 17 * len(self.log))
@@ -262,8 +134,8 @@ def test_batched_burn_in_is_bitwise_the_frame_by_frame_one(monkeypatch, p_end):
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
-# The pipelined loop (env_loop._pipelined_env_loop) against the sequential one, on toy envs whose resets are served from a POOL
-# in row order (so that a wrong pool order, a wrong row, a stale frame or a draw out of order changes the result).
+# toy envs whose resets are served from a POOL in row order (so that a wrong pool order, a wrong row, a stale frame or a draw out of
+# order changes the result)
 
 
 def _pool_row(k, t=4):
@@ -322,116 +194,8 @@ class PoolEnv:
         return self.ctx[:, -1].clone(), rew, end, trunc, info
 
 
-class PipeEnv(PoolEnv):
-    """The same env behind WorldModelEnv's pipelining protocol (env_loop.PIPELINE_PROTOCOL): planned resets for the truncations
-    the host can foresee, speculative step_begin, per-row repair after unplanned deaths."""
-
-    def __init__(self, b, p_end, horizon, stagger=False, speculate=True, policy_spec=True):
-        super().__init__(b, p_end, horizon, stagger)
-        self.speculate, self.policy_spec, self._asked = speculate, policy_spec, 0
-        self._pending = self._plan = self._issued = self._repair = self._drawn = None
-        self.counts = {"planned": 0, "void": 0, "repairs": 0, "spec": 0, "mixed": 0}
-
-    def step(self, act):
-        self.step_begin(act)
-        self.step_end_issue()
-        return self.step_end_finish()
-
-    def predraw(self):
-        assert self._drawn is None
-        self._drawn = self._draw()
-
-    def step_begin(self, act, speculative=False):
-        assert self._pending is None
-        self.log.append("begin-spec" if speculative else "begin")
-        self.counts["spec"] += int(speculative)
-        (noise, e_rew, e_end), self._drawn = (self._drawn if self._drawn is not None else self._draw()), None
-        self._acts = act.clone()
-        nxt = self._dynamics(self.ctx, act, noise)
-        self._pending, self._spec = (nxt, e_rew, e_end, noise), speculative
-        return nxt
-
-    def step_begin_repair(self, act):
-        rows, self._repair = self._repair, None
-        nxt, _, _, noise = self._pending
-        self.counts["repairs"] += 1
-        nxt[rows] = self._dynamics(self.ctx[rows], act[rows], noise[rows])
-        return nxt
-
-    def may_speculate(self):
-        return self.speculate
-
-    def policy_speculation_pays(self):
-        self._asked += 1
-        return self._asked % 3 != 0 if self.policy_spec == "alternate" else self.policy_spec
-
-    def plan_resets(self):
-        assert self._pending is not None and self._plan is None
-        rows = (self.t + 1 >= self.horizon).nonzero().flatten()
-        if rows.numel() == 0:
-            return None
-        frames = torch.stack([_pool_row(self.cursor + i) for i in range(rows.numel())])  # (peek)
-        self._plan = {"rows": rows, "frames": frames, "cursor": self.cursor}
-        return {"rows": rows, "burnin_obs": frames[:, :-1], "obs": frames[:, -1]}
-
-    def step_end_issue(self):
-        nxt, e_rew, e_end, _ = self._pending
-        self._pending, self._spec = None, False
-        rew, end = self._rew_end(nxt, e_rew, e_end)
-        self.t += 1
-        trunc = (self.t >= self.horizon).long()
-        self.ctx = torch.cat([self.ctx[:, 1:], nxt[:, None]], 1)
-        if self._plan is not None:
-            self.ctx[self._plan["rows"]] = self._plan["frames"]
-            self.t[self._plan["rows"]] = 0
-        self._issued = (nxt, rew, end, trunc, torch.logical_or(end, trunc))
-
-    def step_end_finish(self):
-        self.log.append("end")
-        nxt, rew, end, trunc, dead = self._issued
-        plan, self._plan = self._plan, None
-        rows = dead.nonzero().flatten()
-        info = {"any_dead": rows.numel() > 0}
-        obs = nxt
-        if info["any_dead"]:
-            total = rows.numel()
-            void = rows
-            if plan is not None:
-                planned = plan["rows"]
-                assert all(int(r) in rows.tolist() for r in planned)
-                if planned.numel() == total:
-                    self.cursor += total
-                    void = rows[:0]
-                else:
-                    self.counts["mixed"] += 1
-                    first = min(set(rows.tolist()) - set(planned.tolist()))
-                    keep = int((planned < first).sum())
-                    fresh = torch.stack([_pool_row(self.cursor + i) for i in range(total)])
-                    self.cursor += total
-                    void = rows[keep:]
-                    self.ctx[void] = fresh[keep:]
-                    self.t[void] = 0
-            else:
-                self.ctx[rows] = self._serve(total)
-                self.t[rows] = 0
-            self.counts["planned"] += total - void.numel()
-            self.counts["void"] += void.numel()
-            info["dead_rows"] = rows
-            info["final_observation"] = nxt[rows]
-            info["burnin_obs"] = self.ctx[rows, :-1]
-            obs = self.ctx[:, -1].clone()
-            if void.numel():
-                info["void_rows"] = void
-                info["void_pos"] = None if void.numel() == total else torch.arange(total - void.numel(), total)
-                if self._pending is not None and self._spec:
-                    self._repair = void
-                    info["repair_pending"] = True
-        return obs, rew, end, trunc, info
-
-
-def _windows(env, pol, windows, t, monkeypatch, mode):
+def _windows(env, pol, windows, t, monkeypatch):
     monkeypatch.setattr(EL, "sample_categorical", lambda logits, expo: (torch.softmax(logits.detach(), -1) / expo).argmax(-1))
-    monkeypatch.setenv("DIAMOND_SPECULATIVE_POLICY", mode)
     torch.manual_seed(11)
     random.seed(5)
     loop = EL.make_env_loop(env, pol, epsilon=0.0)
@@ -440,58 +204,6 @@ def _windows(env, pol, windows, t, monkeypatch, mode):
         *cols, infos = loop.send(t)
         outs.append([c.clone() for c in cols])
     return outs
-
-
-@pytest.mark.parametrize("separable", [True, False])
-@pytest.mark.parametrize("speculate,policy_spec", [(True, True), (False, True), (False, False), (True, "alternate")])
-@pytest.mark.parametrize("p_end,horizon,stagger", [(0.0, 6, False), (0.0, 7, True), (0.02, 7, True), (0.12, 7, True), (0.35, 5, False), (0.6, 9, True)])
-def test_pipelined_loop_is_bitwise_the_sequential_one(monkeypatch, p_end, horizon, stagger, speculate, policy_spec, separable):
-    """planned truncation resets inside the pipeline, speculative sampler steps, unplanned deaths repaired row by row, deaths at
-    the last step of a window, mixed steps (an `end` in front of planned truncations: pool order), all of it on ONE shared random
-    stream against the reference's order of operations"""
-    b, t, windows = 9, 6, 5
-    pol = lambda: SeparablePolicy(True) if separable else ToyPolicy()
-    seq = _windows(PoolEnv(b, p_end, horizon, stagger), pol(), windows, t, monkeypatch, "1")  # (no protocol: the generic loop)
-    env = PipeEnv(b, p_end, horizon, stagger, speculate, policy_spec)
-    pipe = _windows(env, pol(), windows, t, monkeypatch, "1")
-    names = ("obs", "act", "rew", "end", "trunc", "logits", "val", "val_bootstrap")
-    for w, (wa, wb) in enumerate(zip(seq, pipe)):
-        for name, a, b_ in zip(names, wa, wb):
-            assert torch.equal(a, b_), (w, name)
-    c = env.counts
-    if speculate:
-        assert c["spec"] > 0
-    if policy_spec is False:  # the reference's order + one encoder pass per step: nothing planned, nothing speculated
-        assert c["planned"] == 0 and c["spec"] == 0 and c["repairs"] == 0
-    else:
-        if (stagger or horizon % t) and p_end < 0.5:  # (at p = 0.6 hardly an episode reaches the horizon)
-            assert c["planned"] > 0, "no truncation was planned"
-        if p_end > 0:
-            assert c["void"] > 0 and (c["repairs"] > 0) == speculate
-        if 0.12 <= p_end < 0.5 and stagger:
-            assert c["mixed"] > 0, "no step had an unplanned death next to planned truncations"
-    # the protocol-less path on the same env class gives the same thing (PipeEnv.step = begin + issue + finish without a plan)
-    again = _windows(PipeEnv(b, p_end, horizon, stagger), pol(), windows, t, monkeypatch, "0")
-    for wa, wb in zip(seq, again):
-        for a, b_ in zip(wa, wb):
-            assert torch.equal(a, b_)
-
-
-def test_pipelined_loop_gradients_match_the_sequential_ones(monkeypatch):
-    """index_copy merges of recomputed rows carry the same gradient as the sequential graph (up to summation order)"""
-    outs = []
-    for cls in (PoolEnv, PipeEnv):
-        pol = SeparablePolicy(True)
-        pol.w.requires_grad_(True)
-        cols = _windows(cls(9, 0.12, 7, True), pol, 1, 6, monkeypatch, "1")
-        monkeypatch.setattr(EL, "sample_categorical", lambda logits, expo: (torch.softmax(logits.detach(), -1) / expo).argmax(-1))
-        torch.manual_seed(11)
-        random.seed(5)
-        loop = EL.make_env_loop(cls(9, 0.12, 7, True), pol, epsilon=0.0)
-        *c, _ = loop.send(6)
-        (c[5].square().sum() + c[6].sum()).backward()
-        outs.append(pol.w.grad.clone())
-    assert torch.allclose(outs[0], outs[1], rtol=1e-5, atol=1e-6)
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -616,10 +328,10 @@ def test_slots_loop_is_bitwise_the_sequential_one(monkeypatch, p_end, horizon, s
     ONE shared random stream against the reference's order of operations"""
     b, t, windows = 9, 6, 5
     monkeypatch.setenv("DIAMOND_ENV_LOOP", "sequential")
-    seq = _windows(PoolEnv(b, p_end, horizon, stagger), SlotsPolicy(), windows, t, monkeypatch, "1")
+    seq = _windows(PoolEnv(b, p_end, horizon, stagger), SlotsPolicy(), windows, t, monkeypatch)
     monkeypatch.setenv("DIAMOND_ENV_LOOP", "slots")
     env = SlotsEnv(b, p_end, horizon, stagger, margin)
-    got = _windows(env, SlotsPolicy(), windows, t, monkeypatch, "1")
+    got = _windows(env, SlotsPolicy(), windows, t, monkeypatch)
     names = ("obs", "act", "rew", "end", "trunc", "logits", "val", "val_bootstrap")
     for w, (wa, wb) in enumerate(zip(seq, got)):
         for name, a, b_ in zip(names, wa, wb):
@@ -652,3 +364,18 @@ def test_slots_loop_gradients_match_the_sequential_ones(monkeypatch):
         (g,) = torch.autograd.grad(loss, pol.w)
         grads.append(g)
     assert torch.allclose(grads[0], grads[1], rtol=1e-6, atol=1e-7), float((grads[0] - grads[1]).abs().max())
+
+
+def test_epsilon_greedy_rollouts_take_the_sequential_loop(monkeypatch):
+    """epsilon > 0 (the collector's loop over real envs): the reference's order of calls whatever the env offers -- one env.step per
+    step, the python generator consumed once per step (reference env_loop.py:34)"""
+    monkeypatch.setattr(EL, "sample_categorical", lambda logits, expo: (torch.softmax(logits.detach(), -1) / expo).argmax(-1))
+    torch.manual_seed(11)
+    random.seed(5)
+    calls = []
+    real = random.random
+    monkeypatch.setattr(random, "random", lambda: (calls.append(1), real())[1])
+    env = SlotsEnv(5, 0.2, 7)
+    loop = EL.make_env_loop(env, SlotsPolicy(), epsilon=0.3)
+    loop.send(6)
+    assert env.log.count("step") == 6 and "begin" not in env.log and len(calls) == 6

@@ -407,12 +407,17 @@ def test_full_window_vs_reference_golden(fixture="window.pt", ag=None):
         assert torch.equal(act.cpu(), w["act"]), "sampled actions differ from the reference"
         assert torch.equal(end.cpu(), w["end"]) and torch.equal(trunc.cpu(), w["trunc"])
         assert torch.equal(rew.cpu(), w["rew"])
-        check_quantised(u8(all_obs), w["obs_u8"], max_frac=2e-3)
-        assert rel_err(logits_act.detach(), w["logits_act"]) < 1e-2  # quantisation-flip noise, see oracle test
-        assert rel_err(val.detach(), w["val"]) < 1e-2
+        # FREE-RUNNING bars (the contract's 1e-4 bars are the teacher-forced tests: test_window_teacher_forced_vs_reference_golden_1e4
+        # and test_quantised_frame_budget_on_200k_pixels_vs_reference_golden).  Here a pixel within ~1e-6 of a rounding boundary that lands
+        # on the other uint8 level (2/255 = 8e-3 of the frame's range) is fed back into 4 context frames x 15 steps x 2 windows, so the
+        # budgets are those of an accumulating quantisation flip, not of the arithmetic: the INTEGER trajectory above is what is exact.
+        free = "free-running window: an off-level pixel feeds back through the context (teacher-forced bars: 1e-4, see the comment)"
+        check_quantised(u8(all_obs), w["obs_u8"], max_frac=2e-3, what=free)
+        assert rel_err(logits_act.detach(), w["logits_act"]) < 1e-2, free
+        assert rel_err(val.detach(), w["val"]) < 1e-2, free
         from diamond_amd.actor_critic import actor_critic_loss
         loss, metrics = actor_critic_loss(logits_act, val, act, rew, end, trunc, vb, ac.loss_cfg)
-        assert rel_err(loss.detach(), w["loss"]) < 1e-2
+        assert rel_err(loss.detach(), w["loss"]) < 1e-2, free
         loss.backward()
         for k, p in ac.named_parameters():
             n = float(w["grad_norms"][k])
@@ -828,18 +833,18 @@ def test_sampler_branches_bit_exact_vs_oracle_control_flow(agent, name, steps, o
     assert torch.equal(x.cpu(), x_ref)
 
 
-def test_speculative_policy_step_is_bitwise_the_sequential_one(monkeypatch):
-    """env_loop issues the policy's next step between WorldModelEnv.step_begin and step_end (before the step's host
-    synchronisation) and drops it when an episode ended: two windows with many mid-window resets (the golden's unbiased
-    synthetic end-logits), same seeds, with and without the speculation -- every output bitwise identical."""
+def test_slots_loop_with_injected_draws_is_bitwise_the_sequential_one(monkeypatch):
+    """env_loop's default (slots) loop against the reference's sequential order of calls with HOST-INJECTED random draws (the
+    goldens' hooks: such a stream cannot be rewound, so every step gets a slot per env and no window is ever repeated): two
+    windows with many mid-window resets (the golden's unbiased synthetic end-logits), same seeds -- every output bitwise identical."""
     import random
     import diamond_amd as D
 
     gold = load_golden("window.pt")
     b, t = gold["b"], gold["backup_every"]
     runs = []
-    for mode in ("1", "0"):
-        monkeypatch.setenv("DIAMOND_SPECULATIVE_POLICY", mode)
+    for mode in ("slots", "sequential"):
+        monkeypatch.setenv("DIAMOND_ENV_LOOP", mode)
         ag = make_agent()
         env = D.WorldModelEnv(ag.denoiser, ag.rew_end_model, _Loader(b, gold["pool_seed"]),
                               D.WorldModelEnvConfig(horizon=gold["horizon"], num_batches_to_preload=gold["preload"],
@@ -893,13 +898,15 @@ def test_fused_burn_in_is_bitwise_the_frame_by_frame_one():
         assert rel_err(out[0][3][n], out[1][3][n]) < 1e-5, n
 
 
-@pytest.mark.parametrize("spec,policy", [("1", "1"), ("0", "1"), ("0", "0"), ("auto", "auto")])
-@pytest.mark.parametrize("b,horizon,p_end,stagger", [(24, 5, 0.03, True), (12, 7, 0.25, False), (16, 6, 0.0, True)])
-def test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon, p_end, stagger, spec, policy, loop="pipelined", tail=None):
-    """env_loop's pipelined form (planned truncation resets inside the speculated pipeline, unplanned deaths repaired row by row on
-    a small batch: env_loop._pipelined_env_loop, WorldModelEnv.plan_resets / step_begin_repair) against the reference's sequential
-    order of operations (DIAMOND_SPECULATIVE_POLICY=0), three windows on the DEVICE random generator at batches the graphed
-    sampler does not take: every output bitwise identical, and the paths in question were actually taken."""
+@pytest.mark.parametrize("tail", [1e-7, 0.9])
+@pytest.mark.parametrize("b,horizon,p_end,stagger", [(24, 5, 0.03, True), (24, 7, 0.25, True), (12, 7, 0.25, False), (16, 6, 0.0, True), (16, 6, 0.0, False)])
+def test_slots_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon, p_end, stagger, tail):
+    """env_loop's default form -- a step's deaths resolved ON THE DEVICE into reset slots (dmd_resolve_deaths / dmd_reset_slots /
+    dmd_merge_slots), the host one step behind, pool rounds prefetched and picked by the device (env_loop._slots_env_loop,
+    WorldModelEnv.step_end_slots) -- against the reference's sequential order of operations (DIAMOND_ENV_LOOP=sequential): three
+    windows on the DEVICE random generator at batches the graphed sampler does not take, every output bitwise identical,
+    gradients to rounding.  tail = 0.9 sizes the slots with no margin for sampled ends: windows overflow, are restored from
+    their snapshot (env state, pool position, device generator) and repeated."""
     import random
     import sys
     import diamond_amd as D
@@ -909,19 +916,15 @@ def test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon,
 
     t = 6
     runs, stats, grads = [], None, []
-    for mode in ("1", "0"):
-        monkeypatch.setenv("DIAMOND_SPECULATIVE_POLICY", mode)
-        monkeypatch.setenv("DIAMOND_ENV_LOOP", loop)
-        for k, v in (("DIAMOND_SPEC_SAMPLER", spec), ("DIAMOND_SPEC_POLICY", policy)):  # pinned modes, or the env's own running averages
-            monkeypatch.delenv(k, raising=False) if v == "auto" else monkeypatch.setenv(k, v)
+    for mode in ("slots", "sequential"):
+        monkeypatch.setenv("DIAMOND_ENV_LOOP", mode)
         monkeypatch.setenv("DIAMOND_CHECK_RESET_RNG", "1")
         ag = make_agent()
         set_end_rate(ag, p_end if p_end > 0 else 1e-9)
         env = D.WorldModelEnv(ag.denoiser, ag.rew_end_model, _Loader(b, 77),
                               D.WorldModelEnvConfig(horizon=horizon, num_batches_to_preload=2,
                                                     diffusion_sampler=D.DiffusionSamplerConfig(num_steps_denoising=2)))
-        if tail is not None:
-            env.DR_END_TAIL = tail
+        env.DR_END_TAIL = tail
         ag.setup_training(D.SigmaDistributionConfig(-0.4, 1.2, 2e-3, 20),
                           D.ActorCriticLossConfig(backup_every=t, gamma=0.985, lambda_=0.95, weight_value_loss=1.0,
                                                   weight_entropy_loss=0.001), env)
@@ -933,15 +936,15 @@ def test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon,
             outs.append([x.detach().cpu() for x in (all_obs, act, rew, end, trunc, logits_act, val, vb)])
             if w == 0 and stagger:
                 env.set_episode_lengths(torch.arange(b) % horizon)
-        # ... and the gradients of the last window's loss: the merged encoder pass, the index_copy merges of recomputed rows
-        # and the planned resets build a different autograd graph for the same function
+        # ... and the gradients of the last window's loss: the merged encoder pass with its unused slots and the merges of the
+        # burnt-in states build a different autograd graph for the same function
         from diamond_amd.actor_critic import actor_critic_loss
         ag.actor_critic.zero_grad()
         loss, _ = actor_critic_loss(logits_act, val, act, rew, end, trunc, vb, ag.actor_critic.loss_cfg)
         loss.backward()
         grads.append({k: p.grad.detach().double().cpu() for k, p in ag.actor_critic.named_parameters()})
         runs.append(outs)
-        if mode == "1":
+        if mode == "slots":
             stats = dict(env.stats)
     print(stats)
     names = ("obs", "act", "rew", "end", "trunc", "logits", "val", "val_bootstrap")
@@ -949,35 +952,17 @@ def test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon,
         for name, a, b_ in zip(names, wa, wb):
             assert torch.equal(a, b_), (w, name)
     gerr = {k: float((grads[0][k] - g).abs().max() / g.abs().max().clamp_min(1e-30)) for k, g in grads[1].items()}
-    print("pipelined vs sequential gradient rel diff:", f"{max(gerr.values()):.2e}")
+    print("slots vs sequential gradient rel diff:", f"{max(gerr.values()):.2e}")
     assert max(gerr.values()) < 1e-4, {k: f"{v:.1e}" for k, v in gerr.items() if v >= 1e-4}
-    if loop == "slots":
-        return stats
-    if policy == "1":
-        assert stats["planned_rows"] > 0, stats
-        if p_end > 0:
-            assert stats["void_rows"] > 0 and (stats["repairs"] > 0) == (spec == "1"), stats
-        assert (stats["speculated"] > 0) == (spec == "1"), stats
-    elif policy == "0":  # the reference's order with one encoder pass per step: nothing planned, nothing speculated
-        assert stats["planned_rows"] == 0 and stats["speculated"] == 0 and stats["repairs"] == 0, stats
-
-
-@pytest.mark.parametrize("tail", [1e-7, 0.9])
-@pytest.mark.parametrize("b,horizon,p_end,stagger", [(24, 5, 0.03, True), (24, 7, 0.25, True), (12, 7, 0.25, False), (16, 6, 0.0, True), (16, 6, 0.0, False)])
-def test_slots_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon, p_end, stagger, tail):
-    """env_loop's default form -- a step's deaths resolved ON THE DEVICE into reset slots (dmd_resolve_deaths / dmd_reset_slots /
-    dmd_merge_slots), the host one step behind (env_loop._slots_env_loop, WorldModelEnv.step_end_slots) -- against the reference's
-    sequential order of operations: three windows on the DEVICE random generator, every output bitwise identical, gradients to
-    rounding.  tail = 0.9 sizes the slots with no margin for sampled ends: windows overflow, are restored from their snapshot
-    (env state, pool position, device generator) and repeated."""
-    stats = test_pipelined_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon, p_end, stagger, "auto", "auto", loop="slots", tail=tail)
-    assert stats["steps"] >= 18 and stats["speculated"] == 0 and stats["planned_rows"] == 0, stats
+    assert stats["steps"] >= 18, stats
     if p_end > 0 or stagger:
         assert stats["dead_rows"] > 0 and stats["slots"] >= stats["dead_rows"] - 24 * stats["slot_overflows"], stats
+        assert stats["pool_rounds"] > 0, f"no step was served from a prefetched pool round: {stats}"
     if tail == 0.9 and p_end >= 0.25:
         assert stats["slot_overflows"] > 0, f"the repeated-window path was not exercised: {stats}"
     if tail == 1e-7 and p_end <= 0.03:
         assert stats["slot_overflows"] <= 1, stats  # (at most the very first end: the running mean starts at zero)
+    return stats
 
 
 @pytest.mark.parametrize("num_actions", [6, 18])

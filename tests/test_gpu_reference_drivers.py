@@ -90,7 +90,7 @@ def test_reference_env_loop_drives_our_env_and_actor_critic_bit_exact_vs_golden(
 
 def test_reference_style_reassignment_of_predict_next_obs_and_predict_rew_end(monkeypatch):
     """trainer.py:182-184 replaces rl_env.predict_next_obs / predict_rew_end by wrappers (torch.compile objects) AFTER the env was
-    built: the env -- including the pipelined loop's step_begin / step_end_issue -- must call through the attributes"""
+    built: the env -- including the slots loop's step_begin / step_end_slots -- must call through the attributes"""
     import diamond_amd as D
     from diamond_amd.actor_critic import actor_critic_loss
 

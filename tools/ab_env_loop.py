@@ -1,8 +1,8 @@
 """Same-process, same-box A/B of the env loop under episodes that END (measurement scaffolding, not product).
 
-Arms: this tree's slots loop (round 6: a step's deaths resolved on the device, DIAMOND_ENV_LOOP=slots), the round-5 pipelined loop
-(host-planned resets, speculation decided by the env's running averages; AB_ALL_ARMS=1: also with the speculation pinned on /
-off), the reference's sequential order (DIAMOND_SPECULATIVE_POLICY=0), and -- if its files are there -- the ROUND-4 loop + env
+Arms: this tree's slots loop (round 6: a step's deaths resolved on the device, DIAMOND_ENV_LOOP=slots), the reference's sequential
+order of calls (DIAMOND_ENV_LOOP=sequential) and -- if its files are there -- the ROUND-4 loop + env (the round-5 pipelined loop,
+host-planned resets + speculation, was removed after profiles/r06c_ab_env_loop.txt: the slots loop beat it in every regime but p = 0.5)
 (diamond_amd/ablate/r04_{env_loop,world_model_env}.py = `git show d83241c:diamond_amd/...`, git-ignored, loaded beside the
 current modules).  Regimes: end probability p per env-step through the synthetic reward/end head, from synchronised episodes
 ("lockstep") or from episode lengths spread over the horizon ("steady": the state the reference's training loop converges
@@ -61,11 +61,7 @@ def main():
         arms[name] = (env, loop, environ)
 
     add("slots loop (round 6: deaths resolved on the device)", D.WorldModelEnv, EL.make_env_loop, {"DIAMOND_ENV_LOOP": "slots"})
-    add("pipelined loop (round 5: planned resets + speculation by running averages)", D.WorldModelEnv, EL.make_env_loop, {"DIAMOND_ENV_LOOP": "pipelined"})
-    if os.environ.get("AB_ALL_ARMS") == "1":
-        add("pipelined, policy + sampler speculation pinned on", D.WorldModelEnv, EL.make_env_loop, {"DIAMOND_ENV_LOOP": "pipelined", "DIAMOND_SPEC_POLICY": "1", "DIAMOND_SPEC_SAMPLER": "1"})
-        add("pipelined, no speculation, one encoder pass per step", D.WorldModelEnv, EL.make_env_loop, {"DIAMOND_ENV_LOOP": "pipelined", "DIAMOND_SPEC_POLICY": "0"})
-    add("sequential (reference order, generic loop)", D.WorldModelEnv, EL.make_env_loop, {"DIAMOND_SPECULATIVE_POLICY": "0"})
+    add("sequential (reference order of calls)", D.WorldModelEnv, EL.make_env_loop, {"DIAMOND_ENV_LOOP": "sequential"})
     if legacy:
         add("round-4 loop", L_env.WorldModelEnv, L_loop.make_env_loop, {})
 
