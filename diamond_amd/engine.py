@@ -155,6 +155,7 @@ class WeightAudit:
     # networks but 6.5 ms where `lstm.weight_ih` is 2048 x 32768 (configs[4]: 2 % of a window) -- at most AUDIT_BYTES_PER_S of
     # parameter bytes are re-read per second of wall time, i.e. large models are audited every few windows instead of every window
     AUDIT_BYTES_PER_S = 256e6
+    AUDIT_FREE_BYTES = 64e6  # (cache groups below this size -- every one of the 64x64 networks -- are audited by lookup count alone)
     CAPACITY = 4096
 
     def __init__(self, what: str) -> None:
@@ -242,7 +243,7 @@ class WeightAudit:
         if self.ticks % self.AUDIT_EVERY == 0:
             now = time.monotonic()
             nbytes = 4 * sum(p.numel() for p in (r() for r in self._refs) if p is not None)
-            if now - self._last_run >= nbytes / self.AUDIT_BYTES_PER_S:
+            if nbytes < self.AUDIT_FREE_BYTES or now - self._last_run >= nbytes / self.AUDIT_BYTES_PER_S:
                 self._last_run = now
                 self.run()
 

@@ -898,6 +898,9 @@ def test_fused_burn_in_is_bitwise_the_frame_by_frame_one():
         assert rel_err(out[0][3][n], out[1][3][n]) < 1e-5, n
 
 
+LAST_SLOTS_STATS = {}  # (env.stats of the last test_slots_window_is_bitwise_the_sequential_one run: tests/test_simt_host.py reads it)
+
+
 @pytest.mark.parametrize("tail", [1e-7, 0.9])
 @pytest.mark.parametrize("b,horizon,p_end,stagger", [(24, 5, 0.03, True), (24, 7, 0.25, True), (12, 7, 0.25, False), (16, 6, 0.0, True), (16, 6, 0.0, False)])
 def test_slots_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon, p_end, stagger, tail):
@@ -962,7 +965,8 @@ def test_slots_window_is_bitwise_the_sequential_one(monkeypatch, b, horizon, p_e
         assert stats["slot_overflows"] > 0, f"the repeated-window path was not exercised: {stats}"
     if tail == 1e-7 and p_end <= 0.03:
         assert stats["slot_overflows"] <= 1, stats  # (at most the very first end: the running mean starts at zero)
-    return stats
+    LAST_SLOTS_STATS.clear()
+    LAST_SLOTS_STATS.update(stats)
 
 
 @pytest.mark.parametrize("num_actions", [6, 18])

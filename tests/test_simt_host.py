@@ -101,7 +101,8 @@ def test_slots_window_is_bitwise_the_sequential_one_on_the_interpreter(models, m
     """env_loop's default form through the REAL WorldModelEnv (deaths resolved into reset slots by dmd_resolve_deaths / dmd_reset_slots,
     the host one step behind, windows repeated from their snapshot after a slot overflow) against the sequential order, on the CPU"""
     M, counter = models
-    stats = M.test_slots_window_is_bitwise_the_sequential_one(monkeypatch, 3, 4, 0.15, True, 0.9)
+    M.test_slots_window_is_bitwise_the_sequential_one(monkeypatch, 3, 4, 0.15, True, 0.9)
+    stats = dict(M.LAST_SLOTS_STATS)
     assert counter.n.get("dmd_resolve_deaths", 0) >= 9 and counter.n.get("dmd_reset_slots", 0) >= 9 and stats["dead_rows"] > 0, (counter.n, stats)
 
 
