@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import time
 from dataclasses import dataclass
 from typing import Any, Callable, Dict, Iterator, List, Optional, Tuple
 
@@ -381,8 +382,9 @@ class WorldModelEnv:
         self._pending = None                              # (imagined frame, trajectory, reward / end draws, noise) between the two halves of a step
         self._slots_inflight = None                       # (event, pinned report, K, pool token, two rounds given) of the last step_end_slots
         self._end_mean = getattr(self, "_end_mean", 0.0)  # running mean of sampled `end`s per step (survives a reset())
-        self._end_last = getattr(self, "_end_last", 0)    # ... and the last step's count
-        self.stats = {"steps": 0, "steps_with_deaths": 0, "slots": 0, "dead_rows": 0, "slot_overflows": 0, "pool_rounds": 0}
+        self._end_last = getattr(self, "_end_last", 0)    # ... the last step's count
+        self._end_steps = getattr(self, "_end_steps", 0)  # ... and how many steps the mean has seen
+        self.stats = {"steps": 0, "steps_with_deaths": 0, "slots": 0, "dead_rows": 0, "slot_overflows": 0, "pool_rounds": 0, "report_wait_ms": 0.0}
 
     @property
     def device(self) -> torch.device:
@@ -592,14 +594,18 @@ class WorldModelEnv:
         if all_slots or self._ep_len_host is None:
             return b
         n_trunc = int(np.count_nonzero(self._ep_len_host + 1 >= self.horizon))
-        m = max(self._end_mean, float(self._end_last))  # (fast attack: a regime whose ends jump up is believed at once)
+        # running mean of ends per step: bias-corrected while young (the mean of the steps seen so far, not a mean pulled to zero),
+        # never below the last step's count (fast attack: a regime whose ends jump up is believed at once), and with a prior of
+        # half an end per step that fades over the first ~60 steps (a fresh env's first `end` then finds a spare slot)
+        n = self._end_steps
+        m = max(self._end_mean / (1.0 - 0.95 ** n) if n else 0.0, float(self._end_last), 0.5 * 0.95 ** n)
         k = n_trunc + (0 if m < 1e-3 else _poisson_quantile(m, self.DR_END_TAIL))
         return 0 if k == 0 else min(b, (k + 3) // 4 * 4)
 
     def reset_statistics(self) -> None:
         """Forget the running statistics the slot margin is sized from (a caller that CHANGES the regime, e.g. bench.py between its
         end-rate lines; otherwise they adapt within ~20 steps)."""
-        self._end_mean, self._end_last = 0.0, 0
+        self._end_mean, self._end_last, self._end_steps = 0.0, 0, 0
 
     def slots_can_repeat(self) -> bool:
         """Can a window be repeated after a SlotOverflow?  Not when random draws come from stateful hooks (the tests' injected
@@ -704,7 +710,9 @@ class WorldModelEnv:
             return
         event, host, k, token, two_rounds = inflight
         if event is not None:
+            t0 = time.perf_counter()
             event.synchronize()
+            self.stats["report_wait_ms"] += 1e3 * (time.perf_counter() - t0)  # (the host's slack: ~0 means the HOST paces the loop)
             check_weight_audits()  # (the host is synchronised anyway: did an audit of the packed weight copies find a silent write?)
         self._slots_account(host.numpy(), k, token, two_rounds)
 
@@ -717,6 +725,7 @@ class WorldModelEnv:
             self._ep_len_host[rows_host] = 0
         self._end_mean = 0.95 * self._end_mean + 0.05 * n_end
         self._end_last = n_end
+        self._end_steps += 1
         self.stats["dead_rows"] += n_dead
         if n_dead:
             self.stats["steps_with_deaths"] += 1
