@@ -797,10 +797,15 @@ static int wgrad_plan(const dmd_wgrad_params* p, int* tiles, int* num_wg, int* t
   const int sub = p->N * (p->H / 8) * (p->W / 8);
   *tiles = (sub + 1) / 2;
   // at most `cap` workgroups, each walking a contiguous range of tiles with its accumulators in registers: every workgroup
-  // writes one partial of the whole gradient, so fewer of them is less reduction traffic.  DIAMOND_WGRAD_MAX_WG (1..1024; a
-  // test hook for the multi-tile paths) changes the cap of 256 = one workgroup per CU; the workspace is always sized for 1024.
-  static DmdEnvInt cap_env{"DIAMOND_WGRAD_MAX_WG", 256};
-  const int cap = cap_env.get() >= 1 && cap_env.get() <= 1024 ? cap_env.get() : 256;
+  // writes one partial of the whole gradient, so fewer of them is less reduction traffic.  256 = one workgroup per CU (round 4:
+  // measured on the 64-output-channel instances, whose 80-105 KB of LDS allow one or barely two per CU); the 32-output-channel
+  // 3x3 instances of the actor-critic encoder use 64 KB, two fit a CU and hide each other's load latency: 512 (round 6, same
+  // box: wgrad<2,2,9> 6.45 -> 4.44 ms and <2,1,9> 2.42 -> 1.62 ms per window against +0.4 ms of reduction,
+  // profiles/r06g_ab_wgrad_cap.txt).  The choice depends on the shape only.  DIAMOND_WGRAD_MAX_WG (1..1024; a test hook for the
+  // multi-tile paths, and the A/B's knob) overrides it; the workspace is always sized for 1024.
+  static DmdEnvInt cap_env{"DIAMOND_WGRAD_MAX_WG", -1};
+  const int shape_cap = (p->Cout / 16 <= 2 && p->taps == 9) ? 512 : 256;
+  const int cap = cap_env.get() >= 1 && cap_env.get() <= 1024 ? cap_env.get() : shape_cap;
   int n = *tiles < cap ? *tiles : cap;
   *tpw = (*tiles + n - 1) / n;
   *num_wg = (*tiles + *tpw - 1) / *tpw;

@@ -43,8 +43,7 @@ class GradAllReducer:
         total = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.bucket = torch.zeros(total, device=ref.device, dtype=ref.dtype)
-        for p in self.params[:self.num_early]:
-            p.register_post_accumulate_grad_hook(self._early_ready)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._early_ready) for p in self.params[:self.num_early]]
         # measurement hook (bench.py): with `timing` on, every all_reduce_mean is bracketed by two events on the current
         # stream (the collective runs on RCCL's own stream, but a blocking dist.all_reduce makes the current stream wait
         # for it, so the pair spans it); `elapsed_ms()` reads them after a synchronisation
@@ -55,6 +54,12 @@ class GradAllReducer:
             n = p.numel()
             p.grad = self.bucket[off:off + n].view_as(p)  # autograd accumulates in place into the view
             off += n
+
+    def close(self) -> None:
+        """Remove the early slice's hooks from the parameters (a reducer that is replaced by another one)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
 
     def _ensure_views(self) -> None:
         """If something replaced p.grad (e.g. zero_grad(set_to_none=True)), copy back into the bucket."""

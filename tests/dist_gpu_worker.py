@@ -113,6 +113,20 @@ def main():
     loss, _ = ac()
     loss.backward()
     g_ref = red.all_reduce_mean().clone()
+    named_ref = {n: p.grad.detach().clone() for n, p in ac.named_parameters()}
+    ac.zero_grad(set_to_none=True)
+    # the early slice (LSTM + heads) all-reduced on a side stream from INSIDE backward(), the encoder's slice afterwards: same gradients
+    setup(make_env())
+    torch.manual_seed(7)
+    red_e = GradAllReducer(list(ac.parameters()), early=[p for n, p in ac.named_parameters() if not n.startswith("encoder.")])
+    loss_e, _ = ac()
+    loss_e.backward()
+    out["early_slice_launched_inside_backward"] = red_e.early_launches == 1 and red_e._early_work is not None
+    red_e.all_reduce_mean()
+    torch.cuda.synchronize()
+    out["early_slice_mb"] = red_e.early_numel * 4 / 2 ** 20
+    out["early_grad_rel_diff"] = max(float((p.grad - named_ref[n]).abs().max() / named_ref[n].abs().max().clamp_min(1e-30)) for n, p in ac.named_parameters())
+    red_e.close()
     ac.zero_grad(set_to_none=True)
     # the reference's own wrapper: DistributedDataParallel(actor_critic) (utils.py:105-106), same seed, fresh env
     setup(make_env())

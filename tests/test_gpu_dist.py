@@ -33,6 +33,8 @@ def test_rccl_world1_broadcast_allreduce_ddp():
     assert out["wm_allreduce_ok"] and out["wm_bucket_mb"] > 10
     assert out["grads_finite"] and out["loss_equal"]
     assert out["ddp_grad_rel_diff"] < 1e-6, out  # same kernels, same seed: DDP's bucketed all-reduce changes nothing at world 1
+    # the LSTM / head slice went out on a side stream from inside backward() (RCCL async work + stream waits), same gradients
+    assert out["early_slice_launched_inside_backward"] and out["early_grad_rel_diff"] < 1e-6 and out["early_slice_mb"] > 10, out
 
 
 def test_bench_distributed_branch_world1():

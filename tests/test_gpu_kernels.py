@@ -368,7 +368,7 @@ WGRAD_CASES = [
 ]
 
 
-# launch plans: at most DIAMOND_WGRAD_MAX_WG workgroups (default 256) walk contiguous tile ranges; 7: many tiles per workgroup
+# launch plans: at most DIAMOND_WGRAD_MAX_WG workgroups (default 256; 512 for the 32-output-channel 3x3 shapes) walk contiguous tile ranges; 7: many tiles per workgroup
 # (accumulators carried across tiles, the next tile's loads in flight under the MFMAs), 1024: the two-pass partial reduction
 @pytest.mark.parametrize("max_wg", [None, 7, 1024], ids=["plan256", "plan7", "plan1024"])
 @pytest.mark.parametrize("split", [False, True], ids=["exact", "f16x2"])

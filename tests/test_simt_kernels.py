@@ -235,7 +235,7 @@ WGRAD_CASES = [
 ]
 
 
-# the launcher's plan: at most DIAMOND_WGRAD_MAX_WG workgroups (default 256), each walking a contiguous range of tiles with its
+# the launcher's plan: at most DIAMOND_WGRAD_MAX_WG workgroups (default 256; 512 for the 32-output-channel 3x3 shapes), each walking a contiguous range of tiles with its
 # accumulators in registers and the next tile's loads in flight under the current tile's MFMAs
 WGRAD_PLANS = [dict(), dict(max_wg=1), dict(max_wg=3), dict(max_wg=1024)]
 

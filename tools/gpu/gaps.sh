@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}; cd $R
 O=$R/gpurun_out/${1:-gaps}; mkdir -p $O
 export TMPDIR=/tmp
 for mode in no_ends steady_p003 unbiased; do
-  extra=""; [ $mode = unbiased ] && extra="--no-end-logit-bias"; [ $mode = steady_p003 ] && extra="--stagger --end-rate 0.003"
+  extra="--no-ends"; [ $mode = unbiased ] && extra="--no-end-logit-bias"; [ $mode = steady_p003 ] && extra=""  # (the steady state is bench.py's default since round 6)
   (cd /tmp && rm -rf /tmp/gaps_$mode && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/gaps_$mode -o t -- \
      python $R/bench.py --steps 1 --warmup 3 --no-cpu-baseline --no-exact-fp32 --no-roofline --no-also $extra > $O/$mode.log 2>&1)
   t=$(find /tmp/gaps_$mode -name "*kernel_trace.csv" | head -1)
