@@ -660,14 +660,13 @@ class WorldModelEnv:
             if two_rounds:
                 pool.prefetch()  # (normally loaded steps ago, below)
         self._slots_inflight = (event, host, k, token, two_rounds)
-        oldest = self._head
-        self._head = (self._head + 1) % t
+        self._head = (self._head + 1) % t  # the ring advances: dmd_reset_slots writes the imagined frame into the slot this frees
         enc_in = torch.empty((b + t * k,) + tuple(next_obs.shape[1:]), dtype=torch.float32, device=dev)
         nxt = next_obs if (next_obs.dtype == torch.float32 and next_obs.is_contiguous()) else next_obs.float().contiguous()
         p = nv.ResetSlotsParams()
         p.B, p.K, p.T, p.head, p.per_frame = b, k, t, self._head, nxt[0].numel()
         p.row_slot, p.next_obs, p.ctx, p.enc_in = nv.ptr(row_slot), nv.fptr(nxt), nv.fptr(self._ctx), nv.fptr(enc_in)
-        keep = []
+        keep = []  # (tensor views whose pointers the launch parameters hold)
         if k > 0:
             assert self._act.is_contiguous() and self._act.dtype == torch.long
             rounds = [(pool.frames_u8, pool.frames_f32, pool.act, pool.hx, pool.cx, pool.pad)] + ([pool._next.fields()] if two_rounds else [])
