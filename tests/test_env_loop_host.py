@@ -379,3 +379,44 @@ def test_epsilon_greedy_rollouts_take_the_sequential_loop(monkeypatch):
     loop = EL.make_env_loop(env, SlotsPolicy(), epsilon=0.3)
     loop.send(6)
     assert env.log.count("step") == 6 and "begin" not in env.log and len(calls) == 6
+
+
+def test_slot_margin_quantile_and_estimator():
+    """WorldModelEnv.slot_count: truncations the host mirror foresees + a Poisson-tail margin for sampled ends from a running mean that
+    is bias-corrected while young, never below the last step's count, with a prior that fades (host logic only: no kernel, no GPU)"""
+    import math
+
+    import numpy as np
+    from diamond_amd.world_model_env import WorldModelEnv, _poisson_quantile
+
+    for mean, tail in ((0.77, 1e-4), (0.77, 1e-7), (2.56, 1e-4), (0.02, 1e-4), (30.0, 1e-4)):
+        x = _poisson_quantile(mean, tail)
+        cdf = lambda k: sum(math.exp(-mean) * mean ** i / math.factorial(i) for i in range(k + 1))
+        assert 1.0 - cdf(x) < tail and (x == 0 or 1.0 - cdf(x - 1) >= tail), (mean, tail, x)
+    assert _poisson_quantile(0.0) == 0 and _poisson_quantile(128.0, 1e-4) >= 128 + 5 * math.sqrt(128)
+
+    env = WorldModelEnv.__new__(WorldModelEnv)
+    env.num_envs, env.horizon = 256, 15
+    env._ep_len_host = np.arange(256) % 15  # the staggered steady state: 17 rows are at 14 -> they truncate in the pending step
+    env._end_mean, env._end_last, env._end_steps = 0.0, 0, 0
+    n_trunc = int((env._ep_len_host + 1 >= 15).sum())
+    assert n_trunc == 17
+    k0 = env.slot_count()  # a fresh env: the prior of half an end per step gives its first `end` a spare slot
+    assert k0 % 4 == 0 and n_trunc + _poisson_quantile(0.5, env.DR_END_TAIL) <= k0 < n_trunc + 12
+    assert env.slot_count(all_slots=True) == 256
+    rng = np.random.default_rng(0)
+    for _ in range(200):  # p = 0.003: 0.77 ends per step
+        n_end = int(rng.binomial(256, 0.003))
+        env._end_mean = 0.95 * env._end_mean + 0.05 * n_end
+        env._end_last, env._end_steps = n_end, env._end_steps + 1
+    env._end_last = 0
+    k = env.slot_count()
+    assert n_trunc + 4 <= k <= n_trunc + 12 and k % 4 == 0, k
+    env._end_last = 40  # a regime whose ends jump up is believed at once
+    assert env.slot_count() >= n_trunc + 40 + 3 * 6
+    env.reset_statistics()
+    env._ep_len_host = np.zeros(256, dtype=np.int64)
+    env._end_steps = 500  # no truncation ahead, no end seen for a long time: no slots at all (the no-ends regime pays nothing)
+    assert env.slot_count() == 0
+    env._ep_len_host = None  # (an env without the mirror: a slot per env)
+    assert env.slot_count() == 256
