@@ -68,6 +68,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #undef WS_ABL
 #define WS_ABL 0
 #endif
+// WS_WRITEOUT_PRIO (DMD_LAB builds only, same results): s_setprio of a consumer group while it WRITES ITS TILE OUT (3 while it computes; the
+// shipped library keeps 3 throughout): does the computing group's MFMA chain gain from winning arbitration against the write-out wave?
+#if defined(DMD_LAB) && defined(WS_WRITEOUT_PRIO)
+#define WS_PRIO_COMPUTE() __builtin_amdgcn_s_setprio(3)
+#define WS_PRIO_WRITEOUT() __builtin_amdgcn_s_setprio(WS_WRITEOUT_PRIO)
+#else
+#define WS_PRIO_COMPUTE() do {} while (0)
+#define WS_PRIO_WRITEOUT() do {} while (0)
+#endif
 // WS_ABL (DMD_LAB builds only, WRONG results: timing proxies for profiles/): 2 = no activation global loads, 4 = no staging arithmetic,
 // 16 = no MFMA loop, 32 = no weight movement, 128 = no epilogue global stores / residual loads.
 
@@ -1128,6 +1137,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       // ---- this group's tile: fragment reads + MFMAs only ----
       // (only if the other group's tile had too few steps to finish the write-out; PROJ launches have 4 steps per tile)
       if (!G::PROJ && pending < 4) epi_blocks(4);
+      WS_PRIO_COMPUTE();
       {
         // lane owns couts cb*32 + 8 qd + 4 g + (0..3), qd = 0..3, of its pixel of each block
         f32x4 bq[4];
@@ -1169,6 +1179,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       }
       epi_begin(k);  // written out while the other group computes the next tile
       if (k + 1 >= nmy) break;
+      WS_PRIO_WRITEOUT();
       // ---- the other group's tile: write our finished tile out, a slice per chunk step, and move the weights ----
       if constexpr (G::PROJ) {
         // 4 chunk steps per tile (eligibility), block s of the finished tile in step s: straight-line code, so that
