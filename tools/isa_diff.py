@@ -62,7 +62,7 @@ def main():
         os.makedirs(os.path.join(tmp, "old", "include"))
         names = subprocess.check_output(["git", "ls-tree", "--name-only", rev, "diamond_amd/csrc/", "include/"], cwd=ROOT, text=True).split()
         for n in names:
-            if n.endswith((".hip", ".h", ".cpp")):
+            if n.endswith((".hip", ".h", ".cpp", "extra_flags.txt")):  # (the per-source flags are part of what a revision compiles to)
                 with open(os.path.join(tmp, "old", n), "wb") as fh:
                     fh.write(subprocess.check_output(["git", "show", f"{rev}:{n}"], cwd=ROOT))
         os.makedirs(os.path.join(tmp, "o")), os.makedirs(os.path.join(tmp, "n"))
