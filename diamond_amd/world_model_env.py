@@ -589,18 +589,20 @@ class WorldModelEnv:
 
     def slot_count(self, all_slots: bool = False) -> int:
         """Reset slots of the pending step: the truncations it WILL have (host mirror of ep_len, exact) + a Poisson-tail margin for
-        the `end`s the reward/end model may sample, from the running mean of ends per step; multiples of 4, at most one per env."""
+        the `end`s the reward/end model may sample, from the running mean of ends per step; multiples of 4 (batches of 64 envs and more), at most one per env."""
         b = self.num_envs
         if all_slots or self._ep_len_host is None:
             return b
         n_trunc = int(np.count_nonzero(self._ep_len_host + 1 >= self.horizon))
         # running mean of ends per step: bias-corrected while young (the mean of the steps seen so far, not a mean pulled to zero),
         # never below the last step's count (fast attack: a regime whose ends jump up is believed at once), and with a prior of
-        # half an end per step that fades over the first ~60 steps (a fresh env's first `end` then finds a spare slot)
+        # half an end per step that fades within the first two windows (a fresh env's first `end` then finds a spare slot; a
+        # regime in which nobody ever ends stops paying for slots after ~28 steps)
         n = self._end_steps
-        m = max(self._end_mean / (1.0 - 0.95 ** n) if n else 0.0, float(self._end_last), 0.5 * 0.95 ** n)
+        m = max(self._end_mean / (1.0 - 0.95 ** n) if n else 0.0, float(self._end_last), 0.5 * 0.8 ** n)
         k = n_trunc + (0 if m < 1e-3 else _poisson_quantile(m, self.DR_END_TAIL))
-        return 0 if k == 0 else min(b, (k + 3) // 4 * 4)
+        g = 4 if b >= 64 else 1  # (small batches -- configs[4] has 8 envs per GPU -- pay four encoder frames per spare slot: none is added)
+        return 0 if k == 0 else min(b, (k + g - 1) // g * g)
 
     def reset_statistics(self) -> None:
         """Forget the running statistics the slot margin is sized from (a caller that CHANGES the regime, e.g. bench.py between its
