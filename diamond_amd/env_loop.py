@@ -72,7 +72,7 @@ def _policy_step_slots(model, obs_ext: Tensor, hx: Tensor, cx: Tensor, slots):
     return logits, val, hc, (h0, c0), slots.merge(torch.zeros_like(val.detach()), val_final.detach())
 
 
-def _slots_env_loop(env, model, expo_fn: Optional[Callable[[Tensor], Tensor]], num_steps: int):
+def _slots_env_loop(env, model, expo_fn: Optional[Callable[[Tensor], Tensor]], num_steps: int, obs: Tensor):
     """make_env_loop for an env that resolves a step's deaths on the device (SLOTS_PROTOCOL: WorldModelEnv), epsilon = 0.
 
     The reference has ONE data-dependent branch per imagined step (`if dead.any()`, world_model_env.py:77, env_loop.py:45): a host
@@ -90,8 +90,6 @@ def _slots_env_loop(env, model, expo_fn: Optional[Callable[[Tensor], Tensor]], n
     b = env.num_envs
     hx = torch.zeros(b, model.lstm_dim, device=dev)
     cx = torch.zeros(b, model.lstm_dim, device=dev)
-    seed = random.randint(0, 2 ** 31 - 1)
-    obs, _ = env.reset(seed=[seed + i for i in range(b)])
     slots = None  # the resets of the last step: they ride in the next policy step
 
     def draw_expo(logits: Tensor) -> Tensor:
@@ -155,14 +153,18 @@ def make_env_loop(env, model, epsilon: float = 0.0, expo_fn: Optional[Callable[[
     kind = os.environ.get("DIAMOND_ENV_LOOP", "slots")
     assert kind in ("slots", "sequential"), f"DIAMOND_ENV_LOOP={kind!r}: slots | sequential"
     separable = all(hasattr(model, a) for a in ("encode", "predict_from_features", "burn_in_from_features"))
-    if epsilon == 0.0 and kind == "slots" and separable and all(hasattr(env, a) for a in SLOTS_PROTOCOL):
-        yield from _slots_env_loop(env, model, expo_fn, num_steps)
-        return
     dev = model.device
-    hx = torch.zeros(env.num_envs, model.lstm_dim, device=dev)
-    cx = torch.zeros(env.num_envs, model.lstm_dim, device=dev)
     seed = random.randint(0, 2 ** 31 - 1)
     obs, _ = env.reset(seed=[seed + i for i in range(env.num_envs)])
+    # (an env may decline, once it has been reset: WorldModelEnv with a replayed sampler graph -- at most 8 small frames -- is
+    #  latency-bound anyway, and its in-graph random draws cannot be rewound for a window's repetition: it would need a slot per
+    #  env, i.e. 5x the encoder frames, at every step)
+    if (epsilon == 0.0 and kind == "slots" and separable and all(hasattr(env, a) for a in SLOTS_PROTOCOL)
+            and getattr(env, "slots_preferred", lambda: True)()):
+        yield from _slots_env_loop(env, model, expo_fn, num_steps, obs)
+        return
+    hx = torch.zeros(env.num_envs, model.lstm_dim, device=dev)
+    cx = torch.zeros(env.num_envs, model.lstm_dim, device=dev)
 
     def draw_expo(logits: Tensor) -> Tensor:
         e = expo_fn(logits) if expo_fn is not None else None

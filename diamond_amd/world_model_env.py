@@ -609,6 +609,11 @@ class WorldModelEnv:
         end-rate lines; otherwise they adapt within ~20 steps)."""
         self._end_mean, self._end_last, self._end_steps = 0.0, 0, 0
 
+    def slots_preferred(self) -> bool:
+        """Should env_loop take the slots loop for this env (asked after reset())?  Not while the sampler is replayed as a hipGraph
+        (a few small frames: see make_env_loop)."""
+        return not self._use_graph()
+
     def slots_can_repeat(self) -> bool:
         """Can a window be repeated after a SlotOverflow?  Not when random draws come from stateful hooks (the tests' injected
         draws) or from inside a replayed sampler graph: then every step gets a slot per env (no overflow is possible)."""
