@@ -23,6 +23,7 @@ def _worker(rank, world, port, q):
 
     from diamond_amd.dist import parameter_checksum
 
+    torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))  # (the ranks share the host's cores: no oversubscription)
     torch.manual_seed(rank)  # different default init per rank: broadcast must fix it
     ac = D.ActorCritic(D.default_agent_config().actor_critic)
     if rank == 0:
@@ -46,8 +47,9 @@ def _worker(rank, world, port, q):
 
     red = GradAllReducer(list(ac.parameters()))
     g = torch.Generator().manual_seed(40)
-    obs_all = synthetic_frames(g, 2 * world, 3, 64, 64)
-    obs = obs_all[rank * 2:(rank + 1) * 2]
+    per = 2 if world == 2 else 1  # (frames per rank: the oracle's backward on 8 cores shared by 4 ranks is the test's run time)
+    obs_all = synthetic_frames(g, per * world, 3, 64, 64)
+    obs = obs_all[rank * per:(rank + 1) * per]
     # a first backward, then zero_grad(set_to_none=True): the reducer must re-attach its bucket views
     logits, val = predict(ac, obs)
     (logits.square().mean() + val.mean()).backward()
