@@ -464,7 +464,7 @@ def stagger_episodes(env, horizon):
 def _is_split(key):
     """kernels that run split-fp16 arithmetic (3 f16 MFMAs per algorithmic MAC) are priced against the f16 peak"""
     last_arg_true = key.rstrip(">").rstrip().endswith("true")  # (the SPLIT template argument is the last one: "..., true>" / "..., true>>")
-    return (key.startswith("conv_f16ws") or key.startswith("attention_f16x2") or key.startswith("lowres_chain")
+    return (key.startswith("conv_f16ws") or key.startswith("attention_f16x2") or key.startswith("lowres_chain") or key.startswith("wgrad_ps_kernel")
             or ((key.startswith("conv1x1_stream") or key.startswith("conv_mfma") or key.startswith("wgrad_kernel")) and last_arg_true))
 
 

@@ -713,6 +713,252 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, in
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// wgrad_ps_kernel -- the split-fp16 weight gradient as a producer / consumer pair (round 6).
+//
+// wgrad_kernel<G, true> above runs its two phases one after the other on four waves: a 128-pixel tile is staged (GroupNorm / FiLM /
+// SiLU, h/l split, LDS writes: vector ALU), a barrier, then contracted (ds_read + MFMA: matrix pipe), a barrier -- one wave per
+// SIMD, so nothing hides the other phase's latencies.  Measured (tools/wgrad_bench.py): 99.5 us for the 64 -> 64 weight gradient
+// of 32 images of 64 x 64 (97 TFLOP/s algorithmic, 12 % of the f16 peak by executed MFMAs), ~21 us per tile and CU of which the
+// MFMAs are 3.3.  Here a 512-thread workgroup splits the roles:
+//   waves 0-3  CONSUME: accumulators in registers, operands from LDS, MFMAs only (wave w owns column blocks w, w + 4, ...);
+//   waves 4-7  PRODUCE: the raw loads of sub-tile u + 2 fly while sub-tile u is activated, split and written to the OTHER
+//              LDS buffer (two register sets, two LDS buffers: a sub-tile = one 8 x 8 pixel patch = half of the old tile, so
+//              the pair of buffers is the old tile's LDS);
+// one workgroup barrier per sub-tile.  A SIMD holds one wave of each role: the staging arithmetic issues under the MFMAs.
+// Same plan (wgrad_plan: a workgroup = a contiguous range of 128-pixel tiles = sub-tiles 2 t, 2 t + 1), same partial layout,
+// same order of accumulation per accumulator element (sub-tile by sub-tile, 32 pixels per MFMA, h.l + l.h + h.h) and per bias
+// element: with DMD_PROLOGUE_NONE the partials are BITWISE those of wgrad_kernel<G, true>; a normalised source differs in the
+// last bit of its activations (v_exp / v_rcp SiLU like the forward's split-fp16 kernels instead of expf and an IEEE division:
+// the exact form is 45 instructions per element and would make the producers the critical path).
+// The per-image table (mean, scale, shift per channel) is double-buffered in LDS and rebuilt by the producers one barrier
+// ahead of the first sub-tile of a new image.
+// ------------------------------------------------------------------------------------------------
+template <class G>
+struct WgradPs {
+  static constexpr int BUF_FLOATS = G::PP * G::SB + 64 * G::SA;  // one sub-tile: [PP][SB] patch + [64][SA] dy
+  static constexpr int TAB_FLOATS = 2 * 3 * G::CIN;              // two images' [mean | scale | shift][CIN]
+  static constexpr int SMEM_BYTES = (2 * BUF_FLOATS + TAB_FLOATS) * 4;
+  static constexpr int CQI = G::CIN / 4, CQO = G::COUT / 4;
+  static constexpr int NPQ = G::PP * CQI;         // patch quads of a sub-tile
+  static constexpr int NP = (NPQ + 255) / 256;    // ... per producer thread
+  static constexpr int ND = (64 * CQO) / 256;     // dy quads per producer thread (COUT >= 16: >= 1)
+  static_assert(256 % CQI == 0 && 256 % CQO == 0 && (64 * CQO) % 256 == 0, "a producer thread keeps one channel quad");
+};
+
+template <class G>
+__global__ __launch_bounds__(512) void wgrad_ps_kernel(const dmd_wgrad_params p, int tiles_total, int tiles_per_wg) {
+  using P = WgradPs<G>;
+  DMD_DYNAMIC_LDS(float, smem);
+  float* tab = smem + 2 * P::BUF_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = wave >= 4;
+  const int Cx = p.src.C;  // == CIN (checked on the host)
+  const int Hv = p.valid_h ? p.valid_h : p.H, Wv = p.valid_w ? p.valid_w : p.W;
+  const int txs = p.W / 8, per_img = txs * (p.H / 8);
+  const int sub_total = p.N * per_img;
+  const int sub_begin = 2 * blockIdx.x * tiles_per_wg;
+  const int sub_end = min(sub_total, 2 * min(tiles_total, (int)(blockIdx.x + 1) * tiles_per_wg));
+  const int n = sub_end - sub_begin;  // > 0 (wgrad_plan), uniform
+  constexpr int PER_TOTAL = G::NB * G::NCO * 256 + G::COUT;
+  float* part = p.workspace + (size_t)blockIdx.x * PER_TOTAL;
+
+  if (producer) {
+    // ================================ producers ================================
+    const int ptid = tid - 256;
+    const int qi = ptid % P::CQI, qo = ptid % P::CQO;  // this thread's channel quads (the same for every item)
+    f32x4 pxa[P::NP], pda[P::ND], pxb[P::NP], pdb[P::ND];
+    f32x4 bsum = (f32x4){0.f, 0.f, 0.f, 0.f};  // bias gradient of dy channel quad qo
+    const bool normed = p.src.prologue != DMD_PROLOGUE_NONE;
+    const bool silu = p.src.prologue == DMD_PROLOGUE_NORM_SILU;
+    // Every request is UNCONDITIONAL (an item outside the image, the valid extent or the patch reads pixel (0, 0) of its image
+    // and is zeroed when it is staged): a predicated load is a branch to hipcc, and behind a branch its wait insertion stops
+    // counting -- `s_waitcnt vmcnt(0)` right behind the requests, i.e. no prefetch at all (the first version of this kernel:
+    // loads, staging and MFMAs of the 32-channel launches added up to the launch time, 1,133 + 470 + 693 us of 2,064).
+    auto fetch = [&](f32x4 (&px)[P::NP], f32x4 (&pd)[P::ND], int u) __attribute__((always_inline)) {
+      const int img = u / per_img, r = u - img * per_img;
+      const int y0 = (r / txs) * 8, x0 = (r % txs) * 8;
+      const float* xs = p.src.x + (size_t)img * p.H * p.W * Cx + 4 * qi;
+#pragma unroll
+      for (int it = 0; it < P::NP; ++it) {
+        const int pp = it * (256 / P::CQI) + ptid / P::CQI;
+        const int py = pp / G::PW, pxx = pp - py * G::PW;
+        const int iy = y0 - G::PAD + py, ix = x0 - G::PAD + pxx;
+        const bool ok = pp < G::PP && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+        px[it] = *(const f32x4*)(xs + (ok ? (size_t)(iy * p.W + ix) * Cx : (size_t)0));
+      }
+      const float* ds = p.dy + (size_t)img * p.H * p.W * G::COUT + 4 * qo;
+#pragma unroll
+      for (int it = 0; it < P::ND; ++it) {
+        const int pix = it * (256 / P::CQO) + ptid / P::CQO;
+        const int oy = y0 + (pix >> 3), ox = x0 + (pix & 7);
+        pd[it] = *(const f32x4*)(ds + ((oy < Hv && ox < Wv) ? (size_t)(oy * p.W + ox) * G::COUT : (size_t)0));
+      }
+    };
+    auto build_table = [&](int img, int which) __attribute__((always_inline)) {
+      if (ptid < G::CIN) {
+        float m, a, ad;
+        norm_entry(p.src.norm, img, ptid, Cx, (double)(Cx < DMD_GN_GROUP ? Cx : DMD_GN_GROUP) * Hv * Wv, &m, &a, &ad);
+        float* t = tab + which * 3 * G::CIN;
+        t[ptid] = m;
+        t[G::CIN + ptid] = a;
+        t[2 * G::CIN + ptid] = ad;
+      }
+    };
+    int which = 0;  // the table of the image being staged
+    auto stage = [&](const f32x4 (&px)[P::NP], const f32x4 (&pd)[P::ND], int u, float* buf) __attribute__((always_inline)) {
+      const int img = u / per_img, r = u - img * per_img;
+      const int y0 = (r / txs) * 8, x0 = (r % txs) * 8;
+      float tm[4], ta[4], tad[4];
+      if (normed) {
+        const float* t = tab + which * 3 * G::CIN + 4 * qi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          tm[e] = t[e];
+          ta[e] = t[G::CIN + e];
+          tad[e] = t[2 * G::CIN + e];
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < P::NP; ++it) {
+        const int pp = it * (256 / P::CQI) + ptid / P::CQI;
+        if (pp >= G::PP) continue;  // (uniform per wave when it is not compile-time: 256 / CQI patch pixels per round)
+        const int py = pp / G::PW, pxx = pp - py * G::PW;
+        const int iy = y0 - G::PAD + py, ix = x0 - G::PAD + pxx;
+        const bool ok = iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;  // (outside: the convolution's zero padding, after the prologue)
+        f32x4 v = px[it];
+        if (normed) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float w = (v[e] - tm[e]) * ta[e] + tad[e];
+            if (silu) w = dmd_silu_fast(w);
+            v[e] = w;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = wg_pack_hl(ok ? v[e] : 0.f);
+        *(f32x4*)(buf + (size_t)pp * G::SB + 4 * qi) = v;
+      }
+      float* dyt = buf + G::PP * G::SB;
+#pragma unroll
+      for (int it = 0; it < P::ND; ++it) {
+        const int pix = it * (256 / P::CQO) + ptid / P::CQO;
+        const bool ok = y0 + (pix >> 3) < Hv && x0 + (pix & 7) < Wv;
+        f32x4 v = pd[it];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+        bsum += v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = wg_pack_hl(v[e]);
+        *(f32x4*)(dyt + (size_t)pix * G::SA + 4 * qo) = v;
+      }
+    };
+    // one step of the pipeline: sub-tile sub_begin + k out of register set (px, pd) into buffer k & 1, its successor-but-one
+    // requested into the same registers, the next image's table if sub-tile k + 1 starts one
+    auto step = [&](f32x4 (&px)[P::NP], f32x4 (&pd)[P::ND], int k) __attribute__((always_inline)) {
+      if (k < n) {
+        const int u = sub_begin + k;
+        if (!(p.precision & 0x200)) stage(px, pd, u, smem + (k & 1) * P::BUF_FLOATS);
+        if (k + 2 < n && !(p.precision & 0x400)) fetch(px, pd, u + 2);
+        if (normed && k + 1 < n && (u + 1) / per_img != u / per_img) {
+          which ^= 1;
+          build_table((u + 1) / per_img, which);
+        }
+      }
+    };
+    if (normed) build_table(sub_begin / per_img, 0);
+    fetch(pxa, pda, sub_begin);
+    if (n > 1) fetch(pxb, pdb, sub_begin + 1);
+    __syncthreads();  // the first table
+    for (int k = 0; k <= n; k += 2) {
+      step(pxa, pda, k);
+      __syncthreads();
+      if (k + 1 <= n) {
+        step(pxb, pdb, k + 1);
+        __syncthreads();
+      }
+    }
+    // ---- bias partial: sum over the producer threads with the same channel quad, in thread order ----
+    f32x4* red = (f32x4*)smem;  // (every consumer read of the buffers is behind the last barrier)
+    red[ptid] = bsum;
+    __syncthreads();
+    if (ptid < P::CQO) {
+      f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int l = 0; l < 256 / P::CQO; ++l) a += red[l * P::CQO + ptid];
+      *(f32x4*)(part + G::NB * G::NCO * 256 + 4 * ptid) = a;
+    }
+    return;
+  }
+
+  // ================================ consumers ================================
+  const int i = lane & 15, kg = lane >> 4;
+  f32x4 acc[G::NCO][G::CB];
+#pragma unroll
+  for (int a = 0; a < G::NCO; ++a)
+#pragma unroll
+    for (int s = 0; s < G::CB; ++s) acc[a][s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int boff[G::CB];  // per-slot B offset: column block b = wave + 4 s -> (tap, ci block)
+#pragma unroll
+  for (int s = 0; s < G::CB; ++s) {
+    int b = wave + 4 * s;
+    b = b < G::NB ? b : 0;  // surplus slots recompute block 0 and are never stored
+    const int tap = b / G::NCI, cib = b - tap * G::NCI;
+    const int ty = G::TAPS == 9 ? tap / 3 : 0, tx = G::TAPS == 9 ? tap % 3 : 0;
+    boff[s] = (ty * G::PW + tx + kg) * G::SB + cib * 16 + i;
+  }
+  const int aoff = kg * G::SA + i;
+  auto contract = [&](const float* buf) __attribute__((always_inline)) {
+    const float* dyt = buf + G::PP * G::SB;
+#pragma unroll 1
+    for (int j = 0; j < 2; ++j) {  // 32 pixels (rows 4 j .. 4 j + 3 of the patch) per MFMA
+      const float* ap = dyt + (size_t)(j * 32) * G::SA + aoff;
+      const float* bp = buf + (size_t)(4 * j * G::PW) * G::SB;
+      wg_h8 ah[G::NCO], al[G::NCO];
+#pragma unroll
+      for (int a = 0; a < G::NCO; ++a) {
+        float r[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) r[v] = ap[a * 16 + ((v >> 1) * 8 + 4 * (v & 1)) * G::SA];
+        wg_unpack8(r, ah[a], al[a]);
+      }
+#pragma unroll
+      for (int b = 0; b < G::CB; ++b) {
+        const float* q0 = bp + boff[b];
+        float r[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) r[v] = q0[((v >> 1) * G::PW + 4 * (v & 1)) * G::SB];
+        wg_h8 bh, bl;
+        wg_unpack8(r, bh, bl);
+#pragma unroll
+        for (int a = 0; a < G::NCO; ++a) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bl, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[a], bh, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bh, acc[a][b], 0, 0, 0);
+        }
+      }
+    }
+  };
+  __syncthreads();  // (the producers' first table)
+  for (int k = 0; k <= n; k += 2) {
+    if (k >= 1 && !(p.precision & 0x100)) contract(smem + ((k - 1) & 1) * P::BUF_FLOATS);
+    __syncthreads();
+    if (k + 1 <= n) {
+      if (!(p.precision & 0x100)) contract(smem + (k & 1) * P::BUF_FLOATS);
+      __syncthreads();
+    }
+  }
+  // ---- partial results: [wg][NB][NCO][64 lanes][4] ----
+#pragma unroll
+  for (int s = 0; s < G::CB; ++s) {
+    const int b = wave + 4 * s;
+    if (b < G::NB) {
+#pragma unroll
+      for (int a = 0; a < G::NCO; ++a) *(f32x4*)(part + ((size_t)(b * G::NCO + a) * 64 + lane) * 4) = acc[a][s];
+    }
+  }
+  __syncthreads();  // (the producers' bias reduction)
+}
+
 // Reduction of the per-workgroup partials, two deterministic passes:
 //   pass 1: grid (elements / 256, WGRAD_SLICES): slice s sums workgroups {s, s + S, ...} -> ws2[s][e]
 //   pass 2: element e of [NB][NCO][64][4] (+ bias) sums the S slices in order -> OIHW gradient
@@ -834,10 +1080,17 @@ static int launch_wgrad(const dmd_wgrad_params& p, hipStream_t st) {
                                        G::SMEM_BYTES);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ps_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              WgradPs<G>::SMEM_BYTES);
     DMD_CHECK_ARG(e == hipSuccess, "wgrad: hipFuncSetAttribute(%d bytes): %s", G::SMEM_BYTES, hipGetErrorString(e));
     attr_set[dev] = true;
   }
-  if ((p.precision & 0xff) == DMD_PRECISION_F16X2)
+  // DIAMOND_WGRAD_PS=0: the split-fp16 gradient on the single-role kernel (A/B, and the tests' bitwise comparison of the two)
+  static DmdEnvInt ps_env{"DIAMOND_WGRAD_PS", 1};
+  if ((p.precision & 0xff) == DMD_PRECISION_F16X2 && ps_env.get() != 0)
+    hipLaunchKernelGGL((wgrad_ps_kernel<G>), dim3(num_wg), dim3(512), WgradPs<G>::SMEM_BYTES, st, p, tiles, tpw);
+  else if ((p.precision & 0xff) == DMD_PRECISION_F16X2)
     hipLaunchKernelGGL((wgrad_kernel<G, true>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
   else
     hipLaunchKernelGGL((wgrad_kernel<G, false>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);

@@ -288,6 +288,32 @@ def test_conv2d_wgrad(case, plan, schedule, monkeypatch, request, dmd_env):
         np.testing.assert_allclose(db, g.sum(axis=0), rtol=0, atol=2e-5 * np.abs(g.sum(axis=0)).max() + 1e-5)
 
 
+@pytest.mark.parametrize("max_wg", [None, 2])
+@pytest.mark.parametrize("shape", [(3, 16, 16, 64, 64, 3), (5, 8, 8, 32, 32, 3), (2, 8, 16, 32, 64, 1)], ids=str)
+def test_conv2d_wgrad_two_roles_same_bits(shape, max_wg, dmd_env):
+    """wgrad_ps_kernel (producer / consumer waves, the default of the split-fp16 gradient) against wgrad_kernel<G, true>
+    (DIAMOND_WGRAD_PS=0) on a source without prologue: the same plan, the same order of accumulation -- the same bits."""
+    rng = np.random.default_rng(21)
+    L = S.lib()
+    n, h, w, cin, cout, k = shape
+    x = G((rng.standard_normal((n, h, w, cin)) * 1.2 - 0.2).astype(np.float32))
+    dy = G(rng.standard_normal((n, h, w, cout)).astype(np.float32))
+    got = []
+    for ps in (1, 0):
+        dmd_env(DIAMOND_WGRAD_PS=ps, DIAMOND_WGRAD_MAX_WG=max_wg)
+        p = nv.WgradParams()
+        p.N, p.H, p.W, p.Cout, p.taps, p.cin_real, p.precision = n, h, w, cout, k * k, cin, 1
+        p.src.x, p.src.C, p.src.prologue = S.ptr(x), cin, 0
+        p.dy = S.ptr(dy)
+        ws = G(np.full(L.dmd_wgrad_workspace_floats(p), np.nan, dtype=np.float32))
+        dw = G(np.full((cout, cin, k, k), np.nan, dtype=np.float32))
+        db = np.full(cout, np.nan, dtype=np.float32)
+        p.workspace, p.dw, p.dbias = S.ptr(ws), S.ptr(dw), S.ptr(db)
+        S.check(L.dmd_conv2d_wgrad(p, None), "dmd_conv2d_wgrad")
+        got.append((np.array(dw), db.copy()))
+    assert np.isfinite(got[0][0]).all() and np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+
+
 def test_conv2d_wgrad_many_partials(dmd_env):
     """more partials than the single-pass reduction takes (64): the two-pass reduction, against the single pass of a small plan"""
     rng = np.random.default_rng(12)
