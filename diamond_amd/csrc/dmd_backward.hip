@@ -734,17 +734,51 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const dmd_wgrad_params p, in
 // The per-image table (mean, scale, shift per channel) is double-buffered in LDS and rebuilt by the producers one barrier
 // ahead of the first sub-tile of a new image.
 // ------------------------------------------------------------------------------------------------
+// LDS operand layout of wgrad_ps_kernel: PIXEL PAIRS.  The k index of v_mfma_f32_16x16x32_f16 runs over pixels, a lane supplies
+// k = 8 kg .. 8 kg + 7 = (row d, column kg) and (row d, column kg + 4), d = 0..3, of a 4-row slice -- one register per pair.  The
+// single-role kernel stores one dword {h | l << 16} per (pixel, channel), so a consumer builds every operand register out of
+// two loaded dwords (v_perm: 16 per operand, 1.5 vector instructions per MFMA -- on a SIMD whose vector issue the producer
+// wave needs too: the first version of this kernel, same layout, ran staging + contraction additively).  Here the producers
+// store what the MFMA reads: per pair (row, column c | c + 4) and channel one dword {h(c) | h(c + 4) << 16} in an H plane and
+// one {l(c) | l(c + 4) << 16} in an L plane -- v_cvt_pk_f16_f32 + two v_fma_mix per two values instead of five instructions
+// per value -- and an operand is four ds_read_b32, no arithmetic.  A patch row of 10 pixels is 6 pairs (columns 4, 5 are in two).
 template <class G>
 struct WgradPs {
-  static constexpr int BUF_FLOATS = G::PP * G::SB + 64 * G::SA;  // one sub-tile: [PP][SB] patch + [64][SA] dy
-  static constexpr int TAB_FLOATS = 2 * 3 * G::CIN;              // two images' [mean | scale | shift][CIN]
+  static constexpr int NPC = G::TAPS == 9 ? 6 : 4;         // pair columns of a patch row
+  static constexpr int SPB = 2 * G::CIN + 16;               // dwords per patch pair: [H: CIN][L: CIN][pad]  (== 16 mod 32: the two
+  static constexpr int SPA = 2 * G::COUT + 16;              //  k groups of a 32-lane read land in different bank halves)
+  static constexpr int PATCH_DW = G::PW * NPC * SPB, DY_DW = 32 * SPA;
+  static constexpr int BUF_FLOATS = PATCH_DW + DY_DW;       // one sub-tile
+  static constexpr int TAB_FLOATS = 2 * 3 * G::CIN;         // two images' [mean | scale | shift][CIN]
   static constexpr int SMEM_BYTES = (2 * BUF_FLOATS + TAB_FLOATS) * 4;
   static constexpr int CQI = G::CIN / 4, CQO = G::COUT / 4;
-  static constexpr int NPQ = G::PP * CQI;         // patch quads of a sub-tile
-  static constexpr int NP = (NPQ + 255) / 256;    // ... per producer thread
-  static constexpr int ND = (64 * CQO) / 256;     // dy quads per producer thread (COUT >= 16: >= 1)
-  static_assert(256 % CQI == 0 && 256 % CQO == 0 && (64 * CQO) % 256 == 0, "a producer thread keeps one channel quad");
+  static constexpr int NPI = G::PW * NPC * CQI, NDI = 32 * CQO;  // items (pair x channel quad) of a sub-tile
+  static constexpr int NP = (NPI + 255) / 256, ND = (NDI + 255) / 256;  // ... per producer thread
+  static_assert(256 % CQI == 0 && 256 % CQO == 0, "a producer thread keeps one channel quad");
 };
+
+typedef unsigned wg_u4 __attribute__((ext_vector_type(4)));
+// -DDMD_LAB builds only (tools/wgrad_bench.py, WGRAD_LAB=bits in dmd_wgrad_params.precision >> 8): 1 no contraction, 2 no staging,
+// 4 no prefetch -- how the three overlap (profiles/r06l_wgrad_bench_ps_*.txt).  The shipped library has no such switch.
+#ifdef DMD_LAB
+#define WG_LAB(bit) ((p.precision & (bit)) != 0)
+#else
+#define WG_LAB(bit) false
+#endif
+#ifdef WS_HOST_HELPERS
+#define wg_low_pair ws_low_pair
+#else
+// {fp16(x0 - h0), fp16(x1 - h1)} of h01 = {h0, h1}: one mixed-precision fma per value (the difference is exact in fp32)
+__device__ __forceinline__ unsigned wg_low_pair(float x0, float x1, unsigned h01) {
+  unsigned l01;
+  asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(l01)
+      : "v"(x0), "v"(x1), "v"(h01));
+  return l01;
+}
+#endif
+typedef _Float16 wg_h2 __attribute__((ext_vector_type(2)));
 
 template <class G>
 __global__ __launch_bounds__(512) void wgrad_ps_kernel(const dmd_wgrad_params p, int tiles_total, int tiles_per_wg) {
@@ -767,32 +801,39 @@ __global__ __launch_bounds__(512) void wgrad_ps_kernel(const dmd_wgrad_params p,
     // ================================ producers ================================
     const int ptid = tid - 256;
     const int qi = ptid % P::CQI, qo = ptid % P::CQO;  // this thread's channel quads (the same for every item)
-    f32x4 pxa[P::NP], pda[P::ND], pxb[P::NP], pdb[P::ND];
+    f32x4 pxa[2 * P::NP], pda[2 * P::ND], pxb[2 * P::NP], pdb[2 * P::ND];  // (both pixels of a pair)
     f32x4 bsum = (f32x4){0.f, 0.f, 0.f, 0.f};  // bias gradient of dy channel quad qo
     const bool normed = p.src.prologue != DMD_PROLOGUE_NONE;
     const bool silu = p.src.prologue == DMD_PROLOGUE_NORM_SILU;
-    // Every request is UNCONDITIONAL (an item outside the image, the valid extent or the patch reads pixel (0, 0) of its image
-    // and is zeroed when it is staged): a predicated load is a branch to hipcc, and behind a branch its wait insertion stops
-    // counting -- `s_waitcnt vmcnt(0)` right behind the requests, i.e. no prefetch at all (the first version of this kernel:
-    // loads, staging and MFMAs of the 32-channel launches added up to the launch time, 1,133 + 470 + 693 us of 2,064).
-    auto fetch = [&](f32x4 (&px)[P::NP], f32x4 (&pd)[P::ND], int u) __attribute__((always_inline)) {
+    // Every request is UNCONDITIONAL (a pixel outside the image, the valid extent or the item count reads pixel (0, 0) of its
+    // image and is zeroed when it is staged): a predicated load is a branch to hipcc, and behind a branch its wait insertion
+    // stops counting -- `s_waitcnt vmcnt(0)` right behind the requests, i.e. no prefetch at all (the first version of this
+    // kernel: loads, staging and MFMAs of the 32-channel launches added up to the launch time, 1,133 + 470 + 693 us of 2,064).
+    auto fetch = [&](f32x4 (&px)[2 * P::NP], f32x4 (&pd)[2 * P::ND], int u) __attribute__((always_inline)) {
       const int img = u / per_img, r = u - img * per_img;
       const int y0 = (r / txs) * 8, x0 = (r % txs) * 8;
       const float* xs = p.src.x + (size_t)img * p.H * p.W * Cx + 4 * qi;
 #pragma unroll
       for (int it = 0; it < P::NP; ++it) {
-        const int pp = it * (256 / P::CQI) + ptid / P::CQI;
-        const int py = pp / G::PW, pxx = pp - py * G::PW;
-        const int iy = y0 - G::PAD + py, ix = x0 - G::PAD + pxx;
-        const bool ok = pp < G::PP && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
-        px[it] = *(const f32x4*)(xs + (ok ? (size_t)(iy * p.W + ix) * Cx : (size_t)0));
+        const int pair = it * (256 / P::CQI) + ptid / P::CQI;
+        const int prow = pair / P::NPC, pc = pair - prow * P::NPC;
+        const int iy = y0 - G::PAD + prow, ix = x0 - G::PAD + pc;
+        const bool oky = pair < G::PW * P::NPC && iy >= 0 && iy < Hv;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int ixh = ix + 4 * h;
+          px[2 * it + h] = *(const f32x4*)(xs + ((oky && ixh >= 0 && ixh < Wv) ? (size_t)(iy * p.W + ixh) * Cx : (size_t)0));
+        }
       }
       const float* ds = p.dy + (size_t)img * p.H * p.W * G::COUT + 4 * qo;
 #pragma unroll
       for (int it = 0; it < P::ND; ++it) {
-        const int pix = it * (256 / P::CQO) + ptid / P::CQO;
-        const int oy = y0 + (pix >> 3), ox = x0 + (pix & 7);
-        pd[it] = *(const f32x4*)(ds + ((oy < Hv && ox < Wv) ? (size_t)(oy * p.W + ox) * G::COUT : (size_t)0));
+        const int pair = it * (256 / P::CQO) + ptid / P::CQO;
+        const int oy = y0 + (pair >> 2), ox = x0 + (pair & 3);
+        const bool oky = pair < 32 && oy < Hv;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          pd[2 * it + h] = *(const f32x4*)(ds + ((oky && ox + 4 * h < Wv) ? (size_t)(oy * p.W + ox + 4 * h) * G::COUT : (size_t)0));
       }
     };
     auto build_table = [&](int img, int which) __attribute__((always_inline)) {
@@ -806,7 +847,7 @@ __global__ __launch_bounds__(512) void wgrad_ps_kernel(const dmd_wgrad_params p,
       }
     };
     int which = 0;  // the table of the image being staged
-    auto stage = [&](const f32x4 (&px)[P::NP], const f32x4 (&pd)[P::ND], int u, float* buf) __attribute__((always_inline)) {
+    auto stage = [&](const f32x4 (&px)[2 * P::NP], const f32x4 (&pd)[2 * P::ND], int u, float* buf) __attribute__((always_inline)) {
       const int img = u / per_img, r = u - img * per_img;
       const int y0 = (r / txs) * 8, x0 = (r % txs) * 8;
       float tm[4], ta[4], tad[4];
@@ -821,45 +862,68 @@ __global__ __launch_bounds__(512) void wgrad_ps_kernel(const dmd_wgrad_params p,
       }
 #pragma unroll
       for (int it = 0; it < P::NP; ++it) {
-        const int pp = it * (256 / P::CQI) + ptid / P::CQI;
-        if (pp >= G::PP) continue;  // (uniform per wave when it is not compile-time: 256 / CQI patch pixels per round)
-        const int py = pp / G::PW, pxx = pp - py * G::PW;
-        const int iy = y0 - G::PAD + py, ix = x0 - G::PAD + pxx;
-        const bool ok = iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;  // (outside: the convolution's zero padding, after the prologue)
-        f32x4 v = px[it];
-        if (normed) {
+        const int pair = it * (256 / P::CQI) + ptid / P::CQI;
+        if (pair >= G::PW * P::NPC) continue;  // (only the last round, and whole waves when 256 / CQI divides the pair count's tail)
+        const int prow = pair / P::NPC, pc = pair - prow * P::NPC;
+        const int iy = y0 - G::PAD + prow, ix = x0 - G::PAD + pc;
+        const bool oky = iy >= 0 && iy < Hv;
+        f32x4 v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const bool ok = oky && ix + 4 * h >= 0 && ix + 4 * h < Wv;  // (outside: the convolution's zero padding, after the prologue)
+          v[h] = px[2 * it + h];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float w = (v[e] - tm[e]) * ta[e] + tad[e];
-            if (silu) w = dmd_silu_fast(w);
-            v[e] = w;
+            float w = v[h][e];
+            if (normed) {
+              w = (w - tm[e]) * ta[e] + tad[e];
+              if (silu) w = dmd_silu_fast(w);
+            }
+            v[h][e] = ok ? w : 0.f;
           }
         }
+        wg_u4 hh, ll;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = wg_pack_hl(ok ? v[e] : 0.f);
-        *(f32x4*)(buf + (size_t)pp * G::SB + 4 * qi) = v;
+        for (int e = 0; e < 4; ++e) {
+          hh[e] = __builtin_bit_cast(unsigned, (wg_h2){(_Float16)v[0][e], (_Float16)v[1][e]});
+          ll[e] = wg_low_pair(v[0][e], v[1][e], hh[e]);
+        }
+        float* dst = buf + (size_t)pair * P::SPB + 4 * qi;
+        *(wg_u4*)dst = hh;
+        *(wg_u4*)(dst + G::CIN) = ll;
       }
-      float* dyt = buf + G::PP * G::SB;
+      float* dyt = buf + P::PATCH_DW;
 #pragma unroll
       for (int it = 0; it < P::ND; ++it) {
-        const int pix = it * (256 / P::CQO) + ptid / P::CQO;
-        const bool ok = y0 + (pix >> 3) < Hv && x0 + (pix & 7) < Wv;
-        f32x4 v = pd[it];
+        const int pair = it * (256 / P::CQO) + ptid / P::CQO;
+        if (pair >= 32) continue;  // (COUT = 16: half of the producer threads have no dy item)
+        const bool oky = y0 + (pair >> 2) < Hv;
+        f32x4 v[2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
-        bsum += v;
+        for (int h = 0; h < 2; ++h) {
+          const bool ok = oky && x0 + (pair & 3) + 4 * h < Wv;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = wg_pack_hl(v[e]);
-        *(f32x4*)(dyt + (size_t)pix * G::SA + 4 * qo) = v;
+          for (int e = 0; e < 4; ++e) v[h][e] = ok ? pd[2 * it + h][e] : 0.f;
+          bsum += v[h];
+        }
+        wg_u4 hh, ll;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          hh[e] = __builtin_bit_cast(unsigned, (wg_h2){(_Float16)v[0][e], (_Float16)v[1][e]});
+          ll[e] = wg_low_pair(v[0][e], v[1][e], hh[e]);
+        }
+        float* dst = dyt + (size_t)pair * P::SPA + 4 * qo;
+        *(wg_u4*)dst = hh;
+        *(wg_u4*)(dst + G::COUT) = ll;
       }
     };
     // one step of the pipeline: sub-tile sub_begin + k out of register set (px, pd) into buffer k & 1, its successor-but-one
     // requested into the same registers, the next image's table if sub-tile k + 1 starts one
-    auto step = [&](f32x4 (&px)[P::NP], f32x4 (&pd)[P::ND], int k) __attribute__((always_inline)) {
+    auto step = [&](f32x4 (&px)[2 * P::NP], f32x4 (&pd)[2 * P::ND], int k) __attribute__((always_inline)) {
       if (k < n) {
         const int u = sub_begin + k;
-        if (!(p.precision & 0x200)) stage(px, pd, u, smem + (k & 1) * P::BUF_FLOATS);
-        if (k + 2 < n && !(p.precision & 0x400)) fetch(px, pd, u + 2);
+        if (!WG_LAB(0x200)) stage(px, pd, u, smem + (k & 1) * P::BUF_FLOATS);
+        if (k + 2 < n && !WG_LAB(0x400)) fetch(px, pd, u + 2);
         if (normed && k + 1 < n && (u + 1) / per_img != u / per_img) {
           which ^= 1;
           build_table((u + 1) / per_img, which);
@@ -897,38 +961,45 @@ __global__ __launch_bounds__(512) void wgrad_ps_kernel(const dmd_wgrad_params p,
   for (int a = 0; a < G::NCO; ++a)
 #pragma unroll
     for (int s = 0; s < G::CB; ++s) acc[a][s] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  int boff[G::CB];  // per-slot B offset: column block b = wave + 4 s -> (tap, ci block)
+  int boff[G::CB];  // per-slot B offset (dwords): column block b = wave + 4 s -> (tap, ci block)
 #pragma unroll
   for (int s = 0; s < G::CB; ++s) {
     int b = wave + 4 * s;
     b = b < G::NB ? b : 0;  // surplus slots recompute block 0 and are never stored
     const int tap = b / G::NCI, cib = b - tap * G::NCI;
     const int ty = G::TAPS == 9 ? tap / 3 : 0, tx = G::TAPS == 9 ? tap % 3 : 0;
-    boff[s] = (ty * G::PW + tx + kg) * G::SB + cib * 16 + i;
+    boff[s] = (ty * P::NPC + tx + kg) * P::SPB + cib * 16 + i;
   }
-  const int aoff = kg * G::SA + i;
+  const int aoff = kg * P::SPA + i;
   auto contract = [&](const float* buf) __attribute__((always_inline)) {
-    const float* dyt = buf + G::PP * G::SB;
+    const unsigned* dyt = (const unsigned*)buf + P::PATCH_DW;
+    const unsigned* pat = (const unsigned*)buf;
 #pragma unroll 1
-    for (int j = 0; j < 2; ++j) {  // 32 pixels (rows 4 j .. 4 j + 3 of the patch) per MFMA
-      const float* ap = dyt + (size_t)(j * 32) * G::SA + aoff;
-      const float* bp = buf + (size_t)(4 * j * G::PW) * G::SB;
+    for (int j = 0; j < 2; ++j) {  // 32 pixels (rows 4 j .. 4 j + 3 of the sub-tile) per MFMA
+      const unsigned* ap = dyt + (4 * j * 4) * P::SPA + aoff;
+      const unsigned* bp = pat + (4 * j * P::NPC) * P::SPB;
       wg_h8 ah[G::NCO], al[G::NCO];
 #pragma unroll
       for (int a = 0; a < G::NCO; ++a) {
-        float r[8];
+        wg_u4 h, l;
 #pragma unroll
-        for (int v = 0; v < 8; ++v) r[v] = ap[a * 16 + ((v >> 1) * 8 + 4 * (v & 1)) * G::SA];
-        wg_unpack8(r, ah[a], al[a]);
+        for (int d = 0; d < 4; ++d) {
+          h[d] = ap[(d * 4) * P::SPA + a * 16];
+          l[d] = ap[(d * 4) * P::SPA + a * 16 + G::COUT];
+        }
+        ah[a] = __builtin_bit_cast(wg_h8, h);
+        al[a] = __builtin_bit_cast(wg_h8, l);
       }
 #pragma unroll
       for (int b = 0; b < G::CB; ++b) {
-        const float* q0 = bp + boff[b];
-        float r[8];
+        const unsigned* q0 = bp + boff[b];
+        wg_u4 h, l;
 #pragma unroll
-        for (int v = 0; v < 8; ++v) r[v] = q0[((v >> 1) * G::PW + 4 * (v & 1)) * G::SB];
-        wg_h8 bh, bl;
-        wg_unpack8(r, bh, bl);
+        for (int d = 0; d < 4; ++d) {
+          h[d] = q0[(d * P::NPC) * P::SPB];
+          l[d] = q0[(d * P::NPC) * P::SPB + G::CIN];
+        }
+        const wg_h8 bh = __builtin_bit_cast(wg_h8, h), bl = __builtin_bit_cast(wg_h8, l);
 #pragma unroll
         for (int a = 0; a < G::NCO; ++a) {
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bl, acc[a][b], 0, 0, 0);
@@ -940,10 +1011,10 @@ __global__ __launch_bounds__(512) void wgrad_ps_kernel(const dmd_wgrad_params p,
   };
   __syncthreads();  // (the producers' first table)
   for (int k = 0; k <= n; k += 2) {
-    if (k >= 1 && !(p.precision & 0x100)) contract(smem + ((k - 1) & 1) * P::BUF_FLOATS);
+    if (k >= 1 && !WG_LAB(0x100)) contract(smem + ((k - 1) & 1) * P::BUF_FLOATS);
     __syncthreads();
     if (k + 1 <= n) {
-      if (!(p.precision & 0x100)) contract(smem + (k & 1) * P::BUF_FLOATS);
+      if (!WG_LAB(0x100)) contract(smem + (k & 1) * P::BUF_FLOATS);
       __syncthreads();
     }
   }

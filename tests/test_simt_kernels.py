@@ -292,7 +292,8 @@ def test_conv2d_wgrad(case, plan, schedule, monkeypatch, request, dmd_env):
 @pytest.mark.parametrize("shape", [(3, 16, 16, 64, 64, 3), (5, 8, 8, 32, 32, 3), (2, 8, 16, 32, 64, 1)], ids=str)
 def test_conv2d_wgrad_two_roles_same_bits(shape, max_wg, dmd_env):
     """wgrad_ps_kernel (producer / consumer waves, the default of the split-fp16 gradient) against wgrad_kernel<G, true>
-    (DIAMOND_WGRAD_PS=0) on a source without prologue: the same plan, the same order of accumulation -- the same bits."""
+    (DIAMOND_WGRAD_PS=0) on a source without prologue: the same plan, the same pixels at the same k of every MFMA, the same order of
+    accumulation -- the same bits of the weight gradient."""
     rng = np.random.default_rng(21)
     L = S.lib()
     n, h, w, cin, cout, k = shape
@@ -311,7 +312,9 @@ def test_conv2d_wgrad_two_roles_same_bits(shape, max_wg, dmd_env):
         p.workspace, p.dw, p.dbias = S.ptr(ws), S.ptr(dw), S.ptr(db)
         S.check(L.dmd_conv2d_wgrad(p, None), "dmd_conv2d_wgrad")
         got.append((np.array(dw), db.copy()))
-    assert np.isfinite(got[0][0]).all() and np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+    # (the bias gradient is summed by the producer threads over pixel PAIRS: another order of fp32 additions)
+    assert np.isfinite(got[0][0]).all() and np.array_equal(got[0][0], got[1][0])
+    np.testing.assert_allclose(got[0][1], got[1][1], rtol=0, atol=2e-5 * np.abs(got[1][1]).max())
 
 
 def test_conv2d_wgrad_many_partials(dmd_env):
