@@ -337,6 +337,157 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_kernel(const dmd_gn_bwd_para
   }
 }
 
+// Round 6, for launches of at most one workgroup per CU (the denoiser training step's batch of 32: a launch is 32 workgroups and
+// their latency, 14.7 us): the image stays in REGISTERS between the two passes (at most GN_FUSED_ITEMS float4 pairs per thread, requested up
+// front: a workgroup per image is one wave of loads, not 16 dependent round trips, and pass B neither reloads nor recomputes
+// sigmoid(u)); images with more items per thread (C = 128 at 16 x 16) take the two loops of round 4.  Same sums in the same order.  It
+// needs every register of a SIMD (one workgroup per CU): launches of more images (the actor-critic backward: 3,840) stay on
+// gn_bwd_fused_kernel above, which measured 259 us where this one takes 352 (tools/wgrad_bench.py gn, 16 x 16 x 64 channels).
+#define GN_FUSED_ITEMS 16
+__global__ __launch_bounds__(256) void gn_bwd_fused_regs_kernel(const dmd_gn_bwd_params p) {
+  __shared__ float g_mean[GN_BWD_MAXG], g_rstd[GN_BWD_MAXG], g_m1[GN_BWD_MAXG], g_m2[GN_BWD_MAXG];
+  __shared__ double red[4][GN_BWD_MAXG][2];
+  __shared__ float cred[256][8];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int C = p.C, CQ = C / 4, G = C / DMD_GN_GROUP > 0 ? C / DMD_GN_GROUP : 1;
+  const int gsz = C / G;
+  const double cnt = (double)gsz * gn_bwd_count(p);
+  const int q = tid % CQ;
+  const int c0 = 4 * q;
+  const int lanes = 256 / CQ;  // pixels per round
+  const bool in_regs = p.HW <= GN_FUSED_ITEMS * lanes;  // uniform
+  // ---- every request of the image first (unconditional: an item behind the image re-reads its last pixel, unused) ----
+  f32x4 xr[GN_FUSED_ITEMS], dr[GN_FUSED_ITEMS];
+  if (in_regs) {
+#pragma unroll
+    for (int it = 0; it < GN_FUSED_ITEMS; ++it) {
+      const int pix = min(tid / CQ + it * lanes, p.HW - 1);
+      const size_t off = ((size_t)n * p.HW + pix) * C + c0;
+      xr[it] = *(const f32x4*)(p.x + off);
+      dr[it] = *(const f32x4*)(p.da + off);
+    }
+  }
+  if (tid < G) {
+    float m, r;
+    dmd_finalize_stats(p.norm.stats + ((size_t)(n * G + tid) * p.norm.stat_tiles) * 2, p.norm.stat_tiles, cnt, &m, &r);
+    g_mean[tid] = m;
+    g_rstd[tid] = r;
+  }
+  __syncthreads();
+  const int g = c0 / gsz;
+  const float mean = g_mean[g], rstd = g_rstd[g];
+  float mul[4], add[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float m = p.norm.mul ? p.norm.mul[(size_t)n * p.norm.mul_stride + c0 + e] : 1.0f;
+    if (p.norm.mul_plus_one) m = 1.0f + m;
+    mul[e] = m;
+    add[e] = p.norm.add ? p.norm.add[(size_t)n * p.norm.add_stride + c0 + e] : 0.0f;
+  }
+  double s1 = 0.0, s2 = 0.0;
+  float dm[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
+  if (in_regs) {
+#pragma unroll
+    for (int it = 0; it < GN_FUSED_ITEMS; ++it) {
+      const int pix = tid / CQ + it * lanes;
+      if (pix >= p.HW || !gn_bwd_exists(p, pix)) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const GnBwdElem r = gn_bwd_elem(xr[it][e], dr[it][e], mean, rstd, mul[e], add[e], p.identity_activation == 0);
+        s1 += (double)r.dxh;
+        s2 += (double)r.dxh * (double)r.xh;
+        dm[e] += r.du * r.xh;
+        db[e] += r.du;
+        xr[it][e] = r.xh;   // (kept for pass B: the normalised value and the gradient through the activation)
+        dr[it][e] = r.dxh;
+      }
+    }
+  } else {
+    for (int pix = tid / CQ; pix < p.HW; pix += lanes) {
+      if (!gn_bwd_exists(p, pix)) continue;
+      const size_t off = ((size_t)n * p.HW + pix) * C + c0;
+      const f32x4 xv = *(const f32x4*)(p.x + off);
+      const f32x4 dv = *(const f32x4*)(p.da + off);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const GnBwdElem r = gn_bwd_elem(xv[e], dv[e], mean, rstd, mul[e], add[e], p.identity_activation == 0);
+        s1 += (double)r.dxh;
+        s2 += (double)r.dxh * (double)r.xh;
+        dm[e] += r.du * r.xh;
+        db[e] += r.du;
+      }
+    }
+  }
+  for (int gg = 0; gg < G; ++gg) {
+    const double a = dmd_wave_sum(g == gg ? s1 : 0.0);
+    const double b = dmd_wave_sum(g == gg ? s2 : 0.0);
+    if ((tid & 63) == 0) {
+      red[tid >> 6][gg][0] = a;
+      red[tid >> 6][gg][1] = b;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    cred[tid][e] = dm[e];
+    cred[tid][4 + e] = db[e];
+  }
+  __syncthreads();
+  if (tid < G) {
+    double a = 0.0, b = 0.0;
+    for (int w = 0; w < 4; ++w) {
+      a += red[w][tid][0];
+      b += red[w][tid][1];
+    }
+    g_m1[tid] = (float)(a / cnt);
+    g_m2[tid] = (float)(b / cnt);
+  }
+  if (tid < C) {
+    const int qq = tid >> 2, e = tid & 3;
+    float a = 0.f, b = 0.f;
+    for (int l = 0; l < 256 / CQ; ++l) {
+      a += cred[l * CQ + qq][e];
+      b += cred[l * CQ + qq][4 + e];
+    }
+    p.dmul[(size_t)n * C + tid] = a;
+    p.dadd[(size_t)n * C + tid] = b;
+  }
+  __syncthreads();
+  const float m1 = g_m1[g], m2 = g_m2[g];
+  if (in_regs) {
+#pragma unroll
+    for (int it = 0; it < GN_FUSED_ITEMS; ++it) {
+      const int pix = tid / CQ + it * lanes;
+      if (pix >= p.HW) continue;
+      const size_t off = ((size_t)n * p.HW + pix) * C + c0;
+      f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (gn_bwd_exists(p, pix)) {
+        if (p.dskip) o = *(const f32x4*)(p.dskip + off);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += rstd * (dr[it][e] - m1 - xr[it][e] * m2);
+      }
+      *(f32x4*)(p.dx + off) = o;
+    }
+    return;
+  }
+  for (int pix = tid / CQ; pix < p.HW; pix += lanes) {
+    const size_t off = ((size_t)n * p.HW + pix) * C + c0;
+    if (!gn_bwd_exists(p, pix)) {
+      *(f32x4*)(p.dx + off) = (f32x4){0.f, 0.f, 0.f, 0.f};
+      continue;
+    }
+    const f32x4 xv = *(const f32x4*)(p.x + off);
+    const f32x4 dv = *(const f32x4*)(p.da + off);
+    f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (p.dskip) o = *(const f32x4*)(p.dskip + off);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const GnBwdElem r = gn_bwd_elem(xv[e], dv[e], mean, rstd, mul[e], add[e], p.identity_activation == 0);
+      o[e] += rstd * (r.dxh - m1 - r.xh * m2);
+    }
+    *(f32x4*)(p.dx + off) = o;
+  }
+}
+
 static inline int gn_bwd_tiles(int HW) { return (HW + GN_BWD_PIX - 1) / GN_BWD_PIX; }
 
 extern "C" int64_t dmd_gn_bwd_workspace_bytes(int N, int HW, int C) {
@@ -361,7 +512,12 @@ extern "C" int dmd_gn_silu_bwd(const dmd_gn_bwd_params* pp, dmd_stream_t stream)
   hipStream_t st = (hipStream_t)stream;
   static DmdEnvInt fused_env{"DIAMOND_GN_BWD_FUSED", 1};
   if (T == 1 && fused_env.get() != 0) {
-    hipLaunchKernelGGL(gn_bwd_fused_kernel, dim3(p.N), dim3(256), 0, st, p);
+    // (DIAMOND_GN_BWD_FUSED: 0 two launches, 1 by launch size, 2 / 3 always the one / the other single launch -- test hooks:
+    //  all four are bit-identical)
+    if (fused_env.get() == 3 || (fused_env.get() != 2 && p.N <= 256))
+      hipLaunchKernelGGL(gn_bwd_fused_regs_kernel, dim3(p.N), dim3(256), 0, st, p);
+    else
+      hipLaunchKernelGGL(gn_bwd_fused_kernel, dim3(p.N), dim3(256), 0, st, p);
     DMD_LAUNCH_CHECK();
     return 0;
   }
@@ -930,9 +1086,11 @@ __global__ __launch_bounds__(512) void wgrad_ps_kernel(const dmd_wgrad_params p,
         }
       }
     };
-    if (normed) build_table(sub_begin / per_img, 0);
+    // (the requests first: the table's own round trips -- partial sums, scale, shift -- then run under them; a launch of the
+    //  16 x 16 or 8 x 8 level is two sub-tiles per workgroup and little else than this prologue)
     fetch(pxa, pda, sub_begin);
     if (n > 1) fetch(pxb, pdb, sub_begin + 1);
+    if (normed) build_table(sub_begin / per_img, 0);
     __syncthreads();  // the first table
     for (int k = 0; k <= n; k += 2) {
       step(pxa, pda, k);

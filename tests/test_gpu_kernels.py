@@ -365,6 +365,7 @@ WGRAD_CASES = [
     ("c64_64_8x8_odd", 3, 8, 8, 64, 64, 64, 9, 1),
     ("skip1x1_32_64", 3, 16, 16, 32, 32, 64, 1, 0),
     ("c32_32_many_tiles", 40, 64, 64, 32, 32, 32, 9, 1),
+    ("c64_64_many_tiles", 6, 32, 32, 64, 64, 64, 9, 1),  # the denoiser's shape: eight sub-tiles per image, table refreshes per image
 ]
 
 
@@ -400,6 +401,33 @@ def test_conv_wgrad(case, split, max_wg, dmd_env):
     torch.cuda.synchronize()
     assert rel_err(dw, wgt.grad) < 2e-5, f"{name}: dW rel err {rel_err(dw, wgt.grad):.3e}"
     assert rel_err(db, bias.grad) < 2e-5, f"{name}: db rel err {rel_err(db, bias.grad):.3e}"
+
+
+@pytest.mark.parametrize("max_wg", [None, 5], ids=["plan256", "plan5"])
+@pytest.mark.parametrize("shape", [(7, 32, 32, 64, 64, 9), (9, 16, 24, 32, 32, 9), (5, 16, 16, 32, 64, 1)], ids=str)
+def test_conv_wgrad_two_roles_same_bits(shape, max_wg, dmd_env):
+    """wgrad_ps_kernel (producer / consumer waves; the split-fp16 default) against wgrad_kernel<G, true> (DIAMOND_WGRAD_PS=0) on a
+    source without prologue: the same pixels at the same k of every MFMA in the same order -- the same bits on the hardware too."""
+    from diamond_amd import ac_native as A
+
+    n, h, w, cin, cout, taps = shape
+    g = torch.Generator().manual_seed(n * 31 + cin)
+    x = (torch.randn(n, h, w, cin, generator=g) * 1.3 + 0.2).to(DEV)
+    dy = torch.randn(n, h, w, cout, generator=g).to(DEV)
+    got = []
+    for ps in (1, 0):
+        dmd_env(DIAMOND_WGRAD_PS=ps, DIAMOND_WGRAD_MAX_WG=max_wg)
+        dw, db = A._wgrad(E_act(x), 0, None, dy, taps, cin, split=True)
+        torch.cuda.synchronize()
+        got.append((dw.cpu(), db.cpu()))
+    assert torch.isfinite(got[0][0]).all() and torch.equal(got[0][0], got[1][0])
+    assert rel_err(got[0][1], got[1][1].double()) < 1e-5  # (the bias gradient is summed over pixel pairs: another fp32 order)
+
+
+def E_act(t):
+    from diamond_amd import engine as E
+
+    return E.Act(t)
 
 
 @pytest.mark.parametrize("n,c,h,w,skip", [(3, 32, 16, 16, True), (2, 64, 8, 8, False), (2, 32, 64, 64, True), (2, 64, 24, 40, True)])

@@ -64,7 +64,7 @@ def test_denoiser_training_step_vs_reference_golden_on_the_interpreter(models, d
     errs = M.denoiser_training_step_errors(("f16x2",))["f16x2"]
     bad = {k: v for k, v in errs.items() if v >= 1e-4}
     assert not bad, bad
-    assert sum(v for k, v in counter.n.items() if k.startswith("wgrad_kernel<")) > 100 and counter.n.get("dmd_gn_silu_bwd", 0) > 50, counter.n
+    assert sum(v for k, v in counter.n.items() if k.startswith("wgrad_ps_kernel<")) > 100 and counter.n.get("dmd_gn_silu_bwd", 0) > 50, counter.n
     # (the reductions of those weight gradients: deferred to one table per backward, three launches of <= 32 jobs each)
     assert 1 <= counter.n.get("dmd_wgrad_reduce_jobs", 0) <= 4, counter.n
 

@@ -526,13 +526,17 @@ def test_gn_silu_bwd(n, hw, c, identity, skip, dmd_env):
     np.testing.assert_allclose(dmul, (du * xh).sum(axis=1), rtol=0, atol=2e-5 * np.abs(du * xh).sum(axis=1).max())
     np.testing.assert_allclose(dadd, du.sum(axis=1), rtol=0, atol=2e-5 * np.abs(du).sum(axis=1).max())
     if hw <= 256:
-        dmd_env(DIAMOND_GN_BWD_FUSED=0)
-        dx2 = G(np.full_like(x, np.nan))
-        dmul2, dadd2 = G(np.full((n, c), np.nan, dtype=np.float32)), G(np.full((n, c), np.nan, dtype=np.float32))
-        p.dx, p.dmul, p.dadd = S.ptr(dx2), S.ptr(dmul2), S.ptr(dadd2)
-        S.check(L.dmd_gn_silu_bwd(p, None), "dmd_gn_silu_bwd")
-        assert np.array_equal(dx, dx2) and np.array_equal(dmul, dmul2) and np.array_equal(dadd, dadd2)
-        assert ws.any()  # (the two launches went through the workspace; the fused one had left it untouched)
+        # the other two forms of the same sums: the single launch for many images (2; the default took the register-resident one
+        # for few) and the two launches (0) -- the same bits
+        for form in (2, 3, 0):
+            dmd_env(DIAMOND_GN_BWD_FUSED=form)
+            dx2 = G(np.full_like(x, np.nan))
+            dmul2, dadd2 = G(np.full((n, c), np.nan, dtype=np.float32)), G(np.full((n, c), np.nan, dtype=np.float32))
+            p.dx, p.dmul, p.dadd = S.ptr(dx2), S.ptr(dmul2), S.ptr(dadd2)
+            assert not ws.any()  # (a single launch leaves the workspace untouched)
+            S.check(L.dmd_gn_silu_bwd(p, None), "dmd_gn_silu_bwd")
+            assert np.array_equal(dx, dx2) and np.array_equal(dmul, dmul2) and np.array_equal(dadd, dadd2), form
+        assert ws.any()  # (the two launches went through the workspace)
     else:
         assert ws.any()
 
@@ -549,7 +553,7 @@ def test_gn_silu_bwd_one_launch_on_a_valid_extent_is_bitwise_the_two_launches(dm
     v = x.astype(np.float64).reshape(n, h, w, 2, 32)[:, :vh, :vw]
     st = np.ascontiguousarray(np.stack([v.sum(axis=(1, 2, 4)), (v * v).sum(axis=(1, 2, 4))], axis=-1)[:, :, None, :])  # (N, G, 1 tile, 2)
     got = {}
-    for fused in (1, 0):
+    for fused in (1, 2, 0):
         dmd_env(DIAMOND_GN_BWD_FUSED=fused)
         p = nv.GnBwdParams()
         p.N, p.HW, p.C, p.identity_activation, p.W, p.valid_h, p.valid_w = n, h * w, c, 0, w, vh, vw
@@ -561,7 +565,7 @@ def test_gn_silu_bwd_one_launch_on_a_valid_extent_is_bitwise_the_two_launches(dm
         S.check(L.dmd_gn_silu_bwd(p, None), "dmd_gn_silu_bwd")
         assert bool(ws.any()) == (fused == 0)
         got[fused] = (dx.copy(), dmul.copy(), dadd.copy())
-    assert all(np.array_equal(a_, b_) for a_, b_ in zip(got[0], got[1]))
+    assert all(np.array_equal(a_, b_) for a_, b_ in zip(got[0], got[1])) and all(np.array_equal(a_, b_) for a_, b_ in zip(got[0], got[2]))
     dxv = got[1][0].reshape(n, h, w, c)
     assert np.isfinite(dxv).all() and not dxv[:, vh:].any() and not dxv[:, :, vw:].any() and dxv[:, :vh, :vw].any()
 
