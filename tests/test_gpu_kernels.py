@@ -424,6 +424,30 @@ def test_conv_wgrad_two_roles_same_bits(shape, max_wg, dmd_env):
     assert rel_err(got[0][1], got[1][1].double()) < 1e-5  # (the bias gradient is summed over pixel pairs: another fp32 order)
 
 
+@pytest.mark.parametrize("shape", [(32, 64, 64, 64, 64, 9, 1), (96, 64, 64, 32, 32, 9, 1), (64, 16, 16, 32, 64, 9, 1)], ids=str)
+def test_conv_wgrad_run_to_run(shape):
+    """the producer / consumer weight gradient at launch sizes of the training step (many sub-tiles per workgroup, two workgroups
+    per CU for the 32-channel shape, a new image's table every few sub-tiles), 12 runs: one answer -- a missing barrier between
+    the roles, or a buffer reused a step early, would show as differing bits now and then"""
+    from diamond_amd import ac_native as A, engine as E
+
+    n, h, w, cin, cout, taps, prologue = shape
+    g = torch.Generator().manual_seed(n + cin)
+    x = (torch.randn(n, h, w, cin, generator=g) * 1.3 + 0.2).to(DEV)
+    dy = torch.randn(n, h, w, cout, generator=g).to(DEV)
+    xa = E.gn_stats(x)
+    spec = E.NormSpec(mul=(torch.randn(cin, generator=g) * 0.2 + 1).to(DEV), add=(torch.randn(cin, generator=g) * 0.2).to(DEV))
+    first = None
+    for _ in range(12):
+        dw, db = A._wgrad(xa, prologue, spec, dy, taps, cin, split=True)
+        torch.cuda.synchronize()
+        if first is None:
+            first = (dw.clone(), db.clone())
+            assert torch.isfinite(dw).all() and float(dw.abs().max()) > 0
+        else:
+            assert torch.equal(dw, first[0]) and torch.equal(db, first[1])
+
+
 def E_act(t):
     from diamond_amd import engine as E
 
