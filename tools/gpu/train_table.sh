@@ -1,3 +1,5 @@
+#!/bin/bash
+# The denoiser training step (f2): ms per replayed step and the kernel table of its roofline (bench.py --config train).  ~1 GPU-minute.
 python bench.py --config train --steps 30 --warmup 5 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
