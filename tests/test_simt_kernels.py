@@ -232,6 +232,8 @@ WGRAD_CASES = [
     dict(n=2, h=8, w=8, cin=32, cout=32, k=3, no_bias=True),
     dict(n=3, h=16, w=16, cin=64, cout=64, k=3, prologue=1, film=True, precision=1),  # 6 tiles, three images: table refreshes
     dict(n=5, h=8, w=8, cin=32, cout=64, k=3, prologue=1, precision=1),                # 2.5 tiles: a tile spanning two images
+    dict(n=3, h=8, w=16, cin=16, cin_real=15, cout=64, k=3, precision=1),              # conv_in on the producer / consumer kernel: 240 patch items for 256 producer threads
+    dict(n=2, h=16, w=8, cin=32, cout=32, k=1, prologue=2, film=True, precision=1),    # 1x1, normalised without SiLU
 ]
 
 
