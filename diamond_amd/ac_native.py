@@ -173,7 +173,7 @@ def _wgrad(x: Act, prologue: int, spec: Optional[NormSpec], dy: Tensor, taps: in
             # (spelled like rocprofv3's kernel trace: bench.py's records and profiles/*pmc*.json share one key)
             # (the split-fp16 gradient runs on the producer / consumer kernel, csrc/dmd_backward.hip)
             geom = f"WgradGeom<{cout // 16}, {x.C // 16}, {taps}>"
-            nv.PROFILER.annotate(f"wgrad_ps_kernel<{geom}>" if split and os.environ.get("DIAMOND_WGRAD_PS", "1") != "0" else
+            nv.PROFILER.annotate(f"wgrad_ps_kernel<{geom}, {'true' if prologue else 'false'}>" if split and os.environ.get("DIAMOND_WGRAD_PS", "1") != "0" else
                                  f"wgrad_kernel<{geom}, {'true' if split else 'false'}>",
                                  2.0 * taps * cin_real * cout * n * h * w, 4.0 * n * h * w * (x.C + cout))
     else:

@@ -936,7 +936,17 @@ __device__ __forceinline__ unsigned wg_low_pair(float x0, float x1, unsigned h01
 #endif
 typedef _Float16 wg_h2 __attribute__((ext_vector_type(2)));
 
-template <class G>
+// NORMED = the source has a prologue (GroupNorm, with or without SiLU), a template parameter: as a run-time flag every element's
+// arithmetic sat between two scalar branches (290 scalar instructions per sub-tile next to 380 vector ones).  WHICH prologue stays
+// a run-time flag, on purpose: with the SiLU compiled as straight-line code (three instantiations, the whole prologue a constant)
+// the 32 -> 32 launches of the actor-critic -- the one shape with TWO staging waves per SIMD, two workgroups per CU -- returned
+// element 1 of every channel quad wrong now and then, run to run (1e-3 relative; only NORM_SILU sources, only above 256
+// workgroups: tools/debug/wgrad_race.py, profiles/r06n_wgrad_race.txt).  The straight-line code overwrites a transcendental's
+// source register in the very next instruction (`v_rcp_f32 v98, v92` / `v_add_f32 v92, 1.0, v93`); two idle cycles behind every
+// v_exp / v_rcp made the errors rarer, not zero.  Behind a scalar branch per element the code is the second version's, which the
+// run-to-run test has never caught.  (One kernel with three copies of the pipeline: 154 registers instead of 111 for that shape,
+// its second workgroup per CU no longer fits, 1,630 -> 1,740 us: profiles/r06n_ab_wgrad_v3.txt.)
+template <class G, bool NORMED>
 __global__ __launch_bounds__(512) void wgrad_ps_kernel(const dmd_wgrad_params p, int tiles_total, int tiles_per_wg) {
   using P = WgradPs<G>;
   DMD_DYNAMIC_LDS(float, smem);
@@ -959,38 +969,66 @@ __global__ __launch_bounds__(512) void wgrad_ps_kernel(const dmd_wgrad_params p,
     const int qi = ptid % P::CQI, qo = ptid % P::CQO;  // this thread's channel quads (the same for every item)
     f32x4 pxa[2 * P::NP], pda[2 * P::ND], pxb[2 * P::NP], pdb[2 * P::ND];  // (both pixels of a pair)
     f32x4 bsum = (f32x4){0.f, 0.f, 0.f, 0.f};  // bias gradient of dy channel quad qo
-    const bool normed = p.src.prologue != DMD_PROLOGUE_NONE;
+    constexpr bool normed = NORMED;
     const bool silu = p.src.prologue == DMD_PROLOGUE_NORM_SILU;
     // Every request is UNCONDITIONAL (a pixel outside the image, the valid extent or the item count reads pixel (0, 0) of its
     // image and is zeroed when it is staged): a predicated load is a branch to hipcc, and behind a branch its wait insertion
     // stops counting -- `s_waitcnt vmcnt(0)` right behind the requests, i.e. no prefetch at all (the first version of this
     // kernel: loads, staging and MFMAs of the 32-channel launches added up to the launch time, 1,133 + 470 + 693 us of 2,064).
-    auto fetch = [&](f32x4 (&px)[2 * P::NP], f32x4 (&pd)[2 * P::ND], int u) __attribute__((always_inline)) {
+    // What an item is never changes -- its pair's row / column inside the sub-tile, its place in LDS: computed once.  Per
+    // sub-tile a request is then the wave-uniform image base + a 32-bit byte offset, and whether it exists one bit of a mask
+    // that travels with the register set (SQ counters of the second version: 400 vector instructions per producer wave and
+    // sub-tile of the 32-channel shape, 150 of them arithmetic on values, vector issue 0.58 of the kernel's cycles).
+    int prow_[P::NP], pcol_[P::NP], pdst_[P::NP], drow_[P::ND], dcol_[P::ND], ddst_[P::ND];
+#pragma unroll
+    for (int it = 0; it < P::NP; ++it) {
+      const int pair = it * (256 / P::CQI) + ptid / P::CQI;
+      const int prow = pair / P::NPC;
+      prow_[it] = pair < G::PW * P::NPC ? prow - G::PAD : -(1 << 20);  // (an item beyond the patch: never inside any image)
+      pcol_[it] = pair - prow * P::NPC - G::PAD;
+      pdst_[it] = pair * P::SPB + 4 * qi;
+    }
+#pragma unroll
+    for (int it = 0; it < P::ND; ++it) {
+      const int pair = it * (256 / P::CQO) + ptid / P::CQO;
+      drow_[it] = pair < 32 ? (pair >> 2) : (1 << 20);
+      dcol_[it] = pair & 3;
+      ddst_[it] = pair * P::SPA + 4 * qo;
+    }
+    unsigned oka = 0, okb = 0;  // bit 2 it + h: patch pixel h of item it exists; bit 16 + 2 it + h: dy pixel
+    auto fetch = [&](f32x4 (&px)[2 * P::NP], f32x4 (&pd)[2 * P::ND], unsigned& okm, int u) __attribute__((always_inline)) {
       const int img = u / per_img, r = u - img * per_img;
       const int y0 = (r / txs) * 8, x0 = (r % txs) * 8;
-      const float* xs = p.src.x + (size_t)img * p.H * p.W * Cx + 4 * qi;
+      const char* xs = (const char*)(p.src.x + (size_t)img * p.H * p.W * Cx);  // wave-uniform
+      const char* ds = (const char*)(p.dy + (size_t)img * p.H * p.W * G::COUT);
+      unsigned m = 0;
 #pragma unroll
       for (int it = 0; it < P::NP; ++it) {
-        const int pair = it * (256 / P::CQI) + ptid / P::CQI;
-        const int prow = pair / P::NPC, pc = pair - prow * P::NPC;
-        const int iy = y0 - G::PAD + prow, ix = x0 - G::PAD + pc;
-        const bool oky = pair < G::PW * P::NPC && iy >= 0 && iy < Hv;
+        const int iy = y0 + prow_[it];
+        const bool oky = (unsigned)iy < (unsigned)Hv;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int ixh = ix + 4 * h;
-          px[2 * it + h] = *(const f32x4*)(xs + ((oky && ixh >= 0 && ixh < Wv) ? (size_t)(iy * p.W + ixh) * Cx : (size_t)0));
+          const int ix = x0 + pcol_[it] + 4 * h;
+          const bool ok = oky && (unsigned)ix < (unsigned)Wv;
+          m |= ok ? 1u << (2 * it + h) : 0u;
+          const unsigned off = ok ? ((unsigned)(iy * p.W + ix) * (unsigned)Cx + 4u * qi) * 4u : 16u * qi;  // (bytes inside the image: < 2^32)
+          px[2 * it + h] = *(const f32x4*)(xs + off);
         }
       }
-      const float* ds = p.dy + (size_t)img * p.H * p.W * G::COUT + 4 * qo;
 #pragma unroll
       for (int it = 0; it < P::ND; ++it) {
-        const int pair = it * (256 / P::CQO) + ptid / P::CQO;
-        const int oy = y0 + (pair >> 2), ox = x0 + (pair & 3);
-        const bool oky = pair < 32 && oy < Hv;
+        const int oy = y0 + drow_[it];
+        const bool oky = (unsigned)oy < (unsigned)Hv;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-          pd[2 * it + h] = *(const f32x4*)(ds + ((oky && ox + 4 * h < Wv) ? (size_t)(oy * p.W + ox + 4 * h) * G::COUT : (size_t)0));
+        for (int h = 0; h < 2; ++h) {
+          const int ox = x0 + dcol_[it] + 4 * h;
+          const bool ok = oky && ox < Wv;
+          m |= ok ? 1u << (16 + 2 * it + h) : 0u;
+          const unsigned off = ok ? ((unsigned)(oy * p.W + ox) * (unsigned)G::COUT + 4u * qo) * 4u : 16u * qo;
+          pd[2 * it + h] = *(const f32x4*)(ds + off);
+        }
       }
+      okm = m;
     };
     auto build_table = [&](int img, int which) __attribute__((always_inline)) {
       if (ptid < G::CIN) {
@@ -1003,9 +1041,7 @@ __global__ __launch_bounds__(512) void wgrad_ps_kernel(const dmd_wgrad_params p,
       }
     };
     int which = 0;  // the table of the image being staged
-    auto stage = [&](const f32x4 (&px)[2 * P::NP], const f32x4 (&pd)[2 * P::ND], int u, float* buf) __attribute__((always_inline)) {
-      const int img = u / per_img, r = u - img * per_img;
-      const int y0 = (r / txs) * 8, x0 = (r % txs) * 8;
+    auto stage = [&](const f32x4 (&px)[2 * P::NP], const f32x4 (&pd)[2 * P::ND], unsigned okm, float* buf) __attribute__((always_inline)) {
       float tm[4], ta[4], tad[4];
       if (normed) {
         const float* t = tab + which * 3 * G::CIN + 4 * qi;
@@ -1018,15 +1054,11 @@ __global__ __launch_bounds__(512) void wgrad_ps_kernel(const dmd_wgrad_params p,
       }
 #pragma unroll
       for (int it = 0; it < P::NP; ++it) {
-        const int pair = it * (256 / P::CQI) + ptid / P::CQI;
-        if (pair >= G::PW * P::NPC) continue;  // (only the last round, and whole waves when 256 / CQI divides the pair count's tail)
-        const int prow = pair / P::NPC, pc = pair - prow * P::NPC;
-        const int iy = y0 - G::PAD + prow, ix = x0 - G::PAD + pc;
-        const bool oky = iy >= 0 && iy < Hv;
+        if ((it + 1) * (256 / P::CQI) > G::PW * P::NPC && prow_[it] < -G::PAD) continue;  // (only the last round can lie beyond the patch)
         f32x4 v[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const bool ok = oky && ix + 4 * h >= 0 && ix + 4 * h < Wv;  // (outside: the convolution's zero padding, after the prologue)
+          const bool ok = (okm >> (2 * it + h)) & 1;  // (outside: the convolution's zero padding, after the prologue)
           v[h] = px[2 * it + h];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -1044,20 +1076,18 @@ __global__ __launch_bounds__(512) void wgrad_ps_kernel(const dmd_wgrad_params p,
           hh[e] = __builtin_bit_cast(unsigned, (wg_h2){(_Float16)v[0][e], (_Float16)v[1][e]});
           ll[e] = wg_low_pair(v[0][e], v[1][e], hh[e]);
         }
-        float* dst = buf + (size_t)pair * P::SPB + 4 * qi;
+        float* dst = buf + pdst_[it];
         *(wg_u4*)dst = hh;
         *(wg_u4*)(dst + G::CIN) = ll;
       }
       float* dyt = buf + P::PATCH_DW;
 #pragma unroll
       for (int it = 0; it < P::ND; ++it) {
-        const int pair = it * (256 / P::CQO) + ptid / P::CQO;
-        if (pair >= 32) continue;  // (COUT = 16: half of the producer threads have no dy item)
-        const bool oky = y0 + (pair >> 2) < Hv;
+        if (P::NDI < 256 && drow_[it] >= 8) continue;  // (COUT = 16: half of the producer threads have no dy item)
         f32x4 v[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const bool ok = oky && x0 + (pair & 3) + 4 * h < Wv;
+          const bool ok = (okm >> (16 + 2 * it + h)) & 1;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[h][e] = ok ? pd[2 * it + h][e] : 0.f;
           bsum += v[h];
@@ -1068,35 +1098,35 @@ __global__ __launch_bounds__(512) void wgrad_ps_kernel(const dmd_wgrad_params p,
           hh[e] = __builtin_bit_cast(unsigned, (wg_h2){(_Float16)v[0][e], (_Float16)v[1][e]});
           ll[e] = wg_low_pair(v[0][e], v[1][e], hh[e]);
         }
-        float* dst = dyt + (size_t)pair * P::SPA + 4 * qo;
+        float* dst = dyt + ddst_[it];
         *(wg_u4*)dst = hh;
         *(wg_u4*)(dst + G::COUT) = ll;
       }
     };
-    // one step of the pipeline: sub-tile sub_begin + k out of register set (px, pd) into buffer k & 1, its successor-but-one
-    // requested into the same registers, the next image's table if sub-tile k + 1 starts one
-    auto step = [&](f32x4 (&px)[2 * P::NP], f32x4 (&pd)[2 * P::ND], int k) __attribute__((always_inline)) {
+    // (the requests first: the table's own round trips -- partial sums, scale, shift -- then run under them; a launch of the
+    //  16 x 16 or 8 x 8 level is two sub-tiles per workgroup and little else than this prologue)
+    fetch(pxa, pda, oka, sub_begin);
+    if (n > 1) fetch(pxb, pdb, okb, sub_begin + 1);
+    if (normed) build_table(sub_begin / per_img, 0);
+    __syncthreads();  // the first table
+    // one step: sub-tile sub_begin + k out of register set (px, pd) into buffer k & 1, its successor-but-one requested into the
+    // same registers, the next image's table if sub-tile k + 1 starts one
+    auto step = [&](f32x4 (&px)[2 * P::NP], f32x4 (&pd)[2 * P::ND], unsigned& okm, int k) __attribute__((always_inline)) {
       if (k < n) {
         const int u = sub_begin + k;
-        if (!WG_LAB(0x200)) stage(px, pd, u, smem + (k & 1) * P::BUF_FLOATS);
-        if (k + 2 < n && !WG_LAB(0x400)) fetch(px, pd, u + 2);
+        if (!WG_LAB(0x200)) stage(px, pd, okm, smem + (k & 1) * P::BUF_FLOATS);
+        if (k + 2 < n && !WG_LAB(0x400)) fetch(px, pd, okm, u + 2);
         if (normed && k + 1 < n && (u + 1) / per_img != u / per_img) {
           which ^= 1;
           build_table((u + 1) / per_img, which);
         }
       }
     };
-    // (the requests first: the table's own round trips -- partial sums, scale, shift -- then run under them; a launch of the
-    //  16 x 16 or 8 x 8 level is two sub-tiles per workgroup and little else than this prologue)
-    fetch(pxa, pda, sub_begin);
-    if (n > 1) fetch(pxb, pdb, sub_begin + 1);
-    if (normed) build_table(sub_begin / per_img, 0);
-    __syncthreads();  // the first table
     for (int k = 0; k <= n; k += 2) {
-      step(pxa, pda, k);
+      step(pxa, pda, oka, k);
       __syncthreads();
       if (k + 1 <= n) {
-        step(pxb, pdb, k + 1);
+        step(pxb, pdb, okb, k + 1);
         __syncthreads();
       }
     }
@@ -1310,16 +1340,22 @@ static int launch_wgrad(const dmd_wgrad_params& p, hipStream_t st) {
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM_BYTES);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ps_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize,
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ps_kernel<G, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              WgradPs<G>::SMEM_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ps_kernel<G, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               WgradPs<G>::SMEM_BYTES);
     DMD_CHECK_ARG(e == hipSuccess, "wgrad: hipFuncSetAttribute(%d bytes): %s", G::SMEM_BYTES, hipGetErrorString(e));
     attr_set[dev] = true;
   }
   // DIAMOND_WGRAD_PS=0: the split-fp16 gradient on the single-role kernel (A/B, and the tests' bitwise comparison of the two)
   static DmdEnvInt ps_env{"DIAMOND_WGRAD_PS", 1};
-  if ((p.precision & 0xff) == DMD_PRECISION_F16X2 && ps_env.get() != 0)
-    hipLaunchKernelGGL((wgrad_ps_kernel<G>), dim3(num_wg), dim3(512), WgradPs<G>::SMEM_BYTES, st, p, tiles, tpw);
-  else if ((p.precision & 0xff) == DMD_PRECISION_F16X2)
+  if ((p.precision & 0xff) == DMD_PRECISION_F16X2 && ps_env.get() != 0) {
+    if (p.src.prologue != DMD_PROLOGUE_NONE)
+      hipLaunchKernelGGL((wgrad_ps_kernel<G, true>), dim3(num_wg), dim3(512), WgradPs<G>::SMEM_BYTES, st, p, tiles, tpw);
+    else
+      hipLaunchKernelGGL((wgrad_ps_kernel<G, false>), dim3(num_wg), dim3(512), WgradPs<G>::SMEM_BYTES, st, p, tiles, tpw);
+  } else if ((p.precision & 0xff) == DMD_PRECISION_F16X2)
     hipLaunchKernelGGL((wgrad_kernel<G, true>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);
   else
     hipLaunchKernelGGL((wgrad_kernel<G, false>), dim3(num_wg), dim3(256), G::SMEM_BYTES, st, p, tiles, tpw);

@@ -195,7 +195,7 @@ __device__ __forceinline__ void ws_barrier() {
 // WS_TRACE (DMD_LAB builds only): s_memtime stamps of workgroup WS_TRACE_WG, one stream per role, read back with
 // tools/ws_trace.py: which role waits for which in a chunk step.
 #if defined(DMD_LAB) && defined(WS_TRACE)
-#define WS_TRACE_WG 37
+#define WS_TRACE_WG (gridDim.x > 37 ? 37 : 0)
 #define WS_TRACE_N 4096
 __device__ unsigned long long ws_trace_buf[3][WS_TRACE_N];
 __device__ int ws_trace_cnt[3];
@@ -435,6 +435,7 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
   const int tid = (int)(threadIdx.x & 255);  // index inside the role
   WS_TRACE_DECL;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  WS_STAMP(role, 13, 0);  // kernel entry
   const int up = p.upsample;
   const int Hs = p.H >> up, Ws = p.W >> up;
   // valid extent (include/diamond_hip.h): conv-input coordinates (= output coordinates: stride 1) and stored-source ones
@@ -739,8 +740,11 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
       // element e + 1, real or dummy], in this order: every stage_S(e) is followed by issue_S(e + 2) into the same set.
       issue_S(0, stage0, zm0, sl0);
       issue_S(1, stage1, zm1, sl1);
+      WS_STAMP(2, 14, 0);
       ws_barrier();  // B(-1): the tables written by setup_tile are visible to all producers
+      WS_STAMP(2, 15, 0);
       stage_S(0, stage0, zm0, sl0, 2);
+      WS_STAMP(2, 12, 0);
       ws_barrier();  // B0: buffer 0 = element 0
       // step j: consumers compute element j, producers fill element j + 1 (register set (j + 1) & 1)
       for (int j = 0; j < S; j += 2) {
@@ -1107,11 +1111,14 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
     // the bias row of the convolution: accumulators START from it (no bias loads / adds in the write-out)
     if (role == 0 && tid < G::COUT)
       bias_lds[tid] = (p.bias ? p.bias[tid] : 0.f) + ((G::PROJ && p.proj_bias) ? p.proj_bias[tid] : 0.f);
+    WS_STAMP(role, 14, 0);
     ws_barrier();  // B(-1)
+    WS_STAMP(role, 15, 0);
     if (role == 1) {  // group 1 is idle during tile 0: it provides the first chunk's weights
       cons_load_W(0, 0);
       cons_land_W();
     }
+    WS_STAMP(role, 12, 0);
     ws_barrier();  // B0
     int j = 0;
     // The two groups take alternate tiles: group `role` computes tiles k = role, role + 2, ... and, while the other group
@@ -1214,7 +1221,9 @@ __global__ __launch_bounds__(768, 3) void conv_f16ws_kernel(const dmd_conv_param
         }
       }
     }
+    WS_STAMP(role, 13, 1);
     if (pending < 4) epi_blocks(4);  // tail: the last tile(s) of the range
+    WS_STAMP(role, 13, 2);
   }
 #undef WS_TILE
 }

@@ -24,7 +24,9 @@ COUT = int(os.environ.get("CONV_BENCH_COUT", "64"))
 if COUT == 32:
     SHAPES = [(256, 64, [32], 1, True, False), (256, 64, [16], 0, False, False), (256, 32, [32], 1, True, False),
               (256, 16, [32], 1, True, False)]
+NB = int(os.environ.get("CONV_BENCH_N", "0"))  # another batch than 256 (the B = 1 latency regime)
 for n, h, cins, prologue, res, up in SHAPES:
+    n = NB or n
     hs = h // 2 if up else h
     srcs = []
     for c in cins:
@@ -46,7 +48,7 @@ for n, h, cins, prologue, res, up in SHAPES:
         run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 20
+    reps = 20 if not NB else 200
     e0.record()
     for _ in range(reps):
         run()

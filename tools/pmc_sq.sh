@@ -1,6 +1,7 @@
 #!/bin/bash
 # SQ-level counters for the conv kernels (passes of <= 8 counters of one block each: SQ x 4, TCC, TCP / TA), denoiser forwards only.
 #   bash tools/pmc_sq.sh <tag> [lib.so]     -> gpurun_out/pmc_sq_<tag>/pass{1,2}.json
+#   PMC_TARGET="tools/wgrad_bench.py wgrad 3 f2" PMC_KERNELS=wgrad bash tools/pmc_sq.sh <tag>     (another workload / kernel family)
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-head}
@@ -18,16 +19,16 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum"; do
   i=$((i+1))
   rm -rf /tmp/sq_${TAG}_$i
-  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/sq_${TAG}_$i -o sq -- python $R/tools/pmc_target.py 256 > $O/pass$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/sq_${TAG}_$i -o sq -- python $R/${PMC_TARGET:-tools/pmc_target.py 256} > $O/pass$i.log 2>&1
   echo "rc=$?" >> $O/pass$i.log
   f=$(find /tmp/sq_${TAG}_$i -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python $R/tools/pmc_parse_multi.py $f > $O/pass$i.json
   k=$(find /tmp/sq_${TAG}_$i -name "*kernel_trace.csv" | head -1)
-  [ -n "$k" ] && python - "$k" > $O/pass${i}_durations.json <<'PY'
+  [ -n "$k" ] && python - "$k" "${PMC_KERNELS:-conv}" > $O/pass${i}_durations.json <<'PY'
 import csv, json, sys, collections
 d = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
     d[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-print(json.dumps({k: {"launches": len(v), "avg_us": sum(v) / len(v) / 1e3} for k, v in d.items() if "conv" in k}, indent=1))
+print(json.dumps({k: {"launches": len(v), "avg_us": sum(v) / len(v) / 1e3} for k, v in d.items() if sys.argv[2] in k}, indent=1))
 PY
 done

@@ -1,7 +1,7 @@
 """gpurun_out/pmc_sq_<tag>/pass{1,2}.json (+ durations) of tools/pmc_sq.sh -> profiles/<set>_sq_counters.json and profiles/sq_counters.json
 (the copy bench.py reads for `roofline.kernels[*].mfma_busy`).
 
-    python tools/pmc_sq_to_profile.py gpurun_out/pmc_sq_r06 r06
+    python tools/pmc_sq_to_profile.py gpurun_out/pmc_sq_r06 r06 [--tagged-only]
 
 Derived per kernel (per-launch averages summed over the chip):
   mfma_busy          SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs  over  SQ_BUSY_CYCLES / 32 shader engines' SQs: the share of the kernel's busy
@@ -23,6 +23,7 @@ Derived per kernel (per-launch averages summed over the chip):
 import json, os, sys
 
 src, tag = sys.argv[1], sys.argv[2]
+only_tagged = len(sys.argv) > 3 and sys.argv[3] == "--tagged-only"  # (another workload than bench.py's: profiles/sq_counters.json stays)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import glob
 passes = {}
@@ -75,7 +76,7 @@ for k in sorted(set(p1) | set(p2)):
         d["wait_inst_share"] = round(d.get("SQ_WAIT_INST_ANY", 0.0) / d["SQ_WAVE_CYCLES"], 4)
     short = k.replace("void ", "").split("(")[0].replace("> >", ">>")
     out["kernels"][short] = d
-for name in (f"{tag}_sq_counters.json", "sq_counters.json"):
+for name in (f"{tag}_sq_counters.json",) + (() if only_tagged else ("sq_counters.json",)):
     json.dump(out, open(os.path.join(root, "profiles", name), "w"), indent=1)
 for k, d in out["kernels"].items():
     print(f"{k[:64]:64s} mfma_busy {d.get('mfma_busy')}  valu {d.get('valu_active')}  vmem {d.get('vmem_active')}  lds {d.get('lds_active')}  coexec {d.get('mfma_valu_coexec')}  valu_issue~ {d.get('valu_issue_share_est')}  neither~ {d.get('neither_pipe_share_est')}  l2hit {d.get('l2_hit_rate')}  wait_inst {d.get('wait_inst_share')}")

@@ -10,7 +10,7 @@ from diamond_amd import ac_native as A, engine as E, native as nv
 
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-only = sys.argv[3] if len(sys.argv) > 3 else ""
+only = sys.argv[3] if len(sys.argv) > 3 else os.environ.get("WGRAD_ONLY", "")  # (the env form: for wrappers that cannot quote)
 nv.PRECISION_F16X2 |= int(os.environ.get("WGRAD_LAB", "0")) << 8  # (a library built with EXTRA_HIPCC_FLAGS=-DDMD_LAB only: 1 no contraction, 2 no staging, 4 no prefetch loads)
 dev = torch.device("cuda")
 g = torch.Generator(device="cuda").manual_seed(1)

@@ -18,7 +18,8 @@ cin = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 res = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 cout = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 dev = "cuda"
-n, h = 256, (int(sys.argv[4]) if len(sys.argv) > 4 else 64)
+h = int(sys.argv[4]) if len(sys.argv) > 4 else 64
+n = int(sys.argv[5]) if len(sys.argv) > 5 else 256  # n < 38: workgroup 0 is traced, and every stamp is listed
 srcs = []
 for c in ([64] * (cin // 64) if cin >= 64 else [cin]):
     a = E.gn_stats(torch.randn(n, h, h, c, device=dev))
@@ -55,6 +56,10 @@ for role in range(3):
         tmin = t if tmin is None else min(tmin, t)
         tmax = max(tmax, t)
 print(f"launch {us:.1f} us, counts {list(cnt)}, span {tmax - tmin} ticks = {(tmax - tmin) / us:.0f} ticks/us")
+if n < 38:  # the raw timeline of a few-tile launch (tags 13: kernel entry / in front of / behind the tail write-out, 14 / 15: in front of / behind B(-1), 12: in front of B0)
+    ev = sorted((rows[s][k], k[0], k[1], s) for s in rows for k in rows[s])
+    for t, role, tag, step in ev:
+        print(f"  +{t - tmin:7d} ticks  role {role} tag {tag:2d} step {step}")
 # producer: 0 start, 7 register set landed, 1 staged, 2 issued, 3 past barrier.  active consumer: 4 start, 5 body done, 6 past barrier.
 # write-out consumer: 8 start, 9 DMA issued, 10 epilogue + landing done, 11 past barrier
 tot, num = collections.Counter(), collections.Counter()
