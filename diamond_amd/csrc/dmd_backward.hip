@@ -11,6 +11,7 @@
 //   * MaxPool backward = scatter by the saved argmax.
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 #include "dmd_common.h"
 
@@ -85,6 +86,7 @@ __device__ __forceinline__ double gn_bwd_count(const dmd_gn_bwd_params& p) { ret
 #define GN_BWD_PIX 256  // pixels per workgroup in passes A and B
 #define GN_BWD_MAXG 8   // C <= 256
 
+template <int GN_BWD_U>  // pixels requested per thread and trip (dmd_gn_silu_bwd picks by launch size)
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const dmd_gn_bwd_params p, int T, double* __restrict__ group_partial,
                                                             float* __restrict__ chan_partial) {
   __shared__ float g_mean[GN_BWD_MAXG], g_rstd[GN_BWD_MAXG];
@@ -115,19 +117,37 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const dmd_gn_bwd_par
   }
   double s1 = 0.0, s2 = 0.0;
   float dm[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
+  // GN_BWD_U pixels per trip, every request in front of the first use (a thread's pixels in the same order as one at a time: the
+  // same sums, the same bits).  A launch of the denoiser's training step (batch 32: 512 workgroups at 64 x 64, 128 at 32 x 32) has
+  // two waves per SIMD or fewer, one request pair each: 4 requests deep the two passes take 26.8 instead of 28.3 us on average,
+  // the step 7.80 instead of 7.89 ms; the actor-critic's launches (3,840 images: 61k workgroups, the SIMDs full) are 3 % FASTER one
+  // deep -- occupancy already supplies the requests, and the deeper trip's registers cost a wave (profiles/r06n_ab_gn_bwd.txt).
+  // A pixel that does not exist -- beyond the tile, outside the valid extent -- requests the trip's first pixel instead (a
+  // predicated load is a branch, and behind a branch hipcc waits for everything: see wgrad_ps_kernel).
   const int pix_end = min(p.HW, (t + 1) * GN_BWD_PIX);
-  for (int pix = t * GN_BWD_PIX + tid / CQ; pix < pix_end; pix += 256 / CQ) {
-    if (!gn_bwd_exists(p, pix)) continue;  // outside the valid extent: not part of any sum
-    const size_t off = ((size_t)n * p.HW + pix) * C + c0;
-    const f32x4 xv = *(const f32x4*)(p.x + off);
-    const f32x4 dv = *(const f32x4*)(p.da + off);
+  const int pstride = 256 / CQ;
+  for (int pix0 = t * GN_BWD_PIX + tid / CQ; pix0 < pix_end; pix0 += GN_BWD_U * pstride) {
+    f32x4 xv[GN_BWD_U], dv[GN_BWD_U];
+    bool ok[GN_BWD_U];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const GnBwdElem r = gn_bwd_elem(xv[e], dv[e], mean, rstd, mul[e], add[e], p.identity_activation == 0);
-      s1 += (double)r.dxh;
-      s2 += (double)r.dxh * (double)r.xh;
-      dm[e] += r.du * r.xh;
-      db[e] += r.du;
+    for (int u = 0; u < GN_BWD_U; ++u) {
+      const int pix = pix0 + u * pstride;
+      ok[u] = pix < pix_end && gn_bwd_exists(p, pix);  // outside the valid extent: not part of any sum
+      const size_t off = ((size_t)n * p.HW + (ok[u] ? pix : pix0)) * C + c0;
+      xv[u] = *(const f32x4*)(p.x + off);
+      dv[u] = *(const f32x4*)(p.da + off);
+    }
+#pragma unroll
+    for (int u = 0; u < GN_BWD_U; ++u) {
+      if (!ok[u]) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const GnBwdElem r = gn_bwd_elem(xv[u][e], dv[u][e], mean, rstd, mul[e], add[e], p.identity_activation == 0);
+        s1 += (double)r.dxh;
+        s2 += (double)r.dxh * (double)r.xh;
+        dm[e] += r.du * r.xh;
+        db[e] += r.du;
+      }
     }
   }
   // group sums: threads of a wave may belong to different groups (C = 64: quads 0-7 / 8-15)
@@ -170,6 +190,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const dmd_gn_bwd_par
 
 // Workgroup (0, n) also sums the T per-tile channel partials of image n into dmul / dadd, in tile order (round 4: a separate
 // launch until then; bitwise the same sums, one launch less per normalisation: 12.05 -> 11.90 ms per denoiser training step)
+template <int GN_BWD_U>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const dmd_gn_bwd_params p, int T, const double* __restrict__ group_partial,
                                                            const float* __restrict__ chan_partial) {
   __shared__ float g_mean[GN_BWD_MAXG], g_rstd[GN_BWD_MAXG], g_m1[GN_BWD_MAXG], g_m2[GN_BWD_MAXG];
@@ -217,23 +238,44 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const dmd_gn_bwd_para
     add[e] = p.norm.add ? p.norm.add[(size_t)n * p.norm.add_stride + c0 + e] : 0.0f;
   }
   const int pix_end = min(p.HW, (t + 1) * GN_BWD_PIX);
-  for (int pix = t * GN_BWD_PIX + tid / CQ; pix < pix_end; pix += 256 / CQ) {
-    const size_t off = ((size_t)n * p.HW + pix) * C + c0;
-    if (!gn_bwd_exists(p, pix)) {  // outside the valid extent: a zero gradient
-      *(f32x4*)(p.dx + off) = (f32x4){0.f, 0.f, 0.f, 0.f};
-      continue;
-    }
-    const f32x4 xv = *(const f32x4*)(p.x + off);
-    const f32x4 dv = *(const f32x4*)(p.da + off);
-    f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (p.dskip) o = *(const f32x4*)(p.dskip + off);
+  const int pstride = 256 / CQ;
+  // (two copies of the loop, with and without the skip gradient's request: a request under `if (p.dskip)` inside the loop is a branch)
+  auto pass = [&](auto skip_c) __attribute__((always_inline)) {
+    constexpr bool SKIP = decltype(skip_c)::value;
+    for (int pix0 = t * GN_BWD_PIX + tid / CQ; pix0 < pix_end; pix0 += GN_BWD_U * pstride) {  // (GN_BWD_U requests deep: see pass A)
+      f32x4 xv[GN_BWD_U], dv[GN_BWD_U], sv[SKIP ? GN_BWD_U : 1];
+      bool ok[GN_BWD_U];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const GnBwdElem r = gn_bwd_elem(xv[e], dv[e], mean, rstd, mul[e], add[e], p.identity_activation == 0);
-      o[e] += rstd * (r.dxh - m1 - r.xh * m2);
+      for (int u = 0; u < GN_BWD_U; ++u) {
+        const int pix = pix0 + u * pstride;
+        ok[u] = pix < pix_end && gn_bwd_exists(p, pix);
+        const size_t off = ((size_t)n * p.HW + (ok[u] ? pix : pix0)) * C + c0;
+        xv[u] = *(const f32x4*)(p.x + off);
+        dv[u] = *(const f32x4*)(p.da + off);
+        if (SKIP) sv[SKIP ? u : 0] = *(const f32x4*)(p.dskip + off);
+      }
+#pragma unroll
+      for (int u = 0; u < GN_BWD_U; ++u) {
+        const int pix = pix0 + u * pstride;
+        if (pix >= pix_end) continue;
+        const size_t off = ((size_t)n * p.HW + pix) * C + c0;
+        f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (ok[u]) {  // (outside the valid extent: a zero gradient)
+          if (SKIP) o = sv[SKIP ? u : 0];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const GnBwdElem r = gn_bwd_elem(xv[u][e], dv[u][e], mean, rstd, mul[e], add[e], p.identity_activation == 0);
+            o[e] += rstd * (r.dxh - m1 - r.xh * m2);
+          }
+        }
+        *(f32x4*)(p.dx + off) = o;
+      }
     }
-    *(f32x4*)(p.dx + off) = o;
-  }
+  };
+  if (p.dskip)
+    pass(std::true_type{});
+  else
+    pass(std::false_type{});
 }
 
 // HW <= 256 (the 16x16 and 8x8 levels: half of a training step's normalisations): ONE workgroup holds a whole image, so both
@@ -521,8 +563,13 @@ extern "C" int dmd_gn_silu_bwd(const dmd_gn_bwd_params* pp, dmd_stream_t stream)
     DMD_LAUNCH_CHECK();
     return 0;
   }
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(T, p.N), dim3(256), 0, st, p, T, group_partial, chan_partial);
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(T, p.N), dim3(256), 0, st, p, T, (const double*)group_partial, (const float*)chan_partial);
+  if ((long long)T * p.N <= 1024) {  // (at most four workgroups per CU: the requests have to come from inside a thread)
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<4>, dim3(T, p.N), dim3(256), 0, st, p, T, group_partial, chan_partial);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<4>, dim3(T, p.N), dim3(256), 0, st, p, T, (const double*)group_partial, (const float*)chan_partial);
+  } else {
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<1>, dim3(T, p.N), dim3(256), 0, st, p, T, group_partial, chan_partial);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<1>, dim3(T, p.N), dim3(256), 0, st, p, T, (const double*)group_partial, (const float*)chan_partial);
+  }
   DMD_LAUNCH_CHECK();
   return 0;
 }
