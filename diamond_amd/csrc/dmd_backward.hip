@@ -988,10 +988,10 @@ typedef _Float16 wg_h2 __attribute__((ext_vector_type(2)));
 // a run-time flag, on purpose: with the SiLU compiled as straight-line code (three instantiations, the whole prologue a constant)
 // the 32 -> 32 launches of the actor-critic -- the one shape with TWO staging waves per SIMD, two workgroups per CU -- returned
 // element 1 of every channel quad wrong now and then, run to run (1e-3 relative; only NORM_SILU sources, only above 256
-// workgroups: tools/debug/wgrad_race.py, profiles/r06n_wgrad_race.txt).  The straight-line code overwrites a transcendental's
-// source register in the very next instruction (`v_rcp_f32 v98, v92` / `v_add_f32 v92, 1.0, v93`); two idle cycles behind every
-// v_exp / v_rcp made the errors rarer, not zero.  Behind a scalar branch per element the code is the second version's, which the
-// run-to-run test has never caught.  (One kernel with three copies of the pipeline: 154 registers instead of 111 for that shape,
+// workgroups: tools/debug/wgrad_race.py, profiles/r06n_wgrad_race.txt).  Two idle cycles behind every v_exp / v_rcp made the errors
+// rarer, not zero; the register reuse hipcc chose there (`v_rcp_f32 v98, v92` / `v_add_f32 v92, 1.0, v93`) is safe on its own at
+// every occupancy (tools/probe/trans_war_probe.hip, profiles/r06o_trans_war_probe.txt): the mechanism is NOT established.  Behind a
+// scalar branch per element the code is the second version's, which the run-to-run test has never caught.  (One kernel with three copies of the pipeline: 154 registers instead of 111 for that shape,
 // its second workgroup per CU no longer fits, 1,630 -> 1,740 us: profiles/r06n_ab_wgrad_v3.txt.)
 template <class G, bool NORMED>
 __global__ __launch_bounds__(512) void wgrad_ps_kernel(const dmd_wgrad_params p, int tiles_total, int tiles_per_wg) {
