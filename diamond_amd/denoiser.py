@@ -7,7 +7,7 @@ diffusion_sampler.py:53) or a python float.
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Optional, Tuple, Union
+from typing import List, Optional, Sequence, Tuple, Union
 
 import torch
 from torch import Tensor, nn
@@ -90,7 +90,7 @@ class Denoiser(nn.Module):
     @torch.no_grad()
     def compute_model_output(self, noisy_next_obs: Tensor, obs: Tensor, act: Tensor, sigma: Union[Tensor, float],
                              naive: Optional[bool] = None, precision: Optional[str] = None,
-                             ring: Optional[Tuple[int, int]] = None) -> Tensor:
+                             ring: Optional[Tuple[int, int]] = None, table: Optional[Tensor] = None) -> Tensor:
         """F = inner_model(x * c_in, c_noise, obs / sigma_data, act)  (reference :74-77).
         precision: None (engine.WORLD_MODEL_PRECISION) | "f32" | "f16x2".
         ring = (obs_head, act_head): `obs` is then the PHYSICAL ring (N, T, C, H, W) of conditioning frames and `act`
@@ -125,8 +125,9 @@ class Denoiser(nn.Module):
         nv.check(nv.lib().dmd_edm_pack_input(nv.fptr(xc), nv.fptr(oc), nv.fptr(cond), stride, float(self.cfg.sigma_data),
                                              nv.fptr(packed), n, cx, cobs, h, w, cpad, t_ring, obs_head, nv.stream()),
                  "dmd_edm_pack_input")
-        cvec = self.inner_model.cond_vector(cond, stride, act, act_head)
-        out = self.inner_model.run(packed, cvec, naive, precision, valid=valid)
+        # (table: this forward's FiLM table, if the caller computed the tables of several steps at once -- film_tables below)
+        cvec = self.inner_model.cond_vector(cond, stride, act, act_head) if table is None else None
+        out = self.inner_model.run(packed, cvec, naive, precision, table=table, valid=valid)
         return out if valid is None else out[:, :, :valid[0], :valid[1]].contiguous()
 
     @torch.no_grad()
@@ -150,9 +151,25 @@ class Denoiser(nn.Module):
 
     @torch.no_grad()
     def denoise(self, noisy_next_obs: Tensor, sigma: Union[Tensor, float], obs: Tensor, act: Tensor,
-                ring: Optional[Tuple[int, int]] = None) -> Tensor:
-        f = self.compute_model_output(noisy_next_obs, obs, act, sigma, ring=ring)
+                ring: Optional[Tuple[int, int]] = None, table: Optional[Tensor] = None) -> Tensor:
+        f = self.compute_model_output(noisy_next_obs, obs, act, sigma, ring=ring, table=table)
         return self.wrap_model_output(noisy_next_obs, f, sigma)
+
+    # at most this many bytes of FiLM tables at once (a 50-step schedule at batch 256 would be 367 MB: computed per step instead)
+    FILM_TABLES_MAX_BYTES = 64 << 20
+
+    @torch.no_grad()
+    def film_tables(self, sigmas: Sequence[Union[Tensor, float]], act: Tensor, act_head: int = 0) -> Optional[List[Tensor]]:
+        """The FiLM tables of `denoise` at each of `sigmas` (scalars) for one action context, computed together (the noise
+        embedding differs per step, cond_proj and the AdaGroupNorm linears are the same three GEMMs: three launches instead of three
+        per denoising step, bitwise the per-step tables).  None: too large to keep (the caller then leaves `table` unset)."""
+        im = self.inner_model
+        per_step = act.shape[0] * 4 * sum(2 * m.in_channels for m in im.unet.modules() if type(m).__name__ == "AdaGroupNorm")
+        if len(sigmas) < 2 or len(sigmas) * per_step > self.FILM_TABLES_MAX_BYTES:
+            return None
+        conds = [self.compute_conditioners(s) for s in sigmas]
+        assert all(stride == 0 for _, stride in conds), "film_tables: scalar sigmas"
+        return im.film_tables(conds, act, act_head)
 
     # -- training step (reference denoiser.py:60-63,93-122) -------------------------------------------------------
     def _randn(self, shape, device) -> Tensor:

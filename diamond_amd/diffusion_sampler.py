@@ -6,6 +6,7 @@ tensors inside the loop, forcing a sync per step, diffusion_sampler.py:39,47); t
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Tuple
 
@@ -14,6 +15,9 @@ from torch import Tensor
 
 from . import native as nv
 from .denoiser import Denoiser
+
+# the FiLM tables of a frame's denoising steps computed together in front of the loop (DIAMOND_BATCH_FILM=0: per step, the A/B arm)
+BATCH_FILM_TABLES = os.environ.get("DIAMOND_BATCH_FILM", "1") != "0"
 
 
 @dataclass
@@ -129,13 +133,17 @@ class DiffusionSampler:
         gamma_ = min(self.cfg.s_churn / (len(sig) - 1), 2 ** 0.5 - 1)
         x = noise if noise is not None else self._randn((b, c, h, w), device)
         trajectory = [x]
-        for sigma, next_sigma in zip(sig[:-1], sig[1:]):  # 0-dim fp32 CPU tensors
+        # the conditioning of every step depends on (sigma, actions) only: the FiLM tables of the whole schedule in front of the
+        # loop, as three GEMM launches instead of three per step (bitwise the per-step tables; None: schedule too long to keep)
+        tables = self.denoiser.film_tables(list(sig[:-1]), ctx_act, act_head) if BATCH_FILM_TABLES else None
+        tab = (lambda i: tables[i]) if tables is not None else (lambda i: None)
+        for i, (sigma, next_sigma) in enumerate(zip(sig[:-1], sig[1:])):  # 0-dim fp32 CPU tensors
             gamma = gamma_ if self.cfg.s_tmin <= sigma <= self.cfg.s_tmax else 0
             sigma_hat = sigma * (gamma + 1)
             if gamma > 0:
                 eps = self._randn(x.shape, device) * self.cfg.s_noise
                 x = x + eps * float((sigma_hat ** 2 - sigma ** 2) ** 0.5)
-            denoised = self.denoiser.denoise(x, sigma, ctx_obs, ctx_act, ring=ring)  # sigma, not sigma_hat: reference :44
+            denoised = self.denoiser.denoise(x, sigma, ctx_obs, ctx_act, ring=ring, table=tab(i))  # sigma, not sigma_hat: reference :44
             dt = next_sigma - sigma_hat  # fp32 subtraction like the reference
             if self.cfg.order == 1 or next_sigma == 0:
                 x = self._euler(x, denoised, float(sigma_hat), float(dt))
@@ -143,7 +151,7 @@ class DiffusionSampler:
                 x_2 = self._euler(x, denoised, float(sigma_hat), float(dt))
                 # the reference passes next_sigma as a (B,) tensor of equal values (:53); one scalar
                 # yields the same per-sample conditioners without a per-sample array
-                denoised_2 = self.denoiser.denoise(x_2, next_sigma, ctx_obs, ctx_act, ring=ring)
+                denoised_2 = self.denoiser.denoise(x_2, next_sigma, ctx_obs, ctx_act, ring=ring, table=tab(i + 1))  # (next_sigma != 0: step i + 1 exists)
                 x = self._heun(x, denoised, x_2, denoised_2, float(sigma_hat), float(next_sigma), float(dt))
             trajectory.append(x)
         return x, trajectory

@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import os
 from dataclasses import dataclass
-from typing import Tuple, List, Optional
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 from torch import Tensor, nn
@@ -62,9 +62,38 @@ class InnerModel(nn.Module):
         fw, ew = self._cache.f32(self.noise_emb.weight), self._cache.f32(emb)
         nv.check(nv.lib().dmd_cond_embed(nv.fptr(cond), cond_stride, nv.fptr(fw), nv.ptr(act), nv.fptr(ew), nv.fptr(x), n,
                                          half, t, emb.shape[1], act_head, emb.shape[0], nv.stream()), "dmd_cond_embed")
+        return self._cond_proj(x)
+
+    def _cond_proj(self, x: Tensor) -> Tensor:
         l0, l2 = self.cond_proj[0], self.cond_proj[2]
         y = E.linear(x, self._cache.f32(l0.weight), self._cache.f32(l0.bias), silu=True)
         return E.linear(y, self._cache.f32(l2.weight), self._cache.f32(l2.bias))
+
+    def film_tables(self, conds: Sequence[Tuple[Tensor, int]], act: Tensor, act_head: int = 0) -> List[Tensor]:
+        """The FiLM tables of SEVERAL forwards that share `act` (the denoising steps of one sampled frame: one sigma each) as
+        three launches of dmd_linear instead of three per forward: the embeddings of all steps are rows of one (K * N, .) matrix.
+        dmd_linear sums an output row in the same order whatever the row count (csrc/dmd_linear.hip), so table k is bitwise
+        `FilmTable.compute(cond_vector(conds[k], ...))`.  Returns K row-slices of one buffer."""
+        assert act.dtype == torch.long and act.ndim == 2
+        n, t = act.shape
+        emb = self.act_emb[0].weight
+        if _DEBUG_CHECKS:
+            lo, hi = int(act.min()), int(act.max())
+            if lo < 0 or hi >= emb.shape[0]:
+                raise IndexError(f"action index out of range [0, {emb.shape[0]}): min {lo}, max {hi}")
+        half = self.noise_emb.weight.shape[1]
+        k = len(conds)
+        x = torch.empty(k * n, 2 * half, device=act.device, dtype=torch.float32)
+        act = act.contiguous()
+        fw, ew = self._cache.f32(self.noise_emb.weight), self._cache.f32(emb)
+        for i, (cond, stride) in enumerate(conds):
+            xi = x[i * n:(i + 1) * n]
+            nv.check(nv.lib().dmd_cond_embed(nv.fptr(cond), stride, nv.fptr(fw), nv.ptr(act), nv.fptr(ew), nv.fptr(xi), n,
+                                             half, t, emb.shape[1], act_head, emb.shape[0], nv.stream()), "dmd_cond_embed")
+        if self._film is None:
+            self._film = FilmTable(self.unet)
+        table = self._film.compute(self._cond_proj(x))
+        return [table[i * n:(i + 1) * n] for i in range(k)]
 
     def run(self, packed_in: Tensor, cond: Optional[Tensor], naive: Optional[bool] = None, precision: Optional[str] = None,
             table: Optional[Tensor] = None, valid: Optional[Tuple[int, int]] = None) -> Tensor:

@@ -260,6 +260,41 @@ def test_sampler_heun5_batch2_every_step_teacher_forced_vs_reference_golden(agen
         assert frac <= 5e-4, (i, frac)
 
 
+@pytest.mark.parametrize("steps,order,churn,b", [(3, 1, 0.0, 3), (4, 2, 1.0, 2)], ids=["euler3", "heun4_churn"])
+def test_film_tables_of_a_frame_computed_together_are_bitwise_the_per_step_ones(agent, monkeypatch, steps, order, churn, b):
+    """DiffusionSampler computes the FiLM tables of all denoising steps of a frame in front of the loop (three dmd_linear launches over
+    K * B rows instead of three per step, Denoiser.film_tables): dmd_linear sums an output row in the same order whatever the row
+    count, so the tables -- and with them every trajectory point -- are bitwise those of the per-step route (DIAMOND_BATCH_FILM=0)."""
+    import diamond_amd as D
+    from diamond_amd import diffusion_sampler as DS
+    from diamond_amd.testing import synthetic_actions, synthetic_frames
+
+    g = torch.Generator().manual_seed(41 + steps)
+    prev_obs = synthetic_frames(g, b, 4, 3, 64, 64).to(DEV)
+    prev_act = synthetic_actions(g, 4, b, 4).to(DEV)
+    noise = torch.randn(steps + 1, b, 3, 64, 64, generator=g)
+    cfg = D.DiffusionSamplerConfig(num_steps_denoising=steps, order=order, s_churn=churn, s_tmin=0.0, s_tmax=float("inf"))
+    runs = []
+    for batched in (True, False):
+        monkeypatch.setattr(DS, "BATCH_FILM_TABLES", batched)
+        sampler = D.DiffusionSampler(agent.denoiser, cfg)
+        draws = iter(noise)
+        sampler.noise_fn = lambda shape, dev: next(draws).to(dev)
+        x, traj = sampler.sample(prev_obs, prev_act)
+        runs.append([t.cpu() for t in traj])
+    assert len(runs[0]) == steps + 1 and all(torch.equal(a, c) for a, c in zip(*runs))
+    # ... and the tables themselves, against cond_vector + FilmTable.compute of each step
+    den, im = agent.denoiser, agent.denoiser.inner_model
+    sig = [s for s in sampler._host_sigmas[:-1]]
+    tables = den.film_tables(sig, prev_act, 0)
+    assert tables is not None and len(tables) == steps
+    for s, tab in zip(sig, tables):
+        cond, stride = den.compute_conditioners(s)
+        assert torch.equal(tab, im._film.compute(im.cond_vector(cond, stride, prev_act, 0)))
+    monkeypatch.setattr(den, "FILM_TABLES_MAX_BYTES", 1)  # a schedule too long to keep: the per-step route
+    assert den.film_tables(sig, prev_act, 0) is None
+
+
 def test_sampler_heun_step_budget_on_200k_pixels_vs_reference_golden(agent):
     """BASELINE configs[3]'s 2nd-order Heun step (two denoiser evaluations + the fused dmd_heun_step) where the budget can be
     resolved: 208,896 values per step, teacher-forced from the REFERENCE's own trajectory points (tests/golden/make_golden.py

@@ -76,6 +76,11 @@ def test_deferred_wgrad_reductions_are_bitwise_on_the_interpreter(models, monkey
     assert counter.n.get("dmd_wgrad_reduce_jobs", 0) >= 1, counter.n
 
 
+def test_film_tables_of_a_frame_computed_together_on_the_interpreter(models, monkeypatch):
+    M, _ = models
+    M.test_film_tables_of_a_frame_computed_together_are_bitwise_the_per_step_ones(M.make_agent(), monkeypatch, 3, 1, 0.0, 2)
+
+
 def test_rew_end_model_and_actor_critic_vs_goldens_on_the_interpreter(models):
     """reward / end model (32-channel AdaGN encoder, fused 8x8 tail, LSTM, head) and the actor-critic (forward + every gradient)
     against the reference-generated goldens"""
