@@ -11,7 +11,7 @@ def setcap(c):
     nv.lib().dmd_reload_env()
 
 DEV = "cuda"
-n, h, w, cin, cout, taps = 96, 64, 64, 32, 32, 9
+n, h, w, cin, cout, taps = int(os.environ.get("RACE_N", "96")), 64, 64, 32, 32, 9
 for prologue in (0, 1, 2):
     g = torch.Generator().manual_seed(n + cin)
     x = (torch.randn(n, h, w, cin, generator=g) * 1.3 + 0.2).to(DEV)
@@ -21,7 +21,7 @@ for prologue in (0, 1, 2):
     setcap("256")
     ref, refb = A._wgrad(xa, prologue, spec, dy, taps, cin, split=True)
     torch.cuda.synchronize()
-    for cap in ("256", "384", "512", "512", "512"):
+    for cap in ("256", "384") + ("512",) * int(os.environ.get("RACE_REPS", "3")):
         setcap(cap)
         dw, db = A._wgrad(xa, prologue, spec, dy, taps, cin, split=True)
         torch.cuda.synchronize()
